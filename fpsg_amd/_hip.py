@@ -1,0 +1,89 @@
+"""ctypes binding of ``libfpsg_hip.so`` (C ABI: ``include/fpsg_hip.h``).
+
+There is NO fallback: if the HIP library is missing, or a tensor is not a contiguous fp32
+/ int32 tensor on a ROCm device, the call raises.  Tensors are passed as raw device
+pointers together with torch's current HIP stream, so the kernels are ordered with the
+surrounding PyTorch work without any synchronisation.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import threading
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfpsg_hip.so")
+
+_c_f32p = ctypes.c_void_p
+_c_i32p = ctypes.c_void_p
+_c_int = ctypes.c_int
+_c_stream = ctypes.c_void_p
+
+# name -> argtypes (restype is int unless listed in _RESTYPES); mirrors include/fpsg_hip.h
+SIGNATURES = {
+    "fpsg_version": [],
+    "fpsg_last_error": [],
+    "fpsg_chamfer_fwd": [_c_f32p, _c_f32p, _c_int, _c_int, _c_int,
+                         _c_f32p, _c_i32p, _c_f32p, _c_i32p, _c_stream],
+    "fpsg_chamfer_bwd": [_c_f32p, _c_f32p, _c_i32p, _c_i32p, _c_f32p, _c_f32p,
+                         _c_int, _c_int, _c_int, _c_f32p, _c_f32p, _c_stream],
+}
+_RESTYPES = {"fpsg_last_error": ctypes.c_char_p}
+
+_lib = None
+_lock = threading.Lock()
+
+
+class FpsgHipError(RuntimeError):
+    pass
+
+
+def load() -> ctypes.CDLL:
+    """Loads the library once; raises (never falls back) when it is absent."""
+    global _lib
+    if _lib is None:
+        with _lock:
+            if _lib is None:
+                if not os.path.exists(LIB_PATH):
+                    raise FpsgHipError(
+                        f"{LIB_PATH} not found: build it with `make -C fpsg_amd/csrc` "
+                        "(or `python -c 'import __graft_entry__ as g; g.build()'`). "
+                        "fpsg_amd has no CPU or PyTorch fallback for its HIP ops.")
+                lib = ctypes.CDLL(LIB_PATH)
+                for name, argtypes in SIGNATURES.items():
+                    fn = getattr(lib, name)
+                    fn.argtypes = argtypes
+                    fn.restype = _RESTYPES.get(name, ctypes.c_int)
+                _lib = lib
+    return _lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().fpsg_last_error()
+        raise FpsgHipError(f"{what} failed (code {rc}): {msg.decode() if msg else ''}")
+
+
+def dev_tensor(t: torch.Tensor, dtype: torch.dtype, name: str) -> torch.Tensor:
+    """Validates that `t` is something the C ABI accepts."""
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name}: expected a torch.Tensor, got {type(t)}")
+    if t.device.type != "cuda":
+        raise FpsgHipError(
+            f"{name}: tensor is on '{t.device}'; fpsg_amd HIP ops run on a ROCm GPU only "
+            "(no CPU fallback)")
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected dtype {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name}: tensor must be contiguous")
+    return t
+
+
+def stream_of(t: torch.Tensor) -> int:
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def ptr(t: torch.Tensor) -> int:
+    return t.data_ptr()

@@ -1,0 +1,70 @@
+/*
+ * fpsg_hip.h -- C ABI of libfpsg_hip.so, the MI355X (gfx950) hot-path library.
+ *
+ * The reference (voidstrike/FPSG) has no native code of its own; its hot ops live in
+ * third-party CUDA packages reached through Python imports.  Each entry point below
+ * names the reference call site it replaces (paths relative to /root/reference).
+ *
+ * Conventions:
+ *   - every pointer is a DEVICE pointer to a contiguous, 4-byte aligned buffer owned by
+ *     the caller; the library never allocates, frees or keeps device memory;
+ *   - a call only enqueues work on `stream` and returns (asynchronous);
+ *   - return value 0 = success; >0 = hipError_t from the launch; <0 = argument check
+ *     (FPSG_E_*); fpsg_last_error() gives a thread-local message for the last failure;
+ *   - no C++ exception crosses the boundary; no global state besides that message.
+ *   - index outputs are int32 (the Python mirror widens to int64 where the reference
+ *     API exposes int64).
+ */
+#ifndef FPSG_HIP_H
+#define FPSG_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* hipStream_t without dragging hip headers into C callers */
+typedef void* fpsg_stream_t;
+
+#define FPSG_ABI_VERSION 1
+
+#define FPSG_E_NULL   (-1)  /* null pointer argument            */
+#define FPSG_E_SHAPE  (-2)  /* non-positive / unsupported shape */
+#define FPSG_E_ALIGN  (-3)  /* pointer not 4-byte aligned       */
+#define FPSG_E_LIMIT  (-4)  /* size beyond a documented limit   */
+
+int         fpsg_version(void);
+const char* fpsg_last_error(void);
+
+/* ---- K1: Chamfer sided distances ------------------------------------------------
+ * Replaces kaolin.metrics.pointcloud.chamfer_distance (Kaolin 0.9.0, its CUDA
+ * `sided_distance` forward), bound at src/models/few_shot.py:13,57 and called at
+ * src/models/few_shot.py:110,117,167.
+ *
+ * xyz1 [B,N,3], xyz2 [B,M,3] fp32.  For every point of xyz1 the squared L2 distance to
+ * its nearest point of xyz2 and that point's index (lowest index on ties), and vice
+ * versa:  dist1,idx1 [B,N];  dist2,idx2 [B,M].
+ * d(i,j) = fma(dz,dz, fma(dy,dy, dx*dx)),  dx = xyz2[j].x - xyz1[i].x  (fp32, RN).
+ */
+int fpsg_chamfer_fwd(const float* xyz1, const float* xyz2, int B, int N, int M,
+                     float* dist1, int32_t* idx1, float* dist2, int32_t* idx2,
+                     fpsg_stream_t stream);
+
+/* Backward of the two sided distances w.r.t. both clouds (Kaolin's
+ * sided_distance backward, reached through autograd from
+ * src/trainNetwork.py:144 `ttl_loss.backward()`).
+ * g1 [B,N], g2 [B,M] are the upstream gradients of dist1/dist2.
+ * gxyz1 [B,N,3], gxyz2 [B,M,3] are fully overwritten.  Deterministic: every output
+ * element is summed by one thread in ascending source-index order (no float atomics).
+ */
+int fpsg_chamfer_bwd(const float* xyz1, const float* xyz2,
+                     const int32_t* idx1, const int32_t* idx2,
+                     const float* g1, const float* g2,
+                     int B, int N, int M,
+                     float* gxyz1, float* gxyz2, fpsg_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FPSG_HIP_H */

@@ -1,0 +1,144 @@
+"""CPU ORACLE -- test infrastructure, NOT product code.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may
+import this package; nothing under ``fpsg_amd/`` does.  It wraps ``oracle/fpsg_oracle.c``
+(plain-C restatement of the hot-path arithmetic, see that file's header for what each
+function follows in the reference and for the parity status of each op) with numpy, and
+adds torch ``autograd.Function`` shims over the same C code so that the reference's
+model code can be driven end to end on CPU as the checker / CPU baseline.
+
+Parity status in one line each (details: oracle/fpsg_oracle.c):
+  Chamfer  -- Kaolin 0.9.0 algorithm restated; pinned by the Kaolin docstring KAT and a
+              float64 brute force (the reference itself holds no test for it).
+  kNN/edge -- follow src/dgcnn/model.py:13-42; pinned by goldens generated from the
+              reference's own functions (tests/golden/make_golden.py).
+  EMD      -- PARITY UNPINNED (neuralnet_pytorch absent, unpinned); bounded against
+              exact assignment (scipy) in tests.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "_build", "libfpsg_oracle.so")
+
+_f32p = ctypes.POINTER(ctypes.c_float)
+_i32p = ctypes.POINTER(ctypes.c_int32)
+
+
+def build(force: bool = False) -> str:
+    """Compile oracle/fpsg_oracle.c with gcc (idempotent)."""
+    src = os.path.join(_HERE, "fpsg_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.run(["make", "-C", _HERE] + (["-B"] if force else []), check=True,
+                       stdout=subprocess.DEVNULL)
+    return _SO
+
+
+_lib = None
+
+
+def lib() -> ctypes.CDLL:
+    global _lib
+    if _lib is None:
+        _lib = ctypes.CDLL(build())
+    return _lib
+
+
+def _f32(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _i32(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def _p(a: np.ndarray):
+    if a.dtype == np.float32:
+        return a.ctypes.data_as(_f32p)
+    if a.dtype == np.int32:
+        return a.ctypes.data_as(_i32p)
+    raise TypeError(a.dtype)
+
+
+# ----------------------------------------------------------------------------- Chamfer
+def sided_distance(a, b):
+    """a [B,N,3], b [B,M,3] -> (dist [B,N] f32, idx [B,N] i32)."""
+    a, b = _f32(a), _f32(b)
+    B, N, _ = a.shape
+    M = b.shape[1]
+    dist = np.empty((B, N), np.float32)
+    idx = np.empty((B, N), np.int32)
+    lib().oracle_sided_distance(_p(a), _p(b), B, N, M, _p(dist), _p(idx))
+    return dist, idx
+
+
+def chamfer_fwd(xyz1, xyz2):
+    """-> dist1 [B,N], idx1 [B,N], dist2 [B,M], idx2 [B,M]."""
+    xyz1, xyz2 = _f32(xyz1), _f32(xyz2)
+    B, N, _ = xyz1.shape
+    M = xyz2.shape[1]
+    d1 = np.empty((B, N), np.float32)
+    i1 = np.empty((B, N), np.int32)
+    d2 = np.empty((B, M), np.float32)
+    i2 = np.empty((B, M), np.int32)
+    lib().oracle_chamfer_fwd(_p(xyz1), _p(xyz2), B, N, M, _p(d1), _p(i1), _p(d2), _p(i2))
+    return d1, i1, d2, i2
+
+
+def chamfer_bwd(xyz1, xyz2, idx1, idx2, g1, g2):
+    xyz1, xyz2, g1, g2 = _f32(xyz1), _f32(xyz2), _f32(g1), _f32(g2)
+    idx1, idx2 = _i32(idx1), _i32(idx2)
+    B, N, _ = xyz1.shape
+    M = xyz2.shape[1]
+    gx1 = np.empty_like(xyz1)
+    gx2 = np.empty_like(xyz2)
+    lib().oracle_chamfer_bwd(_p(xyz1), _p(xyz2), _p(idx1), _p(idx2), _p(g1), _p(g2),
+                             B, N, M, _p(gx1), _p(gx2))
+    return gx1, gx2
+
+
+def chamfer_distance_np(p1, p2, w1=1.0, w2=1.0):
+    """Kaolin 0.9.0 chamfer_distance: w1*mean_i(dist1) + w2*mean_j(dist2), shape [B].
+    The means are taken in float32 by numpy (pairwise summation)."""
+    d1, _, d2, _ = chamfer_fwd(p1, p2)
+    return (np.float32(w1) * d1.mean(axis=1, dtype=np.float32)
+            + np.float32(w2) * d2.mean(axis=1, dtype=np.float32))
+
+
+# -------------------------------------------------------------- torch shims (CPU only)
+def _torch():
+    import torch
+    return torch
+
+
+def make_torch_chamfer():
+    """Returns a CPU, differentiable ``chamfer_distance(p1, p2, w1=1., w2=1.) -> [B]``
+    backed by the C oracle (used to run the model code on CPU as checker/baseline)."""
+    torch = _torch()
+
+    class _SidedPair(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, p1, p2):
+            assert p1.device.type == "cpu" and p2.device.type == "cpu"
+            d1, i1, d2, i2 = chamfer_fwd(p1.detach().numpy(), p2.detach().numpy())
+            ctx.save_for_backward(p1, p2, torch.from_numpy(i1), torch.from_numpy(i2))
+            return torch.from_numpy(d1), torch.from_numpy(d2)
+
+        @staticmethod
+        def backward(ctx, g1, g2):
+            p1, p2, i1, i2 = ctx.saved_tensors
+            gx1, gx2 = chamfer_bwd(p1.detach().numpy(), p2.detach().numpy(), i1.numpy(),
+                                   i2.numpy(), g1.contiguous().numpy(),
+                                   g2.contiguous().numpy())
+            return torch.from_numpy(gx1), torch.from_numpy(gx2)
+
+    def chamfer_distance(p1, p2, w1=1.0, w2=1.0):
+        d1, d2 = _SidedPair.apply(p1.contiguous().float(), p2.contiguous().float())
+        return w1 * d1.mean(dim=-1) + w2 * d2.mean(dim=-1)
+
+    return chamfer_distance

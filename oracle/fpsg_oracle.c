@@ -1,0 +1,106 @@
+/*
+ * fpsg_oracle.c -- CPU ORACLE (test infrastructure, NOT product code).
+ *
+ * Plain-C restatement of the arithmetic on FPSG's hot path, used only as the checker
+ * by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.  Nothing under
+ * fpsg_amd/ may import, link or call this file.
+ *
+ * Parity status:
+ *   - Chamfer: the reference calls kaolin.metrics.pointcloud.chamfer_distance
+ *     (Kaolin 0.9.0, pinned only in README.md:36; NOT vendored under /root/reference;
+ *     call sites src/models/few_shot.py:13,57,110,117,167).  The algorithm restated
+ *     here is Kaolin's published `sided_distance` (the Fan et al. NNDistance kernel):
+ *     per query, squared-L2 to every candidate, strict `<` running minimum (lowest
+ *     index wins ties); chamfer = mean_i d1 + mean_j d2.  The reference holds no test
+ *     or golden vector for it; it is pinned by the Kaolin docstring known-answer
+ *     (tests/golden/kaolin_chamfer_kat.json) and by a float64 brute force.
+ *   - kNN / edge features follow src/dgcnn/model.py:13-42 (in-repo Python; pinned by
+ *     goldens generated from the reference's own functions, tests/golden/).
+ *   - EMD: the reference calls neuralnet_pytorch.metrics.emd_loss(sinkhorn=True)
+ *     (src/models/utils.py:9,12-13; package absent, version unpinned): PARITY UNPINNED.
+ *     The approx-match solver restated here is the published Fan et al. auction
+ *     scheme; it is bounded against exact Hungarian EMD in tests.
+ *
+ * Build: see oracle/Makefile (-O2 -mfma -ffp-contract=off: every fused multiply-add is
+ * an explicit fmaf() so that the HIP kernels can reproduce the results bit for bit).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* d(i,j) exactly as declared in include/fpsg_hip.h */
+static inline float sq_dist(const float* q, const float* c) {
+  float dx = c[0] - q[0];
+  float dy = c[1] - q[1];
+  float dz = c[2] - q[2];
+  return fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+}
+
+/* One side: for each of the N points of `a`, nearest of the M points of `b`.
+ * Kaolin sided_distance forward: strict `<`, first candidate wins ties. */
+void oracle_sided_distance(const float* a, const float* b, int B, int N, int M,
+                           float* dist, int32_t* idx) {
+  for (int bb = 0; bb < B; ++bb) {
+    const float* pa = a + (size_t)bb * N * 3;
+    const float* pb = b + (size_t)bb * M * 3;
+    for (int i = 0; i < N; ++i) {
+      float best = INFINITY;
+      int32_t bi = 0;
+      for (int j = 0; j < M; ++j) {
+        float d = sq_dist(pa + 3 * i, pb + 3 * j);
+        if (d < best) { best = d; bi = j; }
+      }
+      dist[(size_t)bb * N + i] = best;
+      idx[(size_t)bb * N + i] = bi;
+    }
+  }
+}
+
+void oracle_chamfer_fwd(const float* xyz1, const float* xyz2, int B, int N, int M,
+                        float* dist1, int32_t* idx1, float* dist2, int32_t* idx2) {
+  oracle_sided_distance(xyz1, xyz2, B, N, M, dist1, idx1);
+  oracle_sided_distance(xyz2, xyz1, B, M, N, dist2, idx2);
+}
+
+/* Gradient of (dist_a, dist_b) w.r.t. cloud `a` only:
+ *   own term      : ga[i]  = (2*g_a[i]) * (a_i - b[idx_a[i]])
+ *   scatter terms : ga[i] += (2*g_b[j]) * (a_i - b_j)   for every j with idx_b[j]==i,
+ *                   ascending j  (d(b_j, a_i) = |b_j - a_i|^2, d/da_i = 2 (a_i - b_j))
+ * each component accumulated with fmaf(t, diff, acc), t = 2*g.                    */
+static void grad_one_cloud(const float* a, const float* b, const int32_t* idx_a,
+                           const int32_t* idx_b, const float* g_a, const float* g_b,
+                           int Na, int Nb, float* ga) {
+  for (int i = 0; i < Na; ++i) {
+    const float* p = a + 3 * i;
+    const float* q = b + 3 * idx_a[i];
+    float t = 2.0f * g_a[i];
+    ga[3 * i + 0] = t * (p[0] - q[0]);
+    ga[3 * i + 1] = t * (p[1] - q[1]);
+    ga[3 * i + 2] = t * (p[2] - q[2]);
+  }
+  for (int j = 0; j < Nb; ++j) {
+    int i = idx_b[j];
+    const float* p = a + 3 * i;
+    const float* q = b + 3 * j;
+    float t = 2.0f * g_b[j];
+    ga[3 * i + 0] = fmaf(t, p[0] - q[0], ga[3 * i + 0]);
+    ga[3 * i + 1] = fmaf(t, p[1] - q[1], ga[3 * i + 1]);
+    ga[3 * i + 2] = fmaf(t, p[2] - q[2], ga[3 * i + 2]);
+  }
+}
+
+void oracle_chamfer_bwd(const float* xyz1, const float* xyz2, const int32_t* idx1,
+                        const int32_t* idx2, const float* g1, const float* g2, int B,
+                        int N, int M, float* gxyz1, float* gxyz2) {
+  for (int b = 0; b < B; ++b) {
+    const float* p1 = xyz1 + (size_t)b * N * 3;
+    const float* p2 = xyz2 + (size_t)b * M * 3;
+    grad_one_cloud(p1, p2, idx1 + (size_t)b * N, idx2 + (size_t)b * M,
+                   g1 + (size_t)b * N, g2 + (size_t)b * M, N, M,
+                   gxyz1 + (size_t)b * N * 3);
+    grad_one_cloud(p2, p1, idx2 + (size_t)b * M, idx1 + (size_t)b * N,
+                   g2 + (size_t)b * M, g1 + (size_t)b * N, M, N,
+                   gxyz2 + (size_t)b * M * 3);
+  }
+}

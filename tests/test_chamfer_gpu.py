@@ -1,0 +1,147 @@
+"""K1 parity: HIP Chamfer (through the C ABI) vs the CPU oracle -- bit-exact distances
+and indices, gradients bit-exact; plus size-independent properties at full size."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, unit_ball_clouds
+
+pytestmark = pytest.mark.gpu
+
+
+def _run_fwd(p1, p2, dev):
+    from fpsg_amd.metrics import sided_distances
+    t1 = torch.from_numpy(p1).to(dev)
+    t2 = torch.from_numpy(p2).to(dev)
+    d1, i1, d2, i2 = sided_distances(t1, t2)
+    return d1.cpu().numpy(), i1.cpu().numpy(), d2.cpu().numpy(), i2.cpu().numpy()
+
+
+# (B, N, M): covers every (R, W) launch configuration, ragged sizes, N != M, tiny clouds,
+# clouds larger than one LDS tile (4096) and sizes that are not multiples of 16.
+SHAPES = [(1, 2048, 2048), (5, 2048, 2048), (32, 2048, 2048), (2, 1024, 1024), (3, 1, 1),
+          (2, 7, 1), (2, 1, 50), (3, 333, 1000), (2, 4097, 5000), (1, 9000, 100),
+          (70, 512, 300), (130, 256, 256)]
+
+
+@pytest.mark.parametrize("B,N,M", SHAPES)
+def test_fwd_bit_exact_vs_oracle(gpu, oracle, B, N, M):
+    rng = np.random.default_rng(B * 1000003 + N * 131 + M)
+    p1 = unit_ball_clouds(rng, B, N)
+    p2 = np.tanh(rng.standard_normal((B, M, 3))).astype(np.float32)  # decoder-range stand-in
+    d1, i1, d2, i2 = _run_fwd(p1, p2, gpu)
+    od1, oi1, od2, oi2 = oracle.chamfer_fwd(p1, p2)
+    assert np.array_equal(i1, oi1) and np.array_equal(i2, oi2)
+    assert np.array_equal(d1.view(np.uint32), od1.view(np.uint32))
+    assert np.array_equal(d2.view(np.uint32), od2.view(np.uint32))
+
+
+def test_ties_pick_lowest_index(gpu, oracle):
+    """Duplicated points (the reference pads short clouds with repeats,
+    src/datasets/modelnet.py:61-64) and lattice points give exact ties."""
+    rng = np.random.default_rng(7)
+    base = rng.integers(-3, 4, size=(4, 300, 3)).astype(np.float32)  # many exact ties
+    p1 = np.concatenate([base, base[:, :212]], axis=1)                # 512 with repeats
+    p2 = np.concatenate([base[:, ::-1], base[:, :100]], axis=1)
+    d1, i1, d2, i2 = _run_fwd(p1, p2, gpu)
+    od1, oi1, od2, oi2 = oracle.chamfer_fwd(p1, p2)
+    assert np.array_equal(i1, oi1) and np.array_equal(i2, oi2)
+    assert np.array_equal(d1, od1) and np.array_equal(d2, od2)
+
+
+def test_kaolin_docstring_known_answer(gpu):
+    from fpsg_amd.metrics import chamfer_distance
+    kat = json.load(open(os.path.join(GOLDEN, "kaolin_chamfer_kat.json")))
+    p1 = torch.tensor(kat["p1"], dtype=torch.float32, device=gpu)
+    p2 = torch.tensor(kat["p2"], dtype=torch.float32, device=gpu)
+    out = chamfer_distance(p1, p2).cpu().numpy()
+    np.testing.assert_allclose(out, np.array(kat["expected"]), rtol=1e-4)  # north_star tol
+
+
+@pytest.mark.parametrize("B,N,M", [(1, 2048, 2048), (5, 2048, 2048), (3, 333, 1000),
+                                   (2, 4097, 5000), (2, 1, 50)])
+def test_bwd_bit_exact_vs_oracle(gpu, oracle, B, N, M):
+    from fpsg_amd.metrics import _SidedPair
+    rng = np.random.default_rng(B + N + M)
+    p1 = unit_ball_clouds(rng, B, N)
+    p2 = np.tanh(rng.standard_normal((B, M, 3))).astype(np.float32)
+    g1 = rng.standard_normal((B, N)).astype(np.float32)
+    g2 = rng.standard_normal((B, M)).astype(np.float32)
+    t1 = torch.from_numpy(p1).to(gpu).requires_grad_()
+    t2 = torch.from_numpy(p2).to(gpu).requires_grad_()
+    d1, d2, i1, i2 = _SidedPair.apply(t1, t2)
+    torch.autograd.backward([d1, d2], [torch.from_numpy(g1).to(gpu), torch.from_numpy(g2).to(gpu)])
+    _, oi1, _, oi2 = oracle.chamfer_fwd(p1, p2)
+    ogx1, ogx2 = oracle.chamfer_bwd(p1, p2, oi1, oi2, g1, g2)
+    assert np.array_equal(t1.grad.cpu().numpy().view(np.uint32), ogx1.view(np.uint32))
+    assert np.array_equal(t2.grad.cpu().numpy().view(np.uint32), ogx2.view(np.uint32))
+
+
+def test_chamfer_value_and_grad_vs_float64(gpu):
+    """Within north_star's 1e-4 relative fp32 tolerance of the float64 definition."""
+    from fpsg_amd.metrics import chamfer_distance
+    from oracle.ref_f64 import chamfer_f64
+    rng = np.random.default_rng(11)
+    p1 = unit_ball_clouds(rng, 4, 2048)
+    p2 = np.tanh(rng.standard_normal((4, 2048, 3))).astype(np.float32)
+    t1 = torch.from_numpy(p1).to(gpu).requires_grad_()
+    t2 = torch.from_numpy(p2).to(gpu).requires_grad_()
+    cd = chamfer_distance(t1, t2)
+    cd.sum().backward()
+    ref = chamfer_f64(p1, p2)[0]
+    np.testing.assert_allclose(cd.detach().cpu().numpy(), ref, rtol=1e-4)
+    a = torch.tensor(p1, dtype=torch.float64, requires_grad=True)
+    b = torch.tensor(p2, dtype=torch.float64, requires_grad=True)
+    D = ((a[:, :, None] - b[:, None]) ** 2).sum(-1)
+    (D.min(2)[0].mean(1) + D.min(1)[0].mean(1)).sum().backward()
+    np.testing.assert_allclose(t1.grad.cpu().numpy(), a.grad.numpy(), rtol=1e-4, atol=1e-9)
+    np.testing.assert_allclose(t2.grad.cpu().numpy(), b.grad.numpy(), rtol=1e-4, atol=1e-9)
+
+
+def test_full_size_properties(gpu):
+    """BASELINE.json sizes (B=37 = 32-shot + 5-query clouds of 2048 points), checked
+    through properties that need no oracle: self-distance is exactly zero with identity
+    argmin, permutation of the candidate cloud permutes indices and keeps distances
+    bit-identical, the two directions swap bit for bit when the arguments swap, and every
+    reported distance is the distance to the reported index."""
+    from fpsg_amd.metrics import sided_distances, chamfer_distance
+    g = torch.Generator(device="cpu").manual_seed(5)
+    B, N = 37, 2048
+    p1 = (torch.rand(B, N, 3, generator=g) * 2 - 1).to(gpu)
+    p2 = torch.tanh(torch.randn(B, N, 3, generator=g)).to(gpu)
+    d1, i1, d2, i2 = sided_distances(p1, p1.clone())
+    assert torch.count_nonzero(d1) == 0 and torch.count_nonzero(d2) == 0
+    ar = torch.arange(N, device=gpu).expand(B, N)
+    assert torch.equal(i1, ar) and torch.equal(i2, ar)
+    # permutation equivariance (distinct random points => no ties)
+    perm = torch.randperm(N, generator=g).to(gpu)
+    a1, ai1, a2, ai2 = sided_distances(p1, p2)
+    b1, bi1, b2, bi2 = sided_distances(p1, p2[:, perm].contiguous())
+    assert torch.equal(a1, b1) and torch.equal(perm[bi1], ai1)
+    assert torch.equal(a2[:, perm], b2) and torch.equal(ai2[:, perm], bi2)
+    # symmetry: swapping arguments swaps the two sides bit for bit
+    c1, ci1, c2, ci2 = sided_distances(p2, p1)
+    assert torch.equal(c1, a2) and torch.equal(c2, a1) and torch.equal(ci1, ai2)
+    assert torch.equal(chamfer_distance(p1, p2), chamfer_distance(p2, p1))
+    # every reported distance is the distance to the reported index
+    gathered = torch.gather(p2, 1, ai1.unsqueeze(-1).expand(-1, -1, 3))
+    assert torch.allclose(((p1 - gathered) ** 2).sum(-1), a1, rtol=1e-5, atol=1e-7)
+
+
+def test_rejects_bad_inputs(gpu):
+    from fpsg_amd.metrics import chamfer_distance
+    from fpsg_amd._hip import FpsgHipError
+    a = torch.rand(2, 8, 3)
+    with pytest.raises(FpsgHipError):
+        chamfer_distance(a, a)  # CPU tensors: no fallback
+    with pytest.raises(TypeError):
+        chamfer_distance(a.double().to(gpu), a.double().to(gpu))
+    with pytest.raises(ValueError):
+        chamfer_distance(a.to(gpu).transpose(1, 2), a.to(gpu).transpose(1, 2))
+    with pytest.raises(ValueError):
+        chamfer_distance(a.to(gpu)[:, :, :2].contiguous(), a.to(gpu))
+    with pytest.raises(ValueError):
+        chamfer_distance(a.to(gpu)[:, :0], a.to(gpu))
