@@ -1,0 +1,162 @@
+"""Episode-sharded data parallelism: one process per GPU, RCCL all-reduce over xGMI.
+
+The reference is single-process / single-GPU (no ``torch.distributed`` anywhere, SURVEY.md
+2b); this module is the new multi-GPU row of the hot path:
+
+  * a global optimizer step consists of ``E`` independent episodes; rank ``r`` of ``W``
+    runs episodes ``r, r+W, ...`` one after the other (BatchNorm statistics stay
+    per-episode -- no SyncBN, as in the reference) and accumulates their gradients;
+  * every parameter's ``.grad`` is a view into ONE flat fp32 buffer (77 M elements =
+    310 MB for the full model), cut into a few large buckets.  During the LAST local
+    episode's backward, a bucket's ``all_reduce(SUM)`` is launched asynchronously as soon
+    as all of its gradients have been accumulated (decoder first, VGG last), overlapping
+    the collective with the rest of backward; xGMI is point-to-point, so few large
+    messages are what keep each link busy;
+  * the summed gradient is divided by ``E`` (mean over the step's episodes), so a step has
+    the gradient scale of the reference's one-episode step and ``--lr`` keeps its meaning.
+
+``backend='nccl'`` is RCCL on ROCm; on CPU the same code runs over ``gloo`` (tests).
+"""
+from __future__ import annotations
+
+import os
+from typing import Iterable
+
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+
+def env_world() -> tuple[int, int, int]:
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")),
+            int(os.environ.get("WORLD_SIZE", "1")))
+
+
+def init_distributed(device_type: str | None = None) -> tuple[int, int, torch.device]:
+    """Initialises the default process group from the torchrun environment.
+    Returns ``(rank, world, device)``; a no-op (0, 1, device) when WORLD_SIZE is 1."""
+    rank, local_rank, world = env_world()
+    if device_type is None:
+        device_type = "cuda" if torch.cuda.is_available() else "cpu"
+    if device_type == "cuda":
+        torch.cuda.set_device(local_rank)
+        device = torch.device("cuda", local_rank)
+    else:
+        device = torch.device("cpu")
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        kwargs = {}
+        if device_type == "cuda":
+            kwargs["device_id"] = device
+        dist.init_process_group(backend="nccl" if device_type == "cuda" else "gloo",
+                                rank=rank, world_size=world, **kwargs)
+    return rank, world, device
+
+
+def shutdown() -> None:
+    if dist.is_initialized():
+        dist.destroy_process_group()
+
+
+class FlatGradBuckets:
+    """Flat gradient storage + bucketed, overlapped all-reduce for ``model``."""
+
+    def __init__(self, model: nn.Module, bucket_mb: float = 80.0, group=None):
+        params = [p for p in model.parameters() if p.requires_grad]
+        if not params:
+            raise ValueError("model has no trainable parameters")
+        self.params = params
+        self.group = group
+        dev, dt = params[0].device, params[0].dtype
+        total = sum(p.numel() for p in params)
+        self.flat = torch.zeros(total, dtype=dt, device=dev)
+        # Buckets follow the order gradients become ready in backward = reverse of the
+        # registration order (decoder, point encoder, image encoder).
+        cap = max(1, int(bucket_mb * (1 << 20) / self.flat.element_size()))
+        self.buckets: list[tuple[int, int]] = []   # [start, end) into flat
+        self._bucket_of: dict[int, int] = {}
+        self._bucket_size: list[int] = []
+        off, start, count = 0, 0, 0
+        for p in reversed(params):
+            n = p.numel()
+            p.grad = self.flat[off:off + n].view_as(p)
+            self._bucket_of[id(p)] = len(self.buckets)
+            off += n
+            count += 1
+            if off - start >= cap:
+                self.buckets.append((start, off))
+                self._bucket_size.append(count)
+                start, count = off, 0
+        if off > start:
+            self.buckets.append((start, off))
+            self._bucket_size.append(count)
+        self._pending = [0] * len(self.buckets)
+        self._handles: list = []
+        self._armed = False
+        self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in params]
+
+    # -- bookkeeping ---------------------------------------------------------------
+    @property
+    def world(self) -> int:
+        return dist.get_world_size(self.group) if dist.is_initialized() else 1
+
+    def zero(self) -> None:
+        """Replaces ``optimizer.zero_grad()``: grads must stay views of the flat buffer."""
+        self.flat.zero_()
+
+    def arm(self) -> None:
+        """Call before the backward of the LAST local episode of a step: buckets are
+        all-reduced as they complete during that backward."""
+        self._armed = self.world > 1
+        self._pending = list(self._bucket_size)
+        self._handles = []
+
+    def _on_grad(self, p: torch.Tensor) -> None:
+        if not self._armed:
+            return
+        b = self._bucket_of[id(p)]
+        self._pending[b] -= 1
+        if self._pending[b] == 0:
+            s, e = self.buckets[b]
+            self._handles.append(
+                dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.group,
+                                async_op=True))
+
+    def finish(self, n_episodes_global: int) -> None:
+        """Waits for the in-flight buckets, reduces any bucket whose parameters received no
+        gradient in the armed backward, and turns the sum into the mean over episodes."""
+        if self._armed:
+            for b, left in enumerate(self._pending):
+                if left > 0:  # e.g. parameters unused by this step's graph
+                    s, e = self.buckets[b]
+                    self._handles.append(dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM,
+                                                         group=self.group, async_op=True))
+            for h in self._handles:
+                h.wait()
+            self._handles = []
+            self._armed = False
+        if n_episodes_global > 1:
+            self.flat.mul_(1.0 / n_episodes_global)
+
+    def remove(self) -> None:
+        for h in self._hooks:
+            h.remove()
+
+
+def broadcast_parameters(model: nn.Module, src: int = 0) -> None:
+    """Makes every rank start from rank ``src``'s weights and buffers."""
+    if not dist.is_initialized():
+        return
+    for t in list(model.parameters()) + list(model.buffers()):
+        dist.broadcast(t.data, src=src)
+
+
+def all_reduce_scalars(values: Iterable[float], device) -> list[float]:
+    """Sum of a few python floats over ranks (logging only)."""
+    t = torch.tensor(list(values), dtype=torch.float64, device=device)
+    if dist.is_initialized():
+        if device.type == "cuda":
+            t = t.float()
+        dist.all_reduce(t)
+    return t.tolist()

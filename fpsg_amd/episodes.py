@@ -1,0 +1,179 @@
+"""Episode assembly: the sample-dict contract the hot path consumes.
+
+Mirrors reference ``src/datasets/utils.py`` (``extract_episode :4-28``,
+``EpisodicBatchSampler :31-42``, ``SequentialBatchSampler :45-54``) and the episode layout
+of ``FewShotModelNet.__getitem__`` (``src/datasets/modelnet.py:110-128``; ShapeNet is the
+same, ``shapenet.py:130-145``): support / query split of one class corpus by a random
+permutation, plus ``n_support`` random (image, cloud) "ad" pairs from the whole corpus.
+The random streams are the reference's (same ``torch.randperm`` calls in the same order),
+pinned by ``tests/golden/episode_streams.npz``.
+
+Fix of a reference defect: ``'tmp'`` is the index of the FIRST query item
+instead of ``query_idx.item()``, which raises for ``n_query != 1``.
+
+``SyntheticFewShot`` provides corpora of the reference's shapes without any files
+(SURVEY.md 8d); with ``device='cuda'`` the corpora live in HBM and an episode is assembled
+by on-device indexing -- no per-step host->device copy of the ~42 MB of images the
+reference re-uploads every step.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+from torch.utils.data import Dataset
+
+
+def extract_episode(n_support: int, n_query: int, d: dict) -> dict:
+    n_examples = d["img_data"].size(0)
+    if n_query == -1:
+        n_query = n_examples - n_support
+    example_idx = torch.randperm(n_examples)[:(n_support + n_query)]
+    support_idx = example_idx[:n_support]
+    query_idx = example_idx[n_support:]
+    dev = d["img_data"].device
+    s_dev, q_dev = support_idx.to(dev), query_idx.to(dev)
+    return {
+        "class": d["class"],
+        "xs": d["img_data"][s_dev],
+        "xq": d["img_data"][q_dev],
+        "pcs": d["pc_data"][s_dev],
+        "pcq": d["pc_data"][q_dev],
+        "tmp": int(query_idx[0]) if query_idx.numel() else -1,
+    }
+
+
+class EpisodicBatchSampler:
+    """``n_episodes`` batches of ``n_way`` random class indices."""
+
+    def __init__(self, n_classes: int, n_way: int, n_episodes: int):
+        self.n_classes, self.n_way, self.n_episodes = n_classes, n_way, n_episodes
+
+    def __len__(self):
+        return self.n_episodes
+
+    def __iter__(self):
+        for _ in range(self.n_episodes):
+            yield torch.randperm(self.n_classes)[:self.n_way]
+
+
+class SequentialBatchSampler:
+    """Every item once, in order, one per batch."""
+
+    def __init__(self, n_classes: int):
+        self.n_classes = n_classes
+
+    def __len__(self):
+        return self.n_classes
+
+    def __iter__(self):
+        for i in range(self.n_classes):
+            yield torch.LongTensor([i])
+
+
+SequentialBatchSamplerV2 = SequentialBatchSampler  # identical in the reference (:57-65)
+
+
+def normalize_unit_ball(points: torch.Tensor) -> torch.Tensor:
+    """Centre on the mean and divide by the largest norm
+    (``src/datasets/modelnet.py:66-69``); ``points [..., N, 3]``."""
+    points = points - points.mean(dim=-2, keepdim=True)
+    return points / points.norm(dim=-1).amax(dim=-1)[..., None, None]
+
+
+def synthetic_clouds(n: int, n_pts: int, generator: torch.Generator) -> torch.Tensor:
+    """Uniform-in-ball clouds, normalised like the reference loader."""
+    direction = torch.randn(n, n_pts, 3, generator=generator)
+    direction = direction / direction.norm(dim=-1, keepdim=True)
+    radius = torch.rand(n, n_pts, 1, generator=generator) ** (1.0 / 3.0)
+    return normalize_unit_ball(direction * radius).contiguous()
+
+
+def synthetic_images(n: int, size: int, generator: torch.Generator) -> torch.Tensor:
+    """U(-1,1) images: the range of ``Normalize(.5,.5)`` output (trainNetwork.py:22-27)."""
+    return torch.rand(n, 3, size, size, generator=generator) * 2 - 1
+
+
+class SyntheticFewShot(Dataset):
+    """File-free stand-in for ``FewShotModelNet`` / ``FewShotShapeNet`` with the same item
+    layout.  ``len()`` = number of corpus items; item ``i`` yields an episode of item ``i``'s
+    class, as the reference datasets do."""
+
+    def __init__(self, n_classes: int = 4, per_class: int = 40, n_support: int = 1,
+                 n_query: int = 1, n_pts: int = 2048, img_size: int = 224, seed: int = 1234,
+                 device: str | torch.device = "cpu"):
+        g = torch.Generator().manual_seed(seed)
+        self.n_support, self.n_query, self.n_way = n_support, n_query, 1
+        if per_class < n_support + max(n_query, 0):
+            raise ValueError("per_class must cover n_support + n_query")
+        self.reference = {}
+        imgs, pcs = [], []
+        for c in range(n_classes):
+            name = f"class{c:02d}"
+            im = synthetic_images(per_class, img_size, g).to(device)
+            pc = synthetic_clouds(per_class, n_pts, g).to(device)
+            self.reference[name] = {"imgs": im, "pcs": pc}
+            imgs.append(im)
+            pcs.append(pc)
+        self.classes = list(self.reference)
+        self.img_corpus = torch.cat(imgs, dim=0)
+        self.pc_corpus = torch.cat(pcs, dim=0)
+        self.per_class = per_class
+        self.item_len = self.img_corpus.size(0)
+
+    def __len__(self):
+        return self.item_len
+
+    def __getitem__(self, index):
+        name = self.classes[int(index) // self.per_class]
+        ans = extract_episode(self.n_support, self.n_query, {
+            "class": name,
+            "img_data": self.reference[name]["imgs"],
+            "pc_data": self.reference[name]["pcs"],
+        })
+        ad_idx = torch.randperm(self.item_len)[:self.n_support].to(self.img_corpus.device)
+        ans["xad"] = self.img_corpus[ad_idx]
+        ans["pcad"] = self.pc_corpus[ad_idx]
+        return ans
+
+
+def collate_episode(sample: dict) -> dict:
+    """What ``DataLoader(batch_sampler=...)`` does to one episode: a leading batch axis of 1
+    on every tensor, ``class`` wrapped in a list."""
+    out = {}
+    for k, v in sample.items():
+        if torch.is_tensor(v):
+            out[k] = v.unsqueeze(0)
+        elif k == "class":
+            out[k] = [v]
+        else:
+            out[k] = torch.tensor([v])
+    return out
+
+
+def synthetic_episode(n_support: int, n_query: int, n_pts: int = 2048, img_size: int = 224,
+                      seed: int = 1234, device="cpu") -> dict:
+    """One collated episode of fresh synthetic data (benchmarks, smoke tests)."""
+    g = torch.Generator().manual_seed(seed)
+    s = {
+        "class": "synthetic",
+        "xs": synthetic_images(n_support, img_size, g),
+        "xq": synthetic_images(n_query, img_size, g),
+        "xad": synthetic_images(n_support, img_size, g),
+        "pcs": synthetic_clouds(n_support, n_pts, g),
+        "pcq": synthetic_clouds(n_query, n_pts, g),
+        "pcad": synthetic_clouds(n_support, n_pts, g),
+        "tmp": 0,
+    }
+    s = collate_episode(s)
+    return {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in s.items()}
+
+
+def shard_episodes(n_episodes: int, rank: int, world: int) -> range:
+    """Episode ids of a global step handled by ``rank``: ``rank, rank+world, ...`` so the
+    episode SET of a step does not depend on the world size."""
+    return range(rank, n_episodes, world)
+
+
+def episodes_per_rank(n_episodes: int, world: int) -> int:
+    return math.ceil(n_episodes / world)

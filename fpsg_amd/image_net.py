@@ -1,0 +1,84 @@
+"""Image branch: VGG16-BN convolutional trunk + global average pool -> ``[B, 512]``.
+
+Mirrors reference ``src/models/image_net.py:6-24`` (``ImageEncoderWarpper``, spelling
+kept so that the reference's entry points import it unchanged).  The reference takes the
+trunk from ``torchvision.models.vgg16_bn(pretrained=True).features``; torchvision and the
+network are absent here, so the trunk is defined below with the SAME ``nn.Sequential``
+numbering, hence the same ``img_feature_extractor.<n>.{weight,bias,running_*}`` state-dict
+keys -- a reference checkpoint, or a torchvision ``vgg16_bn`` state
+dict given by local path, loads key for key.  The dense 3x3 convolutions are plain GEMM
+work and run on MFMA through MIOpen; no hand kernel.
+"""
+from __future__ import annotations
+
+import os
+
+import torch
+import torch.nn as nn
+
+# VGG-16 ("configuration D"): channel widths, 'P' = 2x2 max-pool
+_VGG16_PLAN = (64, 64, "P", 128, 128, "P", 256, 256, 256, "P", 512, 512, 512, "P", 512, 512,
+               512, "P")
+
+
+def vgg16_bn_trunk() -> nn.Sequential:
+    """conv3x3 -> BN -> ReLU triples and max-pools, numbered like torchvision's
+    ``vgg16_bn().features`` (44 entries)."""
+    layers = []
+    c_in = 3
+    for item in _VGG16_PLAN:
+        if item == "P":
+            layers.append(nn.MaxPool2d(kernel_size=2, stride=2))
+            continue
+        conv = nn.Conv2d(c_in, item, kernel_size=3, padding=1)
+        nn.init.kaiming_normal_(conv.weight, mode="fan_out", nonlinearity="relu")
+        nn.init.zeros_(conv.bias)
+        layers += [conv, nn.BatchNorm2d(item), nn.ReLU(inplace=True)]
+        c_in = item
+    return nn.Sequential(*layers)
+
+
+class ImageEncoderWarpper(nn.Module):
+    """``forward(x[B,3,H,W]) -> [B,512]``.
+
+    ``weights`` (extension): path of a local state dict holding either this module's keys
+    or torchvision ``vgg16_bn`` keys (``features.<n>.*``); without it the trunk is randomly
+    initialised (the reference downloads ImageNet weights, which cannot be done offline).
+    As in the reference every trunk parameter is trainable: ``_set_finetune`` exists but is
+    never called by any entry point.
+    """
+
+    def __init__(self, core: str = "vgg_16", finetune_layer: int = 0, weights: str | None = None):
+        super().__init__()
+        if core != "vgg_16":
+            raise NotImplementedError(f"Unsupported Image Encoder Core Compoenent: {core}")
+        self.finetune_layer = finetune_layer
+        self.img_feature_extractor = vgg16_bn_trunk()
+        self.img_feature_pool = nn.AdaptiveAvgPool2d(output_size=(1, 1))
+        if weights:
+            self.load_trunk(weights)
+
+    def load_trunk(self, path: str) -> None:
+        if not os.path.exists(path):
+            raise FileNotFoundError(path)
+        sd = torch.load(path, map_location="cpu", weights_only=True)
+        if any(k.startswith("features.") for k in sd):
+            sd = {k[len("features."):]: v for k, v in sd.items() if k.startswith("features.")}
+        elif any(k.startswith("img_feature_extractor.") for k in sd):
+            sd = {k[len("img_feature_extractor."):]: v for k, v in sd.items()
+                  if k.startswith("img_feature_extractor.")}
+        self.img_feature_extractor.load_state_dict(sd)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return self.img_feature_pool(self.img_feature_extractor(x)).flatten(1)
+
+    def _set_finetune(self, new_layer: int | None = None) -> None:
+        """Un-freezes the last ``finetune_layer`` convolutions, freezes the others
+        (reference ``image_net.py:26-39``)."""
+        if new_layer is not None:
+            self.finetune_layer = new_layer
+        budget = self.finetune_layer
+        for layer in reversed(self.img_feature_extractor):
+            if isinstance(layer, nn.Conv2d):
+                layer.requires_grad_(budget > 0)
+                budget -= 1 if budget > 0 else 0

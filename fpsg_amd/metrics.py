@@ -11,6 +11,27 @@ import torch
 
 from . import _hip
 
+# Optional launch probe (bench.py): a callable ``probe(kind, B, N, M)`` returning a context
+# manager that brackets the enqueue of one kernel on the current stream (HIP events).
+_launch_probe = None
+
+
+def set_launch_probe(probe) -> None:
+    global _launch_probe
+    _launch_probe = probe
+
+
+class _NoProbe:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
+def _probe(kind, B, N, M):
+    return _NoProbe() if _launch_probe is None else _launch_probe(kind, B, N, M)
+
 
 def _check_clouds(p1: torch.Tensor, p2: torch.Tensor):
     if p1.dim() != 3 or p2.dim() != 3 or p1.size(2) != 3 or p2.size(2) != 3:
@@ -40,7 +61,7 @@ class _SidedPair(torch.autograd.Function):
         dist2 = torch.empty((B, M), dtype=torch.float32, device=p1.device)
         idx1 = torch.empty((B, N), dtype=torch.int32, device=p1.device)
         idx2 = torch.empty((B, M), dtype=torch.int32, device=p1.device)
-        with torch.cuda.device(p1.device):
+        with torch.cuda.device(p1.device), _probe("chamfer_fwd", B, N, M):
             rc = lib.fpsg_chamfer_fwd(_hip.ptr(p1), _hip.ptr(p2), B, N, M, _hip.ptr(dist1),
                                       _hip.ptr(idx1), _hip.ptr(dist2), _hip.ptr(idx2),
                                       _hip.stream_of(p1))
@@ -60,7 +81,7 @@ class _SidedPair(torch.autograd.Function):
             else g2.contiguous().float()
         gx1 = torch.empty_like(p1)
         gx2 = torch.empty_like(p2)
-        with torch.cuda.device(p1.device):
+        with torch.cuda.device(p1.device), _probe("chamfer_bwd", B, N, M):
             rc = _hip.load().fpsg_chamfer_bwd(_hip.ptr(p1), _hip.ptr(p2), _hip.ptr(idx1),
                                               _hip.ptr(idx2), _hip.ptr(g1), _hip.ptr(g2), B, N,
                                               M, _hip.ptr(gx1), _hip.ptr(gx2),

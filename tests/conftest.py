@@ -38,6 +38,8 @@ def unit_ball_clouds(rng, B, N):
     v /= np.linalg.norm(v, axis=-1, keepdims=True)
     r = rng.random((B, N, 1)) ** (1.0 / 3.0)
     p = v * r
+    if N < 4:  # a single point has no extent to normalise by
+        return p.astype(np.float32)
     p = p - p.mean(axis=1, keepdims=True)
     p = p / np.sqrt((p ** 2).sum(-1)).max(axis=1)[:, None, None]
     return p.astype(np.float32)
