@@ -1,0 +1,138 @@
+"""Multi-GPU row on CPU: world_size-2 ``gloo`` runs of the episode-sharded step.
+The N>1 path has no data-path collective besides the bucketed gradient all-reduce; the
+checks are (a) buckets cover every gradient exactly once and are reduced while backward is
+still running, (b) a 2-rank step over episodes {0,1} equals a 1-rank step over the same two
+episodes (same mean gradient, same updated weights)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+import torch.nn as nn
+
+from fpsg_amd import dist as fdist
+from fpsg_amd.engine import TrainStep
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+class TinyEpisodeNet(nn.Module):
+    """Stand-in with the model API TrainStep needs: ``loss(sample) -> {'ttl_loss': ...}``."""
+
+    def __init__(self):
+        super().__init__()
+        torch.manual_seed(5)
+        self.a = nn.Linear(6, 32)
+        self.bn = nn.BatchNorm1d(32)
+        self.b = nn.Linear(32, 32)
+        self.c = nn.Linear(32, 3)
+        self.unused = nn.Linear(4, 4)          # never receives a gradient
+
+    def loss(self, sample):
+        h = torch.relu(self.bn(self.a(sample["x"])))
+        out = self.c(torch.relu(self.b(h)))
+        l = ((out - sample["y"]) ** 2).sum()
+        return {"ttl_loss": l, "recon_loss": l, "query_rec_loss": l, "support_rec_loss": l * 0}
+
+
+def _episode(i):
+    g = torch.Generator().manual_seed(100 + i)
+    return {"x": torch.randn(16, 6, generator=g), "y": torch.randn(16, 3, generator=g)}
+
+
+def _run_rank(rank, world, port, n_eps, bucket_mb, out_dir):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    r, w, dev = fdist.init_distributed("cpu")
+    assert (r, w, dev.type) == (rank, world, "cpu")
+    model = TinyEpisodeNet()
+    if rank != 0:                              # ranks start different, broadcast fixes it
+        with torch.no_grad():
+            for p in model.parameters():
+                p.add_(1.0)
+    fdist.broadcast_parameters(model, src=0)
+    optimizer = torch.optim.SGD(model.parameters(), lr=0.1)
+    step = TrainStep(model, optimizer, world=world, bucket_mb=bucket_mb)
+    assert len(step.buckets.buckets) >= (3 if bucket_mb < 1e-3 else 1)
+    local = [_episode(i) for i in range(rank, n_eps, world)]
+    res = step(local, n_episodes_global=n_eps)
+    assert len(res) == len(local)
+    torch.save({"params": [p.detach().clone() for p in model.parameters()],
+                "grad": step.buckets.flat.clone()}, os.path.join(out_dir, f"rank{rank}.pt"))
+    fdist.shutdown()
+
+
+def _single(n_eps):
+    model = TinyEpisodeNet()
+    optimizer = torch.optim.SGD(model.parameters(), lr=0.1)
+    step = TrainStep(model, optimizer, world=1)
+    step([_episode(i) for i in range(n_eps)], n_episodes_global=n_eps)
+    return [p.detach().clone() for p in model.parameters()], step.buckets.flat.clone()
+
+
+@pytest.mark.parametrize("n_eps,bucket_mb", [(2, 80.0), (4, 1e-4), (3, 1e-4)])
+def test_two_ranks_equal_one_rank(tmp_path, n_eps, bucket_mb):
+    world = 2
+    port = _free_port()
+    mp.spawn(_run_rank, args=(world, port, n_eps, bucket_mb, str(tmp_path)), nprocs=world, join=True)
+    ref_params, ref_grad = _single(n_eps)
+    outs = [torch.load(tmp_path / f"rank{r}.pt") for r in range(world)]
+    for o in outs:
+        assert torch.allclose(o["grad"], ref_grad, rtol=1e-5, atol=1e-7)
+        for a, b in zip(o["params"], ref_params):
+            assert torch.allclose(a, b, rtol=1e-5, atol=1e-7)
+    for a, b in zip(outs[0]["params"], outs[1]["params"]):
+        assert torch.equal(a, b)               # replicas stay bit-identical
+
+
+def test_bucket_layout_follows_backward_order():
+    model = TinyEpisodeNet()
+    fb = fdist.FlatGradBuckets(model, bucket_mb=1e-4)
+    total = sum(p.numel() for p in model.parameters())
+    assert fb.flat.numel() == total
+    covered = sorted(fb.buckets)
+    assert covered[0][0] == 0 and covered[-1][1] == total
+    assert all(a[1] == b[0] for a, b in zip(covered, covered[1:]))
+    # the LAST registered parameter owns the first slot: its gradient is ready first
+    last = list(model.parameters())[-1]
+    assert last.grad.data_ptr() == fb.flat.data_ptr()
+    fb.zero()
+    model.loss(_episode(0))["ttl_loss"].backward()
+    assert float(fb.flat.abs().sum()) > 0 and model.unused.weight.grad.abs().sum() == 0
+
+
+def test_full_model_two_ranks(tmp_path, oracle):
+    """The real 77 M-parameter model, one tiny episode per rank, over gloo."""
+    port = _free_port()
+    mp.spawn(_run_full, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    a = torch.load(tmp_path / "full0.pt")
+    b = torch.load(tmp_path / "full1.pt")
+    assert a["n"] == 77445125 and torch.equal(a["probe"], b["probe"]) and a["loss"] != b["loss"]
+
+
+def _run_full(rank, world, port, out_dir):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import oracle
+    from fpsg_amd.engine import build_model, build_optimizer, default_options
+    from fpsg_amd.episodes import synthetic_episode
+    torch.set_num_threads(2)
+    fdist.init_distributed("cpu")
+    torch.manual_seed(0)
+    opt = default_options(device="cpu", intra_recon=True)
+    model = build_model(opt)
+    model.pc_metric = oracle.make_torch_chamfer()
+    optimizer, _ = build_optimizer(model, opt)
+    step = TrainStep(model, optimizer, world=world)
+    ep = synthetic_episode(1, 1, n_pts=64, img_size=32, seed=10 + rank)
+    out = step([ep], n_episodes_global=world)
+    probe = torch.cat([p.detach().reshape(-1)[:7] for p in model.parameters()])
+    torch.save({"n": step.buckets.flat.numel(), "probe": probe,
+                "loss": float(out[0]["ttl_loss"].sum())}, os.path.join(out_dir, f"full{rank}.pt"))
+    fdist.shutdown()

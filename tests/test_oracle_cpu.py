@@ -1,0 +1,51 @@
+"""The oracle itself, pinned: Kaolin docstring known-answer, float64 brute force, autograd."""
+import json
+import os
+
+import numpy as np
+import torch
+
+from conftest import GOLDEN, unit_ball_clouds
+
+
+def test_kaolin_known_answer(oracle):
+    kat = json.load(open(os.path.join(GOLDEN, "kaolin_chamfer_kat.json")))
+    out = oracle.chamfer_distance_np(np.array(kat["p1"], np.float32), np.array(kat["p2"], np.float32))
+    np.testing.assert_allclose(out, kat["expected"], rtol=2e-6)
+
+
+def test_sided_distance_vs_float64(oracle):
+    from oracle.ref_f64 import chamfer_f64
+    rng = np.random.default_rng(3)
+    p1 = unit_ball_clouds(rng, 3, 700)
+    p2 = np.tanh(rng.standard_normal((3, 513, 3))).astype(np.float32)
+    d1, i1, d2, i2 = oracle.chamfer_fwd(p1, p2)
+    cd, fd1, fi1, fd2, fi2 = chamfer_f64(p1, p2)
+    assert (i1 == fi1).mean() > 0.999 and (i2 == fi2).mean() > 0.999  # fp32 near-ties only
+    np.testing.assert_allclose(d1, fd1, rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(d2, fd2, rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(oracle.chamfer_distance_np(p1, p2), cd, rtol=1e-5)
+
+
+def test_tie_rule_first_minimum(oracle):
+    p1 = np.zeros((1, 3, 3), np.float32)
+    p2 = np.array([[[1, 0, 0], [0, 1, 0], [0, 0, 1], [1, 0, 0]]], np.float32)
+    d, i = oracle.sided_distance(p1, p2)
+    assert (i == 0).all() and (d == 1).all()
+
+
+def test_backward_vs_float64_autograd(oracle):
+    rng = np.random.default_rng(5)
+    a = unit_ball_clouds(rng, 2, 300)
+    b = np.tanh(rng.standard_normal((2, 411, 3))).astype(np.float32)
+    cd = oracle.make_torch_chamfer()
+    ta = torch.tensor(a, requires_grad=True)
+    tb = torch.tensor(b, requires_grad=True)
+    w = torch.tensor([0.3, 1.7])
+    (cd(ta, tb) * w).sum().backward()
+    a64 = torch.tensor(a, dtype=torch.float64, requires_grad=True)
+    b64 = torch.tensor(b, dtype=torch.float64, requires_grad=True)
+    D = ((a64[:, :, None] - b64[:, None]) ** 2).sum(-1)
+    ((D.min(2)[0].mean(1) + D.min(1)[0].mean(1)) * w.double()).sum().backward()
+    np.testing.assert_allclose(ta.grad.numpy(), a64.grad.numpy(), rtol=1e-4, atol=1e-9)
+    np.testing.assert_allclose(tb.grad.numpy(), b64.grad.numpy(), rtol=1e-4, atol=1e-9)
