@@ -29,6 +29,9 @@ SIGNATURES = {
                          _c_f32p, _c_i32p, _c_f32p, _c_i32p, _c_stream],
     "fpsg_chamfer_bwd": [_c_f32p, _c_f32p, _c_i32p, _c_i32p, _c_f32p, _c_f32p,
                          _c_int, _c_int, _c_int, _c_f32p, _c_f32p, _c_stream],
+    "fpsg_knn": [_c_f32p, _c_int, _c_int, _c_int, _c_int, _c_i32p, _c_f32p, _c_stream],
+    "fpsg_edge_feature_fwd": [_c_f32p, _c_i32p, _c_int, _c_int, _c_int, _c_int, _c_f32p, _c_stream],
+    "fpsg_edge_feature_bwd": [_c_f32p, _c_i32p, _c_int, _c_int, _c_int, _c_int, _c_f32p, _c_stream],
 }
 _RESTYPES = {"fpsg_last_error": ctypes.c_char_p}
 

@@ -64,6 +64,29 @@ int fpsg_chamfer_bwd(const float* xyz1, const float* xyz2,
                      int B, int N, int M,
                      float* gxyz1, float* gxyz2, fpsg_stream_t stream);
 
+/* ---- K3: kNN graph ----------------------------------------------------------------
+ * Replaces `knn(x, k)` of src/dgcnn/model.py:13-20 (torch.matmul into a [B,N,N] matrix +
+ * torch.topk).  x [B,C,N] fp32 channel-major; idx [B,N,k] int32: for every point the k
+ * points with the largest  pd_ij = (-|x_j|^2 + 2 x_i.x_j) - |x_i|^2, nearest first (self
+ * included), equal values -> lower index first.  sqnorm_ws: caller scratch of B*N floats.
+ * Limits: k <= min(64, N); the 16 x N fp32 distance tile plus the 16 x C query tile must fit
+ * 160 KiB of LDS (N <= 2048 for C <= 448).
+ */
+int fpsg_knn(const float* x, int B, int C, int N, int k, int32_t* idx, float* sqnorm_ws,
+             fpsg_stream_t stream);
+
+/* ---- K4a: EdgeConv edge features (materialising form) ------------------------------
+ * Replaces `get_graph_feature(x, k, idx)` of src/dgcnn/model.py:23-42.
+ * out [B,2C,N,k]: out[b,c,n,j] = x[b,c,idx[b,n,j]] - x[b,c,n];  out[b,C+c,n,j] = x[b,c,n].
+ */
+int fpsg_edge_feature_fwd(const float* x, const int32_t* idx, int B, int C, int N, int k,
+                          float* out, fpsg_stream_t stream);
+
+/* Gradient of the above w.r.t. x (gx [B,C,N], fully overwritten).  The neighbour terms
+ * are accumulated with fp32 atomics. */
+int fpsg_edge_feature_bwd(const float* gout, const int32_t* idx, int B, int C, int N, int k,
+                          float* gx, fpsg_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

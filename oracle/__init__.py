@@ -142,3 +142,31 @@ def make_torch_chamfer():
         return w1 * d1.mean(dim=-1) + w2 * d2.mean(dim=-1)
 
     return chamfer_distance
+
+
+# ----------------------------------------------------------------------- DGCNN graph ops
+def knn(x, k):
+    """x [B,C,N] -> int32 [B,N,k] (src/dgcnn/model.py:13-20; arithmetic: fpsg_oracle.c)."""
+    x = _f32(x)
+    B, C, N = x.shape
+    idx = np.empty((B, N, k), np.int32)
+    lib().oracle_knn(_p(x), B, C, N, k, _p(idx))
+    return idx
+
+
+def edge_feature(x, idx):
+    """x [B,C,N], idx [B,N,k] -> [B,2C,N,k] (src/dgcnn/model.py:23-42)."""
+    x, idx = _f32(x), _i32(idx)
+    B, C, N = x.shape
+    k = idx.shape[2]
+    out = np.empty((B, 2 * C, N, k), np.float32)
+    lib().oracle_edge_feature(_p(x), _p(idx), B, C, N, k, _p(out))
+    return out
+
+
+def edge_feature_bwd(gout, idx):
+    gout, idx = _f32(gout), _i32(idx)
+    B, C2, N, k = gout.shape
+    gx = np.empty((B, C2 // 2, N), np.float32)
+    lib().oracle_edge_feature_bwd(_p(gout), _p(idx), B, C2 // 2, N, k, _p(gx))
+    return gx

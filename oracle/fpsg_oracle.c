@@ -104,3 +104,81 @@ void oracle_chamfer_bwd(const float* xyz1, const float* xyz2, const int32_t* idx
                    gxyz2 + (size_t)b * M * 3);
   }
 }
+
+/* ------------------------------------------------------------------------------------
+ * kNN graph of DGCNN: src/dgcnn/model.py:13-20.
+ *   inner = -2 * x^T x ; xx = sum_c x^2 ; pairwise = -xx - inner - xx^T ; topk(k) indices.
+ * x is [B,C,N] (channel-major).  Arithmetic pinned here (fp32, explicit fma):
+ *   dot_ij = fma-chain over c ascending from 0:  acc = fmaf(x[c][i], x[c][j], acc)
+ *   xx_j   = dot_jj
+ *   pd_ij  = fmaf(2, dot_ij, -xx_j) - xx_i          [= (-xx_j - inner_ij) - xx_i]
+ * top-k: the k largest pd_ij per row, descending; equal values -> lower j first.
+ * (torch.matmul/topk round and break ties in an unspecified order, so the reference's
+ *  own output is matched as neighbour SETS up to fp32 near-ties; see tests.)          */
+void oracle_knn(const float* x, int B, int C, int N, int k, int32_t* idx) {
+  float* xx = (float*)malloc(sizeof(float) * (size_t)N);
+  float* pd = (float*)malloc(sizeof(float) * (size_t)N);
+  for (int b = 0; b < B; ++b) {
+    const float* xb = x + (size_t)b * C * N;
+    for (int j = 0; j < N; ++j) {
+      float acc = 0.0f;
+      for (int c = 0; c < C; ++c) acc = fmaf(xb[(size_t)c * N + j], xb[(size_t)c * N + j], acc);
+      xx[j] = acc;
+    }
+    for (int i = 0; i < N; ++i) {
+      for (int j = 0; j < N; ++j) {
+        float acc = 0.0f;
+        for (int c = 0; c < C; ++c) acc = fmaf(xb[(size_t)c * N + i], xb[(size_t)c * N + j], acc);
+        pd[j] = fmaf(2.0f, acc, -xx[j]) - xx[i];
+      }
+      int32_t* out = idx + ((size_t)b * N + i) * k;
+      for (int r = 0; r < k; ++r) {
+        int best = -1;
+        for (int j = 0; j < N; ++j) {
+          if (pd[j] == -INFINITY && best >= 0) continue;
+          if (best < 0 || pd[j] > pd[best]) best = j;
+        }
+        out[r] = best;
+        pd[best] = -INFINITY;
+      }
+    }
+  }
+  free(xx);
+  free(pd);
+}
+
+/* Edge features of EdgeConv: src/dgcnn/model.py:23-42.
+ * out[b, c,     n, j] = x[b, c, idx[b,n,j]] - x[b, c, n]
+ * out[b, C + c, n, j] = x[b, c, n]                          out is [B, 2C, N, k]     */
+void oracle_edge_feature(const float* x, const int32_t* idx, int B, int C, int N, int k,
+                         float* out) {
+  for (int b = 0; b < B; ++b)
+    for (int c = 0; c < C; ++c)
+      for (int n = 0; n < N; ++n) {
+        float ctr = x[((size_t)b * C + c) * N + n];
+        for (int j = 0; j < k; ++j) {
+          int m = idx[((size_t)b * N + n) * k + j];
+          out[(((size_t)b * 2 * C + c) * N + n) * k + j] = x[((size_t)b * C + c) * N + m] - ctr;
+          out[(((size_t)b * 2 * C + C + c) * N + n) * k + j] = ctr;
+        }
+      }
+}
+
+/* Gradient of the edge features w.r.t. x: centre terms summed over j ascending, then the
+ * neighbour terms scattered in ascending (n, j) order (fp32 adds, no fma).            */
+void oracle_edge_feature_bwd(const float* gout, const int32_t* idx, int B, int C, int N, int k,
+                             float* gx) {
+  for (int b = 0; b < B; ++b)
+    for (int c = 0; c < C; ++c) {
+      float* g = gx + ((size_t)b * C + c) * N;
+      const float* gd = gout + (((size_t)b * 2 * C + c) * N) * k;      /* d/d(diff)   */
+      const float* gc = gout + (((size_t)b * 2 * C + C + c) * N) * k;  /* d/d(centre) */
+      for (int n = 0; n < N; ++n) {
+        float acc = 0.0f;
+        for (int j = 0; j < k; ++j) acc += gc[(size_t)n * k + j] - gd[(size_t)n * k + j];
+        g[n] = acc;
+      }
+      for (int n = 0; n < N; ++n)
+        for (int j = 0; j < k; ++j) g[idx[((size_t)b * N + n) * k + j]] += gd[(size_t)n * k + j];
+    }
+}
