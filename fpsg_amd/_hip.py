@@ -32,8 +32,11 @@ SIGNATURES = {
     "fpsg_knn": [_c_f32p, _c_int, _c_int, _c_int, _c_int, _c_i32p, _c_f32p, _c_stream],
     "fpsg_edge_feature_fwd": [_c_f32p, _c_i32p, _c_int, _c_int, _c_int, _c_int, _c_f32p, _c_stream],
     "fpsg_edge_feature_bwd": [_c_f32p, _c_i32p, _c_int, _c_int, _c_int, _c_int, _c_f32p, _c_stream],
+    "fpsg_emd_workspace_floats": [_c_int, _c_int, _c_int],
+    "fpsg_emd_approx": [_c_f32p, _c_f32p, _c_int, _c_int, _c_int, _c_f32p, _c_f32p, _c_f32p, _c_f32p,
+                        _c_stream],
 }
-_RESTYPES = {"fpsg_last_error": ctypes.c_char_p}
+_RESTYPES = {"fpsg_last_error": ctypes.c_char_p, "fpsg_emd_workspace_floats": ctypes.c_size_t}
 
 _lib = None
 _lock = threading.Lock()

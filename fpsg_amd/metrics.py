@@ -113,3 +113,59 @@ def chamfer_distance(p1: torch.Tensor, p2: torch.Tensor, w1: float = 1.0, w2: fl
     if w1 == 1 and w2 == 1:
         return dist_to_p2 + dist_to_p1
     return w1 * dist_to_p2 + w2 * dist_to_p1
+
+
+class _EmdApprox(torch.autograd.Function):
+    """cost [B] of the approximate-assignment solver; the gradients (assignment held
+    constant) are produced by the same solver run and cached for backward."""
+
+    @staticmethod
+    def forward(ctx, p1, p2):
+        _check_clouds(p1, p2)
+        B, N, _ = p1.shape
+        M = p2.size(1)
+        lib = _hip.load()
+        dev = p1.device
+        need1, need2 = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        cost = torch.empty((B,), dtype=torch.float32, device=dev)
+        g1 = torch.empty_like(p1) if need1 else None
+        g2 = torch.empty_like(p2) if need2 else None
+        ws = torch.empty((lib.fpsg_emd_workspace_floats(B, N, M),), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev), _probe("emd_approx", B, N, M):
+            rc = lib.fpsg_emd_approx(_hip.ptr(p1), _hip.ptr(p2), B, N, M, _hip.ptr(cost),
+                                     _hip.ptr(g1) if need1 else None,
+                                     _hip.ptr(g2) if need2 else None, _hip.ptr(ws),
+                                     _hip.stream_of(p1))
+        _hip.check(rc, "fpsg_emd_approx")
+        ctx.grads = (g1, g2)
+        return cost
+
+    @staticmethod
+    def backward(ctx, gcost):
+        g1, g2 = ctx.grads
+        gc = gcost.reshape(-1, 1, 1)
+        return (None if g1 is None else g1 * gc), (None if g2 is None else g2 * gc)
+
+
+def emd_approx(p1: torch.Tensor, p2: torch.Tensor) -> torch.Tensor:
+    """Transport cost ``[B]`` of the approximate assignment between ``p1 [B,N,3]`` and
+    ``p2 [B,M,3]`` (sum over matched pairs of Euclidean distances, not divided by N)."""
+    return _EmdApprox.apply(p1, p2)
+
+
+def emd_loss(p1: torch.Tensor, p2: torch.Tensor, reduce: str = "mean", sinkhorn: bool = False):
+    """Call-site mirror of ``neuralnet_pytorch.metrics.emd_loss(xyz1, xyz2, reduce, sinkhorn)``
+    as used by the reference's ``emd_wrapper`` (``src/models/utils.py:12-13``).
+
+    The approximate-assignment solver (K2) is used for either value of ``sinkhorn``: the
+    reference's ``sinkhorn=True`` branch defers to geomloss' Sinkhorn divergence, whose
+    package and version are not pinned anywhere in the reference -- parity with it is
+    UNPINNED; the flag is accepted so that the call site is unchanged."""
+    cost = emd_approx(p1, p2)
+    if reduce == "sum":
+        return cost.sum()
+    if reduce == "mean":
+        return cost.mean()
+    if reduce in (None, "none"):
+        return cost
+    raise ValueError(f"unknown reduce: {reduce}")

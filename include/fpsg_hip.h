@@ -18,6 +18,7 @@
 #ifndef FPSG_HIP_H
 #define FPSG_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -86,6 +87,20 @@ int fpsg_edge_feature_fwd(const float* x, const int32_t* idx, int B, int C, int 
  * are accumulated with fp32 atomics. */
 int fpsg_edge_feature_bwd(const float* gout, const int32_t* idx, int B, int C, int N, int k,
                           float* gx, fpsg_stream_t stream);
+
+/* ---- K2: EMD, approximate-assignment solver -------------------------------------
+ * Stands where the reference calls neuralnet_pytorch.metrics.emd_loss through
+ * emd_wrapper (src/models/utils.py:12-13, used at src/models/few_shot.py:168).
+ * Auction-style soft assignment over 10 temperature levels (Fan/Su/Guibas approxmatch)
+ * followed by the transport cost sum_kl match_kl * |xyz1_k - xyz2_l|; the N x M match
+ * matrix is never stored.  cost [B].  gxyz1 [B,N,3] / gxyz2 [B,M,3] may each be NULL;
+ * when given they receive d cost / d xyz with the assignment held constant (the
+ * convention of the original matchcost gradient).  ws: caller scratch of
+ * fpsg_emd_workspace_floats(B,N,M) floats.  Deterministic (no float atomics).
+ */
+size_t fpsg_emd_workspace_floats(int B, int N, int M);
+int fpsg_emd_approx(const float* xyz1, const float* xyz2, int B, int N, int M, float* cost,
+                    float* gxyz1, float* gxyz2, float* ws, fpsg_stream_t stream);
 
 #ifdef __cplusplus
 }

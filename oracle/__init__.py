@@ -170,3 +170,19 @@ def edge_feature_bwd(gout, idx):
     gx = np.empty((B, C2 // 2, N), np.float32)
     lib().oracle_edge_feature_bwd(_p(gout), _p(idx), B, C2 // 2, N, k, _p(gx))
     return gx
+
+
+# --------------------------------------------------------------------------------- EMD
+def emd_approx(xyz1, xyz2, want_grad=False):
+    """Approximate-assignment EMD (PARITY UNPINNED, see fpsg_oracle.c): cost [B] and, if
+    asked, the gradients w.r.t. both clouds with the soft assignment held constant."""
+    xyz1, xyz2 = _f32(xyz1), _f32(xyz2)
+    B, N, _ = xyz1.shape
+    M = xyz2.shape[1]
+    cost = np.empty((B,), np.float32)
+    if want_grad:
+        g1, g2 = np.empty_like(xyz1), np.empty_like(xyz2)
+        lib().oracle_emd_approx(_p(xyz1), _p(xyz2), B, N, M, _p(cost), _p(g1), _p(g2))
+        return cost, g1, g2
+    lib().oracle_emd_approx(_p(xyz1), _p(xyz2), B, N, M, _p(cost), None, None)
+    return cost

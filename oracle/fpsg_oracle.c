@@ -182,3 +182,87 @@ void oracle_edge_feature_bwd(const float* gout, const int32_t* idx, int B, int C
         for (int j = 0; j < k; ++j) g[idx[((size_t)b * N + n) * k + j]] += gd[(size_t)n * k + j];
     }
 }
+
+/* ------------------------------------------------------------------------------------
+ * EMD, approximate assignment ("approxmatch" + "matchcost" of Fan, Su, Guibas 2017, the
+ * solver behind the emd_loss(sinkhorn=False) branch of neuralnet_pytorch; the reference's
+ * call is src/models/utils.py:12-13).  PARITY UNPINNED (see the file header).
+ *
+ * For each batch item: remainL[k] = multiL, remainR[l] = multiR
+ *   (multiR = n/m if n >= m else 1; multiL = m/n if m > n else 1; integer division).
+ * For level = -4^7, -4^6, ..., -4^-1, 0 (10 levels):
+ *   e(k,l)    = expf(level * d2(k,l))                       d2 = squared distance (fma form)
+ *   ratioL[k] = remainL[k] / (1e-9 + sum_l e(k,l) * remainR[l])
+ *   sumr[l]   = remainR[l] * sum_k e(k,l) * ratioL[k]
+ *   ratioR[l] = min(remainR[l] / (sumr[l] + 1e-9), 1) * remainR[l]
+ *   remainR[l]= max(0, remainR[l] - sumr[l])
+ *   w(k,l)    = e(k,l) * ratioL[k] * ratioR[l]              (added to match[k][l])
+ *   remainL[k]= max(0, remainL[k] - sum_l w(k,l))
+ * cost = sum_{k,l} match[k][l] * sqrt(d2(k,l));  optional gradients with match held
+ * constant:  g1[k] = sum_l match (x1_k - x2_l)/max(dist,1e-20),  g2[l] = -sum_k (same).
+ * Sums run in ascending index order in fp32; the match matrix is not stored: cost and
+ * gradients are accumulated level by level.                                           */
+void oracle_emd_approx(const float* xyz1, const float* xyz2, int B, int N, int M, float* cost,
+                       float* g1 /* [B,N,3] or NULL */, float* g2 /* [B,M,3] or NULL */) {
+  float* remainL = (float*)malloc(sizeof(float) * (size_t)N);
+  float* ratioL = (float*)malloc(sizeof(float) * (size_t)N);
+  float* remainR = (float*)malloc(sizeof(float) * (size_t)M);
+  float* ratioR = (float*)malloc(sizeof(float) * (size_t)M);
+  float* rowcost = (float*)malloc(sizeof(float) * (size_t)N);
+  const float multiL = (M > N) ? (float)(M / N) : 1.0f;
+  const float multiR = (N >= M) ? (float)(N / M) : 1.0f;
+  for (int b = 0; b < B; ++b) {
+    const float* p1 = xyz1 + (size_t)b * N * 3;
+    const float* p2 = xyz2 + (size_t)b * M * 3;
+    float* gb1 = g1 ? g1 + (size_t)b * N * 3 : NULL;
+    float* gb2 = g2 ? g2 + (size_t)b * M * 3 : NULL;
+    for (int k = 0; k < N; ++k) { remainL[k] = multiL; rowcost[k] = 0.0f; }
+    for (int l = 0; l < M; ++l) remainR[l] = multiR;
+    if (gb1) memset(gb1, 0, sizeof(float) * (size_t)N * 3);
+    if (gb2) memset(gb2, 0, sizeof(float) * (size_t)M * 3);
+    for (int j = 7; j >= -2; --j) {
+      const float level = (j == -2) ? 0.0f : -powf(4.0f, (float)j);
+      for (int k = 0; k < N; ++k) {
+        float s = 0.0f;
+        for (int l = 0; l < M; ++l) s += expf(level * sq_dist(p1 + 3 * k, p2 + 3 * l)) * remainR[l];
+        ratioL[k] = remainL[k] / (s + 1e-9f);
+      }
+      for (int l = 0; l < M; ++l) {
+        float s = 0.0f;
+        for (int k = 0; k < N; ++k) s += expf(level * sq_dist(p1 + 3 * k, p2 + 3 * l)) * ratioL[k];
+        const float sumr = s * remainR[l];
+        const float consumption = fminf(remainR[l] / (sumr + 1e-9f), 1.0f);
+        ratioR[l] = consumption * remainR[l];
+        remainR[l] = fmaxf(0.0f, remainR[l] - sumr);
+      }
+      for (int k = 0; k < N; ++k) {
+        float s = 0.0f, c = 0.0f, gx = 0.0f, gy = 0.0f, gz = 0.0f;
+        for (int l = 0; l < M; ++l) {
+          const float d2 = sq_dist(p1 + 3 * k, p2 + 3 * l);
+          const float w = expf(level * d2) * ratioL[k] * ratioR[l];
+          const float dist = sqrtf(d2);
+          s += w;
+          c = fmaf(w, dist, c);
+          if (gb1 || gb2) {
+            const float f = w / fmaxf(dist, 1e-20f);
+            const float dx = p1[3 * k] - p2[3 * l], dy = p1[3 * k + 1] - p2[3 * l + 1],
+                        dz = p1[3 * k + 2] - p2[3 * l + 2];
+            gx = fmaf(f, dx, gx); gy = fmaf(f, dy, gy); gz = fmaf(f, dz, gz);
+            if (gb2) {
+              gb2[3 * l] = fmaf(-f, dx, gb2[3 * l]);
+              gb2[3 * l + 1] = fmaf(-f, dy, gb2[3 * l + 1]);
+              gb2[3 * l + 2] = fmaf(-f, dz, gb2[3 * l + 2]);
+            }
+          }
+        }
+        rowcost[k] += c;
+        if (gb1) { gb1[3 * k] += gx; gb1[3 * k + 1] += gy; gb1[3 * k + 2] += gz; }
+        remainL[k] = fmaxf(0.0f, remainL[k] - s);
+      }
+    }
+    double tot = 0.0;
+    for (int k = 0; k < N; ++k) tot += rowcost[k];
+    cost[b] = (float)tot;
+  }
+  free(remainL); free(ratioL); free(remainR); free(ratioR); free(rowcost);
+}
