@@ -1,0 +1,141 @@
+#!/usr/bin/env python3
+"""Few-shot image -> point-cloud training on MI355X (entry point of the hot path).
+
+Same command line, log lines and checkpoint files as reference ``src/trainNetwork.py``
+(``main :67-208``); the per-step work is ``fpsg_amd.engine.TrainStep`` (HIP Chamfer loss,
+PyTorch-ROCm networks).  Extras: ``--synthetic`` data, and data-parallel episodes when
+launched with ``python -m torch.distributed.run --nproc-per-node N trainNetwork.py ...``
+(every optimizer step then covers ``--episodes_per_step`` episodes, default one per rank;
+gradients are averaged with an RCCL all-reduce; rank 0 logs, evaluates and saves).
+
+    python trainNetwork.py --synthetic --n_shot 1 --n_query 1 --epoch 2 --n_episode 10 \
+        --pc_encoder_path tests/golden/pretrained_pcencoder_pointnet.pt --model_path /tmp/ckpt
+"""
+from __future__ import annotations
+
+import os
+import statistics
+import time
+from collections import defaultdict
+
+import torch
+
+from fpsg_amd import cli
+from fpsg_amd import dist as fdist
+from fpsg_amd.engine import TrainStep, build_model, build_optimizer, to_device
+
+
+def evaluate(model, dl_test, n_query, n_shot, device, log):
+    """Per-class Chamfer report (reference :157-189); returns the per-item values."""
+    model.eval()
+    per_class = defaultdict(list)
+    every = []
+    with torch.no_grad():
+        for sample in dl_test:
+            out = model.loss(to_device(sample, device))
+            cd = out["query_rec_loss"].item() / n_query
+            per_class[sample["class"][0]].append(cd)
+            every.append(cd)
+    for name in sorted(per_class):
+        vals = per_class[name]
+        spread = statistics.stdev(vals) if len(vals) > 1 else 0.0
+        log(f"Class: {name} -- Rec CD: {statistics.mean(vals)} ({spread})")
+    model.train()
+    return every
+
+
+def main(opt):
+    cli.validate(opt)
+    n_query = opt.n_shot if opt.n_query == 0 else opt.n_query
+    rank, world, device = fdist.init_distributed("cuda" if opt.device.startswith("cuda") else "cpu")
+    if world == 1:
+        device = cli.pick_device(opt)
+    is_main = rank == 0
+
+    timestamp = time.strftime("%m_%d_%H_%M")
+    checkpoint_path = os.path.join(opt.model_path, opt.name)
+    checkpoint_imgs = os.path.join(checkpoint_path, "images")
+    checkpoint_logs = os.path.join(checkpoint_path, f"log_{timestamp}.txt")
+    if is_main:
+        os.makedirs(checkpoint_imgs, exist_ok=True)
+
+    ds, ds_test = cli.build_datasets(opt, n_query, device)
+    dl, dl_test = cli.build_loaders(opt, ds, ds_test)
+
+    model = build_model(opt)
+    start_epoch = 1
+    if opt.resume > 0:
+        start_epoch = opt.resume
+        resume_path = os.path.join(checkpoint_path, f"model_epoch_{start_epoch}.pt")
+        if not os.path.exists(resume_path):
+            raise RuntimeError(f"{resume_path} does not exist, loading failed")
+        print(f"Resume previous training, start from epoch {start_epoch}, loading previous model")
+        model.load_state_dict(torch.load(resume_path, map_location="cpu", weights_only=True))
+    model = model.to(device).train()
+    fdist.broadcast_parameters(model)
+
+    optimizer, scheduler = build_optimizer(model, opt)
+    step = TrainStep(model, optimizer, world=world)
+    eps_per_step = opt.episodes_per_step or world
+    local_n = len(range(rank, eps_per_step, world))
+
+    pending: list[str] = []
+
+    def log(line: str) -> None:
+        if is_main:
+            print(line)
+            pending.append(line)
+
+    for epoch in range(start_epoch, opt.epoch + 1):
+        # every rank draws its own episodes; different seeds per (epoch, rank)
+        torch.manual_seed(1000003 * epoch + rank)
+        sums = torch.zeros(2, dtype=torch.float64, device=device)
+        it = iter(dl)
+        n_steps = max(1, opt.n_episode // eps_per_step)
+        t0 = time.perf_counter()
+        for _ in range(n_steps):
+            local = [to_device(next(it), device) for _ in range(local_n)]
+            for out in step(local, n_episodes_global=eps_per_step):
+                sums[0] += out["query_rec_loss"].sum() / n_query
+                sums[1] += out["support_rec_loss"].sum() / opt.n_shot
+        q_sum, s_sum = fdist.all_reduce_scalars(sums.tolist(), device)   # one host sync per epoch
+        done = n_steps * eps_per_step
+        dt = time.perf_counter() - t0
+        log(f"Training Results for Epoch -- {epoch} are: Query_rec: {q_sum / done}, "
+            f"Support_rec: {s_sum / done}")
+        if is_main:
+            print(f"  [{done / dt:.2f} episodes/s over {world} GPU(s)]")
+        scheduler.step()
+
+        if is_main and (epoch % opt.eval_interval == 0 or epoch == opt.epoch):
+            every = evaluate(model, dl_test, n_query, opt.n_shot, device, log)
+            spread = statistics.stdev(every) if len(every) > 1 else 0.0
+            log(f"Avg testing results across all classes Epoch -- {epoch} are: "
+                f"Query_rec: {sum(every) / max(len(every), 1)} ({spread})")
+            for sample in dl_test:
+                model.eval()
+                model.draw_reconstruction(to_device(sample, device),
+                                          os.path.join(checkpoint_imgs, f"sample_img_{epoch}_test.png"))
+                model.train()
+                break
+
+        if is_main and (epoch % opt.save_interval == 0 or epoch == opt.epoch):
+            torch.save(model.state_dict(), os.path.join(checkpoint_path, f"model_epoch_{epoch}.pt"))
+            with open(checkpoint_logs, "a") as f:
+                f.writelines(f"{line}\n" for line in pending)
+            pending.clear()
+
+        if is_main and epoch % opt.sample_interval == 0:
+            model.eval()
+            for sample in dl:
+                model.draw_reconstruction(to_device(sample, device),
+                                          os.path.join(checkpoint_imgs, f"sample_img_{epoch}.png"))
+                break
+            model.train()
+        if world > 1:
+            torch.distributed.barrier()
+    fdist.shutdown()
+
+
+if __name__ == "__main__":
+    main(cli.few_shot_parser().parse_args())
