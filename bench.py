@@ -101,6 +101,23 @@ def make_episodes(S, Q, count, seed, device):
             for i in range(count)]
 
 
+def usable_cores() -> int:
+    """Cores this process may really use: affinity mask and cgroup CPU quota, not the host's
+    core count (the GPU box exposes every host core but grants a 16-core share)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, int(os.environ.get("FPSG_CPU_THREADS", "16"))))
+
+
 def cpu_baseline(S, Q, intra, encoder, budget_s):
     """The same episode step (fwd + Chamfer + bwd + Adam) on the host cores: the model code
     in PyTorch-CPU with the C oracle's Chamfer.  The reference has no CPU path (hard
@@ -109,7 +126,7 @@ def cpu_baseline(S, Q, intra, encoder, budget_s):
     import oracle
     if encoder != "pointnet":
         return None
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     torch.set_num_threads(cores)
     opt = default_options(device="cpu", intra_recon=intra, pc_encoder=encoder)
     torch.manual_seed(0)
@@ -123,6 +140,7 @@ def cpu_baseline(S, Q, intra, encoder, budget_s):
         step([ep])
         n += 1
         el = time.perf_counter() - t0
+        print(f"[cpu_baseline] {n} episode(s) in {el:.1f} s on {cores} threads", file=sys.stderr, flush=True)
         if el > budget_s or el + el / n > 1.5 * budget_s:
             break
     return {"value": n / el, "unit": "episodes/s", "cores": cores, "kind": "port",
