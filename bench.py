@@ -159,6 +159,8 @@ def main():
     ap.add_argument("--cpu-baseline-seconds", type=float, default=20.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--bucket-mb", type=float, default=80.0)
+    ap.add_argument("--channels-last", action="store_true", help="experiment: NHWC image trunk")
+    ap.add_argument("--miopen-benchmark", action="store_true", help="experiment: MIOpen find mode")
     args = ap.parse_args()
 
     S, Q, intra, encoder, epr, desc = WORKLOADS[args.workload]
@@ -173,14 +175,20 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
 
-    torch.backends.cudnn.benchmark = False
+    torch.backends.cudnn.benchmark = bool(args.miopen_benchmark)
     opt = default_options(device="cuda", intra_recon=intra, pc_encoder=encoder, n_shot=S, n_query=Q)
     torch.manual_seed(0)                      # identical initial weights on every rank
     model = build_model(opt).to(device)
+    if args.channels_last:
+        model.img_encoder.to(memory_format=torch.channels_last)
     model.train()
     optimizer, _ = build_optimizer(model, opt)
     step = TrainStep(model, optimizer, world=world, bucket_mb=args.bucket_mb)
     episodes = make_episodes(S, Q, epr, seed=1234 + rank, device=device)   # resident in HBM
+    if args.channels_last:
+        for ep in episodes:
+            for key in ("xs", "xq", "xad"):
+                ep[key] = ep[key].squeeze(0).contiguous(memory_format=torch.channels_last).unsqueeze(0)
 
     probe = EventProbe()
     metrics.set_launch_probe(probe)

@@ -1,0 +1,259 @@
+// edgeconv.hip -- K4b: fused, non-materialising EdgeConv layer of DGCNN for gfx950.
+//
+// Reference (src/dgcnn/model.py:23-42,53-56,63-76): gather k neighbour rows, build
+// cat(x_j - x_i, x_i) as a [B,2C,N,k] tensor (2.7 GB at C=128, B=64), 1x1 Conv2d, training
+// mode BatchNorm2d over (B,N,k), LeakyReLU(0.2), max over k.
+//
+// Here the [B,2C,N,k] tensor (and the [B,Co,N,k] conv output) never exist:
+//   W [x_j - x_i ; x_i] = W1 x_j + (W2 - W1) x_i  =  P[j] + Q[i]      (two N-row GEMMs, host side)
+//   BatchNorm + LeakyReLU are monotone per channel, increasing if gamma >= 0 and decreasing
+//   otherwise, so  max_j act(bn(y_j)) = act(bn(max_j y_j))  or  act(bn(min_j y_j)).
+// Forward kernel: one wave per point, lanes across the Co output channels (16-B loads of
+// whole P rows = coalesced, L2/MALL resident): for the k neighbours y = P[idx] + Q, track
+// the selected extreme + its neighbour slot, sum y (S1) and sum y^2; per-workgroup partial
+// BatchNorm sums go to a [blocks,2,Co] buffer that the host reduces in float64.
+// Backward kernel: one wave per point m walks the REVERSE graph (in-edges of m, built by a
+// stable sort on the host side, so the summation order is fixed => deterministic, no float
+// atomics): dP[m] = sum_{(n,j)->m} [jsel[n]==j] dzs[n] - cnt (A + Bc (P[m]-mu)) - Bc sum Q[n],
+// dQ[m] = dzs[m] - k A - Bc (S1[m] - k mu)   (A, Bc: the BatchNorm statistic terms).
+#include "fpsg_common.h"
+
+namespace fpsg {
+namespace {
+
+constexpr int kEcThreads = 256;  // 4 waves
+constexpr int kEcPtsPerWave = 8;
+
+template <int VEC>
+struct VecT;
+template <> struct VecT<1> { typedef float type; };
+template <> struct VecT<2> { typedef v2f type; };
+template <> struct VecT<4> { typedef v4f type; };
+
+template <int VEC>
+__device__ __forceinline__ void load_vec(const float* p, float (&v)[VEC]) {
+  typedef typename VecT<VEC>::type T;
+  const T t = *reinterpret_cast<const T*>(p);
+  if constexpr (VEC == 1) {
+    v[0] = t;
+  } else {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) v[i] = t[i];
+  }
+}
+
+template <int VEC>
+__device__ __forceinline__ void store_vec(float* p, const float (&v)[VEC]) {
+  typedef typename VecT<VEC>::type T;
+  T t;
+  if constexpr (VEC == 1) {
+    t = v[0];
+  } else {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) t[i] = v[i];
+  }
+  *reinterpret_cast<T*>(p) = t;
+}
+
+// PQ [B,N,2*Co] (P = first Co columns, Q = last Co), idx [B,N,k], sgn [Co] (+1: take max, -1:
+// take min).  Outputs ysel [B,N,Co], jsel [B,N,Co] (uint8 neighbour slot), s1 [B,N,Co] or null,
+// part [gridDim.y*gridDim.x][2][Co] or null.
+template <int VEC>
+__global__ __launch_bounds__(kEcThreads) void edgeconv_fwd_kernel(
+    const float* __restrict__ PQ, const int32_t* __restrict__ idx, const float* __restrict__ sgn,
+    int N, int k, float* __restrict__ ysel, uint8_t* __restrict__ jsel, float* __restrict__ s1,
+    float* __restrict__ part) {
+  constexpr int Co = 64 * VEC;
+  __shared__ float red[4][2][Co];
+  const int b = blockIdx.y;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int c0 = lane * VEC;
+  const float* __restrict__ base = PQ + (size_t)b * N * 2 * Co;
+  float sg[VEC], sum[VEC], sumsq[VEC];
+  load_vec<VEC>(sgn + c0, sg);
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) { sum[v] = 0.0f; sumsq[v] = 0.0f; }
+
+  const int n_first = (blockIdx.x * 4 + wave) * kEcPtsPerWave;
+  for (int pp = 0; pp < kEcPtsPerWave; ++pp) {
+    const int n = n_first + pp;
+    if (n >= N) break;  // wave-uniform
+    const size_t row = (size_t)b * N + n;
+    int my = lane < k ? idx[row * k + lane] : 0;
+    my = my < 0 ? 0 : (my >= N ? N - 1 : my);
+    float q[VEC], best[VEC], tot[VEC];
+    int bj[VEC];
+    load_vec<VEC>(base + (size_t)n * 2 * Co + Co + c0, q);
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) { best[v] = -__builtin_inff(); bj[v] = 0; tot[v] = 0.0f; }
+    for (int j = 0; j < k; ++j) {
+      const int m = __builtin_amdgcn_readlane(my, j);
+      float p[VEC];
+      load_vec<VEC>(base + (size_t)m * 2 * Co + c0, p);
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) {
+        const float y = p[v] + q[v];
+        tot[v] += y;
+        sumsq[v] = fma_rn(y, y, sumsq[v]);
+        const float t = y * sg[v];          // +-y: one code path for max and min
+        const bool gt = t > best[v];
+        bj[v] = gt ? j : bj[v];
+        best[v] = gt ? t : best[v];
+      }
+    }
+    float out[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) { out[v] = best[v] * sg[v]; sum[v] += tot[v]; }
+    store_vec<VEC>(ysel + row * Co + c0, out);
+    if (s1) store_vec<VEC>(s1 + row * Co + c0, tot);
+    if constexpr (VEC == 1) {
+      jsel[row * Co + c0] = (uint8_t)bj[0];
+    } else if constexpr (VEC == 2) {
+      *reinterpret_cast<uint16_t*>(jsel + row * Co + c0) = (uint16_t)(bj[0] | (bj[1] << 8));
+    } else {
+      *reinterpret_cast<uint32_t*>(jsel + row * Co + c0) =
+          (uint32_t)bj[0] | ((uint32_t)bj[1] << 8) | ((uint32_t)bj[2] << 16) | ((uint32_t)bj[3] << 24);
+    }
+  }
+  if (!part) return;
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) { red[wave][0][c0 + v] = sum[v]; red[wave][1][c0 + v] = sumsq[v]; }
+  __syncthreads();
+  float* dst = part + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 2 * Co;
+  for (int e = threadIdx.x; e < 2 * Co; e += kEcThreads) {
+    const int which = e / Co, c = e - which * Co;
+    dst[e] = (red[0][which][c] + red[1][which][c]) + (red[2][which][c] + red[3][which][c]);
+  }
+}
+
+// dzs [B,N,Co] = dz*scale; jsel; PQ; s1 (or null when coef A=Bc=0); rev [B,N*k] edge ids
+// (n*k+j) grouped by destination, ascending inside a group; off [B,N+1] group offsets;
+// coef [3][Co] = A, Bc, mu.  Output dPQ [B,N,2*Co].
+template <int VEC>
+__global__ __launch_bounds__(kEcThreads) void edgeconv_bwd_kernel(
+    const float* __restrict__ dzs, const uint8_t* __restrict__ jsel, const float* __restrict__ PQ,
+    const float* __restrict__ s1, const int32_t* __restrict__ rev, const int32_t* __restrict__ off,
+    const float* __restrict__ coef, int N, int k, int stats, float* __restrict__ dPQ) {
+  constexpr int Co = 64 * VEC;
+  const int b = blockIdx.y;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int c0 = lane * VEC;
+  float A[VEC], Bc[VEC], mu[VEC];
+  load_vec<VEC>(coef + c0, A);
+  load_vec<VEC>(coef + Co + c0, Bc);
+  load_vec<VEC>(coef + 2 * Co + c0, mu);
+  const float* __restrict__ pq = PQ + (size_t)b * N * 2 * Co;
+  const int32_t* __restrict__ revb = rev + (size_t)b * N * k;
+  const int32_t* __restrict__ offb = off + (size_t)b * (N + 1);
+  const int m_first = (blockIdx.x * 4 + wave) * kEcPtsPerWave;
+  for (int pp = 0; pp < kEcPtsPerWave; ++pp) {
+    const int m = m_first + pp;
+    if (m >= N) break;
+    const size_t rowm = (size_t)b * N + m;
+    int e0 = offb[m], e1 = offb[m + 1];
+    e0 = e0 < 0 ? 0 : e0;
+    e1 = e1 > N * k ? N * k : e1;  // never walk outside the edge list
+    float acc[VEC], accq[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) { acc[v] = 0.0f; accq[v] = 0.0f; }
+    for (int t = e0; t < e1; ++t) {
+      const int e = __builtin_amdgcn_readfirstlane(revb[t]);
+      int n = e / k;
+      n = n < 0 ? 0 : (n >= N ? N - 1 : n);
+      const int j = e - n * k;
+      const size_t rown = (size_t)b * N + n;
+      float g[VEC];
+      load_vec<VEC>(dzs + rown * Co + c0, g);
+      unsigned js;
+      if constexpr (VEC == 1) js = jsel[rown * Co + c0];
+      else if constexpr (VEC == 2) js = *reinterpret_cast<const uint16_t*>(jsel + rown * Co + c0);
+      else js = *reinterpret_cast<const uint32_t*>(jsel + rown * Co + c0);
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) acc[v] += ((int)((js >> (8 * v)) & 0xffu) == j) ? g[v] : 0.0f;
+      if (stats) {
+        float qn[VEC];
+        load_vec<VEC>(pq + (size_t)n * 2 * Co + Co + c0, qn);
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) accq[v] += qn[v];
+      }
+    }
+    float dp[VEC], dq[VEC];
+    load_vec<VEC>(dzs + rowm * Co + c0, dq);
+    if (stats) {
+      float pm[VEC], sm[VEC];
+      load_vec<VEC>(pq + (size_t)m * 2 * Co + c0, pm);
+      load_vec<VEC>(s1 + rowm * Co + c0, sm);
+      const float cnt = (float)(e1 - e0), kf = (float)k;
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) {
+        dp[v] = acc[v] - cnt * (A[v] + Bc[v] * (pm[v] - mu[v])) - Bc[v] * accq[v];
+        dq[v] = dq[v] - kf * A[v] - Bc[v] * (sm[v] - kf * mu[v]);
+      }
+    } else {
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) dp[v] = acc[v];
+    }
+    store_vec<VEC>(dPQ + rowm * 2 * Co + c0, dp);
+    store_vec<VEC>(dPQ + rowm * 2 * Co + Co + c0, dq);
+  }
+}
+
+inline dim3 ec_grid(int B, int N) {
+  return dim3((N + 4 * kEcPtsPerWave - 1) / (4 * kEcPtsPerWave), B);
+}
+
+}  // namespace
+}  // namespace fpsg
+
+extern "C" int fpsg_edgeconv_blocks(int B, int N) {
+  return (int)(((N + 4 * fpsg::kEcPtsPerWave - 1) / (4 * fpsg::kEcPtsPerWave)) * B);
+}
+
+extern "C" int fpsg_edgeconv_fwd(const float* PQ, const int32_t* idx, const float* sgn, int B, int N,
+                                 int k, int Co, float* ysel, uint8_t* jsel, float* s1, float* part,
+                                 fpsg_stream_t stream) {
+  using namespace fpsg;
+  FPSG_REQUIRE(B > 0 && N > 0 && k > 0, FPSG_E_SHAPE,
+               "fpsg_edgeconv_fwd: B,N,k must be positive (got %d,%d,%d)", B, N, k);
+  FPSG_REQUIRE(Co == 64 || Co == 128 || Co == 256, FPSG_E_SHAPE,
+               "fpsg_edgeconv_fwd: Co must be 64, 128 or 256 (got %d)", Co);
+  FPSG_REQUIRE(k <= 64 && B <= 65535, FPSG_E_LIMIT, "fpsg_edgeconv_fwd: k=%d > 64 or B=%d > 65535", k, B);
+  FPSG_REQUIRE_PTR(PQ); FPSG_REQUIRE_PTR(idx); FPSG_REQUIRE_PTR(sgn); FPSG_REQUIRE_PTR(ysel);
+  FPSG_REQUIRE(jsel != nullptr, FPSG_E_NULL, "fpsg_edgeconv_fwd: null pointer 'jsel'");
+  FPSG_REQUIRE((reinterpret_cast<uintptr_t>(PQ) & 15) == 0 && (reinterpret_cast<uintptr_t>(ysel) & 15) == 0 &&
+                   (reinterpret_cast<uintptr_t>(jsel) & 3) == 0 && (reinterpret_cast<uintptr_t>(s1) & 15) == 0,
+               FPSG_E_ALIGN, "fpsg_edgeconv_fwd: PQ/ysel/s1 must be 16-byte and jsel 4-byte aligned");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const dim3 grid = ec_grid(B, N);
+  if (Co == 64) hipLaunchKernelGGL(edgeconv_fwd_kernel<1>, grid, dim3(kEcThreads), 0, s, PQ, idx, sgn, N, k, ysel, jsel, s1, part);
+  else if (Co == 128) hipLaunchKernelGGL(edgeconv_fwd_kernel<2>, grid, dim3(kEcThreads), 0, s, PQ, idx, sgn, N, k, ysel, jsel, s1, part);
+  else hipLaunchKernelGGL(edgeconv_fwd_kernel<4>, grid, dim3(kEcThreads), 0, s, PQ, idx, sgn, N, k, ysel, jsel, s1, part);
+  return launch_status("fpsg_edgeconv_fwd");
+}
+
+extern "C" int fpsg_edgeconv_bwd(const float* dzs, const uint8_t* jsel, const float* PQ, const float* s1,
+                                 const int32_t* rev, const int32_t* off, const float* coef, int B, int N,
+                                 int k, int Co, float* dPQ, fpsg_stream_t stream) {
+  using namespace fpsg;
+  FPSG_REQUIRE(B > 0 && N > 0 && k > 0, FPSG_E_SHAPE,
+               "fpsg_edgeconv_bwd: B,N,k must be positive (got %d,%d,%d)", B, N, k);
+  FPSG_REQUIRE(Co == 64 || Co == 128 || Co == 256, FPSG_E_SHAPE,
+               "fpsg_edgeconv_bwd: Co must be 64, 128 or 256 (got %d)", Co);
+  FPSG_REQUIRE(B <= 65535, FPSG_E_LIMIT, "fpsg_edgeconv_bwd: B=%d > 65535", B);
+  FPSG_REQUIRE_PTR(dzs); FPSG_REQUIRE_PTR(PQ); FPSG_REQUIRE_PTR(rev); FPSG_REQUIRE_PTR(off);
+  FPSG_REQUIRE_PTR(coef); FPSG_REQUIRE_PTR(dPQ);
+  FPSG_REQUIRE(jsel != nullptr, FPSG_E_NULL, "fpsg_edgeconv_bwd: null pointer 'jsel'");
+  FPSG_REQUIRE((reinterpret_cast<uintptr_t>(PQ) & 15) == 0 && (reinterpret_cast<uintptr_t>(dzs) & 15) == 0 &&
+                   (reinterpret_cast<uintptr_t>(dPQ) & 15) == 0 && (reinterpret_cast<uintptr_t>(s1) & 15) == 0 &&
+                   (reinterpret_cast<uintptr_t>(coef) & 15) == 0,
+               FPSG_E_ALIGN, "fpsg_edgeconv_bwd: float buffers must be 16-byte aligned");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const dim3 grid = ec_grid(B, N);
+  const int stats = s1 != nullptr;
+  if (Co == 64) hipLaunchKernelGGL(edgeconv_bwd_kernel<1>, grid, dim3(kEcThreads), 0, s, dzs, jsel, PQ, s1, rev, off, coef, N, k, stats, dPQ);
+  else if (Co == 128) hipLaunchKernelGGL(edgeconv_bwd_kernel<2>, grid, dim3(kEcThreads), 0, s, dzs, jsel, PQ, s1, rev, off, coef, N, k, stats, dPQ);
+  else hipLaunchKernelGGL(edgeconv_bwd_kernel<4>, grid, dim3(kEcThreads), 0, s, dzs, jsel, PQ, s1, rev, off, coef, N, k, stats, dPQ);
+  return launch_status("fpsg_edgeconv_bwd");
+}

@@ -10,7 +10,13 @@ the same state-dict keys ``conv<i>.0.weight``, ``conv<i>.1.{weight,bias,running_
     ``[B,2C,N,k]`` (drop-in form; no hard-coded ``torch.device('cuda')``: the device is the
     input's).
 
-There is no CPU path for either (raises on CPU tensors).
+  * ``DGCNNfeat.forward`` does not call ``get_graph_feature`` at all: each EdgeConv layer is
+    ``fpsg_knn`` + one GEMM (``x^T [W1 ; W2-W1]^T``) + ``fpsg_edgeconv_fwd/bwd`` (K4b), which
+    fuses the neighbour gather, the BatchNorm statistics and the max over k without ever
+    materialising the ``[B,2C,N,k]`` edge tensor (2.7 GB at C=128, B=64 in the reference).
+    ``DGCNNfeat(fused=False)`` keeps the literal reference chain for parity tests.
+
+There is no CPU path for any of them (raises on CPU tensors).
 """
 from __future__ import annotations
 
@@ -91,14 +97,117 @@ def _edge_block(c_in: int, c_out: int) -> nn.Sequential:
                          nn.LeakyReLU(negative_slope=0.2))
 
 
+def _reverse_graph(idx32: torch.Tensor):
+    """Edges ``e = n*k + j`` grouped by destination ``idx[n,j]`` (stable sort => ascending ``e``
+    inside a group, so the backward's summation order is fixed): ``rev [B,N*k]`` int32 and
+    ``off [B,N+1]`` int32."""
+    B, N, k = idx32.shape
+    vals, order = torch.sort(idx32.reshape(B, N * k), dim=1, stable=True)
+    bounds = torch.arange(N + 1, device=idx32.device, dtype=vals.dtype).expand(B, N + 1).contiguous()
+    off = torch.searchsorted(vals.contiguous(), bounds)
+    return order.to(torch.int32).contiguous(), off.to(torch.int32).contiguous()
+
+
+class _EdgeConvBNMax(torch.autograd.Function):
+    """``out[b,n,c] = max_j LeakyReLU(BN(P[b,idx[b,n,j],c] + Q[b,n,c]))`` with training- or
+    eval-mode BatchNorm over all ``B*N*k`` edges; ``PQ [B,N,2Co]`` -> ``out [B,N,Co]``."""
+
+    @staticmethod
+    def forward(ctx, PQ, idx32, gamma, beta, running_mean, running_var, training, momentum, eps, slope):
+        _hip.dev_tensor(PQ, torch.float32, "PQ")
+        _hip.dev_tensor(idx32, torch.int32, "idx")
+        B, N, Co2 = PQ.shape
+        Co, k = Co2 // 2, idx32.size(2)
+        dev = PQ.device
+        lib = _hip.load()
+        sgn = torch.where(gamma.detach() < 0, -1.0, 1.0).to(torch.float32).contiguous()
+        ysel = torch.empty((B, N, Co), dtype=torch.float32, device=dev)
+        jsel = torch.empty((B, N, Co), dtype=torch.uint8, device=dev)
+        s1 = torch.empty((B, N, Co), dtype=torch.float32, device=dev) if training else None
+        part = (torch.empty((lib.fpsg_edgeconv_blocks(B, N), 2, Co), dtype=torch.float32, device=dev)
+                if training else None)
+        with torch.cuda.device(dev):
+            rc = lib.fpsg_edgeconv_fwd(_hip.ptr(PQ), _hip.ptr(idx32), _hip.ptr(sgn), B, N, k, Co,
+                                       _hip.ptr(ysel), _hip.ptr(jsel),
+                                       _hip.ptr(s1) if training else None,
+                                       _hip.ptr(part) if training else None, _hip.stream_of(PQ))
+        _hip.check(rc, "fpsg_edgeconv_fwd")
+        E = B * N * k
+        if training:
+            sums = part.double().sum(dim=0)                       # fixed-shape reduction
+            mean64 = sums[0] / E
+            var64 = (sums[1] / E - mean64 * mean64).clamp_min_(0.0)
+            mean, var = mean64.float(), var64.float()
+            with torch.no_grad():
+                running_mean.mul_(1 - momentum).add_(mean, alpha=momentum)
+                running_var.mul_(1 - momentum).add_(var * (E / max(E - 1, 1)), alpha=momentum)
+        else:
+            mean, var = running_mean, running_var
+        rstd = torch.rsqrt(var + eps)
+        scale = gamma * rstd
+        z = ysel * scale + (beta - mean * scale)
+        out = torch.where(z > 0, z, z * slope)
+        ctx.save_for_backward(PQ, idx32, ysel, jsel, s1 if training else ysel, mean, rstd, gamma, beta)
+        ctx.cfg = (training, slope, k)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        PQ, idx32, ysel, jsel, s1, mean, rstd, gamma, beta = ctx.saved_tensors
+        training, slope, k = ctx.cfg
+        B, N, Co2 = PQ.shape
+        Co = Co2 // 2
+        E = B * N * k
+        scale = gamma * rstd
+        z = ysel * scale + (beta - mean * scale)
+        dz = g * torch.where(z > 0, 1.0, slope)
+        yhat = (ysel - mean) * rstd
+        dbeta = dz.sum(dim=(0, 1))
+        dgamma = (dz * yhat).sum(dim=(0, 1))
+        dzs = (dz * scale).contiguous()
+        if training:
+            coef = torch.stack([scale * dbeta / E, scale * rstd * dgamma / E, mean]).contiguous()
+        else:
+            coef = torch.zeros((3, Co), dtype=torch.float32, device=PQ.device)
+        rev, off = _reverse_graph(idx32)
+        dPQ = torch.empty_like(PQ)
+        with torch.cuda.device(PQ.device):
+            rc = _hip.load().fpsg_edgeconv_bwd(_hip.ptr(dzs), _hip.ptr(jsel), _hip.ptr(PQ),
+                                               _hip.ptr(s1) if training else None, _hip.ptr(rev),
+                                               _hip.ptr(off), _hip.ptr(coef), B, N, k, Co,
+                                               _hip.ptr(dPQ), _hip.stream_of(PQ))
+        _hip.check(rc, "fpsg_edgeconv_bwd")
+        return dPQ, None, dgamma, dbeta, None, None, None, None, None, None
+
+
+def edgeconv_fused(x_pm: torch.Tensor, idx32: torch.Tensor, block: nn.Sequential) -> torch.Tensor:
+    """One EdgeConv layer on point-major features: ``x_pm [B,N,C]``, neighbour lists
+    ``idx32 [B,N,k]`` and the reference's ``Sequential(Conv2d(2C,Co,1,bias=False),
+    BatchNorm2d(Co), LeakyReLU(0.2))`` -> ``[B,N,Co]`` (= ``block(get_graph_feature(x)).max(-1)``
+    transposed)."""
+    conv, bn, act = block[0], block[1], block[2]
+    C = x_pm.size(2)
+    w = conv.weight.reshape(conv.out_channels, 2 * C)
+    wc = torch.cat((w[:, :C], w[:, C:] - w[:, :C]), dim=0)          # [2Co, C]: rows of P then Q
+    PQ = torch.matmul(x_pm, wc.t())                                  # [B,N,2Co], one GEMM
+    training = bn.training or (bn.running_mean is None)
+    if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked += 1
+    momentum = 0.1 if bn.momentum is None else bn.momentum
+    return _EdgeConvBNMax.apply(PQ.contiguous(), idx32, bn.weight, bn.bias, bn.running_mean,
+                                bn.running_var, training, momentum, bn.eps, act.negative_slope)
+
+
 class DGCNNfeat(nn.Module):
     """4 EdgeConv layers (k=20) -> concat -> 1x1 conv -> max||avg pool: ``[B,3,N] -> [B,1024]``."""
 
-    def __init__(self, embeding_dim: int = 1024, num_neighbors: int = 20, dual_pool: bool = True):
+    def __init__(self, embeding_dim: int = 1024, num_neighbors: int = 20, dual_pool: bool = True,
+                 fused: bool = True):
         super().__init__()
         self.dual_flag = dual_pool
         self.emb_dims = embeding_dim // 2 if dual_pool else embeding_dim
         self.k = num_neighbors
+        self.fused = fused
         self.conv1 = _edge_block(6, 64)
         self.conv2 = _edge_block(128, 64)
         self.conv3 = _edge_block(128, 128)
@@ -106,15 +215,37 @@ class DGCNNfeat(nn.Module):
         self.conv5 = nn.Sequential(nn.Conv1d(512, self.emb_dims, kernel_size=1, bias=False),
                                    nn.BatchNorm1d(self.emb_dims), nn.LeakyReLU(negative_slope=0.2))
 
-    def _edgeconv(self, block: nn.Sequential, x: torch.Tensor) -> torch.Tensor:
-        return block(get_graph_feature(x, k=self.k)).amax(dim=-1)
+    # -- literal reference chain (materialises [B,2C,N,k]); kept for parity tests -------------
+    def _edgeconv_unfused(self, block: nn.Sequential, x: torch.Tensor) -> torch.Tensor:
+        return block(get_graph_feature(x, k=self.k)).max(dim=-1, keepdim=False)[0]
 
-    def forward(self, x: torch.Tensor) -> torch.Tensor:
-        x1 = self._edgeconv(self.conv1, x)
-        x2 = self._edgeconv(self.conv2, x1)
-        x3 = self._edgeconv(self.conv3, x2)
-        x4 = self._edgeconv(self.conv4, x3)
+    def _forward_unfused(self, x: torch.Tensor) -> torch.Tensor:
+        x1 = self._edgeconv_unfused(self.conv1, x)
+        x2 = self._edgeconv_unfused(self.conv2, x1)
+        x3 = self._edgeconv_unfused(self.conv3, x2)
+        x4 = self._edgeconv_unfused(self.conv4, x3)
         h = self.conv5(torch.cat((x1, x2, x3, x4), dim=1))
         if self.dual_flag:
-            return torch.cat((h.amax(dim=2), h.mean(dim=2)), dim=1)
-        return h.amax(dim=2)
+            return torch.cat((h.max(dim=2)[0], h.mean(dim=2)), dim=1)
+        return h.max(dim=2)[0]
+
+    # -- fused path --------------------------------------------------------------------------
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if not self.fused:
+            return self._forward_unfused(x)
+        B, _, N = x.shape
+        x_cm = x.contiguous()                       # channel-major for the kNN kernel
+        x_pm = x_cm.transpose(1, 2).contiguous()    # point-major for the GEMM / gather
+        feats = []
+        for block in (self.conv1, self.conv2, self.conv3, self.conv4):
+            idx32 = knn_int32(x_cm, self.k)
+            x_pm = edgeconv_fused(x_pm, idx32, block)             # [B,N,Co]
+            feats.append(x_pm)
+            x_cm = x_pm.transpose(1, 2).contiguous()
+        cat = torch.cat(feats, dim=2)                              # [B,N,512]
+        conv5, bn5, act5 = self.conv5[0], self.conv5[1], self.conv5[2]
+        h = torch.matmul(cat, conv5.weight.squeeze(-1).t())       # Conv1d(512,emb,1) as a GEMM
+        h = act5(bn5(h.reshape(B * N, -1))).reshape(B, N, -1)     # BatchNorm1d over (B,N) rows
+        if self.dual_flag:
+            return torch.cat((h.max(dim=1)[0], h.mean(dim=1)), dim=1)
+        return h.max(dim=1)[0]

@@ -47,7 +47,7 @@ class STN3d(_PointTrunk):
         h = F.relu(self.bn1(self.conv1(x)))
         h = F.relu(self.bn2(self.conv2(h)))
         h = F.relu(self.bn3(self.conv3(h)))
-        h = h.amax(dim=2)
+        h = h.max(dim=2)[0]
         h = F.relu(self.bn4(self.fc1(h)))
         h = F.relu(self.bn5(self.fc2(h)))
         h = self.fc3(h)
@@ -76,4 +76,4 @@ class PointNetfeat(_PointTrunk):
         h = F.relu(self.bn1(self.conv1(h)))
         h = F.relu(self.bn2(self.conv2(h)))
         h = self.bn3(self.conv3(h))
-        return h.amax(dim=2), trans, None
+        return h.max(dim=2)[0], trans, None

@@ -108,3 +108,53 @@ def test_knn_rejects_bad_inputs(gpu):
         knn(torch.rand(1, 3, 10, device=gpu), 20)          # k > N
     with pytest.raises(FpsgHipError):
         knn(torch.rand(1, 3, 4096, device=gpu), 20)        # beyond the LDS tile limit
+
+
+@pytest.mark.parametrize("mode", ["train", "eval"])
+def test_fused_edgeconv_equals_reference_chain(gpu, mode):
+    """K4b (gather + BN statistics + max fused, nothing materialised) against the literal
+    reference chain get_graph_feature -> Conv2d -> BatchNorm2d -> LeakyReLU -> max (itself
+    checked against the reference goldens above): forward, running statistics, and the
+    gradients of the input and of every parameter."""
+    import copy
+    from fpsg_amd.dgcnn import DGCNNfeat
+    torch.manual_seed(3)
+    a = DGCNNfeat(fused=True)
+    a.load_state_dict(torch.load(os.path.join(GOLDEN, "dgcnn_state.pt"), weights_only=True))  # gammas of both signs
+    a = a.to(gpu)
+    b = copy.deepcopy(a)
+    b.fused = False
+    a.train(mode == "train"); b.train(mode == "train")
+    g = torch.Generator().manual_seed(9)
+    pts = torch.randn(4, 3, 320, generator=g)
+    pts = (pts / pts.norm(dim=1, keepdim=True).amax(dim=2, keepdim=True)).to(gpu)
+    xa = pts.clone().requires_grad_()
+    xb = pts.clone().requires_grad_()
+    fa, fb = a(xa), b(xb)
+    assert fa.shape == fb.shape == (4, 1024)
+    scale = fb.abs().max()
+    assert (fa - fb).abs().max() <= 2e-4 * scale, (fa - fb).abs().max() / scale
+    w = torch.randn(fa.shape, generator=g).to(gpu)
+    (fa * w).sum().backward()
+    (fb * w).sum().backward()
+    gs = xb.grad.abs().max()
+    assert (xa.grad - xb.grad).abs().max() <= 5e-3 * gs, (xa.grad - xb.grad).abs().max() / gs
+    for (n1, p1), (_, p2) in zip(a.named_parameters(), b.named_parameters()):
+        s = p2.grad.abs().max() + 1e-12
+        assert (p1.grad - p2.grad).abs().max() <= 5e-3 * s, (n1, float((p1.grad - p2.grad).abs().max() / s))
+    for (n1, b1), (_, b2) in zip(a.named_buffers(), b.named_buffers()):
+        assert torch.allclose(b1.float(), b2.float(), rtol=1e-4, atol=1e-5), n1
+
+
+def test_fused_edgeconv_is_deterministic(gpu):
+    from fpsg_amd.dgcnn import DGCNNfeat
+    torch.manual_seed(0)
+    net = DGCNNfeat().to(gpu).train()
+    x = torch.randn(3, 3, 512, device=gpu)
+    outs = []
+    for _ in range(2):
+        net.zero_grad()
+        xi = x.clone().requires_grad_()
+        net(xi).square().sum().backward()
+        outs.append((xi.grad.clone(), net.conv3[0].weight.grad.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
