@@ -29,6 +29,7 @@ SIGNATURES = {
                          _c_f32p, _c_i32p, _c_f32p, _c_i32p, _c_stream],
     "fpsg_chamfer_bwd": [_c_f32p, _c_f32p, _c_i32p, _c_i32p, _c_f32p, _c_f32p,
                          _c_int, _c_int, _c_int, _c_f32p, _c_f32p, _c_stream],
+    "fpsg_chamfer_set_config": [_c_int],
     "fpsg_knn": [_c_f32p, _c_int, _c_int, _c_int, _c_int, _c_i32p, _c_f32p, _c_stream],
     "fpsg_edge_feature_fwd": [_c_f32p, _c_i32p, _c_int, _c_int, _c_int, _c_int, _c_f32p, _c_stream],
     "fpsg_edge_feature_bwd": [_c_f32p, _c_i32p, _c_int, _c_int, _c_int, _c_int, _c_f32p, _c_stream],
@@ -41,7 +42,7 @@ SIGNATURES = {
     "fpsg_emd_approx": [_c_f32p, _c_f32p, _c_int, _c_int, _c_int, _c_f32p, _c_f32p, _c_f32p, _c_f32p,
                         _c_stream],
 }
-_RESTYPES = {"fpsg_last_error": ctypes.c_char_p, "fpsg_emd_workspace_floats": ctypes.c_size_t}
+_RESTYPES = {"fpsg_last_error": ctypes.c_char_p, "fpsg_chamfer_set_config": None, "fpsg_emd_workspace_floats": ctypes.c_size_t}
 
 _lib = None
 _lock = threading.Lock()

@@ -39,15 +39,26 @@ __device__ __forceinline__ float sq_dist(float qx, float qy, float qz, float cx,
 // LDS: [3][T] floats (SoA candidates, T a multiple of kChunk), then W*64*R 64-bit merge keys.
 template <int R, int W>
 __global__ __launch_bounds__(64 * W) void chamfer_fwd_kernel(
-    const float* __restrict__ xyz1, const float* __restrict__ xyz2, int N, int M, int T,
+    const float* __restrict__ xyz1, const float* __restrict__ xyz2, int N, int M, int T, int tiles,
     float* __restrict__ dist1, int32_t* __restrict__ idx1, float* __restrict__ dist2,
     int32_t* __restrict__ idx2) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int side = blockIdx.z;
-  const int b = blockIdx.y;
+  // XCD-aware work order: workgroups are dealt round-robin over the 8 XCDs (id % 8), each
+  // with its own L2.  Work items are listed cloud-pair-major (b, side, tile) and every XCD
+  // takes one contiguous chunk of that list, so the workgroups that re-read one pair's
+  // clouds share an L2 (speed only -- any placement gives the same results).
+  int work;
+  {
+    const int nwg = gridDim.x, id = blockIdx.x;
+    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = id & 7;
+    work = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (id >> 3);
+  }
+  const int tile = work % tiles;
+  const int side = (work / tiles) & 1;
+  const int b = work / (2 * tiles);
   const int nq = side ? M : N;
   const int nc = side ? N : M;
-  const int q_base = blockIdx.x * (64 * R);
+  const int q_base = tile * (64 * R);
   if (q_base >= nq) return;  // whole workgroup leaves together
 
   const float* __restrict__ Q = (side ? xyz2 : xyz1) + (size_t)b * nq * 3;
@@ -177,9 +188,10 @@ int launch_fwd(const float* xyz1, const float* xyz2, int B, int N, int M, float*
   int T = ((nmax + kChunk - 1) / kChunk) * kChunk;
   if (T > kTileMax) T = kTileMax;
   const size_t lds_bytes = (size_t)3 * T * sizeof(float) + (size_t)W * 64 * R * 8;
-  dim3 grid((nmax + 64 * R - 1) / (64 * R), B, 2);
+  const int tiles = (nmax + 64 * R - 1) / (64 * R);
+  dim3 grid((unsigned)((size_t)tiles * 2 * B));
   hipLaunchKernelGGL((chamfer_fwd_kernel<R, W>), grid, dim3(64 * W), lds_bytes, s, xyz1, xyz2,
-                     N, M, T, dist1, idx1, dist2, idx2);
+                     N, M, T, tiles, dist1, idx1, dist2, idx2);
   return launch_status("fpsg_chamfer_fwd");
 }
 
@@ -226,23 +238,31 @@ __global__ __launch_bounds__(kBwdThreads) void chamfer_bwd_kernel(
   for (int t0 = 0; t0 < nb; t0 += kBwdTile) {
     if (t0) __syncthreads();
     const int cnt = (nb - t0) < kBwdTile ? (nb - t0) : kBwdTile;
-    const int cnt4 = (cnt + 3) & ~3;
-    for (int e = threadIdx.x; e < cnt4; e += kBwdThreads) sidx[e] = e < cnt ? ib[t0 + e] : -2;
+    const int cnt16 = (cnt + 15) & ~15;
+    for (int e = threadIdx.x; e < cnt16; e += kBwdThreads) sidx[e] = e < cnt ? ib[t0 + e] : -2;
     __syncthreads();
     const v4i* s4 = reinterpret_cast<const v4i*>(sidx);
-    for (int e4 = 0; e4 < cnt4 / 4; ++e4) {
-      const v4i id = s4[e4];  // LDS broadcast: every lane reads the same 16 bytes
-      const bool m0 = id.x == me, m1 = id.y == me, m2 = id.z == me, m3 = id.w == me;
-      if (m0 | m1 | m2 | m3) {
+    for (int e16 = 0; e16 < cnt16 / 16; ++e16) {
+      // 16 indices per step: four independent LDS broadcast reads in flight
+      v4i id[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) id[u] = s4[e16 * 4 + u];
+      bool any = false;
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        any |= (id[u].x == me) | (id[u].y == me) | (id[u].z == me) | (id[u].w == me);
+      if (any) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-          const bool m = u == 0 ? m0 : u == 1 ? m1 : u == 2 ? m2 : m3;
-          if (m) {
-            const int j = t0 + e4 * 4 + u;
-            const float t = 2.0f * gb_up[j];
-            ax = fma_rn(t, px - Bc[3 * j + 0], ax);
-            ay = fma_rn(t, py - Bc[3 * j + 1], ay);
-            az = fma_rn(t, pz - Bc[3 * j + 2], az);
+#pragma unroll
+          for (int w = 0; w < 4; ++w) {
+            if (id[u][w] == me) {      // ascending j: the summation order of the oracle
+              const int j = t0 + e16 * 16 + u * 4 + w;
+              const float t = 2.0f * gb_up[j];
+              ax = fma_rn(t, px - Bc[3 * j + 0], ax);
+              ay = fma_rn(t, py - Bc[3 * j + 1], ay);
+              az = fma_rn(t, pz - Bc[3 * j + 2], az);
+            }
           }
         }
       }
@@ -258,25 +278,37 @@ __global__ __launch_bounds__(kBwdThreads) void chamfer_bwd_kernel(
 }  // namespace
 }  // namespace fpsg
 
+// tuning hook (tools/bench_chamfer.py): -1 = automatic choice of (R, W)
+static int fpsg_chamfer_cfg_override = -1;
+
 extern "C" int fpsg_chamfer_fwd(const float* xyz1, const float* xyz2, int B, int N, int M,
                                 float* dist1, int32_t* idx1, float* dist2, int32_t* idx2,
                                 fpsg_stream_t stream) {
   using namespace fpsg;
   FPSG_REQUIRE(B > 0 && N > 0 && M > 0, FPSG_E_SHAPE,
                "fpsg_chamfer_fwd: B,N,M must be positive (got %d,%d,%d)", B, N, M);
-  FPSG_REQUIRE(B <= 65535, FPSG_E_LIMIT, "fpsg_chamfer_fwd: B=%d exceeds 65535", B);
+  FPSG_REQUIRE((long)B * ((N > M ? N : M) / 64 + 1) * 2 < (1L << 31), FPSG_E_LIMIT,
+               "fpsg_chamfer_fwd: B=%d x N=%d exceeds the grid limit", B, N > M ? N : M);
   FPSG_REQUIRE_PTR(xyz1); FPSG_REQUIRE_PTR(xyz2);
   FPSG_REQUIRE_PTR(dist1); FPSG_REQUIRE_PTR(idx1);
   FPSG_REQUIRE_PTR(dist2); FPSG_REQUIRE_PTR(idx2);
   hipStream_t s = static_cast<hipStream_t>(stream);
-  // Pick queries-per-lane R and waves-per-workgroup W so that the launch has >= ~2-4
-  // waves per SIMD (1024 SIMDs): total waves = 2 sides * B * ceil(n/(64R)) * W.
-  const long pts = (long)B * ((long)N + (long)M);  // query lanes over both sides
-  if (pts >= 64L * 2048 * 8) return launch_fwd<8, 4>(xyz1, xyz2, B, N, M, dist1, idx1, dist2, idx2, s);
-  if (pts >= 64L * 2048 * 2) return launch_fwd<4, 8>(xyz1, xyz2, B, N, M, dist1, idx1, dist2, idx2, s);
-  if (pts >= 64L * 256) return launch_fwd<2, 16>(xyz1, xyz2, B, N, M, dist1, idx1, dist2, idx2, s);
-  return launch_fwd<1, 16>(xyz1, xyz2, B, N, M, dist1, idx1, dist2, idx2, s);
+  int cfg = fpsg_chamfer_cfg_override;
+  if (cfg < 0) {
+    // Queries per lane R and waves per workgroup W: enough waves to fill 1024 SIMDs at >= 2-4
+    // waves each, as much per-wave work as that allows (launch = 2 * B * ceil(n/(64R)) * W waves).
+    const long pts = (long)B * ((long)N + (long)M);  // query lanes over both sides
+    cfg = pts >= 64L * 2048 * 8 ? 3 : pts >= 64L * 2048 ? 2 : pts >= 64L * 256 ? 1 : 0;
+  }
+  switch (cfg) {
+    case 3: return launch_fwd<8, 4>(xyz1, xyz2, B, N, M, dist1, idx1, dist2, idx2, s);
+    case 2: return launch_fwd<4, 8>(xyz1, xyz2, B, N, M, dist1, idx1, dist2, idx2, s);
+    case 1: return launch_fwd<2, 16>(xyz1, xyz2, B, N, M, dist1, idx1, dist2, idx2, s);
+    default: return launch_fwd<1, 16>(xyz1, xyz2, B, N, M, dist1, idx1, dist2, idx2, s);
+  }
 }
+
+extern "C" void fpsg_chamfer_set_config(int cfg) { fpsg_chamfer_cfg_override = cfg; }
 
 extern "C" int fpsg_chamfer_bwd(const float* xyz1, const float* xyz2, const int32_t* idx1,
                                 const int32_t* idx2, const float* g1, const float* g2, int B,

@@ -52,6 +52,11 @@ int fpsg_chamfer_fwd(const float* xyz1, const float* xyz2, int B, int N, int M,
                      float* dist1, int32_t* idx1, float* dist2, int32_t* idx2,
                      fpsg_stream_t stream);
 
+/* Tuning hook for micro-benchmarks: force the forward kernel's (queries per lane, waves per
+ * workgroup) variant: 0=(1,16) 1=(2,16) 2=(4,8) 3=(8,4); -1 (default) = automatic.  Results do
+ * not depend on it. */
+void fpsg_chamfer_set_config(int cfg);
+
 /* Backward of the two sided distances w.r.t. both clouds (Kaolin's
  * sided_distance backward, reached through autograd from
  * src/trainNetwork.py:144 `ttl_loss.backward()`).

@@ -20,6 +20,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reps", type=int, default=200)
     ap.add_argument("--n", type=int, default=2048)
+    ap.add_argument("--sweep", action="store_true", help="time every (R,W) variant of the forward kernel")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     lib = _hip.load()
@@ -42,7 +43,11 @@ def main():
             return lib.fpsg_chamfer_bwd(p1.data_ptr(), p2.data_ptr(), i1.data_ptr(), i2.data_ptr(), g1.data_ptr(),
                                         g2.data_ptr(), B, N, M, gx1.data_ptr(), gx2.data_ptr(), s)
 
-        for name, fn, nbytes in (("fwd", fwd, FWD_BYTES), ("bwd", bwd, BWD_BYTES)):
+        runs = [("fwd", fwd, FWD_BYTES, -1), ("bwd", bwd, BWD_BYTES, -1)]
+        if args.sweep:
+            runs = [(f"fwd[cfg{c}]", fwd, FWD_BYTES, c) for c in range(4)] + runs
+        for name, fn, nbytes, cfg in runs:
+            lib.fpsg_chamfer_set_config(cfg)
             for _ in range(20):
                 assert fn() == 0
             torch.cuda.synchronize()
@@ -54,7 +59,7 @@ def main():
             t = e0.elapsed_time(e1) * 1e-3 / args.reps
             gbps = B * nbytes * scale / t / 1e9
             line = f"{name} B={B:5d} N={N}: {t*1e6:9.2f} us  {gbps:8.1f} GB/s ({gbps*1e9/PEAK_HBM*100:5.2f}% HBM)"
-            if name == "fwd":
+            if name.startswith("fwd"):
                 tf = B * PAIRS * scale * scale * 8 / t
                 line += f"  {tf/1e12:7.2f} TFLOP/s ({tf/PEAK_F32*100:5.1f}% fp32 peak)  {B*PAIRS*scale*scale/t/1e12:6.3f} Tpair/s"
             print(line, flush=True)
