@@ -104,11 +104,28 @@ __global__ __launch_bounds__(64 * W) void chamfer_fwd_kernel(
     const int remain = nc - t0;
     const int valid = (remain < T ? remain : T) * 3;
     const float* __restrict__ src = C + (size_t)t0 * 3;
-    for (int e = tid; e < 3 * T; e += 64 * W) {
-      float v = e < valid ? src[e] : __builtin_inff();
-      int j = e / 3;
-      int c = e - 3 * j;
-      lds[c * T + j] = v;
+    if (((reinterpret_cast<uintptr_t>(src) & 15) == 0) && ((valid & 3) == 0)) {
+      // 16-byte loads of the AoS stream; each float lands in its SoA row
+      const v4f* __restrict__ src4 = reinterpret_cast<const v4f*>(src);
+      for (int e4 = tid; e4 < (3 * T) / 4; e4 += 64 * W) {
+        const int e = 4 * e4;
+        v4f v = {__builtin_inff(), __builtin_inff(), __builtin_inff(), __builtin_inff()};
+        if (e < valid) v = src4[e4];
+        int j = e / 3;
+        int c = e - 3 * j;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          lds[c * T + j] = v[u];
+          if (++c == 3) { c = 0; ++j; }
+        }
+      }
+    } else {
+      for (int e = tid; e < 3 * T; e += 64 * W) {
+        float v = e < valid ? src[e] : __builtin_inff();
+        int j = e / 3;
+        int c = e - 3 * j;
+        lds[c * T + j] = v;
+      }
     }
     __syncthreads();
 
@@ -165,16 +182,35 @@ __global__ __launch_bounds__(64 * W) void chamfer_fwd_kernel(
       key = k2 < key ? k2 : key;
     }
     // exact index inside the winning chunk: same arithmetic, strict '<', ascending j
-    const int j0 = (int)(unsigned)(key & 0xffffffffull) * kChunk;
-    const int j1 = (j0 + kChunk) < nc ? (j0 + kChunk) : nc;
+    const int chunk = (int)(unsigned)(key & 0xffffffffull);
+    const int j0 = chunk * kChunk;
     const float x = Q[3 * q + 0], y = Q[3 * q + 1], z = Q[3 * q + 2];
     float bd = __builtin_inff();
     int bi = 0;
-    for (int j = j0; j < j1; ++j) {
-      float d = sq_dist(x, y, z, C[3 * j + 0], C[3 * j + 1], C[3 * j + 2]);
-      bool lt = d < bd;
-      bi = lt ? j : bi;
-      bd = lt ? d : bd;
+    if (nc <= T) {
+      // the single staged tile still holds every candidate (+inf padded): 12 wide LDS reads
+      const v4f* px = reinterpret_cast<const v4f*>(lx + j0);
+      const v4f* py = reinterpret_cast<const v4f*>(ly + j0);
+      const v4f* pz = reinterpret_cast<const v4f*>(lz + j0);
+#pragma unroll
+      for (int g = 0; g < kChunk / 4; ++g) {
+        const v4f X = px[g], Y = py[g], Z = pz[g];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const float d = sq_dist(x, y, z, X[u], Y[u], Z[u]);
+          const bool lt = d < bd;
+          bi = lt ? j0 + 4 * g + u : bi;
+          bd = lt ? d : bd;
+        }
+      }
+    } else {
+      const int j1 = (j0 + kChunk) < nc ? (j0 + kChunk) : nc;
+      for (int j = j0; j < j1; ++j) {
+        float d = sq_dist(x, y, z, C[3 * j + 0], C[3 * j + 1], C[3 * j + 2]);
+        bool lt = d < bd;
+        bi = lt ? j : bi;
+        bd = lt ? d : bd;
+      }
     }
     dist[q] = bd;
     idx[q] = bi;
