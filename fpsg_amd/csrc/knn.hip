@@ -2,16 +2,21 @@
 // Replaces `knn` of reference src/dgcnn/model.py:13-20 (torch.matmul of x^T x into a
 // [B,N,N] tensor + torch.topk): here the N x N matrix never reaches HBM.
 //
-// One workgroup (4 waves) owns 16 query points of one cloud:
+// One workgroup (4 waves, one per SIMD) owns 16 query points of one cloud:
 //   phase A  the 16 x N block of  pd_ij = (-|x_j|^2 + 2 x_i.x_j) - |x_i|^2  is produced with
 //            fp32-input MFMA (v_mfma_f32_16x16x4_f32: exact k-ordered fma chain, same
-//            64 FLOP/clk/SIMD as the VALU) -- A = the 16 queries (staged once in LDS),
-//            B = 16 candidates straight from global/L2 (coalesced 64-B segments of the
-//            channel-major x), accumulator carried over C/4 steps -- and written to a
-//            16 x N fp32 tile in LDS (128 KiB at N = 2048);
-//   phase B  each wave selects the k largest of 4 rows: every lane keeps N/64 values in
-//            registers, k rounds of {lane-local best, wave-wide 64-bit (value, ~index)
-//            max via cross-lane shuffles, retire the winner}.  Ties go to the lower index.
+//            64 FLOP/clk/SIMD as the VALU).  A = the 16 queries, held in registers for the
+//            whole workgroup lifetime; B = 16 candidates per tile, 64-B segments of the
+//            channel-major rows served from L2, prefetched TWO tiles ahead into a rotating
+//            set of three register buffers so that the ~1 us L2 latency hides under the MFMA
+//            chains of the tiles in flight; the accumulator is carried over C/4 steps.
+//            Scores go to a 16 x N fp32 tile in LDS (128 KiB at N = 2048), never to HBM.
+//   phase B  each wave selects the k largest of 4 rows, all 4 interleaved for ILP.  A lane
+//            holds N/64 scores of each row in registers, in groups of 8 with cached group
+//            maxima.  A round = best of the lane's group maxima, wave-wide argmax with DPP
+//            row operations (value max, then lowest index among the lanes that hold it: ties
+//            go to the lower index), then only the winner's group -- wave-uniform, so a
+//            scalar branch -- is rescanned.  No LDS traffic inside the rounds.
 // Results are bit-identical to oracle_knn (same fma chains, same tie rule).
 #include "fpsg_common.h"
 
@@ -20,6 +25,7 @@ namespace {
 
 constexpr int kQ = 16;            // query rows per workgroup (= MFMA M)
 constexpr int kKnnThreads = 256;
+constexpr int kGroup = 8;         // scores per cached-maximum group in phase B
 
 __global__ __launch_bounds__(256) void sqnorm_kernel(const float* __restrict__ x, int C, int N,
                                                      float* __restrict__ xx) {
@@ -35,118 +41,232 @@ __global__ __launch_bounds__(256) void sqnorm_kernel(const float* __restrict__ x
   xx[(size_t)b * N + j] = acc;
 }
 
-__device__ __forceinline__ unsigned orderable(float f) {
-  const unsigned u = __float_as_uint(f);
-  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+// ---- wave-wide reductions with DPP row operations (gfx9 encodings) ----------------------
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_i(int self) {
+  return __builtin_amdgcn_update_dpp(self, self, CTRL, ROW_MASK, 0xF, false);
+}
+__device__ __forceinline__ float wave_max_f32(float x) {
+#define FPSG_STEP(CTRL, RM) x = __builtin_fmaxf(x, __int_as_float(dpp_i<CTRL, RM>(__float_as_int(x))))
+  FPSG_STEP(0xB1, 0xF);    // quad_perm [1,0,3,2]
+  FPSG_STEP(0x4E, 0xF);    // quad_perm [2,3,0,1]
+  FPSG_STEP(0x141, 0xF);   // row_half_mirror
+  FPSG_STEP(0x140, 0xF);   // row_mirror          -> every row of 16 lanes is uniform
+  FPSG_STEP(0x142, 0xA);   // row_bcast15 into rows 1,3
+  FPSG_STEP(0x143, 0xC);   // row_bcast31 into rows 2,3 -> lane 63 holds the wave maximum
+#undef FPSG_STEP
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 63));
+}
+__device__ __forceinline__ unsigned wave_min_u32(unsigned x) {
+#define FPSG_STEP(CTRL, RM) { const unsigned o = (unsigned)dpp_i<CTRL, RM>((int)x); x = o < x ? o : x; }
+  FPSG_STEP(0xB1, 0xF);
+  FPSG_STEP(0x4E, 0xF);
+  FPSG_STEP(0x141, 0xF);
+  FPSG_STEP(0x140, 0xF);
+  FPSG_STEP(0x142, 0xA);
+  FPSG_STEP(0x143, 0xC);
+#undef FPSG_STEP
+  return (unsigned)__builtin_amdgcn_readlane((int)x, 63);
 }
 
-// LDS: pd[kQ][ldp] floats, then qa[C4*4][16] floats (the 16 queries, channel-major, zero
-// padded to a multiple of 4 channels).
-template <int VPL>
+// ---- phase A helpers --------------------------------------------------------------------
+template <int C4T>
+__device__ __forceinline__ void load_b(const float* __restrict__ xb, int C, int N, int tile, int kk,
+                                       int col, float (&b)[C4T]) {
+  const int j = tile * 16 + col;
+  const bool jin = j < N;   // also false for tiles past the end: no loads are issued
+#pragma unroll
+  for (int c4 = 0; c4 < C4T; ++c4) {
+    const int c = 4 * c4 + kk;
+    b[c4] = (jin && c < C) ? xb[(size_t)c * N + j] : 0.0f;
+  }
+}
+
+template <int C4T>
+__device__ __forceinline__ void score_tile(const float (&a)[C4T], const float (&b)[C4T], int tile,
+                                           int N, int kk, int col, const float* __restrict__ xxb,
+                                           const float (&xxq)[4], float* __restrict__ pd, int ldp) {
+  v4f acc = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+  for (int c4 = 0; c4 < C4T; ++c4) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c4], b[c4], acc, 0, 0, 0);
+  const int j = tile * 16 + col;
+  const bool jin = j < N;
+  const float xxj = jin ? xxb[j] : 0.0f;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    // D layout: column = lane&15 (candidate), row = 4*(lane>>4) + r (query)
+    const float v = fma_rn(2.0f, acc[r], -xxj) - xxq[r];
+    pd[(4 * kk + r) * ldp + j] = jin ? v : -__builtin_inff();
+  }
+}
+
+// LDS: pd[kQ][ldp] floats (+ qa[C4*4][16] floats for the generic-C path).
+// C4T > 0: compile-time channel steps (C <= 4*C4T), register-resident operands.
+// C4T == 0: any C, operands re-read per step (slow path for unusual channel counts).
+template <int VPL, int C4T>
 __global__ __launch_bounds__(kKnnThreads) void knn_kernel(const float* __restrict__ x,
                                                           const float* __restrict__ xx, int C,
                                                           int N, int k, int ldp,
                                                           int32_t* __restrict__ idx) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* pd = lds;
-  float* qa = lds + (size_t)kQ * ldp;
-
   const int b = blockIdx.y;
   const int i0 = blockIdx.x * kQ;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int C4 = (C + 3) >> 2;
   const float* __restrict__ xb = x + (size_t)b * C * N;
   const float* __restrict__ xxb = xx + (size_t)b * N;
-
-  // ---- stage the 16 queries: qa[c][q] = x[c][i0+q] (0 beyond C or N)
-  for (int e = tid; e < C4 * 4 * kQ; e += kKnnThreads) {
-    const int c = e >> 4, q = e & 15;
-    qa[e] = (c < C && i0 + q < N) ? xb[(size_t)c * N + i0 + q] : 0.0f;
-  }
-  __syncthreads();
-
-  // ---- phase A: tiles of 16 candidates, interleaved over the 4 waves
   const int kk = lane >> 4;       // k index inside an MFMA step (0..3)
   const int col = lane & 15;      // candidate column of this lane / query row for A
+  const int n_tiles = (N + 15) >> 4;
   float xxq[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int q = i0 + 4 * kk + r;
     xxq[r] = q < N ? xxb[q] : 0.0f;
   }
-  const int n_tiles = (N + 15) >> 4;
-  for (int t = wave; t < n_tiles; t += 4) {
-    const int j = t * 16 + col;
-    const bool jin = j < N;
-    const float* __restrict__ bp = xb + (jin ? j : 0);
-    v4f acc = {0.0f, 0.0f, 0.0f, 0.0f};
-    for (int c4 = 0; c4 < C4; ++c4) {
-      const int c = 4 * c4 + kk;
-      const float a = qa[c * kQ + col];
-      const float bv = (jin && c < C) ? bp[(size_t)c * N] : 0.0f;
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv, acc, 0, 0, 0);
-    }
-    const float xxj = jin ? xxb[j] : 0.0f;
+
+  // ---------------------------------------------------------------- phase A
+  if constexpr (C4T > 0) {
+    float a[C4T], b0[C4T], b1[C4T], b2[C4T];
+    {
+      const int q = i0 + col;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      // D layout: column = lane&15 (candidate), row = 4*(lane>>4) + r (query)
-      const float v = fma_rn(2.0f, acc[r], -xxj) - xxq[r];
-      pd[(4 * kk + r) * ldp + j] = jin ? v : -__builtin_inff();
+      for (int c4 = 0; c4 < C4T; ++c4) {
+        const int c = 4 * c4 + kk;
+        a[c4] = (c < C && q < N) ? xb[(size_t)c * N + q] : 0.0f;
+      }
+    }
+    load_b<C4T>(xb, C, N, wave, kk, col, b0);
+    load_b<C4T>(xb, C, N, wave + 4, kk, col, b1);
+    for (int t = wave; t < n_tiles; t += 12) {
+      load_b<C4T>(xb, C, N, t + 8, kk, col, b2);
+      score_tile<C4T>(a, b0, t, N, kk, col, xxb, xxq, pd, ldp);
+      if (t + 4 < n_tiles) {
+        load_b<C4T>(xb, C, N, t + 12, kk, col, b0);
+        score_tile<C4T>(a, b1, t + 4, N, kk, col, xxb, xxq, pd, ldp);
+      }
+      if (t + 8 < n_tiles) {
+        load_b<C4T>(xb, C, N, t + 16, kk, col, b1);
+        score_tile<C4T>(a, b2, t + 8, N, kk, col, xxb, xxq, pd, ldp);
+      }
+    }
+  } else {
+    float* qa = lds + (size_t)kQ * ldp;
+    const int C4 = (C + 3) >> 2;
+    for (int e = tid; e < C4 * 4 * kQ; e += kKnnThreads) {
+      const int c = e >> 4, q = e & 15;
+      qa[e] = (c < C && i0 + q < N) ? xb[(size_t)c * N + i0 + q] : 0.0f;
+    }
+    __syncthreads();
+    for (int t = wave; t < n_tiles; t += 4) {
+      const int j = t * 16 + col;
+      const bool jin = j < N;
+      const float* __restrict__ bp = xb + (jin ? j : 0);
+      v4f acc = {0.0f, 0.0f, 0.0f, 0.0f};
+      for (int c4 = 0; c4 < C4; ++c4) {
+        const int c = 4 * c4 + kk;
+        const float av = qa[c * kQ + col];
+        const float bv = (jin && c < C) ? bp[(size_t)c * N] : 0.0f;
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
+      }
+      const float xxj = jin ? xxb[j] : 0.0f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float v = fma_rn(2.0f, acc[r], -xxj) - xxq[r];
+        pd[(4 * kk + r) * ldp + j] = jin ? v : -__builtin_inff();
+      }
     }
   }
   __syncthreads();
 
-  // ---- phase B: wave w selects rows 4w .. 4w+3
+  // ---------------------------------------------------------------- phase B
+  // wave w selects rows 4w .. 4w+3 together; VPL scores per lane and row, groups of 8
+  constexpr int NG = VPL / kGroup;
   const int n_cols = n_tiles * 16;
+  float v[4][VPL];
+  float gmax[4][NG];
+  int gt[4][NG];
+  int mine[4];
+#pragma unroll
   for (int rr = 0; rr < 4; ++rr) {
     const int q = 4 * wave + rr;
-    const int i = i0 + q;
-    if (i >= N) break;  // wave-uniform
-    float v[VPL];
+    mine[rr] = 0;
 #pragma unroll
     for (int t = 0; t < VPL; ++t) {
       const int e = t * 64 + lane;
-      v[t] = e < n_cols ? pd[q * ldp + e] : -__builtin_inff();
+      v[rr][t] = e < n_cols ? pd[q * ldp + e] : -__builtin_inff();
     }
-    int mine = 0;
-    int wt = -1;  // slot retired in this lane at the start of the next round
-    for (int round = 0; round < k; ++round) {
-      float bv = -__builtin_inff();
-      int bt = 0;
 #pragma unroll
-      for (int t = 0; t < VPL; ++t) {
-        const float cur = (t == wt) ? -__builtin_inff() : v[t];
-        v[t] = cur;
-        const bool gt = cur > bv || t == 0;
-        bt = gt ? t : bt;
-        bv = gt ? cur : bv;
+    for (int g = 0; g < NG; ++g) {
+      float m = v[rr][g * kGroup];
+      int mt = g * kGroup;
+#pragma unroll
+      for (int u = 1; u < kGroup; ++u) {
+        const bool gtr = v[rr][g * kGroup + u] > m;   // strict: lower slot wins ties
+        mt = gtr ? g * kGroup + u : mt;
+        m = gtr ? v[rr][g * kGroup + u] : m;
       }
+      gmax[rr][g] = m;
+      gt[rr][g] = mt;
+    }
+  }
+  for (int round = 0; round < k; ++round) {
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      float bv = gmax[rr][0];
+      int bt = gt[rr][0];
+#pragma unroll
+      for (int g = 1; g < NG; ++g) {
+        const bool gtr = gmax[rr][g] > bv;
+        bt = gtr ? gt[rr][g] : bt;
+        bv = gtr ? gmax[rr][g] : bv;
+      }
+      const float m = wave_max_f32(bv);
       const unsigned e = (unsigned)(bt * 64 + lane);
-      unsigned long long key = ((unsigned long long)orderable(bv) << 32) | (unsigned)(~e);
+      const unsigned win = wave_min_u32(bv == m ? e : 0xffffffffu);   // lowest index among maxima
+      mine[rr] = (lane == round) ? (int)win : mine[rr];
+      // retire the winner: only its group (wave-uniform) is rescanned
+      const int wl = (int)(win & 63u), wt = (int)(win >> 6);
+      const int wg = __builtin_amdgcn_readfirstlane(wt / kGroup);
+      const bool me = lane == wl;
 #pragma unroll
-      for (int off = 32; off >= 1; off >>= 1) {
-        const unsigned long long o = __shfl_xor(key, off, 64);
-        key = o > key ? o : key;
+      for (int g = 0; g < NG; ++g) {
+        if (g == wg) {
+          float mm = -__builtin_inff();
+          int mt = g * kGroup;
+#pragma unroll
+          for (int u = 0; u < kGroup; ++u) {
+            const int t = g * kGroup + u;
+            const float cur = (me && t == wt) ? -__builtin_inff() : v[rr][t];
+            v[rr][t] = cur;
+            const bool gtr = cur > mm || u == 0;
+            mt = gtr ? t : mt;
+            mm = gtr ? cur : mm;
+          }
+          gmax[rr][g] = mm;
+          gt[rr][g] = mt;
+        }
       }
-      const unsigned win = ~(unsigned)(key & 0xffffffffull);
-      wt = ((int)(win & 63u) == lane) ? (int)(win >> 6) : -1;
-      mine = (lane == round) ? (int)win : mine;
     }
-    if (lane < k) idx[((size_t)b * N + i) * k + lane] = mine;
+  }
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr) {
+    const int i = i0 + 4 * wave + rr;
+    if (i < N && lane < k) idx[((size_t)b * N + i) * k + lane] = mine[rr];
   }
 }
 
-template <int VPL>
+template <int VPL, int C4T>
 int launch_knn(const float* x, const float* xx, int B, int C, int N, int k, int32_t* idx,
                hipStream_t s) {
   const int n_tiles = (N + 15) / 16;
   const int ldp = n_tiles * 16 + 4;  // +4: the 4 query rows a lane group writes hit disjoint banks
   const int C4 = (C + 3) / 4;
-  const size_t lds_bytes = ((size_t)kQ * ldp + (size_t)C4 * 4 * kQ) * sizeof(float);
+  const size_t lds_bytes = ((size_t)kQ * ldp + (C4T == 0 ? (size_t)C4 * 4 * kQ : 0)) * sizeof(float);
   dim3 grid((N + kQ - 1) / kQ, B);
-  auto kern = knn_kernel<VPL>;
+  auto kern = knn_kernel<VPL, C4T>;
   // one-time opt-in to the full 160 KiB of LDS for this instantiation (per process)
   static const hipError_t lds_optin = hipFuncSetAttribute(
       reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -156,6 +276,15 @@ int launch_knn(const float* x, const float* xx, int B, int C, int N, int k, int3
   }
   hipLaunchKernelGGL(kern, grid, dim3(kKnnThreads), lds_bytes, s, x, xx, C, N, k, ldp, idx);
   return launch_status("fpsg_knn");
+}
+
+template <int VPL>
+int launch_knn_c(const float* x, const float* xx, int B, int C, int N, int k, int32_t* idx,
+                 hipStream_t s) {
+  if (C <= 4) return launch_knn<VPL, 1>(x, xx, B, C, N, k, idx, s);
+  if (C > 32 && C <= 64) return launch_knn<VPL, 16>(x, xx, B, C, N, k, idx, s);
+  if (C > 64 && C <= 128) return launch_knn<VPL, 32>(x, xx, B, C, N, k, idx, s);
+  return launch_knn<VPL, 0>(x, xx, B, C, N, k, idx, s);
 }
 
 }  // namespace
@@ -180,9 +309,8 @@ extern "C" int fpsg_knn(const float* x, int B, int C, int N, int k, int32_t* idx
   int rc = launch_status("fpsg_knn(sqnorm)");
   if (rc) return rc;
   const int vpl = (((N + 15) / 16) * 16 + 63) / 64;
-  if (vpl <= 4) return launch_knn<4>(x, sqnorm_ws, B, C, N, k, idx, s);
-  if (vpl <= 8) return launch_knn<8>(x, sqnorm_ws, B, C, N, k, idx, s);
-  if (vpl <= 16) return launch_knn<16>(x, sqnorm_ws, B, C, N, k, idx, s);
-  if (vpl <= 32) return launch_knn<32>(x, sqnorm_ws, B, C, N, k, idx, s);
-  return launch_knn<40>(x, sqnorm_ws, B, C, N, k, idx, s);
+  if (vpl <= 8) return launch_knn_c<8>(x, sqnorm_ws, B, C, N, k, idx, s);
+  if (vpl <= 16) return launch_knn_c<16>(x, sqnorm_ws, B, C, N, k, idx, s);
+  if (vpl <= 32) return launch_knn_c<32>(x, sqnorm_ws, B, C, N, k, idx, s);
+  return launch_knn_c<40>(x, sqnorm_ws, B, C, N, k, idx, s);
 }
