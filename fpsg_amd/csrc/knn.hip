@@ -12,12 +12,11 @@
 //            chains of the tiles in flight; the accumulator is carried over C/4 steps.
 //            Scores go to a 16 x N fp32 tile in LDS (128 KiB at N = 2048), never to HBM.
 //   phase B  each wave selects the k largest of 4 rows, all 4 interleaved for ILP.  A lane
-//            owns N/64 scores of each row (left in the LDS tile, conflict-free 4-byte
-//            accesses) in groups of 8 whose maxima are cached in registers.  A round = best of
-//            the lane's group maxima, wave-wide argmax with DPP row operations (value max,
-//            then lowest index among the lanes that hold it: ties go to the lower index), the
-//            winner is overwritten with -inf in LDS and only its group (a wave-uniform id) is
-//            re-read: 8 LDS reads per round and row, branch-free.
+//            holds N/64 scores of each row in registers, in groups of 8 with cached group
+//            maxima.  A round = best of the lane's group maxima, wave-wide argmax with DPP
+//            row operations (value max, then lowest index among the lanes that hold it: ties
+//            go to the lower index), then only the winner's group -- wave-uniform, so a
+//            scalar branch -- is rescanned.  No LDS traffic inside the rounds.
 // Results are bit-identical to oracle_knn (same fma chains, same tie rule).
 #include "fpsg_common.h"
 
@@ -183,37 +182,37 @@ __global__ __launch_bounds__(kKnnThreads) void knn_kernel(const float* __restric
   __syncthreads();
 
   // ---------------------------------------------------------------- phase B
-  // wave w selects rows 4w .. 4w+3 together.  Lane l owns the scores e = t*64 + l (t < VPL) of
-  // each row, in groups of 8 slots; only the group maxima live in registers, the scores stay
-  // in the LDS tile (consecutive lanes -> consecutive banks: conflict-free 4-byte accesses).
+  // wave w selects rows 4w .. 4w+3 together; VPL scores per lane and row, groups of 8
   constexpr int NG = VPL / kGroup;
   const int n_cols = n_tiles * 16;
+  float v[4][VPL];
   float gmax[4][NG];
   int gt[4][NG];
   int mine[4];
 #pragma unroll
   for (int rr = 0; rr < 4; ++rr) {
-    const float* row = pd + (4 * wave + rr) * ldp;
+    const int q = 4 * wave + rr;
     mine[rr] = 0;
 #pragma unroll
+    for (int t = 0; t < VPL; ++t) {
+      const int e = t * 64 + lane;
+      v[rr][t] = e < n_cols ? pd[q * ldp + e] : -__builtin_inff();
+    }
+#pragma unroll
     for (int g = 0; g < NG; ++g) {
-      float m = -__builtin_inff();
+      float m = v[rr][g * kGroup];
       int mt = g * kGroup;
 #pragma unroll
-      for (int u = 0; u < kGroup; ++u) {
-        const int t = g * kGroup + u;
-        const int e = t * 64 + lane;
-        const float cur = e < n_cols ? row[e] : -__builtin_inff();
-        const bool gtr = cur > m || u == 0;   // strict: lower slot wins ties
-        mt = gtr ? t : mt;
-        m = gtr ? cur : m;
+      for (int u = 1; u < kGroup; ++u) {
+        const bool gtr = v[rr][g * kGroup + u] > m;   // strict: lower slot wins ties
+        mt = gtr ? g * kGroup + u : mt;
+        m = gtr ? v[rr][g * kGroup + u] : m;
       }
       gmax[rr][g] = m;
       gt[rr][g] = mt;
     }
   }
   for (int round = 0; round < k; ++round) {
-    unsigned win[4];
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) {
       float bv = gmax[rr][0];
@@ -226,32 +225,29 @@ __global__ __launch_bounds__(kKnnThreads) void knn_kernel(const float* __restric
       }
       const float m = wave_max_f32(bv);
       const unsigned e = (unsigned)(bt * 64 + lane);
-      win[rr] = wave_min_u32(bv == m ? e : 0xffffffffu);   // lowest index among the maxima
-      mine[rr] = (lane == round) ? (int)win[rr] : mine[rr];
-      // retire the winner in LDS (one lane writes; the same wave reads it back below)
-      if (lane == (int)(win[rr] & 63u)) pd[(4 * wave + rr) * ldp + win[rr]] = -__builtin_inff();
-    }
-    // every lane rescans, for each row, its own copy of the winner's group (wave-uniform
-    // group id, so the slot addresses differ only by the lane): 8 LDS reads per row
-#pragma unroll
-    for (int rr = 0; rr < 4; ++rr) {
-      const float* row = pd + (4 * wave + rr) * ldp;
-      const int wg = (int)(win[rr] >> 6) / kGroup;
-      float mm = -__builtin_inff();
-      int mt = wg * kGroup;
-#pragma unroll
-      for (int u = 0; u < kGroup; ++u) {
-        const int t = wg * kGroup + u;
-        const int e = t * 64 + lane;
-        const float cur = e < n_cols ? row[e] : -__builtin_inff();
-        const bool gtr = cur > mm || u == 0;
-        mt = gtr ? t : mt;
-        mm = gtr ? cur : mm;
-      }
+      const unsigned win = wave_min_u32(bv == m ? e : 0xffffffffu);   // lowest index among maxima
+      mine[rr] = (lane == round) ? (int)win : mine[rr];
+      // retire the winner: only its group (wave-uniform) is rescanned
+      const int wl = (int)(win & 63u), wt = (int)(win >> 6);
+      const int wg = __builtin_amdgcn_readfirstlane(wt / kGroup);
+      const bool me = lane == wl;
 #pragma unroll
       for (int g = 0; g < NG; ++g) {
-        gmax[rr][g] = (g == wg) ? mm : gmax[rr][g];
-        gt[rr][g] = (g == wg) ? mt : gt[rr][g];
+        if (g == wg) {
+          float mm = -__builtin_inff();
+          int mt = g * kGroup;
+#pragma unroll
+          for (int u = 0; u < kGroup; ++u) {
+            const int t = g * kGroup + u;
+            const float cur = (me && t == wt) ? -__builtin_inff() : v[rr][t];
+            v[rr][t] = cur;
+            const bool gtr = cur > mm || u == 0;
+            mt = gtr ? t : mt;
+            mm = gtr ? cur : mm;
+          }
+          gmax[rr][g] = mm;
+          gt[rr][g] = mt;
+        }
       }
     }
   }
