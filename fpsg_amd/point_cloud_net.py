@@ -155,25 +155,129 @@ class PrimitiveCluster(nn.Module):
         return torch.cat(outs, dim=2)
 
 
+def _group_batch_norm(h, bns, calls_per_bn, act):
+    """BatchNorm over the last axis of ``h [G, C, M]`` with an independent set of statistics
+    per group ``g`` (one reference ``BatchNorm1d`` call each), then ``act``.
+
+    ``bns``: the ``len(bns) * calls_per_bn == G`` modules owning the affine parameters and
+    running statistics; module ``i`` serves groups ``i*calls_per_bn .. (i+1)*calls_per_bn-1``,
+    i.e. it is "called" ``calls_per_bn`` times in that order, as in the reference loop, and
+    its running statistics receive that many sequential momentum updates."""
+    G, C, M = h.shape
+    r = calls_per_bn
+    gamma = torch.stack([b.weight for b in bns]).repeat_interleave(r, dim=0).reshape(G * C)
+    beta = torch.stack([b.bias for b in bns]).repeat_interleave(r, dim=0).reshape(G * C)
+    x = h.reshape(1, G * C, M)
+    if bns[0].training:
+        mean = torch.zeros(G * C, dtype=h.dtype, device=h.device)
+        var = torch.ones(G * C, dtype=h.dtype, device=h.device)
+        y = F.batch_norm(x, mean, var, gamma, beta, True, 1.0, bns[0].eps)   # mean/var <- batch stats
+        with torch.no_grad():
+            # r sequential momentum updates per module, in closed form and as multi-tensor ops:
+            #   run <- (1-m)^r run + m * sum_j (1-m)^(r-1-j) stat_j     (var: unbiased, as torch)
+            m = 0.1 if bns[0].momentum is None else bns[0].momentum
+            coef = torch.tensor([m * (1 - m) ** (r - 1 - j) for j in range(r)], dtype=h.dtype,
+                                device=h.device).view(1, r, 1)
+            new_mean = (mean.view(len(bns), r, C) * coef).sum(dim=1)
+            new_var = (var.view(len(bns), r, C) * coef).sum(dim=1)
+            rms = [b.running_mean for b in bns]
+            rvs = [b.running_var for b in bns]
+            torch._foreach_mul_(rms, (1 - m) ** r)
+            torch._foreach_add_(rms, list(new_mean.unbind(0)))
+            torch._foreach_mul_(rvs, (1 - m) ** r)
+            torch._foreach_add_(rvs, list(new_var.unbind(0)))
+            torch._foreach_add_([b.num_batches_tracked for b in bns], r)
+    else:
+        rm = torch.stack([b.running_mean for b in bns]).repeat_interleave(r, dim=0).reshape(G * C)
+        rv = torch.stack([b.running_var for b in bns]).repeat_interleave(r, dim=0).reshape(G * C)
+        y = F.batch_norm(x, rm, rv, gamma, beta, False, 0.0, bns[0].eps)
+    return act(y.reshape(G, C, M))
+
+
 class PCDecoder(nn.Module):
     """AtlasNet-style decoder: ``num_clusters`` clusters x ``num_nodes`` patches;
-    ``forward(hidden[B, bottleneck]) -> [B, num_pts, 3]`` (contiguous)."""
+    ``forward(hidden[B, bottleneck]) -> [B, num_pts, 3]`` (contiguous).
 
-    def __init__(self, conf, num_pts: int = 2048):
+    ``batched=True`` (default) evaluates all ``clusters x nodes`` patch MLPs together: the
+    per-patch weights are stacked at run time and every layer is ONE batched GEMM + ONE
+    grouped BatchNorm instead of 16 small ones (the looped form is launch-bound on MI355X:
+    ~1000 kernels of a few microseconds per decode).  Same arithmetic per patch, same
+    per-call BatchNorm statistics and running-statistics updates, same state dict."""
+
+    def __init__(self, conf, num_pts: int = 2048, batched: bool = True):
         super().__init__()
         self.conf = conf
         self.device = conf.device
         self.num_nodes = conf.num_nodes
         self.num_clusters = conf.num_clusters
         self.num_pts_per_cluster = num_pts // self.num_clusters
+        self.batched = batched
         self.cluster_pool = nn.ModuleList([
             PrimitiveCluster(conf, MLPDeformer(conf), self.num_pts_per_cluster, self.num_nodes)
             for _ in range(self.num_clusters)
         ])
 
+    def sample_grids(self, batch: int, device, generator=None):
+        """Nested list ``[cluster][node] -> [B, ori_dim, P]`` drawn in the reference's order."""
+        return [c.sample_grids(batch, device, generator) for c in self.cluster_pool]
+
     def forward(self, hidden_feat, grid=None, generator=None):
         """``grid`` (optional): nested list ``[cluster][node] -> [B, ori_dim, P]``."""
+        if self.batched:
+            return self._forward_batched(hidden_feat, grid, generator)
+        return self._forward_looped(hidden_feat, grid, generator)
+
+    def _forward_looped(self, hidden_feat, grid=None, generator=None):
         outs = []
         for ci, cluster in enumerate(self.cluster_pool):
             outs.append(cluster(hidden_feat, None if grid is None else grid[ci], generator))
         return torch.cat(outs, dim=2).transpose(1, 2).contiguous()
+
+    def _forward_batched(self, x, grid=None, generator=None):
+        clusters = list(self.cluster_pool)
+        K, R = len(clusters), self.num_nodes
+        G = K * R
+        B, L = x.shape
+        P = clusters[0].pts_per_node
+        act = clusters[0].deformer.activation
+        if grid is None:
+            dim = clusters[0].template[0].dim
+            if type(clusters[0].template[0]).__name__ == "SquareTemplate":
+                g = torch.empty((G, B, dim, P), dtype=torch.float32, device=x.device).uniform_(0, 1, generator=generator)
+            else:
+                g = torch.empty((G, B, dim, P), dtype=torch.float32, device=x.device).normal_(0, 1, generator=generator)
+        else:
+            g = torch.stack([t for per_cluster in grid for t in per_cluster])          # [G,B,dim,P]
+        h = g.permute(0, 2, 1, 3).reshape(G, g.size(2), B * P)                          # [G,dim,B*P]
+
+        def stack_w(mods, name, repeat=1):
+            w = torch.stack([getattr(m, name).weight.squeeze(-1) for m in mods])       # [n,out,in]
+            b = torch.stack([getattr(m, name).bias for m in mods])                     # [n,out]
+            if repeat > 1:
+                w = w.repeat_interleave(repeat, dim=0)
+                b = b.repeat_interleave(repeat, dim=0)
+            return w, b.unsqueeze(-1)
+
+        # ---- per-cluster deformers, applied to each of the cluster's R patches
+        defs = [c.deformer for c in clusters]
+        w, b = stack_w(defs, "conv1", R)
+        h = _group_batch_norm(torch.baddbmm(b, w, h), [d.bn1 for d in defs], R, act)
+        w, b = stack_w(defs, "conv2", R)
+        h = _group_batch_norm(torch.baddbmm(b, w, h), [d.bn2 for d in defs], R, act)
+        w, b = stack_w(defs, "conv3", R)
+        pts = torch.tanh(torch.baddbmm(b, w, h))                                        # [G,raw,B*P]
+
+        # ---- the G patch MLPs; first layer split into latent and point parts
+        nodes = [n for c in clusters for n in c.node_pool]
+        w, b = stack_w(nodes, "conv1")                                                  # [G,D,D]
+        D = w.size(1)
+        h_lat = torch.matmul(w[:, :, :L], x.t()) + b                                    # [G,D,B]
+        h = torch.bmm(w[:, :, L:], pts).view(G, D, B, P) + h_lat.unsqueeze(-1)
+        h = _group_batch_norm(h.view(G, D, B * P), [n.bn1 for n in nodes], 1, act)
+        w, b = stack_w(nodes, "conv2")
+        h = _group_batch_norm(torch.baddbmm(b, w, h), [n.bn2 for n in nodes], 1, act)
+        w, b = stack_w(nodes, "conv3")
+        h = _group_batch_norm(torch.baddbmm(b, w, h), [n.bn3 for n in nodes], 1, act)
+        w, b = stack_w(nodes, "conv4")
+        out = torch.tanh(torch.baddbmm(b, w, h))                                        # [G,3,B*P]
+        return out.view(G, 3, B, P).permute(2, 0, 3, 1).reshape(B, G * P, 3).contiguous()

@@ -94,3 +94,40 @@ def test_other_shapes():
     x[:, :64] = x[:, :64, :1]                                  # latent constant over the patch
     node.eval()
     assert torch.allclose(node(x), node.forward_split(x[:, :64, 0], x[:, 64:]), atol=1e-5)
+
+
+def test_batched_equals_looped():
+    """The batched evaluation (stacked weights, one GEMM + one grouped BatchNorm per layer) is
+    the looped per-patch evaluation: outputs, gradients and every running statistic."""
+    import copy
+    dec = _decoder()
+    with torch.no_grad():
+        for mod in dec.modules():
+            if isinstance(mod, torch.nn.BatchNorm1d):
+                mod.weight.copy_(torch.randn_like(mod.weight) * 0.5 + 1)
+                mod.bias.copy_(torch.randn_like(mod.bias) * 0.1)
+    loop = copy.deepcopy(dec)
+    loop.batched = False
+    assert dec.batched
+    for mode in ("train", "train", "eval"):
+        dec.train(mode == "train"); loop.train(mode == "train")
+        h1 = torch.randn(3, 1536, requires_grad=True)
+        h2 = h1.detach().clone().requires_grad_()
+        grids = dec.sample_grids(3, "cpu", torch.Generator().manual_seed(4))
+        a, b = dec(h1, grid=grids), loop(h2, grid=grids)
+        assert torch.allclose(a, b, rtol=1e-4, atol=5e-5)
+        dec.zero_grad(); loop.zero_grad()
+        a.square().sum().backward(); b.square().sum().backward()
+        scale = h2.grad.abs().max()
+        assert (h1.grad - h2.grad).abs().max() <= 3e-3 * scale
+        ga = dec.cluster_pool[2].node_pool[1].conv2.weight.grad
+        gb = loop.cluster_pool[2].node_pool[1].conv2.weight.grad
+        assert (ga - gb).abs().max() <= 3e-3 * gb.abs().max()
+        gd = dec.cluster_pool[3].deformer.conv1.weight.grad       # shared by the cluster's 4 patches
+        ge = loop.cluster_pool[3].deformer.conv1.weight.grad
+        assert (gd - ge).abs().max() <= 3e-3 * ge.abs().max()
+    sa, sb = dec.state_dict(), loop.state_dict()
+    for k in sa:
+        assert torch.allclose(sa[k].float(), sb[k].float(), rtol=1e-5, atol=1e-6), k
+    assert int(sa["cluster_pool.0.deformer.bn1.num_batches_tracked"]) == 8     # 4 calls per forward
+    assert int(sa["cluster_pool.0.node_pool.0.bn1.num_batches_tracked"]) == 2
