@@ -80,7 +80,9 @@ class FlatGradBuckets:
         off, start, count = 0, 0, 0
         for p in reversed(params):
             n = p.numel()
-            p.grad = self.flat[off:off + n].view_as(p)
+            # same memory format as the parameter (e.g. channels_last conv weights): the fused
+            # optimizer requires param and grad layouts to match
+            p.grad = self.flat[off:off + n].as_strided(p.size(), p.stride())
             self._bucket_of[id(p)] = len(self.buckets)
             off += n
             count += 1
