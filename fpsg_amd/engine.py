@@ -71,12 +71,59 @@ def to_device(sample: dict, device) -> dict:
 
 
 class TrainStep:
-    """One optimizer step over the local share of a global step's episodes."""
+    """One optimizer step over the local share of a global step's episodes.
 
-    def __init__(self, model, optimizer, world: int = 1, bucket_mb: float = 80.0):
+    ``graph=True`` (GPU only): the forward + backward of an episode is captured once per
+    episode shape into a hipGraph and replayed -- an episode is ~1300 kernel launches, many of
+    them a few microseconds long, and the eager step is partly host-bound.  Inputs are copied
+    into the graph's static buffers; gradients accumulate in place into the flat buffer.  With
+    more than one rank the LAST local episode of a step always runs eagerly, so that its
+    backward can launch the bucketed all-reduce from the autograd hooks."""
+
+    def __init__(self, model, optimizer, world: int = 1, bucket_mb: float = 80.0, graph: bool = False):
         self.model, self.optimizer, self.world = model, optimizer, world
         self.buckets = fdist.FlatGradBuckets(model, bucket_mb=bucket_mb)
+        self.use_graph = bool(graph) and next(model.parameters()).is_cuda
+        self._graphs = {}
+        self._eager_runs = {}
 
+    # ------------------------------------------------------------------ graph plumbing
+    _KEYS = ("xs", "xq", "xad", "pcs", "pcq", "pcad")
+
+    def _shape_key(self, sample):
+        return tuple((k, tuple(sample[k].shape)) for k in self._KEYS)
+
+    def _episode(self, sample):
+        out = self.model.loss(sample)
+        out["ttl_loss"].sum().backward()
+        return {n: v.detach() for n, v in out.items()}
+
+    def _capture(self, sample):
+        static = {k: sample[k].clone() for k in self._KEYS}
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            static_out = self._episode(static)
+        return g, static, static_out
+
+    def _run_graphed(self, sample):
+        key = self._shape_key(sample)
+        if key not in self._graphs:
+            # the first eager runs of a shape let MIOpen / hipBLASLt pick their kernels and
+            # warm the allocator; capture happens on the third use
+            n = self._eager_runs.get(key, 0)
+            if n < 2:
+                self._eager_runs[key] = n + 1
+                return self._episode(sample)
+            keep = self.buckets.flat.clone()      # the capture pass also accumulates gradients
+            self._graphs[key] = self._capture(sample)
+            self.buckets.flat.copy_(keep)
+        g, static, static_out = self._graphs[key]
+        for k in self._KEYS:
+            static[k].copy_(sample[k], non_blocking=True)
+        g.replay()
+        return {n: v.clone() for n, v in static_out.items()}
+
+    # ----------------------------------------------------------------------- the step
     def __call__(self, local_episodes: list[dict], n_episodes_global: int | None = None):
         """Returns the list of loss dicts (device tensors; call ``.item()`` outside the
         timed path).  ``n_episodes_global`` defaults to ``len(local) * world``."""
@@ -88,11 +135,13 @@ class TrainStep:
             self.buckets.arm()
         last = len(local_episodes) - 1
         for k, sample in enumerate(local_episodes):
-            out = self.model.loss(sample)
-            if k == last:
+            final = k == last
+            if final:
                 self.buckets.arm()
-            out["ttl_loss"].sum().backward()
-            results.append({n: v.detach() for n, v in out.items()})
+            if self.use_graph and not (final and self.world > 1):
+                results.append(self._run_graphed(sample))
+            else:
+                results.append(self._episode(sample))
         self.buckets.finish(n_episodes_global)
         self.optimizer.step()
         return results

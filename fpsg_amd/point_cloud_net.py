@@ -176,10 +176,12 @@ def _group_batch_norm(h, bns, calls_per_bn, act):
             # r sequential momentum updates per module, in closed form and as multi-tensor ops:
             #   run <- (1-m)^r run + m * sum_j (1-m)^(r-1-j) stat_j     (var: unbiased, as torch)
             m = 0.1 if bns[0].momentum is None else bns[0].momentum
-            coef = torch.tensor([m * (1 - m) ** (r - 1 - j) for j in range(r)], dtype=h.dtype,
-                                device=h.device).view(1, r, 1)
-            new_mean = (mean.view(len(bns), r, C) * coef).sum(dim=1)
-            new_var = (var.view(len(bns), r, C) * coef).sum(dim=1)
+            mean3, var3 = mean.view(len(bns), r, C), var.view(len(bns), r, C)
+            new_mean = mean3[:, 0] * (m * (1 - m) ** (r - 1))      # python scalars only: no
+            new_var = var3[:, 0] * (m * (1 - m) ** (r - 1))        # host->device copies, so the
+            for j in range(1, r):                                    # step can be graph-captured
+                new_mean = new_mean + mean3[:, j] * (m * (1 - m) ** (r - 1 - j))
+                new_var = new_var + var3[:, j] * (m * (1 - m) ** (r - 1 - j))
             rms = [b.running_mean for b in bns]
             rvs = [b.running_var for b in bns]
             torch._foreach_mul_(rms, (1 - m) ** r)
