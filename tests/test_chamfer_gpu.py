@@ -149,31 +149,35 @@ def test_rejects_bad_inputs(gpu):
 
 def test_graph_replay_equals_eager_step(gpu):
     """TrainStep(graph=True) replays the captured episode: same gradients as the eager step
-    (decoder grid injected so that both paths see the same random patch samples)."""
+    (decoder grid injected so that both paths see the same random patch samples).  Library
+    kernels are not bit-reproducible run to run and the tiny-batch BatchNorms amplify that, so
+    the yardstick is a second EAGER run of the same step."""
     from fpsg_amd.engine import TrainStep, build_model, build_optimizer, default_options
     from fpsg_amd.episodes import synthetic_episode
     import copy
     torch.manual_seed(0)
     opt = default_options(device="cuda", intra_recon=True, lr=0.0)
     base = build_model(opt).to(gpu).train()
-    eps = [synthetic_episode(2, 1, n_pts=2048, img_size=64, seed=s, device=gpu) for s in (1, 2)]
+    eps = [synthetic_episode(4, 2, n_pts=2048, img_size=96, seed=s, device=gpu) for s in (1, 2)]
     grads = {}
-    for mode in ("eager", "graph"):
+    for mode in ("eager", "eager2", "graph"):
         m = copy.deepcopy(base)
         optimizer, _ = build_optimizer(m, opt)
         step = TrainStep(m, optimizer, graph=(mode == "graph"))
-        fixed = m.pc_decoder.sample_grids(2, gpu, torch.Generator(device=gpu).manual_seed(5))
-        fixed1 = m.pc_decoder.sample_grids(1, gpu, torch.Generator(device=gpu).manual_seed(6))
+        fixed = {b: m.pc_decoder.sample_grids(b, gpu, torch.Generator(device=gpu).manual_seed(5 + b)) for b in (4, 2)}
         orig = m.pc_decoder.forward
-        m.pc_decoder.forward = lambda h, grid=None, generator=None: orig(h, grid=fixed if h.size(0) == 2 else fixed1)
+        m.pc_decoder.forward = lambda h, grid=None, generator=None, orig=orig, fixed=fixed: orig(h, grid=fixed[h.size(0)])
         for _ in range(4):                       # graph mode: 2 eager uses, capture, replay
             out = step([eps[0], eps[1]])
+        if mode == "graph":
+            assert len(step._graphs) == 1
         grads[mode] = (step.buckets.flat.clone(), float(out[-1]["ttl_loss"].sum()))
+    cos = torch.nn.functional.cosine_similarity
     g_e, l_e = grads["eager"]
+    g_2, l_2 = grads["eager2"]
     g_g, l_g = grads["graph"]
-    # library kernels picked at capture time may differ from the eager ones (fp32 rounding,
-    # amplified by the tiny-batch BatchNorms): compare at the level that catches a missing or
-    # doubled accumulation, not bit patterns
-    assert abs(l_e - l_g) <= 5e-3 * abs(l_e)
-    cos = torch.nn.functional.cosine_similarity(g_e, g_g, dim=0)
-    assert cos > 0.999 and abs(float(g_g.norm() / g_e.norm()) - 1) < 2e-2, (float(cos), float(g_g.norm() / g_e.norm()))
+    noise = 1 - float(cos(g_e, g_2, dim=0))
+    diff = 1 - float(cos(g_e, g_g, dim=0))
+    assert abs(l_e - l_g) <= max(5e-3 * abs(l_e), 3 * abs(l_e - l_2)), (l_e, l_2, l_g)
+    assert diff <= max(3 * noise, 2e-3), (noise, diff)
+    assert abs(float(g_g.norm() / g_e.norm()) - 1) < max(3 * abs(float(g_2.norm() / g_e.norm()) - 1), 1e-2)
