@@ -96,6 +96,28 @@ class EventProbe:
         return n, sec, pairs, nbytes, flops
 
 
+def pmc_traffic(kind_prefix, probe, kind):
+    """HBM bytes per launch from the committed rocprofv3 PMC summary (profiles/k1_traffic.json,
+    made by tools/pmc_summary.py on this workload's launches); None when a launch shape of this
+    run has no PMC record."""
+    path = os.path.join(ROOT, "profiles", "k1_traffic.json")
+    if not os.path.exists(path):
+        return None
+    table = {}
+    for rec in json.load(open(path)).get("launches", []):
+        if rec["kernel"].startswith(kind_prefix) and "hbm_bytes_per_launch" in rec:
+            table[rec["cloud_pairs"]] = rec["hbm_bytes_per_launch"]
+    total, n = 0.0, 0
+    for (k, B, N, M), _, _ in probe.records:
+        if k != kind:
+            continue
+        if N != 2048 or M != 2048 or B not in table:
+            return None
+        total += table[B]
+        n += 1
+    return total / n if n else None
+
+
 def make_episodes(S, Q, count, seed, device):
     return [synthetic_episode(S, Q, n_pts=2048, img_size=224, seed=seed * 1000 + i, device=device)
             for i in range(count)]
@@ -260,7 +282,10 @@ def main():
                 "bound": "mfma",   # fp32 compute bound: fp32 vector peak == fp32-input MFMA peak
                 "achieved": achieved_flops / 1e12, "peak": F32_PEAK / 1e12, "unit": "TFLOP/s",
                 "frac": achieved_flops / F32_PEAK,
-                "traffic": None,
+                "traffic": pmc_traffic("chamfer_fwd_kernel", probe, "chamfer_fwd"),
+                "traffic_unit": "HBM bytes per launch, rocprofv3 PMC (2*FETCH_SIZE+WRITE_SIZE)*1024, "
+                                "profiles/k1_traffic.json",
+                "algorithmic_bytes_per_launch": nbytes / n_l,
                 "launches": n_l, "avg_launch_us": sec / n_l * 1e6,
                 "cloud_pairs_per_launch": pairs / n_l,
                 "hbm": {"achieved": nbytes / sec / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",

@@ -240,14 +240,22 @@ constexpr int kBwdTile = 4096;  // idx_b entries staged per pass (16 KiB)
 __global__ __launch_bounds__(kBwdThreads) void chamfer_bwd_kernel(
     const float* __restrict__ xyz1, const float* __restrict__ xyz2,
     const int32_t* __restrict__ idx1, const int32_t* __restrict__ idx2,
-    const float* __restrict__ g1, const float* __restrict__ g2, int N, int M,
+    const float* __restrict__ g1, const float* __restrict__ g2, int N, int M, int tiles,
     float* __restrict__ gxyz1, float* __restrict__ gxyz2) {
   __shared__ __attribute__((aligned(16))) int32_t sidx[kBwdTile];
-  const int side = blockIdx.z;
-  const int b = blockIdx.y;
+  // same XCD-aware, cloud-pair-major work order as the forward kernel
+  int work;
+  {
+    const int nwg = gridDim.x, id = blockIdx.x;
+    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = id & 7;
+    work = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (id >> 3);
+  }
+  const int tile = work % tiles;
+  const int side = (work / tiles) & 1;
+  const int b = work / (2 * tiles);
   const int na = side ? M : N;
   const int nb = side ? N : M;
-  if ((int)(blockIdx.x * kBwdThreads) >= na) return;
+  if (tile * kBwdThreads >= na) return;
 
   const float* __restrict__ A = (side ? xyz2 : xyz1) + (size_t)b * na * 3;
   const float* __restrict__ Bc = (side ? xyz1 : xyz2) + (size_t)b * nb * 3;
@@ -257,7 +265,7 @@ __global__ __launch_bounds__(kBwdThreads) void chamfer_bwd_kernel(
   const float* __restrict__ gb_up = (side ? g1 : g2) + (size_t)b * nb;
   float* __restrict__ out = (side ? gxyz2 : gxyz1) + (size_t)b * na * 3;
 
-  const int i = blockIdx.x * kBwdThreads + threadIdx.x;
+  const int i = tile * kBwdThreads + threadIdx.x;
   const bool live = i < na;
   const int ic = live ? i : na - 1;
   const float px = A[3 * ic + 0], py = A[3 * ic + 1], pz = A[3 * ic + 2];
@@ -357,9 +365,10 @@ extern "C" int fpsg_chamfer_bwd(const float* xyz1, const float* xyz2, const int3
   FPSG_REQUIRE_PTR(xyz1); FPSG_REQUIRE_PTR(xyz2); FPSG_REQUIRE_PTR(idx1); FPSG_REQUIRE_PTR(idx2);
   FPSG_REQUIRE_PTR(g1); FPSG_REQUIRE_PTR(g2); FPSG_REQUIRE_PTR(gxyz1); FPSG_REQUIRE_PTR(gxyz2);
   const int nmax = N > M ? N : M;
-  dim3 grid((nmax + kBwdThreads - 1) / kBwdThreads, B, 2);
+  const int tiles = (nmax + kBwdThreads - 1) / kBwdThreads;
+  dim3 grid((unsigned)((size_t)tiles * 2 * B));
   hipLaunchKernelGGL(chamfer_bwd_kernel, grid, dim3(kBwdThreads), 0,
-                     static_cast<hipStream_t>(stream), xyz1, xyz2, idx1, idx2, g1, g2, N, M,
+                     static_cast<hipStream_t>(stream), xyz1, xyz2, idx1, idx2, g1, g2, N, M, tiles,
                      gxyz1, gxyz2);
   return launch_status("fpsg_chamfer_bwd");
 }
