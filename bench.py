@@ -184,6 +184,8 @@ def main():
     ap.add_argument("--graph", dest="graph", action="store_true", default=True,
                     help="replay each episode's fwd+bwd as a captured hipGraph (default)")
     ap.add_argument("--no-graph", dest="graph", action="store_false")
+    ap.add_argument("--overlap", dest="overlap", action="store_true", default=False,
+                    help="run the point encoder on a second stream beside the image trunk")
     ap.add_argument("--channels-last", action="store_true", help="experiment: NHWC image trunk")
     ap.add_argument("--miopen-benchmark", action="store_true", help="experiment: MIOpen find mode")
     args = ap.parse_args()
@@ -209,6 +211,7 @@ def main():
     if args.channels_last:
         model.img_encoder.to(memory_format=torch.channels_last)
     model.train()
+    model.overlap_encoders = bool(args.overlap)
     optimizer, _ = build_optimizer(model, opt)
     step = TrainStep(model, optimizer, world=world, bucket_mb=args.bucket_mb, graph=args.graph)
     episodes = make_episodes(S, Q, epr, seed=1234 + rank, device=device)   # resident in HBM

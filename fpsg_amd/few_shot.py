@@ -50,6 +50,8 @@ class ImgPCProtoNet(nn.Module):
         # evaluation-only distance (reference few_shot.py:168); an attribute so that a test
         # can drive the module on CPU with the oracle's implementations
         self.emd_metric = emd_wrapper
+        self.overlap_encoders = False      # see _encode; switched on by bench.py / the trainer
+        self._side_stream = None
 
     # ------------------------------------------------------------------ shared forward
     def _encode(self, img_s, img_q, img_ad, pc_s, pc_ad):
@@ -58,10 +60,26 @@ class ImgPCProtoNet(nn.Module):
         n_support, n_query = img_s.size(1), img_q.size(1)
         img_corpus = torch.cat([img_ad.reshape(n_support, *img_ad.shape[2:]),
                                 img_q.reshape(n_query, *img_q.shape[2:])], dim=0)
-        img_z = self.img_encoder(img_corpus)
         pc_corpus = torch.cat([pc_s.reshape(n_support, *pc_s.shape[2:]),
                                pc_ad.reshape(n_support, *pc_ad.shape[2:])], dim=0).transpose(2, 1)
-        pc_z = self.pc_encoder(pc_corpus)
+        if self.overlap_encoders and img_corpus.is_cuda:
+            # the two encoders are independent: the point encoder (memory-bound BN / max
+            # passes) runs on a second HIP stream beside the compute-bound image trunk;
+            # autograd replays each backward on its forward stream, so they overlap there too
+            cur = torch.cuda.current_stream()
+            if self._side_stream is None:
+                self._side_stream = torch.cuda.Stream(device=img_corpus.device)
+            side = self._side_stream
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                pc_z = self.pc_encoder(pc_corpus)
+            img_z = self.img_encoder(img_corpus)
+            cur.wait_stream(side)
+            pc_z.record_stream(cur)
+            pc_corpus.record_stream(side)
+        else:
+            img_z = self.img_encoder(img_corpus)
+            pc_z = self.pc_encoder(pc_corpus)
         return img_z[:n_support], img_z[n_support:], pc_z[:n_support], pc_z[n_support:]
 
     def _decode_queries(self, img_zq, pc_z_proto):
