@@ -181,11 +181,13 @@ def main():
     ap.add_argument("--cpu-baseline-seconds", type=float, default=20.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--bucket-mb", type=float, default=80.0)
-    ap.add_argument("--graph", dest="graph", action="store_true", default=True,
-                    help="replay each episode's fwd+bwd as a captured hipGraph (default)")
+    ap.add_argument("--graph", dest="graph", action="store_true", default=None,
+                    help="replay each episode's fwd+bwd as a captured hipGraph "
+                         "[default: on for 1 GPU, off under torch.distributed]")
     ap.add_argument("--no-graph", dest="graph", action="store_false")
-    ap.add_argument("--overlap", dest="overlap", action="store_true", default=False,
-                    help="run the point encoder on a second stream beside the image trunk")
+    ap.add_argument("--overlap", dest="overlap", action="store_true", default=True,
+                    help="run the point encoder on a second stream beside the image trunk (default)")
+    ap.add_argument("--no-overlap", dest="overlap", action="store_false")
     ap.add_argument("--channels-last", action="store_true", help="experiment: NHWC image trunk")
     ap.add_argument("--miopen-benchmark", action="store_true", help="experiment: MIOpen find mode")
     args = ap.parse_args()
@@ -195,15 +197,18 @@ def main():
         epr = args.episodes_per_rank
     steps = args.steps if args.steps is not None else (5 if epr > 1 else 20)
     warmup = args.warmup if args.warmup is not None else (2 if epr > 1 else 5)
-    if args.graph:
-        warmup = max(warmup, 1 if epr >= 4 else 4)   # 2 eager uses + the capture before timing
+
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU (the hot path has no CPU fallback)")
     rank, world, device = fdist.init_distributed("cuda")
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if args.graph is None:
+        args.graph = not torch.distributed.is_initialized()
 
+    if args.graph:
+        warmup = max(warmup, 1 if epr >= 4 else 4)   # 2 eager uses + the capture before timing
     torch.backends.cudnn.benchmark = bool(args.miopen_benchmark)
     opt = default_options(device="cuda", intra_recon=intra, pc_encoder=encoder, n_shot=S, n_query=Q)
     torch.manual_seed(0)                      # identical initial weights on every rank

@@ -43,7 +43,8 @@ def init_distributed(device_type: str | None = None) -> tuple[int, int, torch.de
         device = torch.device("cuda", local_rank)
     else:
         device = torch.device("cpu")
-    if world > 1 and not dist.is_initialized():
+    force = bool(os.environ.get("FPSG_FORCE_DIST"))   # single-rank group: exercises RCCL on one GPU
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         kwargs = {}
@@ -103,6 +104,10 @@ class FlatGradBuckets:
     def world(self) -> int:
         return dist.get_world_size(self.group) if dist.is_initialized() else 1
 
+    @staticmethod
+    def world_initialised() -> bool:
+        return dist.is_initialized()
+
     def zero(self) -> None:
         """Replaces ``optimizer.zero_grad()``: grads must stay views of the flat buffer."""
         self.flat.zero_()
@@ -110,7 +115,7 @@ class FlatGradBuckets:
     def arm(self) -> None:
         """Call before the backward of the LAST local episode of a step: buckets are
         all-reduced as they complete during that backward."""
-        self._armed = self.world > 1
+        self._armed = dist.is_initialized()
         self._pending = list(self._bucket_size)
         self._handles = []
 

@@ -101,7 +101,8 @@ class TrainStep:
     def _capture(self, sample):
         static = {k: sample[k].clone() for k in self._KEYS}
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        # thread_local: an RCCL watchdog thread may query events while this thread captures
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
             static_out = self._episode(static)
         return g, static, static_out
 
@@ -138,7 +139,7 @@ class TrainStep:
             final = k == last
             if final:
                 self.buckets.arm()
-            if self.use_graph and not (final and self.world > 1):
+            if self.use_graph and not (final and self.buckets.world_initialised()):
                 results.append(self._run_graphed(sample))
             else:
                 results.append(self._episode(sample))
