@@ -339,12 +339,18 @@ extern "C" int fpsg_chamfer_fwd(const float* xyz1, const float* xyz2, int B, int
   hipStream_t s = static_cast<hipStream_t>(stream);
   int cfg = fpsg_chamfer_cfg_override;
   if (cfg < 0) {
-    // Queries per lane R and waves per workgroup W: enough waves to fill 1024 SIMDs at >= 2-4
-    // waves each, as much per-wave work as that allows (launch = 2 * B * ceil(n/(64R)) * W waves).
-    const long pts = (long)B * ((long)N + (long)M);  // query lanes over both sides
-    cfg = pts >= 64L * 2048 * 8 ? 3 : pts >= 64L * 2048 ? 2 : pts >= 64L * 256 ? 1 : 0;
+    // Queries per lane R and waves per workgroup W, from a sweep on MI355X at N = M = 2048
+    // (profiles/r01/chamfer_microbench_v4_config_sweep.txt): the launch time is
+    // ~6 us + 0.9 us per cloud pair, quantised by how evenly the workgroups fill the 256 CUs;
+    // small batches want many small workgroups, large ones the most work per wave.
+    const double n_eq = (double)B * ((double)N + (double)M) / 4096.0;   // 2048-point cloud pairs
+    cfg = n_eq < 4.5 ? 0 /*(1,16)*/ : n_eq < 10 ? 1 /*(2,16)*/ : n_eq < 28 ? 5 /*(2,8)*/
+        : n_eq < 35 ? 2 /*(4,8)*/ : n_eq < 44 ? 5 /*(2,8)*/ : n_eq < 60 ? 2 /*(4,8)*/ : 3 /*(8,4)*/;
   }
   switch (cfg) {
+    case 6: return launch_fwd<2, 4>(xyz1, xyz2, B, N, M, dist1, idx1, dist2, idx2, s);
+    case 5: return launch_fwd<2, 8>(xyz1, xyz2, B, N, M, dist1, idx1, dist2, idx2, s);
+    case 4: return launch_fwd<4, 4>(xyz1, xyz2, B, N, M, dist1, idx1, dist2, idx2, s);
     case 3: return launch_fwd<8, 4>(xyz1, xyz2, B, N, M, dist1, idx1, dist2, idx2, s);
     case 2: return launch_fwd<4, 8>(xyz1, xyz2, B, N, M, dist1, idx1, dist2, idx2, s);
     case 1: return launch_fwd<2, 16>(xyz1, xyz2, B, N, M, dist1, idx1, dist2, idx2, s);

@@ -53,7 +53,8 @@ int fpsg_chamfer_fwd(const float* xyz1, const float* xyz2, int B, int N, int M,
                      fpsg_stream_t stream);
 
 /* Tuning hook for micro-benchmarks: force the forward kernel's (queries per lane, waves per
- * workgroup) variant: 0=(1,16) 1=(2,16) 2=(4,8) 3=(8,4); -1 (default) = automatic.  Results do
+ * workgroup) variant: 0=(1,16) 1=(2,16) 2=(4,8) 3=(8,4) 4=(4,4) 5=(2,8) 6=(2,4); -1 (default) =
+ * automatic.  Results do
  * not depend on it. */
 void fpsg_chamfer_set_config(int cfg);
 

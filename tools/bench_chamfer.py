@@ -26,7 +26,7 @@ def main():
     lib = _hip.load()
     N = M = args.n
     scale = (N / 2048.0)
-    for B in (1, 5, 32, 37, 64, 256, 1024):
+    for B in ((1, 2, 3, 5, 8, 12, 16, 24, 32, 37, 48, 64, 96, 128, 256) if args.sweep else (1, 5, 32, 37, 64, 256, 1024)):
         p1 = torch.rand(B, N, 3, device=dev) * 2 - 1
         p2 = torch.tanh(torch.randn(B, M, 3, device=dev))
         d1 = torch.empty(B, N, device=dev); d2 = torch.empty(B, M, device=dev)
@@ -45,7 +45,7 @@ def main():
 
         runs = [("fwd", fwd, FWD_BYTES, -1), ("bwd", bwd, BWD_BYTES, -1)]
         if args.sweep:
-            runs = [(f"fwd[cfg{c}]", fwd, FWD_BYTES, c) for c in range(4)] + runs
+            runs = [(f"fwd[cfg{c}]", fwd, FWD_BYTES, c) for c in range(7)] + runs
         for name, fn, nbytes, cfg in runs:
             lib.fpsg_chamfer_set_config(cfg)
             for _ in range(20):
