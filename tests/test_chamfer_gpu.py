@@ -39,6 +39,26 @@ def test_fwd_bit_exact_vs_oracle(gpu, oracle, B, N, M):
     assert np.array_equal(d2.view(np.uint32), od2.view(np.uint32))
 
 
+@pytest.mark.parametrize("cfg", range(7))
+def test_every_kernel_variant_is_bit_exact(gpu, oracle, cfg):
+    """All (queries per lane, waves per workgroup) variants of the forward kernel, forced
+    through the tuning hook, on ragged sizes (tail lanes, partial chunks, N != M)."""
+    from fpsg_amd import _hip
+    rng = np.random.default_rng(100 + cfg)
+    p1 = unit_ball_clouds(rng, 3, 1000)
+    p2 = np.tanh(rng.standard_normal((3, 777, 3))).astype(np.float32)
+    lib = _hip.load()
+    lib.fpsg_chamfer_set_config(cfg)
+    try:
+        d1, i1, d2, i2 = _run_fwd(p1, p2, gpu)
+    finally:
+        lib.fpsg_chamfer_set_config(-1)
+    od1, oi1, od2, oi2 = oracle.chamfer_fwd(p1, p2)
+    assert np.array_equal(i1, oi1) and np.array_equal(i2, oi2)
+    assert np.array_equal(d1.view(np.uint32), od1.view(np.uint32))
+    assert np.array_equal(d2.view(np.uint32), od2.view(np.uint32))
+
+
 def test_ties_pick_lowest_index(gpu, oracle):
     """Duplicated points (the reference pads short clouds with repeats,
     src/datasets/modelnet.py:61-64) and lattice points give exact ties."""
