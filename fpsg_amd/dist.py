@@ -97,6 +97,7 @@ class FlatGradBuckets:
         self._pending = [0] * len(self.buckets)
         self._handles: list = []
         self._armed = False
+        self._streams: dict = {}     # every stream a gradient was produced on in this backward
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in params]
 
     # -- bookkeeping ---------------------------------------------------------------
@@ -118,13 +119,23 @@ class FlatGradBuckets:
         self._armed = dist.is_initialized()
         self._pending = list(self._bucket_size)
         self._handles = []
+        self._streams = {}
 
     def _on_grad(self, p: torch.Tensor) -> None:
         if not self._armed:
             return
         b = self._bucket_of[id(p)]
         self._pending[b] -= 1
+        if p.is_cuda:
+            cur = torch.cuda.current_stream(p.device)
+            self._streams[cur.cuda_stream] = cur
         if self._pending[b] == 0:
+            if p.is_cuda:
+                # a bucket may hold gradients produced on different streams (the encoders can
+                # run on two): the collective is ordered after all of them
+                for key, st in self._streams.items():
+                    if key != cur.cuda_stream:
+                        cur.wait_stream(st)
             s, e = self.buckets[b]
             self._handles.append(
                 dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.group,
