@@ -267,8 +267,8 @@ def main():
     if rank == 0:
         total_eps = steps * epr * world
         res = {
-            "metric": "episodes/sec (train step: fwd + Chamfer + bwd + all-reduce + Adam), "
-                      "2048-pt clouds, 224x224 images",
+            "metric": "episodes/sec (+ Chamfer-kernel HBM GB/s in roofline.hbm), 2048-pt clouds, "
+                      "224x224 images; episode = fwd + Chamfer + bwd, step = E episodes + all-reduce + Adam",
             "value": total_eps / elapsed,
             "unit": "episodes/s",
             "n_gpus": world, "steps": steps, "warmup": warmup,
