@@ -20,8 +20,8 @@
 //     chunk, which keeps Kaolin's "first minimum wins" tie rule exactly.
 //
 // Backward: one thread per output point, deterministic (no float atomics): the own-side
-// term, then a scan of the other side's argmin indices (staged in LDS, broadcast reads)
-// accumulating every point that chose this one, in ascending index order.
+// term, then the points of the other side that chose this one, found by inverting the argmin
+// list per 256-point tile in LDS and accumulated in ascending index order.
 #include "fpsg_common.h"
 
 namespace fpsg {
@@ -234,15 +234,23 @@ int launch_fwd(const float* xyz1, const float* xyz2, int B, int N, int M, float*
 // ---------------------------------------------------------------------------------
 // Backward.  Thread i of cloud `a` : ga_i = 2 g_a[i] (a_i - b[idx_a[i]])
 //                                        + sum_{j asc, idx_b[j]==i} 2 g_b[j] (a_i - b_j)
+// A workgroup owns 256 output points.  Pass 1 inverts the other side's argmin list for its
+// tile: every source j whose target falls in the tile appends itself to that target's slot
+// list in LDS (integer LDS atomics only hand out slots; the ORDER of accumulation does not
+// depend on them).  Pass 2: each thread walks its list in ascending j (selection by "smallest
+// j greater than the previous one"), so the fp32 sums are bit-identical to the oracle's
+// sequential loop.  Targets chosen by more than kBwdCap sources (duplicate-heavy clouds) fall
+// back to a plain ascending scan of the whole list.
 constexpr int kBwdThreads = 256;
-constexpr int kBwdTile = 4096;  // idx_b entries staged per pass (16 KiB)
+constexpr int kBwdCap = 16;
 
 __global__ __launch_bounds__(kBwdThreads) void chamfer_bwd_kernel(
     const float* __restrict__ xyz1, const float* __restrict__ xyz2,
     const int32_t* __restrict__ idx1, const int32_t* __restrict__ idx2,
     const float* __restrict__ g1, const float* __restrict__ g2, int N, int M, int tiles,
     float* __restrict__ gxyz1, float* __restrict__ gxyz2) {
-  __shared__ __attribute__((aligned(16))) int32_t sidx[kBwdTile];
+  __shared__ int cnt[kBwdThreads];
+  __shared__ int lst[kBwdThreads * kBwdCap];
   // same XCD-aware, cloud-pair-major work order as the forward kernel
   int work;
   {
@@ -255,7 +263,8 @@ __global__ __launch_bounds__(kBwdThreads) void chamfer_bwd_kernel(
   const int b = work / (2 * tiles);
   const int na = side ? M : N;
   const int nb = side ? N : M;
-  if (tile * kBwdThreads >= na) return;
+  const int lo = tile * kBwdThreads;
+  if (lo >= na) return;
 
   const float* __restrict__ A = (side ? xyz2 : xyz1) + (size_t)b * na * 3;
   const float* __restrict__ Bc = (side ? xyz1 : xyz2) + (size_t)b * nb * 3;
@@ -265,58 +274,58 @@ __global__ __launch_bounds__(kBwdThreads) void chamfer_bwd_kernel(
   const float* __restrict__ gb_up = (side ? g1 : g2) + (size_t)b * nb;
   float* __restrict__ out = (side ? gxyz2 : gxyz1) + (size_t)b * na * 3;
 
-  const int i = tile * kBwdThreads + threadIdx.x;
-  const bool live = i < na;
-  const int ic = live ? i : na - 1;
-  const float px = A[3 * ic + 0], py = A[3 * ic + 1], pz = A[3 * ic + 2];
+  const int tid = threadIdx.x;
+  cnt[tid] = 0;
+  __syncthreads();
+  for (int j = tid; j < nb; j += kBwdThreads) {
+    const int t = ib[j] - lo;
+    if (t >= 0 && t < kBwdThreads) {
+      const int slot = atomicAdd(&cnt[t], 1);
+      if (slot < kBwdCap) lst[t * kBwdCap + slot] = j;
+    }
+  }
+  __syncthreads();
+
+  const int i = lo + tid;
+  if (i >= na) return;
+  const float px = A[3 * i + 0], py = A[3 * i + 1], pz = A[3 * i + 2];
   float ax, ay, az;
   {
-    const int j = ia[ic];
-    const float t = 2.0f * ga_up[ic];
+    int j = ia[i];
+    j = j < 0 ? 0 : (j >= nb ? nb - 1 : j);   // never read outside the cloud
+    const float t = 2.0f * ga_up[i];
     ax = t * (px - Bc[3 * j + 0]);
     ay = t * (py - Bc[3 * j + 1]);
     az = t * (pz - Bc[3 * j + 2]);
   }
-  const int me = live ? i : -1;  // dead lanes never match
-
-  for (int t0 = 0; t0 < nb; t0 += kBwdTile) {
-    if (t0) __syncthreads();
-    const int cnt = (nb - t0) < kBwdTile ? (nb - t0) : kBwdTile;
-    const int cnt16 = (cnt + 15) & ~15;
-    for (int e = threadIdx.x; e < cnt16; e += kBwdThreads) sidx[e] = e < cnt ? ib[t0 + e] : -2;
-    __syncthreads();
-    const v4i* s4 = reinterpret_cast<const v4i*>(sidx);
-    for (int e16 = 0; e16 < cnt16 / 16; ++e16) {
-      // 16 indices per step: four independent LDS broadcast reads in flight
-      v4i id[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) id[u] = s4[e16 * 4 + u];
-      bool any = false;
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
-        any |= (id[u].x == me) | (id[u].y == me) | (id[u].z == me) | (id[u].w == me);
-      if (any) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-#pragma unroll
-          for (int w = 0; w < 4; ++w) {
-            if (id[u][w] == me) {      // ascending j: the summation order of the oracle
-              const int j = t0 + e16 * 16 + u * 4 + w;
-              const float t = 2.0f * gb_up[j];
-              ax = fma_rn(t, px - Bc[3 * j + 0], ax);
-              ay = fma_rn(t, py - Bc[3 * j + 1], ay);
-              az = fma_rn(t, pz - Bc[3 * j + 2], az);
-            }
-          }
-        }
+  const int n = cnt[tid];
+  if (n <= kBwdCap) {
+    int prev = -1;
+    for (int s = 0; s < n; ++s) {
+      int j = 0x7fffffff;
+      for (int u = 0; u < n; ++u) {
+        const int c = lst[tid * kBwdCap + u];
+        j = (c > prev && c < j) ? c : j;
+      }
+      prev = j;
+      const float t = 2.0f * gb_up[j];
+      ax = fma_rn(t, px - Bc[3 * j + 0], ax);
+      ay = fma_rn(t, py - Bc[3 * j + 1], ay);
+      az = fma_rn(t, pz - Bc[3 * j + 2], az);
+    }
+  } else {
+    for (int j = 0; j < nb; ++j) {
+      if (ib[j] == i) {
+        const float t = 2.0f * gb_up[j];
+        ax = fma_rn(t, px - Bc[3 * j + 0], ax);
+        ay = fma_rn(t, py - Bc[3 * j + 1], ay);
+        az = fma_rn(t, pz - Bc[3 * j + 2], az);
       }
     }
   }
-  if (live) {
-    out[3 * i + 0] = ax;
-    out[3 * i + 1] = ay;
-    out[3 * i + 2] = az;
-  }
+  out[3 * i + 0] = ax;
+  out[3 * i + 1] = ay;
+  out[3 * i + 2] = az;
 }
 
 }  // namespace

@@ -100,6 +100,27 @@ def test_bwd_bit_exact_vs_oracle(gpu, oracle, B, N, M):
     assert np.array_equal(t2.grad.cpu().numpy().view(np.uint32), ogx2.view(np.uint32))
 
 
+def test_bwd_many_sources_per_target(gpu, oracle):
+    """Duplicate-heavy clouds: some points are the nearest neighbour of hundreds of others
+    (more than the 16 in-edge slots kept in LDS), which takes the backward's overflow path."""
+    from fpsg_amd.metrics import _SidedPair
+    rng = np.random.default_rng(21)
+    base = rng.integers(-2, 3, size=(3, 40, 3)).astype(np.float32)
+    p1 = np.repeat(base, 30, axis=1)[:, :1100]                        # 30 copies of each point
+    p2 = np.concatenate([base[:, :7], rng.standard_normal((3, 900, 3)).astype(np.float32) * 5], axis=1)
+    g1 = rng.standard_normal(p1.shape[:2]).astype(np.float32)
+    g2 = rng.standard_normal(p2.shape[:2]).astype(np.float32)
+    t1 = torch.from_numpy(p1).to(gpu).requires_grad_()
+    t2 = torch.from_numpy(p2).to(gpu).requires_grad_()
+    d1, d2, i1, i2 = _SidedPair.apply(t1, t2)
+    torch.autograd.backward([d1, d2], [torch.from_numpy(g1).to(gpu), torch.from_numpy(g2).to(gpu)])
+    _, oi1, _, oi2 = oracle.chamfer_fwd(p1, p2)
+    assert np.bincount(oi1.reshape(-1)).max() > 100                    # really many-to-one
+    ogx1, ogx2 = oracle.chamfer_bwd(p1, p2, oi1, oi2, g1, g2)
+    assert np.array_equal(t1.grad.cpu().numpy().view(np.uint32), ogx1.view(np.uint32))
+    assert np.array_equal(t2.grad.cpu().numpy().view(np.uint32), ogx2.view(np.uint32))
+
+
 def test_chamfer_value_and_grad_vs_float64(gpu):
     """Within north_star's 1e-4 relative fp32 tolerance of the float64 definition."""
     from fpsg_amd.metrics import chamfer_distance
