@@ -75,6 +75,16 @@ def main(opt):
     fdist.broadcast_parameters(model)
 
     optimizer, scheduler = build_optimizer(model, opt)
+    if opt.resume > 0:
+        # Extension: the reference saves weights only, so a resumed run restarts
+        # Adam's moments and the LR schedule.  A sidecar file keeps them; the weights file keeps
+        # the reference's format and name.
+        state_path = os.path.join(checkpoint_path, f"train_state_epoch_{start_epoch}.pt")
+        if os.path.exists(state_path):
+            state = torch.load(state_path, map_location=device, weights_only=True)
+            optimizer.load_state_dict(state["optimizer"])
+            scheduler.load_state_dict(state["scheduler"])
+            print(f"Restored optimizer / scheduler state from {state_path}")
     step = TrainStep(model, optimizer, world=world)
     eps_per_step = opt.episodes_per_step or world
     local_n = len(range(rank, eps_per_step, world))
@@ -121,6 +131,8 @@ def main(opt):
 
         if is_main and (epoch % opt.save_interval == 0 or epoch == opt.epoch):
             torch.save(model.state_dict(), os.path.join(checkpoint_path, f"model_epoch_{epoch}.pt"))
+            torch.save({"optimizer": optimizer.state_dict(), "scheduler": scheduler.state_dict(),
+                        "epoch": epoch}, os.path.join(checkpoint_path, f"train_state_epoch_{epoch}.pt"))
             with open(checkpoint_logs, "a") as f:
                 f.writelines(f"{line}\n" for line in pending)
             pending.clear()
