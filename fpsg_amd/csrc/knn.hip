@@ -10,7 +10,8 @@
 //            channel-major rows served from L2, prefetched TWO tiles ahead into a rotating
 //            set of three register buffers so that the ~1 us L2 latency hides under the MFMA
 //            chains of the tiles in flight; the accumulator is carried over C/4 steps.
-//            Scores go to a 16 x N fp32 tile in LDS (128 KiB at N = 2048), never to HBM.
+//            Scores go to a 16 x min(N,2048) fp32 tile in LDS (128 KiB), never to HBM; longer
+//            clouds are processed in 2048-column chunks whose top-k lists are merged.
 //   phase B  each wave selects the k largest of 4 rows, all 4 interleaved for ILP.  A lane
 //            holds N/64 scores of each row in registers, in groups of 8 with cached group
 //            maxima.  A round = best of the lane's group maxima, wave-wide argmax with DPP
@@ -39,6 +40,11 @@ __global__ __launch_bounds__(256) void sqnorm_kernel(const float* __restrict__ x
     acc = fma_rn(v, v, acc);
   }
   xx[(size_t)b * N + j] = acc;
+}
+
+__device__ __forceinline__ unsigned orderable(float f) {
+  const unsigned u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
 // ---- wave-wide reductions with DPP row operations (gfx9 encodings) ----------------------
@@ -85,7 +91,8 @@ __device__ __forceinline__ void load_b(const float* __restrict__ xb, int C, int 
 template <int C4T>
 __device__ __forceinline__ void score_tile(const float (&a)[C4T], const float (&b)[C4T], int tile,
                                            int N, int kk, int col, const float* __restrict__ xxb,
-                                           const float (&xxq)[4], float* __restrict__ pd, int ldp) {
+                                           const float (&xxq)[4], float* __restrict__ pd, int ldp,
+                                           int c0) {
   v4f acc = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
   for (int c4 = 0; c4 < C4T; ++c4) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c4], b[c4], acc, 0, 0, 0);
@@ -96,7 +103,7 @@ __device__ __forceinline__ void score_tile(const float (&a)[C4T], const float (&
   for (int r = 0; r < 4; ++r) {
     // D layout: column = lane&15 (candidate), row = 4*(lane>>4) + r (query)
     const float v = fma_rn(2.0f, acc[r], -xxj) - xxq[r];
-    pd[(4 * kk + r) * ldp + j] = jin ? v : -__builtin_inff();
+    pd[(4 * kk + r) * ldp + (j - c0)] = jin ? v : -__builtin_inff();
   }
 }
 
@@ -127,144 +134,203 @@ __global__ __launch_bounds__(kKnnThreads) void knn_kernel(const float* __restric
     xxq[r] = q < N ? xxb[q] : 0.0f;
   }
 
-  // ---------------------------------------------------------------- phase A
+  // candidates are processed in chunks of at most 64*VPL columns (one LDS tile); the running
+  // top-k of every row lives in lanes 0..k-1 (lane r = r-th best) and is merged per chunk
+  const int n_cols = n_tiles * 16;
+  const int CW = (64 * VPL) < n_cols ? (64 * VPL) : n_cols;   // multiple of 16
+  float* qa = lds + (size_t)kQ * ldp;                          // generic-C path only
+  unsigned long long* scratch =
+      reinterpret_cast<unsigned long long*>(lds + (size_t)kQ * ldp + (C4T == 0 ? ((C + 3) >> 2) * 4 * kQ : 0)) +
+      wave * 64;
+  float a[C4T > 0 ? C4T : 1];
   if constexpr (C4T > 0) {
-    float a[C4T], b0[C4T], b1[C4T], b2[C4T];
-    {
-      const int q = i0 + col;
+    const int q = i0 + col;
 #pragma unroll
-      for (int c4 = 0; c4 < C4T; ++c4) {
-        const int c = 4 * c4 + kk;
-        a[c4] = (c < C && q < N) ? xb[(size_t)c * N + q] : 0.0f;
-      }
-    }
-    load_b<C4T>(xb, C, N, wave, kk, col, b0);
-    load_b<C4T>(xb, C, N, wave + 4, kk, col, b1);
-    for (int t = wave; t < n_tiles; t += 12) {
-      load_b<C4T>(xb, C, N, t + 8, kk, col, b2);
-      score_tile<C4T>(a, b0, t, N, kk, col, xxb, xxq, pd, ldp);
-      if (t + 4 < n_tiles) {
-        load_b<C4T>(xb, C, N, t + 12, kk, col, b0);
-        score_tile<C4T>(a, b1, t + 4, N, kk, col, xxb, xxq, pd, ldp);
-      }
-      if (t + 8 < n_tiles) {
-        load_b<C4T>(xb, C, N, t + 16, kk, col, b1);
-        score_tile<C4T>(a, b2, t + 8, N, kk, col, xxb, xxq, pd, ldp);
-      }
+    for (int c4 = 0; c4 < C4T; ++c4) {
+      const int c = 4 * c4 + kk;
+      a[c4] = (c < C && q < N) ? xb[(size_t)c * N + q] : 0.0f;
     }
   } else {
-    float* qa = lds + (size_t)kQ * ldp;
     const int C4 = (C + 3) >> 2;
     for (int e = tid; e < C4 * 4 * kQ; e += kKnnThreads) {
       const int c = e >> 4, q = e & 15;
       qa[e] = (c < C && i0 + q < N) ? xb[(size_t)c * N + i0 + q] : 0.0f;
     }
-    __syncthreads();
-    for (int t = wave; t < n_tiles; t += 4) {
-      const int j = t * 16 + col;
-      const bool jin = j < N;
-      const float* __restrict__ bp = xb + (jin ? j : 0);
-      v4f acc = {0.0f, 0.0f, 0.0f, 0.0f};
-      for (int c4 = 0; c4 < C4; ++c4) {
-        const int c = 4 * c4 + kk;
-        const float av = qa[c * kQ + col];
-        const float bv = (jin && c < C) ? bp[(size_t)c * N] : 0.0f;
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
-      }
-      const float xxj = jin ? xxb[j] : 0.0f;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float v = fma_rn(2.0f, acc[r], -xxj) - xxq[r];
-        pd[(4 * kk + r) * ldp + j] = jin ? v : -__builtin_inff();
-      }
-    }
   }
-  __syncthreads();
+  float run_val[4];
+  int run_idx[4];
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr) { run_val[rr] = -__builtin_inff(); run_idx[rr] = 0; }
 
-  // ---------------------------------------------------------------- phase B
-  // wave w selects rows 4w .. 4w+3 together; VPL scores per lane and row, groups of 8
-  constexpr int NG = VPL / kGroup;
-  const int n_cols = n_tiles * 16;
-  float v[4][VPL];
-  float gmax[4][NG];
-  int gt[4][NG];
-  int mine[4];
-#pragma unroll
-  for (int rr = 0; rr < 4; ++rr) {
-    const int q = 4 * wave + rr;
-    mine[rr] = 0;
-#pragma unroll
-    for (int t = 0; t < VPL; ++t) {
-      const int e = t * 64 + lane;
-      v[rr][t] = e < n_cols ? pd[q * ldp + e] : -__builtin_inff();
-    }
-#pragma unroll
-    for (int g = 0; g < NG; ++g) {
-      float m = v[rr][g * kGroup];
-      int mt = g * kGroup;
-#pragma unroll
-      for (int u = 1; u < kGroup; ++u) {
-        const bool gtr = v[rr][g * kGroup + u] > m;   // strict: lower slot wins ties
-        mt = gtr ? g * kGroup + u : mt;
-        m = gtr ? v[rr][g * kGroup + u] : m;
+  for (int c0 = 0; c0 < n_cols; c0 += CW) {
+    __syncthreads();   // previous chunk's tile fully consumed (and qa staged, first time round)
+    const int t_first = c0 >> 4;
+    const int t_last = ((c0 + CW) >> 4) < n_tiles ? ((c0 + CW) >> 4) : n_tiles;
+    // ---------------------------------------------------------------- phase A
+    if constexpr (C4T > 0) {
+      float b0[C4T], b1[C4T], b2[C4T];
+      const int tw = t_first + wave;
+      load_b<C4T>(xb, C, N, tw < t_last ? tw : n_tiles, kk, col, b0);
+      load_b<C4T>(xb, C, N, tw + 4 < t_last ? tw + 4 : n_tiles, kk, col, b1);
+      for (int t = tw; t < t_last; t += 12) {
+        load_b<C4T>(xb, C, N, t + 8 < t_last ? t + 8 : n_tiles, kk, col, b2);
+        score_tile<C4T>(a, b0, t, N, kk, col, xxb, xxq, pd, ldp, c0);
+        if (t + 4 < t_last) {
+          load_b<C4T>(xb, C, N, t + 12 < t_last ? t + 12 : n_tiles, kk, col, b0);
+          score_tile<C4T>(a, b1, t + 4, N, kk, col, xxb, xxq, pd, ldp, c0);
+        }
+        if (t + 8 < t_last) {
+          load_b<C4T>(xb, C, N, t + 16 < t_last ? t + 16 : n_tiles, kk, col, b1);
+          score_tile<C4T>(a, b2, t + 8, N, kk, col, xxb, xxq, pd, ldp, c0);
+        }
       }
-      gmax[rr][g] = m;
-      gt[rr][g] = mt;
+    } else {
+      const int C4 = (C + 3) >> 2;
+      for (int t = t_first + wave; t < t_last; t += 4) {
+        const int j = t * 16 + col;
+        const bool jin = j < N;
+        const float* __restrict__ bp = xb + (jin ? j : 0);
+        v4f acc = {0.0f, 0.0f, 0.0f, 0.0f};
+        for (int c4 = 0; c4 < C4; ++c4) {
+          const int c = 4 * c4 + kk;
+          const float av = qa[c * kQ + col];
+          const float bv = (jin && c < C) ? bp[(size_t)c * N] : 0.0f;
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
+        }
+        const float xxj = jin ? xxb[j] : 0.0f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float v = fma_rn(2.0f, acc[r], -xxj) - xxq[r];
+          pd[(4 * kk + r) * ldp + (j - c0)] = jin ? v : -__builtin_inff();
+        }
+      }
     }
-  }
-  for (int round = 0; round < k; ++round) {
+    __syncthreads();
+
+    // ---------------------------------------------------------------- phase B
+    // wave w selects rows 4w .. 4w+3 together; VPL scores per lane and row, groups of 8
+    constexpr int NG = VPL / kGroup;
+    const int cw = (n_cols - c0) < CW ? (n_cols - c0) : CW;
+    float v[4][VPL];
+    float gmax[4][NG];
+    int gt[4][NG];
+    int mine[4];
+    float mval[4];
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) {
-      float bv = gmax[rr][0];
-      int bt = gt[rr][0];
+      const int q = 4 * wave + rr;
+      mine[rr] = 0;
+      mval[rr] = -__builtin_inff();
 #pragma unroll
-      for (int g = 1; g < NG; ++g) {
-        const bool gtr = gmax[rr][g] > bv;
-        bt = gtr ? gt[rr][g] : bt;
-        bv = gtr ? gmax[rr][g] : bv;
+      for (int t = 0; t < VPL; ++t) {
+        const int e = t * 64 + lane;
+        v[rr][t] = e < cw ? pd[q * ldp + e] : -__builtin_inff();
       }
-      const float m = wave_max_f32(bv);
-      const unsigned e = (unsigned)(bt * 64 + lane);
-      const unsigned win = wave_min_u32(bv == m ? e : 0xffffffffu);   // lowest index among maxima
-      mine[rr] = (lane == round) ? (int)win : mine[rr];
-      // retire the winner: only its group (wave-uniform) is rescanned
-      const int wl = (int)(win & 63u), wt = (int)(win >> 6);
-      const int wg = __builtin_amdgcn_readfirstlane(wt / kGroup);
-      const bool me = lane == wl;
 #pragma unroll
       for (int g = 0; g < NG; ++g) {
-        if (g == wg) {
-          float mm = -__builtin_inff();
-          int mt = g * kGroup;
+        float m = v[rr][g * kGroup];
+        int mt = g * kGroup;
 #pragma unroll
-          for (int u = 0; u < kGroup; ++u) {
-            const int t = g * kGroup + u;
-            const float cur = (me && t == wt) ? -__builtin_inff() : v[rr][t];
-            v[rr][t] = cur;
-            const bool gtr = cur > mm || u == 0;
-            mt = gtr ? t : mt;
-            mm = gtr ? cur : mm;
-          }
-          gmax[rr][g] = mm;
-          gt[rr][g] = mt;
+        for (int u = 1; u < kGroup; ++u) {
+          const bool gtr = v[rr][g * kGroup + u] > m;   // strict: lower slot wins ties
+          mt = gtr ? g * kGroup + u : mt;
+          m = gtr ? v[rr][g * kGroup + u] : m;
         }
+        gmax[rr][g] = m;
+        gt[rr][g] = mt;
+      }
+    }
+    const int rounds = k < cw ? k : cw;   // a short last chunk may hold fewer than k columns
+    for (int round = 0; round < rounds; ++round) {
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        float bv = gmax[rr][0];
+        int bt = gt[rr][0];
+#pragma unroll
+        for (int g = 1; g < NG; ++g) {
+          const bool gtr = gmax[rr][g] > bv;
+          bt = gtr ? gt[rr][g] : bt;
+          bv = gtr ? gmax[rr][g] : bv;
+        }
+        const float m = wave_max_f32(bv);
+        const unsigned e = (unsigned)(bt * 64 + lane);
+        const unsigned win = wave_min_u32(bv == m ? e : 0xffffffffu);   // lowest index among maxima
+        mine[rr] = (lane == round) ? (int)win + c0 : mine[rr];
+        mval[rr] = (lane == round) ? m : mval[rr];
+        // retire the winner: only its group (wave-uniform) is rescanned
+        const int wl = (int)(win & 63u), wt = (int)(win >> 6);
+        const int wg = __builtin_amdgcn_readfirstlane(wt / kGroup);
+        const bool me = lane == wl;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+          if (g == wg) {
+            float mm = -__builtin_inff();
+            int mt = g * kGroup;
+#pragma unroll
+            for (int u = 0; u < kGroup; ++u) {
+              const int t = g * kGroup + u;
+              const float cur = (me && t == wt) ? -__builtin_inff() : v[rr][t];
+              v[rr][t] = cur;
+              const bool gtr = cur > mm || u == 0;
+              mt = gtr ? t : mt;
+              mm = gtr ? cur : mm;
+            }
+            gmax[rr][g] = mm;
+            gt[rr][g] = mt;
+          }
+        }
+      }
+    }
+    // ---------------------------------------------------------------- merge with earlier chunks
+    if (c0 == 0) {
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) { run_val[rr] = mval[rr]; run_idx[rr] = mine[rr]; }
+    } else {
+      // two lists sorted by (score desc, index asc) in lanes 0..k-1: an element's place in the
+      // merged order is its own rank plus the number of elements of the other list that
+      // precede it; the first k places are written to a per-wave LDS strip and read back
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const bool have_a = lane < k, have_b = lane < rounds;
+        const unsigned long long ka =
+            have_a ? (((unsigned long long)orderable(run_val[rr] + 0.0f) << 32) | (unsigned)~run_idx[rr]) : 0ull;
+        const unsigned long long kb =
+            have_b ? (((unsigned long long)orderable(mval[rr] + 0.0f) << 32) | (unsigned)~mine[rr]) : 0ull;
+        int rank_a = lane, rank_b = lane;
+        for (int s2 = 0; s2 < k; ++s2) {
+          const unsigned long long oa = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(ka >> 32), s2) << 32) |
+                                        (unsigned)__builtin_amdgcn_readlane((int)ka, s2);
+          const unsigned long long ob = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(kb >> 32), s2) << 32) |
+                                        (unsigned)__builtin_amdgcn_readlane((int)kb, s2);
+          rank_a += ob > ka ? 1 : 0;
+          rank_b += oa > kb ? 1 : 0;
+        }
+        if (have_a && rank_a < k) scratch[rank_a] = ka;
+        if (have_b && rank_b < k) scratch[rank_b] = kb;
+        // same-wave LDS write -> read: ordered by the in-order LDS queue
+        const unsigned long long mk = lane < k ? scratch[lane] : 0ull;
+        const unsigned ov = (unsigned)(mk >> 32);
+        run_val[rr] = __uint_as_float((ov & 0x80000000u) ? (ov & 0x7fffffffu) : ~ov);
+        run_idx[rr] = (int)~(unsigned)mk;
       }
     }
   }
 #pragma unroll
   for (int rr = 0; rr < 4; ++rr) {
     const int i = i0 + 4 * wave + rr;
-    if (i < N && lane < k) idx[((size_t)b * N + i) * k + lane] = mine[rr];
+    if (i < N && lane < k) idx[((size_t)b * N + i) * k + lane] = run_idx[rr];
   }
 }
 
 template <int VPL, int C4T>
 int launch_knn(const float* x, const float* xx, int B, int C, int N, int k, int32_t* idx,
                hipStream_t s) {
-  const int n_tiles = (N + 15) / 16;
-  const int ldp = n_tiles * 16 + 4;  // +4: the 4 query rows a lane group writes hit disjoint banks
+  const int n_cols = ((N + 15) / 16) * 16;
+  const int cw = n_cols < 64 * VPL ? n_cols : 64 * VPL;
+  const int ldp = cw + 4;  // +4: the 4 query rows a lane group writes hit disjoint banks
   const int C4 = (C + 3) / 4;
-  const size_t lds_bytes = ((size_t)kQ * ldp + (C4T == 0 ? (size_t)C4 * 4 * kQ : 0)) * sizeof(float);
+  const size_t lds_bytes = ((size_t)kQ * ldp + (C4T == 0 ? (size_t)C4 * 4 * kQ : 0)) * sizeof(float) +
+                           4 * 64 * sizeof(unsigned long long);
   dim3 grid((N + kQ - 1) / kQ, B);
   auto kern = knn_kernel<VPL, C4T>;
   // one-time opt-in to the full 160 KiB of LDS for this instantiation (per process)
@@ -296,12 +362,8 @@ extern "C" int fpsg_knn(const float* x, int B, int C, int N, int k, int32_t* idx
   FPSG_REQUIRE(B > 0 && C > 0 && N > 0 && k > 0, FPSG_E_SHAPE,
                "fpsg_knn: B,C,N,k must be positive (got %d,%d,%d,%d)", B, C, N, k);
   FPSG_REQUIRE(k <= 64 && k <= N, FPSG_E_LIMIT, "fpsg_knn: need k <= min(64, N) (k=%d, N=%d)", k, N);
-  {
-    const size_t need = ((size_t)kQ * (((N + 15) / 16) * 16 + 4) + (size_t)((C + 3) / 4) * 4 * kQ) * 4;
-    FPSG_REQUIRE(need <= 160 * 1024, FPSG_E_LIMIT,
-                 "fpsg_knn: N=%d, C=%d need %zu B of LDS (16 x N distance tile + 16 x C queries); "
-                 "limit is 163840 B (N <= 2048 at C <= 448)", N, C, need);
-  }
+  FPSG_REQUIRE(C <= 440 && (long)N <= (1L << 24), FPSG_E_LIMIT,
+               "fpsg_knn: C=%d exceeds 440 (16 x C query tile beside the 128 KiB score tile) or N=%d > 2^24", C, N);
   FPSG_REQUIRE(B <= 65535, FPSG_E_LIMIT, "fpsg_knn: B=%d exceeds 65535", B);
   FPSG_REQUIRE_PTR(x); FPSG_REQUIRE_PTR(idx); FPSG_REQUIRE_PTR(sqnorm_ws);
   hipStream_t s = static_cast<hipStream_t>(stream);
@@ -311,6 +373,5 @@ extern "C" int fpsg_knn(const float* x, int B, int C, int N, int k, int32_t* idx
   const int vpl = (((N + 15) / 16) * 16 + 63) / 64;
   if (vpl <= 8) return launch_knn_c<8>(x, sqnorm_ws, B, C, N, k, idx, s);
   if (vpl <= 16) return launch_knn_c<16>(x, sqnorm_ws, B, C, N, k, idx, s);
-  if (vpl <= 32) return launch_knn_c<32>(x, sqnorm_ws, B, C, N, k, idx, s);
-  return launch_knn_c<40>(x, sqnorm_ws, B, C, N, k, idx, s);
+  return launch_knn_c<32>(x, sqnorm_ws, B, C, N, k, idx, s);   // N > 2048: chunks of 2048 columns
 }

@@ -76,8 +76,8 @@ int fpsg_chamfer_bwd(const float* xyz1, const float* xyz2,
  * torch.topk).  x [B,C,N] fp32 channel-major; idx [B,N,k] int32: for every point the k
  * points with the largest  pd_ij = (-|x_j|^2 + 2 x_i.x_j) - |x_i|^2, nearest first (self
  * included), equal values -> lower index first.  sqnorm_ws: caller scratch of B*N floats.
- * Limits: k <= min(64, N); the 16 x N fp32 distance tile plus the 16 x C query tile must fit
- * 160 KiB of LDS (N <= 2048 for C <= 448).
+ * Limits: k <= min(64, N), C <= 440.  Any N: the score tile in LDS covers 2048 candidates at a
+ * time, longer clouds are processed in chunks whose sorted top-k lists are merged.
  */
 int fpsg_knn(const float* x, int B, int C, int N, int k, int32_t* idx, float* sqnorm_ws,
              fpsg_stream_t stream);

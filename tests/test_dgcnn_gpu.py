@@ -17,7 +17,8 @@ def gold():
 
 
 KNN_SHAPES = [(2, 3, 256, 20), (2, 3, 2048, 20), (1, 64, 1024, 20), (2, 5, 100, 7), (1, 128, 512, 20),
-              (3, 3, 33, 33), (1, 6, 17, 1), (2, 64, 2048, 20), (1, 3, 64, 64), (1, 130, 300, 16)]
+              (3, 3, 33, 33), (1, 6, 17, 1), (2, 64, 2048, 20), (1, 3, 64, 64), (1, 130, 300, 16),
+              (1, 3, 2049, 20), (2, 3, 5000, 20), (1, 64, 4100, 32), (1, 20, 2500, 5)]   # > one LDS tile
 
 
 @pytest.mark.parametrize("B,C,N,k", KNN_SHAPES)
@@ -107,7 +108,8 @@ def test_knn_rejects_bad_inputs(gpu):
     with pytest.raises(ValueError):
         knn(torch.rand(1, 3, 10, device=gpu), 20)          # k > N
     with pytest.raises(FpsgHipError):
-        knn(torch.rand(1, 3, 4096, device=gpu), 20)        # beyond the LDS tile limit
+        knn(torch.rand(1, 500, 64, device=gpu), 20)        # C beyond the LDS query-tile limit
+    assert knn(torch.rand(1, 3, 4096, device=gpu), 20).shape == (1, 4096, 20)   # any N
 
 
 @pytest.mark.parametrize("mode", ["train", "eval"])
