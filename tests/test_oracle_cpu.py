@@ -49,3 +49,35 @@ def test_backward_vs_float64_autograd(oracle):
     ((D.min(2)[0].mean(1) + D.min(1)[0].mean(1)) * w.double()).sum().backward()
     np.testing.assert_allclose(ta.grad.numpy(), a64.grad.numpy(), rtol=1e-4, atol=1e-9)
     np.testing.assert_allclose(tb.grad.numpy(), b64.grad.numpy(), rtol=1e-4, atol=1e-9)
+
+
+def test_oracle_properties_hypothesis(oracle):
+    """Size-independent properties of the Chamfer restatement on random ragged shapes:
+    permutation equivariance, exact power-of-two scaling, argument symmetry, and that every
+    reported distance is the distance to the reported index."""
+    from hypothesis import given, settings, strategies as st
+
+    @settings(max_examples=25, deadline=None)
+    @given(st.integers(1, 3), st.integers(1, 70), st.integers(1, 90), st.integers(0, 10**6))
+    def check(B, N, M, seed):
+        rng = np.random.default_rng(seed)
+        a = rng.standard_normal((B, N, 3)).astype(np.float32)
+        b = rng.standard_normal((B, M, 3)).astype(np.float32)
+        d1, i1, d2, i2 = oracle.chamfer_fwd(a, b)
+        # symmetry of the two directions
+        e1, j1, e2, j2 = oracle.chamfer_fwd(b, a)
+        assert np.array_equal(d1, e2) and np.array_equal(d2, e1) and np.array_equal(i1, j2)
+        # scaling by 2 is exact in fp32: distances x4, same indices
+        s1, k1, s2, k2 = oracle.chamfer_fwd(2 * a, 2 * b)
+        assert np.array_equal(s1, 4 * d1) and np.array_equal(k1, i1) and np.array_equal(k2, i2)
+        # permuting the candidates permutes the indices
+        perm = rng.permutation(M)
+        p1, q1, _, _ = oracle.chamfer_fwd(a, b[:, perm])
+        assert np.array_equal(p1, d1)
+        assert np.array_equal(np.take_along_axis(b[:, perm], q1[..., None].repeat(3, -1), 1),
+                              np.take_along_axis(b, i1[..., None].repeat(3, -1), 1))
+        # distance to the reported index
+        nb = np.take_along_axis(b, i1[..., None].repeat(3, -1), 1)
+        np.testing.assert_allclose(((a - nb) ** 2).sum(-1), d1, rtol=1e-5, atol=1e-7)
+
+    check()
