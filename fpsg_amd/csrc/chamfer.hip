@@ -239,8 +239,8 @@ int launch_fwd(const float* xyz1, const float* xyz2, int B, int N, int M, float*
 // list in LDS (integer LDS atomics only hand out slots; the ORDER of accumulation does not
 // depend on them).  Pass 2: each thread walks its list in ascending j (selection by "smallest
 // j greater than the previous one"), so the fp32 sums are bit-identical to the oracle's
-// sequential loop.  Targets chosen by more than kBwdCap sources (duplicate-heavy clouds) fall
-// back to a plain ascending scan of the whole list.
+// sequential loop.  Targets chosen by more than kBwdCap sources are summed by the whole wave in
+// a fixed hierarchical order (see below), which the oracle follows too.
 constexpr int kBwdThreads = 256;
 constexpr int kBwdCap = 16;
 
@@ -287,18 +287,19 @@ __global__ __launch_bounds__(kBwdThreads) void chamfer_bwd_kernel(
   __syncthreads();
 
   const int i = lo + tid;
-  if (i >= na) return;
-  const float px = A[3 * i + 0], py = A[3 * i + 1], pz = A[3 * i + 2];
+  const bool live = i < na;
+  const int ic = live ? i : na - 1;
+  const float px = A[3 * ic + 0], py = A[3 * ic + 1], pz = A[3 * ic + 2];
   float ax, ay, az;
   {
-    int j = ia[i];
+    int j = ia[ic];
     j = j < 0 ? 0 : (j >= nb ? nb - 1 : j);   // never read outside the cloud
-    const float t = 2.0f * ga_up[i];
+    const float t = 2.0f * ga_up[ic];
     ax = t * (px - Bc[3 * j + 0]);
     ay = t * (py - Bc[3 * j + 1]);
     az = t * (pz - Bc[3 * j + 2]);
   }
-  const int n = cnt[tid];
+  const int n = live ? cnt[tid] : 0;
   if (n <= kBwdCap) {
     int prev = -1;
     for (int s = 0; s < n; ++s) {
@@ -313,19 +314,45 @@ __global__ __launch_bounds__(kBwdThreads) void chamfer_bwd_kernel(
       ay = fma_rn(t, py - Bc[3 * j + 1], ay);
       az = fma_rn(t, pz - Bc[3 * j + 2], az);
     }
-  } else {
-    for (int j = 0; j < nb; ++j) {
-      if (ib[j] == i) {
+  }
+  // Targets chosen by more than kBwdCap sources (routine early in training, when the generated
+  // cloud is a small blob): the whole wave serves them one at a time.  Lane t sums the sources
+  // j = t (mod 64) in ascending order, the 64 partial sums are folded by a fixed shuffle tree
+  // (32,16,..,1) and added to the own term -- the same fixed order as the oracle.
+  const int lane = tid & 63;
+  unsigned long long heavy = __ballot(n > kBwdCap);
+  while (heavy) {
+    const int L = __builtin_ctzll(heavy);
+    heavy &= heavy - 1;
+    const int tgt = __builtin_amdgcn_readlane(i, L);
+    const float qx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(px), L));
+    const float qy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(py), L));
+    const float qz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pz), L));
+    float sx = 0.0f, sy = 0.0f, sz = 0.0f;
+    for (int j = lane; j < nb; j += 64) {
+      if (ib[j] == tgt) {
         const float t = 2.0f * gb_up[j];
-        ax = fma_rn(t, px - Bc[3 * j + 0], ax);
-        ay = fma_rn(t, py - Bc[3 * j + 1], ay);
-        az = fma_rn(t, pz - Bc[3 * j + 2], az);
+        sx = fma_rn(t, qx - Bc[3 * j + 0], sx);
+        sy = fma_rn(t, qy - Bc[3 * j + 1], sy);
+        sz = fma_rn(t, qz - Bc[3 * j + 2], sz);
       }
     }
+#pragma unroll
+    for (int sft = 32; sft >= 1; sft >>= 1) {
+      sx += __shfl_down(sx, sft, 64);
+      sy += __shfl_down(sy, sft, 64);
+      sz += __shfl_down(sz, sft, 64);
+    }
+    const float tx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sx), 0));
+    const float ty = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sy), 0));
+    const float tz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sz), 0));
+    if (lane == L) { ax += tx; ay += ty; az += tz; }
   }
-  out[3 * i + 0] = ax;
-  out[3 * i + 1] = ay;
-  out[3 * i + 2] = az;
+  if (live) {
+    out[3 * i + 0] = ax;
+    out[3 * i + 1] = ay;
+    out[3 * i + 2] = az;
+  }
 }
 
 }  // namespace
