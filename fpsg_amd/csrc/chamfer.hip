@@ -243,6 +243,7 @@ int launch_fwd(const float* xyz1, const float* xyz2, int B, int N, int M, float*
 // a fixed hierarchical order (see below), which the oracle follows too.
 constexpr int kBwdThreads = 256;
 constexpr int kBwdCap = 16;
+constexpr int kBwdStage = 4096;
 
 __global__ __launch_bounds__(kBwdThreads) void chamfer_bwd_kernel(
     const float* __restrict__ xyz1, const float* __restrict__ xyz2,
@@ -251,6 +252,7 @@ __global__ __launch_bounds__(kBwdThreads) void chamfer_bwd_kernel(
     float* __restrict__ gxyz1, float* __restrict__ gxyz2) {
   __shared__ int cnt[kBwdThreads];
   __shared__ int lst[kBwdThreads * kBwdCap];
+  __shared__ int sib[kBwdStage];   // the other side's argmin list (whole, when it fits)
   // same XCD-aware, cloud-pair-major work order as the forward kernel
   int work;
   {
@@ -277,8 +279,11 @@ __global__ __launch_bounds__(kBwdThreads) void chamfer_bwd_kernel(
   const int tid = threadIdx.x;
   cnt[tid] = 0;
   __syncthreads();
+  const bool staged = nb <= kBwdStage;
   for (int j = tid; j < nb; j += kBwdThreads) {
-    const int t = ib[j] - lo;
+    const int src = ib[j];
+    if (staged) sib[j] = src;
+    const int t = src - lo;
     if (t >= 0 && t < kBwdThreads) {
       const int slot = atomicAdd(&cnt[t], 1);
       if (slot < kBwdCap) lst[t * kBwdCap + slot] = j;
@@ -330,7 +335,7 @@ __global__ __launch_bounds__(kBwdThreads) void chamfer_bwd_kernel(
     const float qz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pz), L));
     float sx = 0.0f, sy = 0.0f, sz = 0.0f;
     for (int j = lane; j < nb; j += 64) {
-      if (ib[j] == tgt) {
+      if ((staged ? sib[j] : ib[j]) == tgt) {
         const float t = 2.0f * gb_up[j];
         sx = fma_rn(t, qx - Bc[3 * j + 0], sx);
         sy = fma_rn(t, qy - Bc[3 * j + 1], sy);
