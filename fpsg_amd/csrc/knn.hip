@@ -2,7 +2,7 @@
 // Replaces `knn` of reference src/dgcnn/model.py:13-20 (torch.matmul of x^T x into a
 // [B,N,N] tensor + torch.topk): here the N x N matrix never reaches HBM.
 //
-// One workgroup (4 waves, one per SIMD) owns 16 query points of one cloud:
+// One workgroup (8 waves, two per SIMD) owns 16 query points of one cloud:
 //   phase A  the 16 x N block of  pd_ij = (-|x_j|^2 + 2 x_i.x_j) - |x_i|^2  is produced with
 //            fp32-input MFMA (v_mfma_f32_16x16x4_f32: exact k-ordered fma chain, same
 //            64 FLOP/clk/SIMD as the VALU).  A = the 16 queries, held in registers for the
@@ -12,7 +12,7 @@
 //            chains of the tiles in flight; the accumulator is carried over C/4 steps.
 //            Scores go to a 16 x min(N,2048) fp32 tile in LDS (128 KiB), never to HBM; longer
 //            clouds are processed in 2048-column chunks whose top-k lists are merged.
-//   phase B  each wave selects the k largest of 4 rows, all 4 interleaved for ILP.  A lane
+//   phase B  each wave selects the k largest of its 2 rows, interleaved for ILP.  A lane
 //            holds N/64 scores of each row in registers, in groups of 8 with cached group
 //            maxima.  A round = best of the lane's group maxima, wave-wide argmax with DPP
 //            row operations (value max, then lowest index among the lanes that hold it: ties
@@ -25,7 +25,9 @@ namespace fpsg {
 namespace {
 
 constexpr int kQ = 16;            // query rows per workgroup (= MFMA M)
-constexpr int kKnnThreads = 256;
+constexpr int kKnnWaves = 8;          // 2 waves per SIMD: the selection rounds are latency-bound
+constexpr int kKnnThreads = 64 * kKnnWaves;
+constexpr int kRowsPerWave = kQ / kKnnWaves;
 constexpr int kGroup = 8;         // scores per cached-maximum group in phase B
 
 __global__ __launch_bounds__(256) void sqnorm_kernel(const float* __restrict__ x, int C, int N,
@@ -157,10 +159,10 @@ __global__ __launch_bounds__(kKnnThreads) void knn_kernel(const float* __restric
       qa[e] = (c < C && i0 + q < N) ? xb[(size_t)c * N + i0 + q] : 0.0f;
     }
   }
-  float run_val[4];
-  int run_idx[4];
+  float run_val[kRowsPerWave];
+  int run_idx[kRowsPerWave];
 #pragma unroll
-  for (int rr = 0; rr < 4; ++rr) { run_val[rr] = -__builtin_inff(); run_idx[rr] = 0; }
+  for (int rr = 0; rr < kRowsPerWave; ++rr) { run_val[rr] = -__builtin_inff(); run_idx[rr] = 0; }
 
   for (int c0 = 0; c0 < n_cols; c0 += CW) {
     __syncthreads();   // previous chunk's tile fully consumed (and qa staged, first time round)
@@ -170,23 +172,24 @@ __global__ __launch_bounds__(kKnnThreads) void knn_kernel(const float* __restric
     if constexpr (C4T > 0) {
       float b0[C4T], b1[C4T], b2[C4T];
       const int tw = t_first + wave;
+      constexpr int NW = kKnnWaves;
       load_b<C4T>(xb, C, N, tw < t_last ? tw : n_tiles, kk, col, b0);
-      load_b<C4T>(xb, C, N, tw + 4 < t_last ? tw + 4 : n_tiles, kk, col, b1);
-      for (int t = tw; t < t_last; t += 12) {
-        load_b<C4T>(xb, C, N, t + 8 < t_last ? t + 8 : n_tiles, kk, col, b2);
+      load_b<C4T>(xb, C, N, tw + NW < t_last ? tw + NW : n_tiles, kk, col, b1);
+      for (int t = tw; t < t_last; t += 3 * NW) {
+        load_b<C4T>(xb, C, N, t + 2 * NW < t_last ? t + 2 * NW : n_tiles, kk, col, b2);
         score_tile<C4T>(a, b0, t, N, kk, col, xxb, xxq, pd, ldp, c0);
-        if (t + 4 < t_last) {
-          load_b<C4T>(xb, C, N, t + 12 < t_last ? t + 12 : n_tiles, kk, col, b0);
-          score_tile<C4T>(a, b1, t + 4, N, kk, col, xxb, xxq, pd, ldp, c0);
+        if (t + NW < t_last) {
+          load_b<C4T>(xb, C, N, t + 3 * NW < t_last ? t + 3 * NW : n_tiles, kk, col, b0);
+          score_tile<C4T>(a, b1, t + NW, N, kk, col, xxb, xxq, pd, ldp, c0);
         }
-        if (t + 8 < t_last) {
-          load_b<C4T>(xb, C, N, t + 16 < t_last ? t + 16 : n_tiles, kk, col, b1);
-          score_tile<C4T>(a, b2, t + 8, N, kk, col, xxb, xxq, pd, ldp, c0);
+        if (t + 2 * NW < t_last) {
+          load_b<C4T>(xb, C, N, t + 4 * NW < t_last ? t + 4 * NW : n_tiles, kk, col, b1);
+          score_tile<C4T>(a, b2, t + 2 * NW, N, kk, col, xxb, xxq, pd, ldp, c0);
         }
       }
     } else {
       const int C4 = (C + 3) >> 2;
-      for (int t = t_first + wave; t < t_last; t += 4) {
+      for (int t = t_first + wave; t < t_last; t += kKnnWaves) {
         const int j = t * 16 + col;
         const bool jin = j < N;
         const float* __restrict__ bp = xb + (jin ? j : 0);
@@ -208,17 +211,17 @@ __global__ __launch_bounds__(kKnnThreads) void knn_kernel(const float* __restric
     __syncthreads();
 
     // ---------------------------------------------------------------- phase B
-    // wave w selects rows 4w .. 4w+3 together; VPL scores per lane and row, groups of 8
+    // wave w selects its kRowsPerWave rows together; VPL scores per lane and row, groups of 8
     constexpr int NG = VPL / kGroup;
     const int cw = (n_cols - c0) < CW ? (n_cols - c0) : CW;
-    float v[4][VPL];
-    float gmax[4][NG];
-    int gt[4][NG];
-    int mine[4];
-    float mval[4];
+    float v[kRowsPerWave][VPL];
+    float gmax[kRowsPerWave][NG];
+    int gt[kRowsPerWave][NG];
+    int mine[kRowsPerWave];
+    float mval[kRowsPerWave];
 #pragma unroll
-    for (int rr = 0; rr < 4; ++rr) {
-      const int q = 4 * wave + rr;
+    for (int rr = 0; rr < kRowsPerWave; ++rr) {
+      const int q = kRowsPerWave * wave + rr;
       mine[rr] = 0;
       mval[rr] = -__builtin_inff();
 #pragma unroll
@@ -243,7 +246,7 @@ __global__ __launch_bounds__(kKnnThreads) void knn_kernel(const float* __restric
     const int rounds = k < cw ? k : cw;   // a short last chunk may hold fewer than k columns
     for (int round = 0; round < rounds; ++round) {
 #pragma unroll
-      for (int rr = 0; rr < 4; ++rr) {
+      for (int rr = 0; rr < kRowsPerWave; ++rr) {
         float bv = gmax[rr][0];
         int bt = gt[rr][0];
 #pragma unroll
@@ -284,13 +287,13 @@ __global__ __launch_bounds__(kKnnThreads) void knn_kernel(const float* __restric
     // ---------------------------------------------------------------- merge with earlier chunks
     if (c0 == 0) {
 #pragma unroll
-      for (int rr = 0; rr < 4; ++rr) { run_val[rr] = mval[rr]; run_idx[rr] = mine[rr]; }
+      for (int rr = 0; rr < kRowsPerWave; ++rr) { run_val[rr] = mval[rr]; run_idx[rr] = mine[rr]; }
     } else {
       // two lists sorted by (score desc, index asc) in lanes 0..k-1: an element's place in the
       // merged order is its own rank plus the number of elements of the other list that
       // precede it; the first k places are written to a per-wave LDS strip and read back
 #pragma unroll
-      for (int rr = 0; rr < 4; ++rr) {
+      for (int rr = 0; rr < kRowsPerWave; ++rr) {
         const bool have_a = lane < k, have_b = lane < rounds;
         const unsigned long long ka =
             have_a ? (((unsigned long long)orderable(run_val[rr] + 0.0f) << 32) | (unsigned)~run_idx[rr]) : 0ull;
@@ -316,8 +319,8 @@ __global__ __launch_bounds__(kKnnThreads) void knn_kernel(const float* __restric
     }
   }
 #pragma unroll
-  for (int rr = 0; rr < 4; ++rr) {
-    const int i = i0 + 4 * wave + rr;
+  for (int rr = 0; rr < kRowsPerWave; ++rr) {
+    const int i = i0 + kRowsPerWave * wave + rr;
     if (i < N && lane < k) idx[((size_t)b * N + i) * k + lane] = run_idx[rr];
   }
 }
@@ -330,7 +333,7 @@ int launch_knn(const float* x, const float* xx, int B, int C, int N, int k, int3
   const int ldp = cw + 4;  // +4: the 4 query rows a lane group writes hit disjoint banks
   const int C4 = (C + 3) / 4;
   const size_t lds_bytes = ((size_t)kQ * ldp + (C4T == 0 ? (size_t)C4 * 4 * kQ : 0)) * sizeof(float) +
-                           4 * 64 * sizeof(unsigned long long);
+                           kKnnWaves * 64 * sizeof(unsigned long long);
   dim3 grid((N + kQ - 1) / kQ, B);
   auto kern = knn_kernel<VPL, C4T>;
   // one-time opt-in to the full 160 KiB of LDS for this instantiation (per process)
