@@ -2,7 +2,7 @@
 // Replaces `knn` of reference src/dgcnn/model.py:13-20 (torch.matmul of x^T x into a
 // [B,N,N] tensor + torch.topk): here the N x N matrix never reaches HBM.
 //
-// One workgroup (8 waves, two per SIMD) owns 16 query points of one cloud:
+// One workgroup (16 waves for C <= 64, else 8) owns 16 query points of one cloud:
 //   phase A  the 16 x N block of  pd_ij = (-|x_j|^2 + 2 x_i.x_j) - |x_i|^2  is produced with
 //            fp32-input MFMA (v_mfma_f32_16x16x4_f32: exact k-ordered fma chain, same
 //            64 FLOP/clk/SIMD as the VALU).  A = the 16 queries, held in registers for the
@@ -12,7 +12,7 @@
 //            chains of the tiles in flight; the accumulator is carried over C/4 steps.
 //            Scores go to a 16 x min(N,2048) fp32 tile in LDS (128 KiB), never to HBM; longer
 //            clouds are processed in 2048-column chunks whose top-k lists are merged.
-//   phase B  each wave selects the k largest of its 2 rows, interleaved for ILP.  A lane
+//   phase B  each wave selects the k largest of its 1-2 rows.  A lane
 //            holds N/64 scores of each row in registers, in groups of 8 with cached group
 //            maxima.  A round = best of the lane's group maxima, wave-wide argmax with DPP
 //            row operations (value max, then lowest index among the lanes that hold it: ties
@@ -25,9 +25,8 @@ namespace fpsg {
 namespace {
 
 constexpr int kQ = 16;            // query rows per workgroup (= MFMA M)
-constexpr int kKnnWaves = 8;          // 2 waves per SIMD: the selection rounds are latency-bound
-constexpr int kKnnThreads = 64 * kKnnWaves;
-constexpr int kRowsPerWave = kQ / kKnnWaves;
+// waves per workgroup NW (template parameter): 16 (4 per SIMD, 128 VGPRs) when the operands
+// fit, else 8; the selection rounds are latency-bound, so more resident waves = more rows in flight
 constexpr int kGroup = 8;         // scores per cached-maximum group in phase B
 
 __global__ __launch_bounds__(256) void sqnorm_kernel(const float* __restrict__ x, int C, int N,
@@ -112,11 +111,14 @@ __device__ __forceinline__ void score_tile(const float (&a)[C4T], const float (&
 // LDS: pd[kQ][ldp] floats (+ qa[C4*4][16] floats for the generic-C path).
 // C4T > 0: compile-time channel steps (C <= 4*C4T), register-resident operands.
 // C4T == 0: any C, operands re-read per step (slow path for unusual channel counts).
-template <int VPL, int C4T>
-__global__ __launch_bounds__(kKnnThreads) void knn_kernel(const float* __restrict__ x,
+template <int VPL, int C4T, int NW>
+__global__ __launch_bounds__(64 * NW) void knn_kernel(const float* __restrict__ x,
                                                           const float* __restrict__ xx, int C,
                                                           int N, int k, int ldp,
                                                           int32_t* __restrict__ idx) {
+  constexpr int kKnnWaves = NW;
+  constexpr int kKnnThreads = 64 * NW;
+  constexpr int kRowsPerWave = kQ / NW;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* pd = lds;
   const int b = blockIdx.y;
@@ -170,21 +172,34 @@ __global__ __launch_bounds__(kKnnThreads) void knn_kernel(const float* __restric
     const int t_last = ((c0 + CW) >> 4) < n_tiles ? ((c0 + CW) >> 4) : n_tiles;
     // ---------------------------------------------------------------- phase A
     if constexpr (C4T > 0) {
-      float b0[C4T], b1[C4T], b2[C4T];
+      float b0[C4T], b1[C4T];
       const int tw = t_first + wave;
-      constexpr int NW = kKnnWaves;
-      load_b<C4T>(xb, C, N, tw < t_last ? tw : n_tiles, kk, col, b0);
-      load_b<C4T>(xb, C, N, tw + NW < t_last ? tw + NW : n_tiles, kk, col, b1);
-      for (int t = tw; t < t_last; t += 3 * NW) {
-        load_b<C4T>(xb, C, N, t + 2 * NW < t_last ? t + 2 * NW : n_tiles, kk, col, b2);
-        score_tile<C4T>(a, b0, t, N, kk, col, xxb, xxq, pd, ldp, c0);
-        if (t + NW < t_last) {
-          load_b<C4T>(xb, C, N, t + 3 * NW < t_last ? t + 3 * NW : n_tiles, kk, col, b0);
-          score_tile<C4T>(a, b1, t + NW, N, kk, col, xxb, xxq, pd, ldp, c0);
+      if constexpr (NW >= 16) {
+        // 4 waves per SIMD (128 VGPRs each): prefetch one tile ahead, two register sets
+        load_b<C4T>(xb, C, N, tw < t_last ? tw : n_tiles, kk, col, b0);
+        for (int t = tw; t < t_last; t += 2 * NW) {
+          load_b<C4T>(xb, C, N, t + NW < t_last ? t + NW : n_tiles, kk, col, b1);
+          score_tile<C4T>(a, b0, t, N, kk, col, xxb, xxq, pd, ldp, c0);
+          if (t + NW < t_last) {
+            load_b<C4T>(xb, C, N, t + 2 * NW < t_last ? t + 2 * NW : n_tiles, kk, col, b0);
+            score_tile<C4T>(a, b1, t + NW, N, kk, col, xxb, xxq, pd, ldp, c0);
+          }
         }
-        if (t + 2 * NW < t_last) {
-          load_b<C4T>(xb, C, N, t + 4 * NW < t_last ? t + 4 * NW : n_tiles, kk, col, b1);
-          score_tile<C4T>(a, b2, t + 2 * NW, N, kk, col, xxb, xxq, pd, ldp, c0);
+      } else {
+        float b2[C4T];
+        load_b<C4T>(xb, C, N, tw < t_last ? tw : n_tiles, kk, col, b0);
+        load_b<C4T>(xb, C, N, tw + NW < t_last ? tw + NW : n_tiles, kk, col, b1);
+        for (int t = tw; t < t_last; t += 3 * NW) {
+          load_b<C4T>(xb, C, N, t + 2 * NW < t_last ? t + 2 * NW : n_tiles, kk, col, b2);
+          score_tile<C4T>(a, b0, t, N, kk, col, xxb, xxq, pd, ldp, c0);
+          if (t + NW < t_last) {
+            load_b<C4T>(xb, C, N, t + 3 * NW < t_last ? t + 3 * NW : n_tiles, kk, col, b0);
+            score_tile<C4T>(a, b1, t + NW, N, kk, col, xxb, xxq, pd, ldp, c0);
+          }
+          if (t + 2 * NW < t_last) {
+            load_b<C4T>(xb, C, N, t + 4 * NW < t_last ? t + 4 * NW : n_tiles, kk, col, b1);
+            score_tile<C4T>(a, b2, t + 2 * NW, N, kk, col, xxb, xxq, pd, ldp, c0);
+          }
         }
       }
     } else {
@@ -325,7 +340,7 @@ __global__ __launch_bounds__(kKnnThreads) void knn_kernel(const float* __restric
   }
 }
 
-template <int VPL, int C4T>
+template <int VPL, int C4T, int NW>
 int launch_knn(const float* x, const float* xx, int B, int C, int N, int k, int32_t* idx,
                hipStream_t s) {
   const int n_cols = ((N + 15) / 16) * 16;
@@ -333,9 +348,9 @@ int launch_knn(const float* x, const float* xx, int B, int C, int N, int k, int3
   const int ldp = cw + 4;  // +4: the 4 query rows a lane group writes hit disjoint banks
   const int C4 = (C + 3) / 4;
   const size_t lds_bytes = ((size_t)kQ * ldp + (C4T == 0 ? (size_t)C4 * 4 * kQ : 0)) * sizeof(float) +
-                           kKnnWaves * 64 * sizeof(unsigned long long);
+                           NW * 64 * sizeof(unsigned long long);
   dim3 grid((N + kQ - 1) / kQ, B);
-  auto kern = knn_kernel<VPL, C4T>;
+  auto kern = knn_kernel<VPL, C4T, NW>;
   // one-time opt-in to the full 160 KiB of LDS for this instantiation (per process)
   static const hipError_t lds_optin = hipFuncSetAttribute(
       reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -343,17 +358,17 @@ int launch_knn(const float* x, const float* xx, int B, int C, int N, int k, int3
     set_error("fpsg_knn: cannot reserve %zu B of LDS: %s", lds_bytes, hipGetErrorString(lds_optin));
     return (int)lds_optin;
   }
-  hipLaunchKernelGGL(kern, grid, dim3(kKnnThreads), lds_bytes, s, x, xx, C, N, k, ldp, idx);
+  hipLaunchKernelGGL(kern, grid, dim3(64 * NW), lds_bytes, s, x, xx, C, N, k, ldp, idx);
   return launch_status("fpsg_knn");
 }
 
 template <int VPL>
 int launch_knn_c(const float* x, const float* xx, int B, int C, int N, int k, int32_t* idx,
                  hipStream_t s) {
-  if (C <= 4) return launch_knn<VPL, 1>(x, xx, B, C, N, k, idx, s);
-  if (C > 32 && C <= 64) return launch_knn<VPL, 16>(x, xx, B, C, N, k, idx, s);
-  if (C > 64 && C <= 128) return launch_knn<VPL, 32>(x, xx, B, C, N, k, idx, s);
-  return launch_knn<VPL, 0>(x, xx, B, C, N, k, idx, s);
+  if (C <= 4) return launch_knn<VPL, 1, 16>(x, xx, B, C, N, k, idx, s);
+  if (C > 32 && C <= 64) return launch_knn<VPL, 16, 16>(x, xx, B, C, N, k, idx, s);
+  if (C > 64 && C <= 128) return launch_knn<VPL, 32, 8>(x, xx, B, C, N, k, idx, s);
+  return launch_knn<VPL, 0, 8>(x, xx, B, C, N, k, idx, s);
 }
 
 }  // namespace
