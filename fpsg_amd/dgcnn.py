@@ -145,8 +145,8 @@ class _EdgeConvBNMax(torch.autograd.Function):
             mean, var = running_mean, running_var
         rstd = torch.rsqrt(var + eps)
         scale = gamma * rstd
-        z = ysel * scale + (beta - mean * scale)
-        out = torch.where(z > 0, z, z * slope)
+        z = torch.addcmul(beta - mean * scale, ysel, scale)        # one pass over [B,N,Co]
+        out = F.leaky_relu(z, slope)
         ctx.save_for_backward(PQ, idx32, ysel, jsel, s1 if training else ysel, mean, rstd, gamma, beta)
         ctx.cfg = (training, slope, k)
         return out
@@ -159,12 +159,12 @@ class _EdgeConvBNMax(torch.autograd.Function):
         Co = Co2 // 2
         E = B * N * k
         scale = gamma * rstd
-        z = ysel * scale + (beta - mean * scale)
-        dz = g * torch.where(z > 0, 1.0, slope)
-        yhat = (ysel - mean) * rstd
+        z = torch.addcmul(beta - mean * scale, ysel, scale)
+        dz = torch.ops.aten.leaky_relu_backward(g.contiguous(), z, slope, False)
         dbeta = dz.sum(dim=(0, 1))
-        dgamma = (dz * yhat).sum(dim=(0, 1))
-        dzs = (dz * scale).contiguous()
+        # sum dz * yhat = (sum dz*ysel - mean * sum dz) * rstd : one fused multiply-reduce
+        dgamma = (torch.einsum("bnc,bnc->c", dz, ysel) - mean * dbeta) * rstd
+        dzs = dz * scale
         if training:
             coef = torch.stack([scale * dbeta / E, scale * rstd * dgamma / E, mean]).contiguous()
         else:
