@@ -162,8 +162,8 @@ class _EdgeConvBNMax(torch.autograd.Function):
         z = torch.addcmul(beta - mean * scale, ysel, scale)
         dz = torch.ops.aten.leaky_relu_backward(g.contiguous(), z, slope, False)
         dbeta = dz.sum(dim=(0, 1))
-        # sum dz * yhat = (sum dz*ysel - mean * sum dz) * rstd : one fused multiply-reduce
-        dgamma = (torch.einsum("bnc,bnc->c", dz, ysel) - mean * dbeta) * rstd
+        # sum dz * yhat = (sum dz*ysel - mean * sum dz) * rstd
+        dgamma = ((dz * ysel).sum(dim=(0, 1)) - mean * dbeta) * rstd
         dzs = dz * scale
         if training:
             coef = torch.stack([scale * dbeta / E, scale * rstd * dgamma / E, mean]).contiguous()
