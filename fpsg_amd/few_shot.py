@@ -19,7 +19,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from .metrics import chamfer_distance
+from .metrics import chamfer_distance, emd_loss
 from .utils import emd_wrapper
 
 _AGGREGATOR = ["single", "multi", "mask_single", "mask_multi"]
@@ -43,7 +43,8 @@ class ImgPCProtoNet(nn.Module):
             self.metric_module = None
             self.pc_metric = chamfer_distance
         elif metric == "emd":
-            self.pc_metric = lambda a, b: emd_wrapper(a, b).reshape(1)
+            # training needs gradients: the differentiable approximate-assignment solver (K2)
+            self.pc_metric = lambda a, b: emd_loss(a, b, reduce="sum", sinkhorn=False).reshape(1)
         else:
             raise NotImplementedError(
                 f"Found unsupported point cloud reconstruction metrics: {metric}")

@@ -153,15 +153,73 @@ def emd_approx(p1: torch.Tensor, p2: torch.Tensor) -> torch.Tensor:
     return _EmdApprox.apply(p1, p2)
 
 
-def emd_loss(p1: torch.Tensor, p2: torch.Tensor, reduce: str = "mean", sinkhorn: bool = False):
-    """Call-site mirror of ``neuralnet_pytorch.metrics.emd_loss(xyz1, xyz2, reduce, sinkhorn)``
-    as used by the reference's ``emd_wrapper`` (``src/models/utils.py:12-13``).
+def softmin(x: torch.Tensor, y: torch.Tensor, h: torch.Tensor, eps: float) -> torch.Tensor:
+    """``out[b,i] = -eps * logsumexp_j(h[b,j] - |x_i - y_j|^2 / (2 eps))`` (K2b), no grad."""
+    _check_clouds(x, y)
+    _hip.dev_tensor(h, torch.float32, "h")
+    B, N, _ = x.shape
+    M = y.size(1)
+    if h.shape != (B, M):
+        raise ValueError(f"h must be [B,M] = {(B, M)}, got {tuple(h.shape)}")
+    out = torch.empty((B, N), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device), _probe("softmin", B, N, M):
+        rc = _hip.load().fpsg_softmin(_hip.ptr(x), _hip.ptr(y), _hip.ptr(h), B, N, M, float(eps),
+                                      _hip.ptr(out), _hip.stream_of(x))
+    _hip.check(rc, "fpsg_softmin")
+    return out
 
-    The approximate-assignment solver (K2) is used for either value of ``sinkhorn``: the
-    reference's ``sinkhorn=True`` branch defers to geomloss' Sinkhorn divergence, whose
-    package and version are not pinned anywhere in the reference -- parity with it is
-    UNPINNED; the flag is accepted so that the call site is unchanged."""
-    cost = emd_approx(p1, p2)
+
+@torch.no_grad()
+def sinkhorn_divergence(p1: torch.Tensor, p2: torch.Tensor, blur: float = 0.05, scaling: float = 0.5,
+                        diameter: float | None = None) -> torch.Tensor:
+    """Debiased Sinkhorn divergence ``[B]`` between uniform clouds, cost ``|x-y|^2/2`` -- what the
+    reference's ``emd_loss(sinkhorn=True)`` computes through ``geomloss.SamplesLoss()`` with its
+    defaults (p=2, blur=.05, scaling=.5, debias): the symmetric Sinkhorn loop annealed over
+    ``eps = diameter^2, ..., blur^2``, four soft-mins (K2b) per step, no [B,N,M] tensor.
+
+    Forward value only (the reference uses it in evaluation, ``few_shot.py:168``); the geomloss
+    package is absent from the reference tree and unpinned, so parity is UNPINNED."""
+    _check_clouds(p1, p2)
+    import math
+    B, N, _ = p1.shape
+    M = p2.size(1)
+    x, y = p1.detach(), p2.detach()
+    if diameter is None:     # one host sync; pass `diameter` to stay asynchronous
+        pts = torch.cat([x.reshape(-1, 3), y.reshape(-1, 3)])
+        diameter = float((pts.amax(0) - pts.amin(0)).norm())
+    eps_s = [diameter ** 2]
+    e = 2 * math.log(diameter)
+    while e > 2 * math.log(blur):
+        eps_s.append(math.exp(e))
+        e += 2 * math.log(scaling)
+    eps_s.append(blur ** 2)
+    a_log = torch.full((B, N), -math.log(N), dtype=torch.float32, device=x.device)
+    b_log = torch.full((B, M), -math.log(M), dtype=torch.float32, device=x.device)
+    e = eps_s[0]
+    a_x, b_y = softmin(x, x, a_log, e), softmin(y, y, b_log, e)
+    a_y, b_x = softmin(y, x, a_log, e), softmin(x, y, b_log, e)
+    for e in eps_s:
+        at_y = softmin(y, x, a_log + b_x / e, e)
+        bt_x = softmin(x, y, b_log + a_y / e, e)
+        at_x = softmin(x, x, a_log + a_x / e, e)
+        bt_y = softmin(y, y, b_log + b_y / e, e)
+        a_y, b_x = 0.5 * (a_y + at_y), 0.5 * (b_x + bt_x)
+        a_x, b_y = 0.5 * (a_x + at_x), 0.5 * (b_y + bt_y)
+    a_y, b_x = softmin(y, x, a_log + b_x / e, e), softmin(x, y, b_log + a_y / e, e)
+    a_x, b_y = softmin(x, x, a_log + a_x / e, e), softmin(y, y, b_log + b_y / e, e)
+    return (b_x - a_x).mean(dim=1) + (a_y - b_y).mean(dim=1)
+
+
+def emd_loss(p1: torch.Tensor, p2: torch.Tensor, reduce: str = "mean", sinkhorn: bool = False):
+    """Call-site mirror of ``neuralnet_pytorch.metrics.emd_loss(xyz1, xyz2, reduce, sinkhorn)`` as
+    used by the reference's ``emd_wrapper`` (``src/models/utils.py:12-13``).
+
+    ``sinkhorn=True`` (what the reference passes): the debiased Sinkhorn divergence of
+    ``geomloss.SamplesLoss()`` (``sinkhorn_divergence``; forward only, as in the reference's
+    evaluation).  ``sinkhorn=False``: the approximate-assignment solver (K2, the package's
+    CUDA ``earth_mover_distance`` branch), differentiable.  Both third-party packages are
+    absent from the reference tree and unversioned: parity is UNPINNED."""
+    cost = sinkhorn_divergence(p1, p2) if sinkhorn else emd_approx(p1, p2)
     if reduce == "sum":
         return cost.sum()
     if reduce == "mean":

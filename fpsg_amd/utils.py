@@ -15,9 +15,10 @@ import torch
 
 
 def emd_wrapper(pc1: torch.Tensor, pc2: torch.Tensor) -> torch.Tensor:
-    """Reference ``emd_wrapper(pc1, pc2)``: approximate EMD summed over the batch, 0-dim."""
+    """Reference ``emd_wrapper(pc1, pc2)`` = ``emd_loss(pc1, pc2, reduce='sum', sinkhorn=True)``:
+    Sinkhorn-divergence EMD summed over the batch, 0-dim."""
     from .metrics import emd_loss
-    return emd_loss(pc1, pc2, reduce="sum")
+    return emd_loss(pc1, pc2, reduce="sum", sinkhorn=True)
 
 
 class Template:

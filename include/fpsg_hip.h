@@ -130,6 +130,16 @@ int fpsg_edgeconv_bwd(const float* dzs, const uint8_t* jsel, const float* PQ, co
                       const int32_t* rev, const int32_t* off, const float* coef, int B, int N, int k,
                       int Co, float* dPQ, fpsg_stream_t stream);
 
+/* ---- K2b: soft-min of the Sinkhorn loop ---------------------------------------------
+ * The operator under neuralnet_pytorch.metrics.emd_loss(sinkhorn=True) = geomloss.SamplesLoss()
+ * (the form src/models/utils.py:12-13 actually calls): with cost |x-y|^2 / 2,
+ *   out[b,i] = -eps * log sum_j exp( h[b,j] - |x_i - y_j|^2 / (2 eps) )
+ * x [B,N,3], y [B,M,3], h [B,M] (log-weights + dual potential / eps), out [B,N].
+ * No [B,N,M] matrix is formed.  Deterministic.
+ */
+int fpsg_softmin(const float* x, const float* y, const float* h, int B, int N, int M, float eps,
+                 float* out, fpsg_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -186,3 +186,51 @@ def emd_approx(xyz1, xyz2, want_grad=False):
         return cost, g1, g2
     lib().oracle_emd_approx(_p(xyz1), _p(xyz2), B, N, M, _p(cost), None, None)
     return cost
+
+
+def softmin(x, y, h, eps):
+    """out[b,i] = -eps * logsumexp_j(h[b,j] - |x_i - y_j|^2 / (2 eps)); x [B,N,3], y [B,M,3], h [B,M]."""
+    x, y, h = _f32(x), _f32(y), _f32(h)
+    B, N, _ = x.shape
+    M = y.shape[1]
+    out = np.empty((B, N), np.float32)
+    lib().oracle_softmin.argtypes = [_f32p, _f32p, _f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                     ctypes.c_float, _f32p]
+    lib().oracle_softmin(_p(x), _p(y), _p(h), B, N, M, ctypes.c_float(eps), _p(out))
+    return out
+
+
+def sinkhorn_epsilons(x, y, p=2, blur=0.05, scaling=0.5):
+    """geomloss' epsilon schedule: diameter^p, then a geometric descent by scaling^p, then blur^p."""
+    pts = np.concatenate([np.asarray(x, np.float64).reshape(-1, 3), np.asarray(y, np.float64).reshape(-1, 3)])
+    diameter = float(np.linalg.norm(pts.max(0) - pts.min(0)))
+    eps = [diameter ** p]
+    eps += [float(np.exp(e)) for e in np.arange(p * np.log(diameter), p * np.log(blur), p * np.log(scaling))]
+    eps += [blur ** p]
+    return eps
+
+
+def sinkhorn_divergence(x, y, blur=0.05, scaling=0.5, softmin_fn=None):
+    """Debiased Sinkhorn divergence between uniform clouds x [B,N,3], y [B,M,3] -> [B]
+    (the symmetric, annealed loop of geomloss.SamplesLoss('sinkhorn', p=2, blur, scaling),
+    restated from its published algorithm; PARITY UNPINNED)."""
+    sm = softmin_fn or softmin
+    x, y = _f32(x), _f32(y)
+    B, N, _ = x.shape
+    M = y.shape[1]
+    a_log = np.full((B, N), -np.log(N), np.float32)
+    b_log = np.full((B, M), -np.log(M), np.float32)
+    eps_s = sinkhorn_epsilons(x, y, 2, blur, scaling)
+    e = eps_s[0]
+    a_x, b_y = sm(x, x, a_log, e), sm(y, y, b_log, e)
+    a_y, b_x = sm(y, x, a_log, e), sm(x, y, b_log, e)
+    for e in eps_s:
+        at_y = sm(y, x, a_log + b_x / e, e)
+        bt_x = sm(x, y, b_log + a_y / e, e)
+        at_x = sm(x, x, a_log + a_x / e, e)
+        bt_y = sm(y, y, b_log + b_y / e, e)
+        a_y, b_x = 0.5 * (a_y + at_y), 0.5 * (b_x + bt_x)
+        a_x, b_y = 0.5 * (a_x + at_x), 0.5 * (b_y + bt_y)
+    a_y, b_x = sm(y, x, a_log + b_x / e, e), sm(x, y, b_log + a_y / e, e)
+    a_x, b_y = sm(x, x, a_log + a_x / e, e), sm(y, y, b_log + b_y / e, e)
+    return ((b_x - a_x).mean(1) + (a_y - b_y).mean(1)).astype(np.float32)

@@ -296,3 +296,31 @@ void oracle_emd_approx(const float* xyz1, const float* xyz2, int B, int N, int M
   }
   free(remainL); free(ratioL); free(remainR); free(ratioR); free(rowcost);
 }
+
+/* ------------------------------------------------------------------------------------
+ * Soft-min (the inner operator of the Sinkhorn loop behind emd_loss(sinkhorn=True), i.e.
+ * geomloss.SamplesLoss() with its defaults: cost C(x,y) = |x-y|^2 / 2; PARITY UNPINNED, see
+ * the file header):
+ *   out[b,i] = -eps * log sum_j exp( h[b,j] - C(x_i, y_j) / eps )
+ * evaluated with the maximum subtracted (float32, natural exp/log).                      */
+void oracle_softmin(const float* x, const float* y, const float* h, int B, int N, int M,
+                    float eps, float* out) {
+  for (int b = 0; b < B; ++b) {
+    const float* xb = x + (size_t)b * N * 3;
+    const float* yb = y + (size_t)b * M * 3;
+    const float* hb = h + (size_t)b * M;
+    for (int i = 0; i < N; ++i) {
+      float m = -INFINITY;
+      for (int j = 0; j < M; ++j) {
+        float v = hb[j] - 0.5f * sq_dist(xb + 3 * i, yb + 3 * j) / eps;
+        if (v > m) m = v;
+      }
+      double s = 0.0;
+      for (int j = 0; j < M; ++j) {
+        float v = hb[j] - 0.5f * sq_dist(xb + 3 * i, yb + 3 * j) / eps;
+        s += exp((double)(v - m));
+      }
+      out[(size_t)b * N + i] = -eps * (m + (float)log(s));
+    }
+  }
+}

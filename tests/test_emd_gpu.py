@@ -53,5 +53,44 @@ def test_deterministic_and_self_distance(gpu):
     same = emd_approx(a, a.clone())
     assert float(same.max()) < 1e-2 * float(c1.min())              # (near) zero to itself
     assert torch.equal(emd_loss(a, b, reduce="sum"), c1.sum()) and emd_loss(a, b, reduce="sum").dim() == 0
+
+
+# ----------------------------------------------------------------- Sinkhorn form (sinkhorn=True)
+@pytest.mark.parametrize("B,N,M,eps", [(2, 300, 500, 0.5), (1, 2048, 2048, 0.0025), (3, 64, 1000, 0.05),
+                                       (2, 1, 7, 0.01), (1, 2500, 2100, 0.02)])
+def test_softmin_vs_oracle(gpu, oracle, B, N, M, eps):
+    from fpsg_amd.metrics import softmin
+    rng = np.random.default_rng(N + M)
+    x = unit_ball_clouds(rng, B, N)
+    y = np.tanh(rng.standard_normal((B, M, 3)) * 0.5).astype(np.float32)
+    h = (rng.standard_normal((B, M)) * 2 - np.log(M)).astype(np.float32)
+    got = softmin(torch.from_numpy(x).to(gpu), torch.from_numpy(y).to(gpu), torch.from_numpy(h).to(gpu), eps)
+    exp = oracle.softmin(x, y, h, eps)
+    # values are eps * O(10): compare on the scale of eps (v_exp_f32/v_log_f32 vs libm)
+    np.testing.assert_allclose(got.cpu().numpy(), exp, rtol=2e-5, atol=2e-4 * eps * 10)
+
+
+def test_sinkhorn_divergence(gpu, oracle):
+    """emd_wrapper == emd_loss(sinkhorn=True): the loop against its CPU restatement, against the
+    exact optimal-transport cost it approximates (|x-y|^2/2, uniform weights), S(x,x) = 0."""
+    from scipy.optimize import linear_sum_assignment
+    from fpsg_amd.metrics import sinkhorn_divergence, emd_loss
     from fpsg_amd.utils import emd_wrapper
-    assert torch.equal(emd_wrapper(a, b), c1.sum())
+    rng = np.random.default_rng(8)
+    x = unit_ball_clouds(rng, 3, 512)
+    y = (unit_ball_clouds(rng, 3, 512) * 0.7 + 0.2).astype(np.float32)
+    tx, ty = torch.from_numpy(x).to(gpu), torch.from_numpy(y).to(gpu)
+    got = sinkhorn_divergence(tx, ty)
+    exp = oracle.sinkhorn_divergence(x, y)
+    np.testing.assert_allclose(got.cpu().numpy(), exp, rtol=2e-3)
+    for b in range(3):
+        C = 0.5 * ((x[b][:, None] - y[b][None]) ** 2).sum(-1)
+        r, c = linear_sum_assignment(C)
+        ot = C[r, c].mean()
+        assert abs(float(got[b]) - ot) <= 0.08 * ot, (float(got[b]), ot)
+    assert float(sinkhorn_divergence(tx, tx.clone()).abs().max()) < 1e-6
+    assert torch.equal(sinkhorn_divergence(tx, ty), got)                      # deterministic
+    assert torch.equal(emd_wrapper(tx, ty), got.sum()) and emd_wrapper(tx, ty).dim() == 0
+    assert torch.equal(emd_loss(tx, ty, reduce="none", sinkhorn=True), got)
+    big = sinkhorn_divergence(torch.rand(5, 2048, 3, device=gpu), torch.rand(5, 2048, 3, device=gpu) * 0.5)
+    assert big.shape == (5,) and bool((big > 0).all())

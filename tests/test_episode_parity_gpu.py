@@ -41,7 +41,7 @@ def test_pointnet_episode_loss_and_gradients(gpu, oracle, mode):
     out_c = cpu.loss(ep)
     out_g = dev.loss(ep_gpu)
     for key in ("query_rec_loss", "support_rec_loss", "ttl_loss"):
-        a, b = float(out_c[key].sum()), float(out_g[key].sum())
+        a, b = float(out_c[key].detach().sum()), float(out_g[key].detach().sum())
         assert abs(a - b) <= 2e-3 * abs(a), (mode, key, a, b)
     if mode == "train":
         out_c["ttl_loss"].sum().backward()
@@ -53,7 +53,7 @@ def test_pointnet_episode_loss_and_gradients(gpu, oracle, mode):
 
 
 def test_evaluation_dict_with_emd(gpu, oracle):
-    """evaluate_Network's per-item values: Chamfer and the approximate-assignment EMD."""
+    """evaluate_Network's per-item values: Chamfer and the Sinkhorn-form EMD."""
     from fpsg_amd.engine import build_model, default_options
     from fpsg_amd.episodes import synthetic_episode
     torch.manual_seed(2)
@@ -61,7 +61,8 @@ def test_evaluation_dict_with_emd(gpu, oracle):
     cpu = build_model(default_options(device="cpu")).eval()
     dev = copy.deepcopy(cpu).to(gpu)
     cpu.pc_metric = oracle.make_torch_chamfer()
-    cpu.emd_metric = lambda a, b: torch.from_numpy(oracle.emd_approx(a.detach().numpy(), b.detach().numpy())).sum()
+    cpu.emd_metric = lambda a, b: torch.from_numpy(
+        oracle.sinkhorn_divergence(a.detach().numpy(), b.detach().numpy())).sum()   # emd_loss(sinkhorn=True)
     ep = synthetic_episode(S, Q, n_pts=2048, img_size=96, seed=4)
     ep_gpu = {k: (v.to(gpu) if torch.is_tensor(v) else v) for k, v in ep.items()}
     grids_cpu = _fixed_grids(cpu, (Q,), "cpu")
