@@ -17,9 +17,11 @@
  *   - kNN / edge features follow src/dgcnn/model.py:13-42 (in-repo Python; pinned by
  *     goldens generated from the reference's own functions, tests/golden/).
  *   - EMD: the reference calls neuralnet_pytorch.metrics.emd_loss(sinkhorn=True)
- *     (src/models/utils.py:9,12-13; package absent, version unpinned): PARITY UNPINNED.
- *     The approx-match solver restated here is the published Fan et al. auction
- *     scheme; it is bounded against exact Hungarian EMD in tests.
+ *     (src/models/utils.py:9,12-13; package absent, version unpinned) which defers to
+ *     geomloss.SamplesLoss() (absent, unpinned): PARITY UNPINNED.  Restated here: the
+ *     soft-min operator of that Sinkhorn loop (the loop itself is in oracle/__init__.py)
+ *     and, for the sinkhorn=False branch, the published Fan et al. approx-match auction
+ *     scheme; both are bounded against exact optimal transport in tests.
  *
  * Build: see oracle/Makefile (-O2 -mfma -ffp-contract=off: every fused multiply-add is
  * an explicit fmaf() so that the HIP kernels can reproduce the results bit for bit).

@@ -93,6 +93,12 @@ def main():
         p2 = torch.tanh(torch.randn(B, N, 3, device=dev))
         t = gpu_time(lambda: emd_approx(p1, p2), 10, 2)
         print(f"K2 emd     B={B}: {t*1e3:8.3f} ms   {B*30*N*N/t/1e12:6.3f} Tpair-sweeps/s")
+    from fpsg_amd.metrics import sinkhorn_divergence
+    for B in (1, 5):
+        p1 = torch.rand(B, N, 3, device=dev) * 2 - 1
+        p2 = torch.tanh(torch.randn(B, N, 3, device=dev))
+        t = gpu_time(lambda: sinkhorn_divergence(p1, p2, diameter=3.5), 5, 2)
+        print(f"K2b sinkhorn divergence B={B}: {t*1e3:8.3f} ms  (~40 soft-mins of N*M pairs)")
     a1 = (torch.rand(1, N, 3) * 2 - 1).numpy(); b1 = torch.tanh(torch.randn(1, N, 3)).numpy()
     t0 = time.perf_counter(); oracle.emd_approx(a1, b1); t_or = time.perf_counter() - t0
     print(f"# CPU: C oracle (1 core) {t_or*1e3:.0f} ms per cloud pair")
