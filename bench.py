@@ -49,8 +49,8 @@ WORKLOADS = {
            "configs[3]: 1-way 32-shot 5-query intra_recon DGCNN(k=20), 224x224, 2048-pt"),
 }
 
-# algorithmic bytes / work of ONE two-sided Chamfer forward on a cloud pair
-CHAMFER_FWD_BYTES_PER_PAIR_2048 = 81920          # 2*2048*12 B read + 2*2048*(4+4) B written
+# one two-sided Chamfer forward on a 2048-point cloud pair = 81,920 algorithmic
+# bytes (2*2048*12 B read + 2*2048*(4+4) B written) and 2*N*M pair evaluations x 8 flop
 HBM_PEAK = 8.0e12                                # B/s  (MI355X_MICROARCH.md)
 F32_PEAK = 157.3e12                              # FLOP/s, fp32 vector == fp32-input MFMA
 
