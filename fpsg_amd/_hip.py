@@ -39,11 +39,18 @@ SIGNATURES = {
     "fpsg_edgeconv_bwd": [_c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_i32p, _c_i32p, _c_f32p, _c_int, _c_int,
                           _c_int, _c_int, _c_f32p, _c_stream],
     "fpsg_softmin": [_c_f32p, _c_f32p, _c_f32p, _c_int, _c_int, _c_int, ctypes.c_float, _c_f32p, _c_stream],
+    "fpsg_bn_workspace_floats": [_c_int, _c_int, _c_int],
+    "fpsg_bn_act_fwd": [_c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_int, _c_int, _c_int, _c_int,
+                        ctypes.c_float, _c_int, ctypes.c_float, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p,
+                        _c_stream],
+    "fpsg_bn_act_bwd": [_c_f32p, _c_f32p, _c_f32p, _c_int, _c_int, _c_int, _c_int, _c_int, ctypes.c_float,
+                        _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_stream],
     "fpsg_emd_workspace_floats": [_c_int, _c_int, _c_int],
     "fpsg_emd_approx": [_c_f32p, _c_f32p, _c_int, _c_int, _c_int, _c_f32p, _c_f32p, _c_f32p, _c_f32p,
                         _c_stream],
 }
-_RESTYPES = {"fpsg_last_error": ctypes.c_char_p, "fpsg_chamfer_set_config": None, "fpsg_emd_workspace_floats": ctypes.c_size_t}
+_RESTYPES = {"fpsg_last_error": ctypes.c_char_p, "fpsg_chamfer_set_config": None,
+             "fpsg_bn_workspace_floats": ctypes.c_size_t, "fpsg_emd_workspace_floats": ctypes.c_size_t}
 
 _lib = None
 _lock = threading.Lock()

@@ -1,0 +1,309 @@
+// bnact.hip -- K5: training-mode BatchNorm fused with its activation, for gfx950.
+//
+// Every BatchNorm of the hot path is followed by ReLU / LeakyReLU (VGG16-BN trunk
+// src/models/image_net.py:14, PointNet src/pointnet/model.py:30-44,220-233, decoder
+// src/models/point_cloud_net.py:52-54,76-79).  The library path runs them as separate passes
+// over activation tensors of up to 475 MB: BN forward (2 reads + 1 write), ReLU (1R+1W), ReLU
+// backward (2R+1W), BN backward (4R+1W).  Here the pair is 2R+1W forward and 4R+1W backward:
+//   forward : per-(row segment) partial sums -> per-channel mean/rstd (fp64 finalize) ->
+//             y = act(x*scale + shift)
+//   backward: the activation mask is RE-DERIVED from x (same arithmetic as the forward), so only
+//             x is saved -- not the BN output nor the activation output;
+//             partial sums of dz and dz*xhat -> per-channel coefficients ->
+//             dx = k1*dz + k2*x + k3.
+// Layout: x is [N, C, L] contiguous (L = H*W or points), statistics per channel over (N, L).
+// All loops are 16-byte (float4) streams over contiguous row segments; work is split so that a
+// 64-channel, 37x224x224 tensor still fills the chip (the per-channel workgroup of the library
+// kernel cannot).  Deterministic: fixed partial layout, no atomics.
+#include "fpsg_common.h"
+
+namespace fpsg {
+namespace {
+
+constexpr int kBnThreads = 256;
+constexpr int kBnSeg = 4096;      // floats per work item (one contiguous row segment)
+constexpr int kBnSlices = 64;     // partial sums per channel
+
+enum BnAct { kActNone = 0, kActRelu = 1, kActLeaky = 2 };
+
+template <int ACT>
+__device__ __forceinline__ float act_fwd(float z, float slope) {
+  if (ACT == kActRelu) return z > 0.0f ? z : 0.0f;
+  if (ACT == kActLeaky) return z > 0.0f ? z : z * slope;
+  return z;
+}
+template <int ACT>
+__device__ __forceinline__ float act_grad(float z, float slope) {
+  if (ACT == kActRelu) return z > 0.0f ? 1.0f : 0.0f;
+  if (ACT == kActLeaky) return z > 0.0f ? 1.0f : slope;
+  return 1.0f;
+}
+
+__device__ __forceinline__ void block_reduce2(float& a, float& b, float* red /*[2][4]*/) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    a += __shfl_down(a, off, 64);
+    b += __shfl_down(b, off, 64);
+  }
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (lane == 0) { red[wave] = a; red[4 + wave] = b; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    a = (red[0] + red[1]) + (red[2] + red[3]);
+    b = (red[4] + red[5]) + (red[6] + red[7]);
+  }
+}
+
+// Work items of channel c: (n, seg) pairs, seg over ceil(L / kBnSeg) segments of a row.
+// Block (s, c) takes items s, s + S, ...
+// MODE 0: sums of x and x^2.   MODE 1: sums of dz and dz*xhat (dz = dy * act'(x*scale+shift)).
+template <int MODE, int ACT>
+__global__ __launch_bounds__(kBnThreads) void bn_reduce_kernel(
+    const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ chan /*[4][C]: scale, shift, mean, rstd*/,
+    int N, int C, int L, int S, float slope, float* __restrict__ part /*[C][S][2]*/) {
+  __shared__ float red[8];
+  const int c = blockIdx.y, s = blockIdx.x;
+  const int segs = (L + kBnSeg - 1) / kBnSeg;
+  const int items = N * segs;
+  float sc = 0.0f, sh = 0.0f, mu = 0.0f, rs = 0.0f;
+  if (MODE == 1) { sc = chan[c]; sh = chan[C + c]; mu = chan[2 * C + c]; rs = chan[3 * C + c]; }
+  float a0 = 0.0f, a1 = 0.0f;
+  const bool vec = (L & 3) == 0;
+  for (int it = s; it < items; it += S) {
+    const int n = it / segs, seg = it - n * segs;
+    const size_t base = ((size_t)n * C + c) * L + (size_t)seg * kBnSeg;
+    const int len = (L - seg * kBnSeg) < kBnSeg ? (L - seg * kBnSeg) : kBnSeg;
+    if (vec) {
+      const v4f* __restrict__ xp = reinterpret_cast<const v4f*>(x + base);
+      const v4f* __restrict__ gp = reinterpret_cast<const v4f*>(MODE == 1 ? dy + base : x + base);
+      for (int e = threadIdx.x; e < len / 4; e += kBnThreads) {
+        const v4f xv = xp[e];
+        if (MODE == 0) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) { a0 += xv[u]; a1 = fma_rn(xv[u], xv[u], a1); }
+        } else {
+          const v4f gv = gp[e];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const float dz = gv[u] * act_grad<ACT>(fma_rn(xv[u], sc, sh), slope);
+            a0 += dz;
+            a1 = fma_rn(dz, (xv[u] - mu) * rs, a1);
+          }
+        }
+      }
+    } else {
+      for (int e = threadIdx.x; e < len; e += kBnThreads) {
+        const float xv = x[base + e];
+        if (MODE == 0) {
+          a0 += xv; a1 = fma_rn(xv, xv, a1);
+        } else {
+          const float dz = dy[base + e] * act_grad<ACT>(fma_rn(xv, sc, sh), slope);
+          a0 += dz;
+          a1 = fma_rn(dz, (xv - mu) * rs, a1);
+        }
+      }
+    }
+  }
+  block_reduce2(a0, a1, red);
+  if (threadIdx.x == 0) {
+    part[((size_t)c * S + s) * 2 + 0] = a0;
+    part[((size_t)c * S + s) * 2 + 1] = a1;
+  }
+}
+
+// forward finalize: mean / biased var -> chan = (scale, shift, mean, rstd); optional outputs of
+// the batch mean and UNBIASED variance (what running statistics are updated with).
+__global__ void bn_fwd_finalize_kernel(const float* __restrict__ part, const float* __restrict__ gamma,
+                                       const float* __restrict__ beta, int C, int S, double count, float eps,
+                                       float* __restrict__ chan, float* __restrict__ batch_mean,
+                                       float* __restrict__ batch_var_unbiased) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s0 = 0.0, s1 = 0.0;
+  for (int s = 0; s < S; ++s) { s0 += part[((size_t)c * S + s) * 2]; s1 += part[((size_t)c * S + s) * 2 + 1]; }
+  const double mean = s0 / count;
+  double var = s1 / count - mean * mean;
+  var = var > 0.0 ? var : 0.0;
+  const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+  const float g = gamma ? gamma[c] : 1.0f, b = beta ? beta[c] : 0.0f;
+  const float scale = g * rstd;
+  chan[c] = scale;
+  chan[C + c] = b - (float)mean * scale;
+  chan[2 * C + c] = (float)mean;
+  chan[3 * C + c] = rstd;
+  if (batch_mean) batch_mean[c] = (float)mean;
+  if (batch_var_unbiased) batch_var_unbiased[c] = (float)(count > 1.0 ? var * count / (count - 1.0) : var);
+}
+
+// eval mode: chan from running statistics
+__global__ void bn_eval_chan_kernel(const float* __restrict__ rmean, const float* __restrict__ rvar,
+                                    const float* __restrict__ gamma, const float* __restrict__ beta, int C,
+                                    float eps, float* __restrict__ chan) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float rstd = 1.0f / sqrtf(rvar[c] + eps);
+  const float g = gamma ? gamma[c] : 1.0f, b = beta ? beta[c] : 0.0f;
+  chan[c] = g * rstd;
+  chan[C + c] = b - rmean[c] * g * rstd;
+  chan[2 * C + c] = rmean[c];
+  chan[3 * C + c] = rstd;
+}
+
+// backward finalize: dgamma, dbeta and the coefficients of dx = k1*dz + k2*x + k3
+__global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, const float* __restrict__ chan, int C,
+                                       int S, double count, int training, float* __restrict__ dgamma,
+                                       float* __restrict__ dbeta, float* __restrict__ coef /*[3][C]*/) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s0 = 0.0, s1 = 0.0;
+  for (int s = 0; s < S; ++s) { s0 += part[((size_t)c * S + s) * 2]; s1 += part[((size_t)c * S + s) * 2 + 1]; }
+  dbeta[c] = (float)s0;
+  dgamma[c] = (float)s1;
+  const double scale = chan[c], mean = chan[2 * C + c], rstd = chan[3 * C + c];
+  coef[c] = (float)scale;
+  if (training) {
+    const double k2 = -scale * s1 * rstd / count;
+    coef[C + c] = (float)k2;
+    coef[2 * C + c] = (float)(-scale * s0 / count - k2 * mean);
+  } else {
+    coef[C + c] = 0.0f;
+    coef[2 * C + c] = 0.0f;
+  }
+}
+
+// MODE 0: y = act(x*scale + shift).   MODE 1: dx = k1*dz + k2*x + k3.
+// grid (N*C rows, segments of the row)
+template <int MODE, int ACT>
+__global__ __launch_bounds__(kBnThreads) void bn_apply_kernel(const float* __restrict__ x,
+                                                              const float* __restrict__ dy,
+                                                              const float* __restrict__ chan,
+                                                              const float* __restrict__ coef, int C, int L,
+                                                              float slope, float* __restrict__ out) {
+  const int row = blockIdx.x;
+  const int c = row % C;
+  const int seg = blockIdx.y;
+  const size_t base = (size_t)row * L + (size_t)seg * kBnSeg;
+  const int len = (L - seg * kBnSeg) < kBnSeg ? (L - seg * kBnSeg) : kBnSeg;
+  const float sc = chan[c], sh = chan[C + c];
+  float k1 = 0.0f, k2 = 0.0f, k3 = 0.0f;
+  if (MODE == 1) { k1 = coef[c]; k2 = coef[C + c]; k3 = coef[2 * C + c]; }
+  if ((L & 3) == 0) {
+    const v4f* __restrict__ xp = reinterpret_cast<const v4f*>(x + base);
+    const v4f* __restrict__ gp = reinterpret_cast<const v4f*>(MODE == 1 ? dy + base : x + base);
+    v4f* __restrict__ op = reinterpret_cast<v4f*>(out + base);
+    for (int e = threadIdx.x; e < len / 4; e += kBnThreads) {
+      const v4f xv = xp[e];
+      v4f r;
+      if (MODE == 0) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) r[u] = act_fwd<ACT>(fma_rn(xv[u], sc, sh), slope);
+      } else {
+        const v4f gv = gp[e];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const float dz = gv[u] * act_grad<ACT>(fma_rn(xv[u], sc, sh), slope);
+          r[u] = fma_rn(k1, dz, fma_rn(k2, xv[u], k3));
+        }
+      }
+      op[e] = r;
+    }
+  } else {
+    for (int e = threadIdx.x; e < len; e += kBnThreads) {
+      const float xv = x[base + e];
+      if (MODE == 0) {
+        out[base + e] = act_fwd<ACT>(fma_rn(xv, sc, sh), slope);
+      } else {
+        const float dz = dy[base + e] * act_grad<ACT>(fma_rn(xv, sc, sh), slope);
+        out[base + e] = fma_rn(k1, dz, fma_rn(k2, xv, k3));
+      }
+    }
+  }
+}
+
+int slices_for(int N, int L) {
+  const int items = N * ((L + kBnSeg - 1) / kBnSeg);
+  return items < kBnSlices ? items : kBnSlices;
+}
+
+template <int MODE>
+void launch_reduce(int act, const float* x, const float* dy, const float* chan, int N, int C, int L, int S,
+                   float slope, float* part, hipStream_t s) {
+  dim3 grid(S, C);
+  if (act == kActRelu) hipLaunchKernelGGL((bn_reduce_kernel<MODE, kActRelu>), grid, dim3(kBnThreads), 0, s, x, dy, chan, N, C, L, S, slope, part);
+  else if (act == kActLeaky) hipLaunchKernelGGL((bn_reduce_kernel<MODE, kActLeaky>), grid, dim3(kBnThreads), 0, s, x, dy, chan, N, C, L, S, slope, part);
+  else hipLaunchKernelGGL((bn_reduce_kernel<MODE, kActNone>), grid, dim3(kBnThreads), 0, s, x, dy, chan, N, C, L, S, slope, part);
+}
+
+template <int MODE>
+void launch_apply(int act, const float* x, const float* dy, const float* chan, const float* coef, int N, int C,
+                  int L, float slope, float* out, hipStream_t s) {
+  dim3 grid((unsigned)((size_t)N * C), (L + kBnSeg - 1) / kBnSeg);
+  if (act == kActRelu) hipLaunchKernelGGL((bn_apply_kernel<MODE, kActRelu>), grid, dim3(kBnThreads), 0, s, x, dy, chan, coef, C, L, slope, out);
+  else if (act == kActLeaky) hipLaunchKernelGGL((bn_apply_kernel<MODE, kActLeaky>), grid, dim3(kBnThreads), 0, s, x, dy, chan, coef, C, L, slope, out);
+  else hipLaunchKernelGGL((bn_apply_kernel<MODE, kActNone>), grid, dim3(kBnThreads), 0, s, x, dy, chan, coef, C, L, slope, out);
+}
+
+int check_dims(const char* fn, int N, int C, int L, int act) {
+  FPSG_REQUIRE(N > 0 && C > 0 && L > 0, FPSG_E_SHAPE, "%s: N,C,L must be positive (got %d,%d,%d)", fn, N, C, L);
+  FPSG_REQUIRE(act >= 0 && act <= 2, FPSG_E_SHAPE, "%s: act must be 0 (none), 1 (relu) or 2 (leaky)", fn);
+  FPSG_REQUIRE(C <= 65535 && (L + kBnSeg - 1) / kBnSeg <= 65535 && (long)N * C < (1L << 31), FPSG_E_LIMIT,
+               "%s: C=%d, L=%d or N*C=%ld beyond the grid limits", fn, C, L, (long)N * C);
+  return 0;
+}
+
+}  // namespace
+}  // namespace fpsg
+
+extern "C" size_t fpsg_bn_workspace_floats(int N, int C, int L) {
+  return (size_t)C * fpsg::kBnSlices * 2;
+}
+
+extern "C" int fpsg_bn_act_fwd(const float* x, const float* gamma, const float* beta,
+                               const float* running_mean, const float* running_var, int N, int C, int L,
+                               int training, float eps, int act, float slope, float* y, float* chan,
+                               float* batch_mean, float* batch_var_unbiased, float* ws, fpsg_stream_t stream) {
+  using namespace fpsg;
+  int rc = check_dims("fpsg_bn_act_fwd", N, C, L, act);
+  if (rc) return rc;
+  FPSG_REQUIRE_PTR(x); FPSG_REQUIRE_PTR(y); FPSG_REQUIRE_PTR(chan);
+  FPSG_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0, FPSG_E_ALIGN,
+               "fpsg_bn_act_fwd: x and y must be 16-byte aligned");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (training) {
+    FPSG_REQUIRE_PTR(ws);
+    const int S = slices_for(N, L);
+    launch_reduce<0>(kActNone, x, nullptr, nullptr, N, C, L, S, 0.0f, ws, s);
+    if ((rc = launch_status("fpsg_bn_act_fwd(stats)"))) return rc;
+    hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, ws, gamma, beta, C, S,
+                       (double)N * (double)L, eps, chan, batch_mean, batch_var_unbiased);
+    if ((rc = launch_status("fpsg_bn_act_fwd(finalize)"))) return rc;
+  } else {
+    FPSG_REQUIRE_PTR(running_mean); FPSG_REQUIRE_PTR(running_var);
+    hipLaunchKernelGGL(bn_eval_chan_kernel, dim3((C + 255) / 256), dim3(256), 0, s, running_mean, running_var,
+                       gamma, beta, C, eps, chan);
+    if ((rc = launch_status("fpsg_bn_act_fwd(eval)"))) return rc;
+  }
+  launch_apply<0>(act, x, nullptr, chan, nullptr, N, C, L, slope, y, s);
+  return launch_status("fpsg_bn_act_fwd(apply)");
+}
+
+extern "C" int fpsg_bn_act_bwd(const float* x, const float* dy, const float* chan, int N, int C, int L,
+                               int training, int act, float slope, float* dx, float* dgamma, float* dbeta,
+                               float* coef, float* ws, fpsg_stream_t stream) {
+  using namespace fpsg;
+  int rc = check_dims("fpsg_bn_act_bwd", N, C, L, act);
+  if (rc) return rc;
+  FPSG_REQUIRE_PTR(x); FPSG_REQUIRE_PTR(dy); FPSG_REQUIRE_PTR(chan); FPSG_REQUIRE_PTR(dx);
+  FPSG_REQUIRE_PTR(dgamma); FPSG_REQUIRE_PTR(dbeta); FPSG_REQUIRE_PTR(coef); FPSG_REQUIRE_PTR(ws);
+  FPSG_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(dx)) & 15) == 0,
+               FPSG_E_ALIGN, "fpsg_bn_act_bwd: x, dy and dx must be 16-byte aligned");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int S = slices_for(N, L);
+  launch_reduce<1>(act, x, dy, chan, N, C, L, S, slope, ws, s);
+  if ((rc = launch_status("fpsg_bn_act_bwd(reduce)"))) return rc;
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, ws, chan, C, S,
+                     (double)N * (double)L, training, dgamma, dbeta, coef);
+  if ((rc = launch_status("fpsg_bn_act_bwd(finalize)"))) return rc;
+  launch_apply<1>(act, x, dy, chan, coef, N, C, L, slope, dx, s);
+  return launch_status("fpsg_bn_act_bwd(apply)");
+}

@@ -1,0 +1,135 @@
+"""BatchNorm fused with its activation (K5) for the module pairs of the reference networks.
+
+``bn_act(bn, x, act)`` is ``act(bn(x))`` for an ``nn.BatchNorm1d/2d`` module ``bn`` and
+``act`` in {None, 'relu', ('leaky', slope)}: same training / eval semantics, same running
+statistics update, same gradients.  On a ROCm tensor with at least 64 values per (sample,
+channel) row it is ONE fused HIP op (2 reads + 1 write forward, 4 reads + 1 write backward,
+only ``x`` saved); otherwise (CPU tensors of the CPU port, ``nn.Linear`` outputs) the plain
+PyTorch modules run -- that is device dispatch of host plumbing, not a fallback for a missing
+library: on a GPU tensor a missing ``libfpsg_hip.so`` raises.
+
+``FPSG_FUSED_BN=0`` switches the fused op off (A/B measurements).
+"""
+from __future__ import annotations
+
+import os
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _hip
+
+_ACT_CODES = {None: 0, "none": 0, "relu": 1, "leaky": 2}
+_MIN_ROW = 64
+
+
+def fused_enabled() -> bool:
+    return os.environ.get("FPSG_FUSED_BN", "1") != "0"
+
+
+def _parse_act(act):
+    if isinstance(act, tuple):
+        return _ACT_CODES[act[0]], float(act[1])
+    return _ACT_CODES[act], 0.0
+
+
+class _BNAct(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, training, eps, act_code, slope, want_stats):
+        N, C = x.shape[0], x.shape[1]
+        L = x.numel() // (N * C)
+        lib = _hip.load()
+        dev = x.device
+        y = torch.empty_like(x)
+        chan = torch.empty((4, C), dtype=torch.float32, device=dev)
+        ws = torch.empty((lib.fpsg_bn_workspace_floats(N, C, L),), dtype=torch.float32, device=dev)
+        bmean = torch.empty((C,), dtype=torch.float32, device=dev) if (training and want_stats) else None
+        bvar = torch.empty((C,), dtype=torch.float32, device=dev) if (training and want_stats) else None
+        with torch.cuda.device(dev):
+            rc = lib.fpsg_bn_act_fwd(
+                _hip.ptr(x), _hip.ptr(weight) if weight is not None else None,
+                _hip.ptr(bias) if bias is not None else None,
+                _hip.ptr(running_mean) if running_mean is not None else None,
+                _hip.ptr(running_var) if running_var is not None else None,
+                N, C, L, 1 if training else 0, float(eps), act_code, float(slope), _hip.ptr(y), _hip.ptr(chan),
+                _hip.ptr(bmean) if bmean is not None else None, _hip.ptr(bvar) if bvar is not None else None,
+                _hip.ptr(ws), _hip.stream_of(x))
+        _hip.check(rc, "fpsg_bn_act_fwd")
+        ctx.save_for_backward(x, chan)
+        ctx.cfg = (N, C, L, training, act_code, slope, weight is not None, bias is not None)
+        ctx.mark_non_differentiable(*(t for t in (bmean, bvar) if t is not None))
+        if training and want_stats:
+            return y, bmean, bvar
+        return y, None, None
+
+    @staticmethod
+    def backward(ctx, gy, _gm, _gv):
+        x, chan = ctx.saved_tensors
+        N, C, L, training, act_code, slope, has_w, has_b = ctx.cfg
+        lib = _hip.load()
+        dev = x.device
+        gy = gy.contiguous()
+        dx = torch.empty_like(x)
+        dgamma = torch.empty((C,), dtype=torch.float32, device=dev)
+        dbeta = torch.empty((C,), dtype=torch.float32, device=dev)
+        coef = torch.empty((3, C), dtype=torch.float32, device=dev)
+        ws = torch.empty((lib.fpsg_bn_workspace_floats(N, C, L),), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            rc = lib.fpsg_bn_act_bwd(_hip.ptr(x), _hip.ptr(gy), _hip.ptr(chan), N, C, L, 1 if training else 0,
+                                     act_code, float(slope), _hip.ptr(dx), _hip.ptr(dgamma), _hip.ptr(dbeta),
+                                     _hip.ptr(coef), _hip.ptr(ws), _hip.stream_of(x))
+        _hip.check(rc, "fpsg_bn_act_bwd")
+        return dx, (dgamma if has_w else None), (dbeta if has_b else None), None, None, None, None, None, None, None
+
+
+def _eligible(x: torch.Tensor) -> bool:
+    if not (x.is_cuda and x.dtype == torch.float32 and x.dim() >= 3 and fused_enabled()):
+        return False
+    row = x.numel() // max(x.shape[0] * x.shape[1], 1)
+    return row >= _MIN_ROW and row % 4 == 0 and x.shape[1] <= 65535
+
+
+def _plain_act(y, act_code, slope):
+    if act_code == 1:
+        return F.relu(y)
+    if act_code == 2:
+        return F.leaky_relu(y, slope)
+    return y
+
+
+def batch_norm_act(x, weight, bias, running_mean, running_var, training, momentum, eps, act=None,
+                   return_stats: bool = False):
+    """Functional form: ``act(F.batch_norm(x, ...))``.  With ``return_stats`` (training only) also
+    returns the batch mean and the UNBIASED batch variance instead of touching the running
+    buffers (the caller applies its own update rule)."""
+    act_code, slope = _parse_act(act)
+    if _eligible(x):
+        xc = x.contiguous()
+        y, bmean, bvar = _BNAct.apply(xc, weight, bias, running_mean, running_var, bool(training), eps,
+                                      act_code, slope, bool(training))
+        if training and not return_stats and running_mean is not None:
+            with torch.no_grad():
+                m = 0.1 if momentum is None else momentum
+                running_mean.mul_(1 - m).add_(bmean, alpha=m)
+                running_var.mul_(1 - m).add_(bvar, alpha=m)
+        return (y, bmean, bvar) if return_stats else y
+    if return_stats:
+        C = x.shape[1]
+        mean = torch.zeros(C, dtype=x.dtype, device=x.device)
+        var = torch.ones(C, dtype=x.dtype, device=x.device)
+        y = F.batch_norm(x, mean, var, weight, bias, True, 1.0, eps)      # mean/var <- batch statistics
+        return _plain_act(y, act_code, slope), mean, var
+    y = F.batch_norm(x, running_mean, running_var, weight, bias, training, 0.1 if momentum is None else momentum, eps)
+    return _plain_act(y, act_code, slope)
+
+
+def bn_act(bn: nn.modules.batchnorm._BatchNorm, x: torch.Tensor, act=None) -> torch.Tensor:
+    """``act(bn(x))`` with the module's parameters, buffers, mode and momentum."""
+    if not _eligible(x) or not bn.track_running_stats:
+        return _plain_act(bn(x), *_parse_act(act))
+    training = bn.training
+    if training and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked += 1
+    return batch_norm_act(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, bn.momentum,
+                          bn.eps, act)

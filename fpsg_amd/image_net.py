@@ -16,6 +16,8 @@ import os
 import torch
 import torch.nn as nn
 
+from .fused_bn import bn_act
+
 # VGG-16 ("configuration D"): channel widths, 'P' = 2x2 max-pool
 _VGG16_PLAN = (64, 64, "P", 128, 128, "P", 256, 256, 256, "P", 512, 512, 512, "P", 512, 512,
                512, "P")
@@ -70,7 +72,17 @@ class ImageEncoderWarpper(nn.Module):
         self.img_feature_extractor.load_state_dict(sd)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        return self.img_feature_pool(self.img_feature_extractor(x)).flatten(1)
+        layers = list(self.img_feature_extractor)
+        i = 0
+        while i < len(layers):
+            layer = layers[i]
+            if isinstance(layer, nn.BatchNorm2d) and i + 1 < len(layers) and isinstance(layers[i + 1], nn.ReLU):
+                x = bn_act(layer, x, "relu")     # BatchNorm + ReLU as one pass (K5) on the GPU
+                i += 2
+            else:
+                x = layer(x)
+                i += 1
+        return self.img_feature_pool(x).flatten(1)
 
     def _set_finetune(self, new_layer: int | None = None) -> None:
         """Un-freezes the last ``finetune_layer`` convolutions, freezes the others

@@ -26,6 +26,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .fused_bn import batch_norm_act, bn_act
 from .pointnet import PointNetfeat
 from .utils import get_template
 
@@ -42,6 +43,13 @@ def get_activation(argument: str):
     if argument not in table:
         raise ValueError(f"Invalid activation: {argument}")
     return table[argument]
+
+
+def _bn_then(bn, x, activation):
+    """``activation(bn(x))``; BatchNorm + ReLU run as one fused pass (K5) on the GPU."""
+    if activation is F.relu:
+        return bn_act(bn, x, "relu")
+    return activation(bn_act(bn, x, None))
 
 
 class PointNetWrapper(nn.Module):
@@ -86,8 +94,8 @@ class MLPDeformer(nn.Module):
         self.activation = get_activation(conf.activation)
 
     def forward(self, x):
-        x = self.activation(self.bn1(self.conv1(x)))
-        x = self.activation(self.bn2(self.conv2(x)))
+        x = _bn_then(self.bn1, self.conv1(x), self.activation)
+        x = _bn_then(self.bn2, self.conv2(x), self.activation)
         return torch.tanh(self.conv3(x))
 
 
@@ -109,9 +117,9 @@ class PrimitiveNode(nn.Module):
         self.activation = get_activation(conf.activation)
 
     def _tail(self, h):
-        h = self.activation(self.bn1(h))
-        h = self.activation(self.bn2(self.conv2(h)))
-        h = self.activation(self.bn3(self.conv3(h)))
+        h = _bn_then(self.bn1, h, self.activation)
+        h = _bn_then(self.bn2, self.conv2(h), self.activation)
+        h = _bn_then(self.bn3, self.conv3(h), self.activation)
         return torch.tanh(self.conv4(h))
 
     def forward(self, x):
@@ -168,10 +176,10 @@ def _group_batch_norm(h, bns, calls_per_bn, act):
     gamma = torch.stack([b.weight for b in bns]).repeat_interleave(r, dim=0).reshape(G * C)
     beta = torch.stack([b.bias for b in bns]).repeat_interleave(r, dim=0).reshape(G * C)
     x = h.reshape(1, G * C, M)
+    fuse = "relu" if act is F.relu else None       # BatchNorm + ReLU as one pass (K5) on the GPU
+    post = (lambda t: t) if act is F.relu else act
     if bns[0].training:
-        mean = torch.zeros(G * C, dtype=h.dtype, device=h.device)
-        var = torch.ones(G * C, dtype=h.dtype, device=h.device)
-        y = F.batch_norm(x, mean, var, gamma, beta, True, 1.0, bns[0].eps)   # mean/var <- batch stats
+        y, mean, var = batch_norm_act(x, gamma, beta, None, None, True, 1.0, bns[0].eps, fuse, return_stats=True)
         with torch.no_grad():
             # r sequential momentum updates per module, in closed form and as multi-tensor ops:
             #   run <- (1-m)^r run + m * sum_j (1-m)^(r-1-j) stat_j     (var: unbiased, as torch)
@@ -192,8 +200,8 @@ def _group_batch_norm(h, bns, calls_per_bn, act):
     else:
         rm = torch.stack([b.running_mean for b in bns]).repeat_interleave(r, dim=0).reshape(G * C)
         rv = torch.stack([b.running_var for b in bns]).repeat_interleave(r, dim=0).reshape(G * C)
-        y = F.batch_norm(x, rm, rv, gamma, beta, False, 0.0, bns[0].eps)
-    return act(y.reshape(G, C, M))
+        y = batch_norm_act(x, gamma, beta, rm, rv, False, 0.0, bns[0].eps, fuse)
+    return post(y.reshape(G, C, M))
 
 
 class PCDecoder(nn.Module):

@@ -17,6 +17,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .fused_bn import bn_act
+
 
 class _PointTrunk(nn.Module):
     """3 -> 64 -> 128 -> 1024 shared-MLP (1x1 conv + BN) followed by a max over points."""
@@ -44,9 +46,9 @@ class STN3d(_PointTrunk):
         self.bn5 = nn.BatchNorm1d(256)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        h = F.relu(self.bn1(self.conv1(x)))
-        h = F.relu(self.bn2(self.conv2(h)))
-        h = F.relu(self.bn3(self.conv3(h)))
+        h = bn_act(self.bn1, self.conv1(x), "relu")
+        h = bn_act(self.bn2, self.conv2(h), "relu")
+        h = bn_act(self.bn3, self.conv3(h), "relu")
         h = h.max(dim=2)[0]
         h = F.relu(self.bn4(self.fc1(h)))
         h = F.relu(self.bn5(self.fc2(h)))
@@ -73,7 +75,7 @@ class PointNetfeat(_PointTrunk):
         trans = self.stn(x)
         # (x^T @ trans)^T == trans^T @ x : one small batched GEMM, no transposed copies
         h = torch.bmm(trans.transpose(1, 2), x)
-        h = F.relu(self.bn1(self.conv1(h)))
-        h = F.relu(self.bn2(self.conv2(h)))
-        h = self.bn3(self.conv3(h))
+        h = bn_act(self.bn1, self.conv1(h), "relu")
+        h = bn_act(self.bn2, self.conv2(h), "relu")
+        h = bn_act(self.bn3, self.conv3(h), None)
         return h.max(dim=2)[0], trans, None

@@ -140,6 +140,27 @@ int fpsg_edgeconv_bwd(const float* dzs, const uint8_t* jsel, const float* PQ, co
 int fpsg_softmin(const float* x, const float* y, const float* h, int B, int N, int M, float eps,
                  float* out, fpsg_stream_t stream);
 
+/* ---- K5: BatchNorm fused with its activation (training and eval mode) -------------------
+ * Replaces the BatchNorm{1,2}d + ReLU / LeakyReLU module pairs of the reference networks
+ * (src/models/image_net.py:14 VGG16-BN trunk; src/pointnet/model.py:30-44,220-233;
+ * src/models/point_cloud_net.py:52-54,76-79) on [N,C,L]-contiguous fp32 tensors; statistics
+ * per channel over (N,L).  act: 0 none, 1 ReLU, 2 LeakyReLU(slope).
+ *   fwd: y = act((x-mean)*rstd*gamma+beta); chan [4][C] receives (scale, shift, mean, rstd) for
+ *        the backward; training != 0: batch statistics (batch_mean / batch_var_unbiased [C] are
+ *        optional outputs for the caller's running-statistics update), else running_mean/var.
+ *   bwd: dx [N,C,L], dgamma [C], dbeta [C] from x, dy and chan (the activation mask is
+ *        re-derived from x); coef [3][C] scratch.
+ * ws: fpsg_bn_workspace_floats(N,C,L) floats.  x, y, dy, dx 16-byte aligned.  Deterministic.
+ */
+size_t fpsg_bn_workspace_floats(int N, int C, int L);
+int fpsg_bn_act_fwd(const float* x, const float* gamma, const float* beta, const float* running_mean,
+                    const float* running_var, int N, int C, int L, int training, float eps, int act,
+                    float slope, float* y, float* chan, float* batch_mean, float* batch_var_unbiased,
+                    float* ws, fpsg_stream_t stream);
+int fpsg_bn_act_bwd(const float* x, const float* dy, const float* chan, int N, int C, int L, int training,
+                    int act, float slope, float* dx, float* dgamma, float* dbeta, float* coef, float* ws,
+                    fpsg_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

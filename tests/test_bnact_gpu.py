@@ -1,0 +1,80 @@
+"""K5 (BatchNorm fused with its activation) through the C ABI against PyTorch's own
+BatchNorm + activation modules: outputs, input/parameter gradients, running statistics, in
+training and eval mode.  fp32 tolerance: the two implementations sum in different orders."""
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+pytestmark = pytest.mark.gpu
+
+CASES = [  # (shape, act)
+    ((4, 64, 56, 56), "relu"), ((3, 512, 14, 14), "relu"), ((6, 1024, 2048), None), ((6, 128, 2048), "relu"),
+    ((1, 16 * 67, 640), "relu"), ((2, 7, 4096 + 64), ("leaky", 0.2)), ((5, 3, 8, 8), "relu"), ((2, 64, 224, 224), "relu"),
+]
+
+
+def _ref(bn, x, act):
+    y = bn(x)
+    if act == "relu":
+        return torch.relu(y)
+    if isinstance(act, tuple):
+        return torch.nn.functional.leaky_relu(y, act[1])
+    return y
+
+
+@pytest.mark.parametrize("shape,act", CASES)
+@pytest.mark.parametrize("mode", ["train", "eval"])
+def test_matches_torch_modules(gpu, shape, act, mode):
+    from fpsg_amd.fused_bn import bn_act, _eligible
+    import copy
+    torch.manual_seed(sum(shape))
+    C = shape[1]
+    bn = (nn.BatchNorm2d if len(shape) == 4 else nn.BatchNorm1d)(C).to(gpu)
+    with torch.no_grad():
+        bn.weight.copy_(torch.randn(C) * 0.5 + 1)
+        bn.bias.copy_(torch.randn(C) * 0.3)
+        bn.running_mean.copy_(torch.randn(C) * 0.2)
+        bn.running_var.copy_(torch.rand(C) + 0.5)
+    ref = copy.deepcopy(bn)
+    bn.train(mode == "train"); ref.train(mode == "train")
+    x1 = (torch.randn(*shape, device=gpu) * 1.7 + 0.4).requires_grad_()
+    x2 = x1.detach().clone().requires_grad_()
+    assert _eligible(x1)
+    y1 = bn_act(bn, x1, act)
+    y2 = _ref(ref, x2, act)
+    assert torch.allclose(y1, y2, rtol=1e-4, atol=1e-5), float((y1 - y2).abs().max())
+    g = torch.randn_like(y1)
+    y1.backward(g); y2.backward(g)
+    s = float(x2.grad.abs().max())
+    assert float((x1.grad - x2.grad).abs().max()) <= 2e-4 * s + 1e-6
+    for a, b in ((bn.weight.grad, ref.weight.grad), (bn.bias.grad, ref.bias.grad)):
+        assert float((a - b).abs().max()) <= 3e-4 * float(b.abs().max()) + 1e-5
+    assert torch.allclose(bn.running_mean, ref.running_mean, rtol=1e-5, atol=1e-6)
+    assert torch.allclose(bn.running_var, ref.running_var, rtol=1e-4, atol=1e-6)
+    assert int(bn.num_batches_tracked) == int(ref.num_batches_tracked)
+
+
+def test_dispatch_rules(gpu):
+    from fpsg_amd.fused_bn import bn_act, _eligible
+    bn = nn.BatchNorm1d(8).to(gpu)
+    assert not _eligible(torch.randn(4, 8, device=gpu))            # nn.Linear output: plain modules
+    assert not _eligible(torch.randn(4, 8, 30, device=gpu))        # short / unaligned rows
+    assert not _eligible(torch.randn(4, 8, 256))                   # CPU tensor of the CPU port
+    y = bn_act(bn, torch.randn(4, 8, 30, device=gpu), "relu")
+    assert y.shape == (4, 8, 30) and float(y.min()) >= 0
+    cpu_bn = nn.BatchNorm1d(8)
+    assert bn_act(cpu_bn, torch.randn(4, 8, 256), "relu").shape == (4, 8, 256)
+
+
+def test_deterministic(gpu):
+    from fpsg_amd.fused_bn import bn_act
+    bn = nn.BatchNorm2d(64).to(gpu).train()
+    x = torch.randn(8, 64, 56, 56, device=gpu)
+    outs = []
+    for _ in range(2):
+        xi = x.clone().requires_grad_()
+        y = bn_act(bn, xi, "relu")
+        y.square().sum().backward()
+        outs.append((y.detach().clone(), xi.grad.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
