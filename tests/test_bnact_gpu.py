@@ -62,7 +62,7 @@ def test_dispatch_rules(gpu):
     assert not _eligible(torch.randn(4, 8, 30, device=gpu))        # short / unaligned rows
     assert not _eligible(torch.randn(4, 8, 256))                   # CPU tensor of the CPU port
     y = bn_act(bn, torch.randn(4, 8, 30, device=gpu), "relu")
-    assert y.shape == (4, 8, 30) and float(y.min()) >= 0
+    assert y.shape == (4, 8, 30) and float(y.detach().min()) >= 0
     cpu_bn = nn.BatchNorm1d(8)
     assert bn_act(cpu_bn, torch.randn(4, 8, 256), "relu").shape == (4, 8, 256)
 
