@@ -25,6 +25,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import _hip
+from .fused_bn import bn_act
 
 
 def knn_int32(x: torch.Tensor, k: int) -> torch.Tensor:
@@ -244,8 +245,8 @@ class DGCNNfeat(nn.Module):
             x_cm = x_pm.transpose(1, 2).contiguous()
         cat = torch.cat(feats, dim=2)                              # [B,N,512]
         conv5, bn5, act5 = self.conv5[0], self.conv5[1], self.conv5[2]
-        h = torch.matmul(cat, conv5.weight.squeeze(-1).t())       # Conv1d(512,emb,1) as a GEMM
-        h = act5(bn5(h.reshape(B * N, -1))).reshape(B, N, -1)     # BatchNorm1d over (B,N) rows
+        h = torch.matmul(conv5.weight.squeeze(-1), cat.transpose(1, 2))   # Conv1d(512,emb,1) as a GEMM -> [B,emb,N]
+        h = bn_act(bn5, h, ("leaky", act5.negative_slope))                # BatchNorm1d + LeakyReLU fused (K5)
         if self.dual_flag:
-            return torch.cat((h.max(dim=1)[0], h.mean(dim=1)), dim=1)
-        return h.max(dim=1)[0]
+            return torch.cat((h.max(dim=2)[0], h.mean(dim=2)), dim=1)
+        return h.max(dim=2)[0]
