@@ -220,6 +220,90 @@ __global__ __launch_bounds__(kBnThreads) void bn_apply_kernel(const float* __res
   }
 }
 
+// Small problems (N*L values per channel fit a few loops of one workgroup): statistics,
+// finalize and apply in ONE launch, one workgroup per channel, the second sweep served by L2.
+// MODE 0 forward, MODE 1 backward.
+constexpr int kBnSmallMax = 16384;
+
+template <int MODE, int ACT>
+__global__ __launch_bounds__(kBnThreads) void bn_small_kernel(
+    const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ gamma,
+    const float* __restrict__ beta, int N, int C, int L, int training, float eps, float slope,
+    float* __restrict__ out, float* __restrict__ chan, float* __restrict__ batch_mean,
+    float* __restrict__ batch_var_unbiased, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  __shared__ float red[8];
+  __shared__ float bc[4];
+  const int c = blockIdx.x;
+  const double count = (double)N * (double)L;
+  float sc = 0.0f, sh = 0.0f, mu = 0.0f, rs = 0.0f;
+  if (MODE == 1 || !training) { sc = chan[c]; sh = chan[C + c]; mu = chan[2 * C + c]; rs = chan[3 * C + c]; }
+  if (MODE == 1 || training) {
+    float a0 = 0.0f, a1 = 0.0f;
+    for (int n = 0; n < N; ++n) {
+      const size_t base = ((size_t)n * C + c) * L;
+      for (int e = threadIdx.x; e < L; e += kBnThreads) {
+        const float xv = x[base + e];
+        if (MODE == 0) {
+          a0 += xv; a1 = fma_rn(xv, xv, a1);
+        } else {
+          const float dz = dy[base + e] * act_grad<ACT>(fma_rn(xv, sc, sh), slope);
+          a0 += dz; a1 = fma_rn(dz, (xv - mu) * rs, a1);
+        }
+      }
+    }
+    block_reduce2(a0, a1, red);
+    if (threadIdx.x == 0) {
+      if (MODE == 0) {
+        const double mean = a0 / count;
+        double var = a1 / count - mean * mean;
+        var = var > 0.0 ? var : 0.0;
+        const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+        const float g = gamma ? gamma[c] : 1.0f, b = beta ? beta[c] : 0.0f;
+        bc[0] = g * rstd; bc[1] = b - (float)mean * g * rstd; bc[2] = (float)mean; bc[3] = rstd;
+        chan[c] = bc[0]; chan[C + c] = bc[1]; chan[2 * C + c] = bc[2]; chan[3 * C + c] = bc[3];
+        if (batch_mean) batch_mean[c] = (float)mean;
+        if (batch_var_unbiased) batch_var_unbiased[c] = (float)(count > 1.0 ? var * count / (count - 1.0) : var);
+      } else {
+        dbeta[c] = a0; dgamma[c] = a1;
+        const double k2 = training ? -(double)sc * a1 * rs / count : 0.0;
+        bc[0] = sc; bc[1] = (float)k2;
+        bc[2] = training ? (float)(-(double)sc * a0 / count - k2 * mu) : 0.0f;
+      }
+    }
+    __syncthreads();
+    if (MODE == 0) { sc = bc[0]; sh = bc[1]; }
+  } else {
+    if (threadIdx.x == 0) { bc[0] = sc; bc[1] = 0.0f; bc[2] = 0.0f; }
+    __syncthreads();
+  }
+  const float k1 = bc[0], k2 = bc[1], k3 = bc[2];
+  for (int n = 0; n < N; ++n) {
+    const size_t base = ((size_t)n * C + c) * L;
+    for (int e = threadIdx.x; e < L; e += kBnThreads) {
+      const float xv = x[base + e];
+      if (MODE == 0) {
+        out[base + e] = act_fwd<ACT>(fma_rn(xv, sc, sh), slope);
+      } else {
+        const float dz = dy[base + e] * act_grad<ACT>(fma_rn(xv, sc, sh), slope);
+        out[base + e] = fma_rn(k1, dz, fma_rn(k2, xv, k3));
+      }
+    }
+  }
+}
+
+template <int MODE>
+void launch_small(int act, const float* x, const float* dy, const float* gamma, const float* beta, int N, int C,
+                  int L, int training, float eps, float slope, float* out, float* chan, float* bm, float* bv,
+                  float* dgamma, float* dbeta, hipStream_t s) {
+  dim3 grid(C);
+#define FPSG_SMALL(A) hipLaunchKernelGGL((bn_small_kernel<MODE, A>), grid, dim3(kBnThreads), 0, s, x, dy, gamma, beta, \
+                                         N, C, L, training, eps, slope, out, chan, bm, bv, dgamma, dbeta)
+  if (act == kActRelu) FPSG_SMALL(kActRelu);
+  else if (act == kActLeaky) FPSG_SMALL(kActLeaky);
+  else FPSG_SMALL(kActNone);
+#undef FPSG_SMALL
+}
+
 int slices_for(int N, int L) {
   const int items = N * ((L + kBnSeg - 1) / kBnSeg);
   return items < kBnSlices ? items : kBnSlices;
@@ -269,6 +353,17 @@ extern "C" int fpsg_bn_act_fwd(const float* x, const float* gamma, const float* 
   FPSG_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0, FPSG_E_ALIGN,
                "fpsg_bn_act_fwd: x and y must be 16-byte aligned");
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if (!training) { FPSG_REQUIRE_PTR(running_mean); FPSG_REQUIRE_PTR(running_var); }
+  if ((long)N * L <= kBnSmallMax) {
+    if (!training) {
+      hipLaunchKernelGGL(bn_eval_chan_kernel, dim3((C + 255) / 256), dim3(256), 0, s, running_mean, running_var,
+                         gamma, beta, C, eps, chan);
+      if ((rc = launch_status("fpsg_bn_act_fwd(eval)"))) return rc;
+    }
+    launch_small<0>(act, x, nullptr, gamma, beta, N, C, L, training, eps, slope, y, chan, batch_mean,
+                    batch_var_unbiased, nullptr, nullptr, s);
+    return launch_status("fpsg_bn_act_fwd(small)");
+  }
   if (training) {
     FPSG_REQUIRE_PTR(ws);
     const int S = slices_for(N, L);
@@ -278,7 +373,6 @@ extern "C" int fpsg_bn_act_fwd(const float* x, const float* gamma, const float* 
                        (double)N * (double)L, eps, chan, batch_mean, batch_var_unbiased);
     if ((rc = launch_status("fpsg_bn_act_fwd(finalize)"))) return rc;
   } else {
-    FPSG_REQUIRE_PTR(running_mean); FPSG_REQUIRE_PTR(running_var);
     hipLaunchKernelGGL(bn_eval_chan_kernel, dim3((C + 255) / 256), dim3(256), 0, s, running_mean, running_var,
                        gamma, beta, C, eps, chan);
     if ((rc = launch_status("fpsg_bn_act_fwd(eval)"))) return rc;
@@ -298,6 +392,11 @@ extern "C" int fpsg_bn_act_bwd(const float* x, const float* dy, const float* cha
   FPSG_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(dx)) & 15) == 0,
                FPSG_E_ALIGN, "fpsg_bn_act_bwd: x, dy and dx must be 16-byte aligned");
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if ((long)N * L <= kBnSmallMax) {
+    launch_small<1>(act, x, dy, nullptr, nullptr, N, C, L, training, 0.0f, slope, dx, const_cast<float*>(chan),
+                    nullptr, nullptr, dgamma, dbeta, s);
+    return launch_status("fpsg_bn_act_bwd(small)");
+  }
   const int S = slices_for(N, L);
   launch_reduce<1>(act, x, dy, chan, N, C, L, S, slope, ws, s);
   if ((rc = launch_status("fpsg_bn_act_bwd(reduce)"))) return rc;

@@ -11,6 +11,8 @@ pytestmark = pytest.mark.gpu
 CASES = [  # (shape, act)
     ((4, 64, 56, 56), "relu"), ((3, 512, 14, 14), "relu"), ((6, 1024, 2048), None), ((6, 128, 2048), "relu"),
     ((1, 16 * 67, 640), "relu"), ((2, 7, 4096 + 64), ("leaky", 0.2)), ((5, 3, 8, 8), "relu"), ((2, 64, 224, 224), "relu"),
+    # more than 16384 values per channel: the multi-launch (sliced) path
+    ((8, 64, 112, 112), "relu"), ((24, 32, 2048), None), ((5, 9, 4096 + 4100), ("leaky", 0.1)), ((37, 16, 56, 56), "relu"),
 ]
 
 
