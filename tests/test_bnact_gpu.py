@@ -49,7 +49,13 @@ def test_matches_torch_modules(gpu, shape, act, mode):
     g = torch.randn_like(y1)
     y1.backward(g); y2.backward(g)
     s = float(x2.grad.abs().max())
-    assert float((x1.grad - x2.grad).abs().max()) <= 2e-4 * s + 1e-6
+    # a pre-activation within fp32 round-off of 0 may fall on either side of the ReLU kink in the
+    # two implementations (z = x*scale+shift here, (x-mean)*rstd*gamma+beta there): such isolated
+    # elements get the other one-sided derivative; everything else must agree tightly
+    bad = (x1.grad - x2.grad).abs() > 2e-4 * s + 1e-6
+    assert int(bad.sum()) <= max(2, int(2e-6 * bad.numel())), int(bad.sum())
+    if bad.any():
+        assert float(y2.detach()[bad].abs().max()) < 1e-5
     for a, b in ((bn.weight.grad, ref.weight.grad), (bn.bias.grad, ref.bias.grad)):
         assert float((a - b).abs().max()) <= 3e-4 * float(b.abs().max()) + 1e-5
     assert torch.allclose(bn.running_mean, ref.running_mean, rtol=1e-5, atol=1e-6)
