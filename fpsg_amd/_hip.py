@@ -40,11 +40,11 @@ SIGNATURES = {
                           _c_int, _c_int, _c_f32p, _c_stream],
     "fpsg_softmin": [_c_f32p, _c_f32p, _c_f32p, _c_int, _c_int, _c_int, ctypes.c_float, _c_f32p, _c_stream],
     "fpsg_bn_workspace_floats": [_c_int, _c_int, _c_int],
-    "fpsg_bn_act_fwd": [_c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_int, _c_int, _c_int, _c_int,
+    "fpsg_bn_act_fwd": [_c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_int, _c_int, _c_int, _c_int,
                         ctypes.c_float, _c_int, ctypes.c_float, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p,
                         _c_stream],
-    "fpsg_bn_act_bwd": [_c_f32p, _c_f32p, _c_f32p, _c_int, _c_int, _c_int, _c_int, _c_int, ctypes.c_float,
-                        _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_stream],
+    "fpsg_bn_act_bwd": [_c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_int, _c_int, _c_int, _c_int, _c_int,
+                        ctypes.c_float, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_stream],
     "fpsg_emd_workspace_floats": [_c_int, _c_int, _c_int],
     "fpsg_emd_approx": [_c_f32p, _c_f32p, _c_int, _c_int, _c_int, _c_f32p, _c_f32p, _c_f32p, _c_f32p,
                         _c_stream],

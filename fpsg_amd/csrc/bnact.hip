@@ -11,6 +11,13 @@
 //             x is saved -- not the BN output nor the activation output;
 //             partial sums of dz and dz*xhat -> per-channel coefficients ->
 //             dx = k1*dz + k2*x + k3.
+// Optional per-channel PRE-BIAS pb (the bias of the convolution in front of the BatchNorm,
+// image_net.py:14 / pointnet/model.py:30-34): the op is then act(BN(x + pb[c])) with x the
+// bias-free convolution output -- fl(x + pb) is formed in registers in every pass, exactly the
+// value the library's separate broadcast-add kernel would have stored, and the backward also
+// returns dpb[c] = sum over (n, l) of dx (what autograd's bias reduction over dx would give),
+// from per-block partial sums of the dx pass.  That removes one full read + write (the add)
+// and one full read (the bias-gradient reduction) of the activation tensor per layer.
 // Layout: x is [N, C, L] contiguous (L = H*W or points), statistics per channel over (N, L).
 // All loops are 16-byte (float4) streams over contiguous row segments; work is split so that a
 // 64-channel, 37x224x224 tensor still fills the chip (the per-channel workgroup of the library
@@ -60,9 +67,10 @@ __device__ __forceinline__ void block_reduce2(float& a, float& b, float* red /*[
 template <int MODE, int ACT>
 __global__ __launch_bounds__(kBnThreads) void bn_reduce_kernel(
     const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ chan /*[4][C]: scale, shift, mean, rstd*/,
-    int N, int C, int L, int S, float slope, float* __restrict__ part /*[C][S][2]*/) {
+    const float* __restrict__ pb, int N, int C, int L, int S, float slope, float* __restrict__ part /*[C][S][2]*/) {
   __shared__ float red[8];
   const int c = blockIdx.y, s = blockIdx.x;
+  const float b = pb ? pb[c] : 0.0f;
   const int segs = (L + kBnSeg - 1) / kBnSeg;
   const int items = N * segs;
   float sc = 0.0f, sh = 0.0f, mu = 0.0f, rs = 0.0f;
@@ -77,7 +85,9 @@ __global__ __launch_bounds__(kBnThreads) void bn_reduce_kernel(
       const v4f* __restrict__ xp = reinterpret_cast<const v4f*>(x + base);
       const v4f* __restrict__ gp = reinterpret_cast<const v4f*>(MODE == 1 ? dy + base : x + base);
       for (int e = threadIdx.x; e < len / 4; e += kBnThreads) {
-        const v4f xv = xp[e];
+        v4f xv = xp[e];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) xv[u] += b;
         if (MODE == 0) {
 #pragma unroll
           for (int u = 0; u < 4; ++u) { a0 += xv[u]; a1 = fma_rn(xv[u], xv[u], a1); }
@@ -93,7 +103,7 @@ __global__ __launch_bounds__(kBnThreads) void bn_reduce_kernel(
       }
     } else {
       for (int e = threadIdx.x; e < len; e += kBnThreads) {
-        const float xv = x[base + e];
+        const float xv = x[base + e] + b;
         if (MODE == 0) {
           a0 += xv; a1 = fma_rn(xv, xv, a1);
         } else {
@@ -177,11 +187,16 @@ template <int MODE, int ACT>
 __global__ __launch_bounds__(kBnThreads) void bn_apply_kernel(const float* __restrict__ x,
                                                               const float* __restrict__ dy,
                                                               const float* __restrict__ chan,
-                                                              const float* __restrict__ coef, int C, int L,
-                                                              float slope, float* __restrict__ out) {
+                                                              const float* __restrict__ coef,
+                                                              const float* __restrict__ pb, int C, int L,
+                                                              float slope, float* __restrict__ out,
+                                                              float* __restrict__ dxpart /*[N*C][segs] or null*/) {
+  __shared__ float red[8];
   const int row = blockIdx.x;
   const int c = row % C;
   const int seg = blockIdx.y;
+  const float b = pb ? pb[c] : 0.0f;
+  float acc = 0.0f, unused = 0.0f;
   const size_t base = (size_t)row * L + (size_t)seg * kBnSeg;
   const int len = (L - seg * kBnSeg) < kBnSeg ? (L - seg * kBnSeg) : kBnSeg;
   const float sc = chan[c], sh = chan[C + c];
@@ -192,7 +207,9 @@ __global__ __launch_bounds__(kBnThreads) void bn_apply_kernel(const float* __res
     const v4f* __restrict__ gp = reinterpret_cast<const v4f*>(MODE == 1 ? dy + base : x + base);
     v4f* __restrict__ op = reinterpret_cast<v4f*>(out + base);
     for (int e = threadIdx.x; e < len / 4; e += kBnThreads) {
-      const v4f xv = xp[e];
+      v4f xv = xp[e];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) xv[u] += b;
       v4f r;
       if (MODE == 0) {
 #pragma unroll
@@ -204,20 +221,42 @@ __global__ __launch_bounds__(kBnThreads) void bn_apply_kernel(const float* __res
           const float dz = gv[u] * act_grad<ACT>(fma_rn(xv[u], sc, sh), slope);
           r[u] = fma_rn(k1, dz, fma_rn(k2, xv[u], k3));
         }
+        acc += (r[0] + r[1]) + (r[2] + r[3]);
       }
       op[e] = r;
     }
   } else {
     for (int e = threadIdx.x; e < len; e += kBnThreads) {
-      const float xv = x[base + e];
+      const float xv = x[base + e] + b;
       if (MODE == 0) {
         out[base + e] = act_fwd<ACT>(fma_rn(xv, sc, sh), slope);
       } else {
         const float dz = dy[base + e] * act_grad<ACT>(fma_rn(xv, sc, sh), slope);
-        out[base + e] = fma_rn(k1, dz, fma_rn(k2, xv, k3));
+        const float r = fma_rn(k1, dz, fma_rn(k2, xv, k3));
+        out[base + e] = r;
+        acc += r;
       }
     }
   }
+  if (MODE == 1 && dxpart) {      // uniform: per-(row, segment) partial of sum(dx)
+    block_reduce2(acc, unused, red);
+    if (threadIdx.x == 0) dxpart[(size_t)row * gridDim.y + seg] = acc;
+  }
+}
+
+// dpb[c] = sum over rows n and segments of the dx partials, one wave per channel, fixed order
+__global__ __launch_bounds__(64) void bn_dxsum_kernel(const float* __restrict__ dxpart, int N, int C, int segs,
+                                                      float* __restrict__ dpb) {
+  const int c = blockIdx.x;
+  const int items = N * segs;
+  double a = 0.0;
+  for (int it = threadIdx.x; it < items; it += 64) {
+    const int n = it / segs, seg = it - n * segs;
+    a += (double)dxpart[((size_t)n * C + c) * segs + seg];
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) a += __shfl_down(a, off, 64);
+  if (threadIdx.x == 0) dpb[c] = (float)a;
 }
 
 // Small problems (N*L values per channel fit a few loops of one workgroup): statistics,
@@ -228,12 +267,14 @@ constexpr int kBnSmallMax = 16384;
 template <int MODE, int ACT>
 __global__ __launch_bounds__(kBnThreads) void bn_small_kernel(
     const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ gamma,
-    const float* __restrict__ beta, int N, int C, int L, int training, float eps, float slope,
-    float* __restrict__ out, float* __restrict__ chan, float* __restrict__ batch_mean,
-    float* __restrict__ batch_var_unbiased, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    const float* __restrict__ beta, const float* __restrict__ pb, int N, int C, int L, int training, float eps,
+    float slope, float* __restrict__ out, float* __restrict__ chan, float* __restrict__ batch_mean,
+    float* __restrict__ batch_var_unbiased, float* __restrict__ dgamma, float* __restrict__ dbeta,
+    float* __restrict__ dpb) {
   __shared__ float red[8];
   __shared__ float bc[4];
   const int c = blockIdx.x;
+  const float b = pb ? pb[c] : 0.0f;
   const double count = (double)N * (double)L;
   float sc = 0.0f, sh = 0.0f, mu = 0.0f, rs = 0.0f;
   if (MODE == 1 || !training) { sc = chan[c]; sh = chan[C + c]; mu = chan[2 * C + c]; rs = chan[3 * C + c]; }
@@ -242,7 +283,7 @@ __global__ __launch_bounds__(kBnThreads) void bn_small_kernel(
     for (int n = 0; n < N; ++n) {
       const size_t base = ((size_t)n * C + c) * L;
       for (int e = threadIdx.x; e < L; e += kBnThreads) {
-        const float xv = x[base + e];
+        const float xv = x[base + e] + b;
         if (MODE == 0) {
           a0 += xv; a1 = fma_rn(xv, xv, a1);
         } else {
@@ -277,27 +318,35 @@ __global__ __launch_bounds__(kBnThreads) void bn_small_kernel(
     __syncthreads();
   }
   const float k1 = bc[0], k2 = bc[1], k3 = bc[2];
+  float acc = 0.0f, unused = 0.0f;
   for (int n = 0; n < N; ++n) {
     const size_t base = ((size_t)n * C + c) * L;
     for (int e = threadIdx.x; e < L; e += kBnThreads) {
-      const float xv = x[base + e];
+      const float xv = x[base + e] + b;
       if (MODE == 0) {
         out[base + e] = act_fwd<ACT>(fma_rn(xv, sc, sh), slope);
       } else {
         const float dz = dy[base + e] * act_grad<ACT>(fma_rn(xv, sc, sh), slope);
-        out[base + e] = fma_rn(k1, dz, fma_rn(k2, xv, k3));
+        const float r = fma_rn(k1, dz, fma_rn(k2, xv, k3));
+        out[base + e] = r;
+        acc += r;
       }
     }
+  }
+  if (MODE == 1 && dpb) {
+    __syncthreads();              // red[] is reused
+    block_reduce2(acc, unused, red);
+    if (threadIdx.x == 0) dpb[c] = acc;
   }
 }
 
 template <int MODE>
-void launch_small(int act, const float* x, const float* dy, const float* gamma, const float* beta, int N, int C,
-                  int L, int training, float eps, float slope, float* out, float* chan, float* bm, float* bv,
-                  float* dgamma, float* dbeta, hipStream_t s) {
+void launch_small(int act, const float* x, const float* dy, const float* gamma, const float* beta, const float* pb,
+                  int N, int C, int L, int training, float eps, float slope, float* out, float* chan, float* bm,
+                  float* bv, float* dgamma, float* dbeta, float* dpb, hipStream_t s) {
   dim3 grid(C);
 #define FPSG_SMALL(A) hipLaunchKernelGGL((bn_small_kernel<MODE, A>), grid, dim3(kBnThreads), 0, s, x, dy, gamma, beta, \
-                                         N, C, L, training, eps, slope, out, chan, bm, bv, dgamma, dbeta)
+                                         pb, N, C, L, training, eps, slope, out, chan, bm, bv, dgamma, dbeta, dpb)
   if (act == kActRelu) FPSG_SMALL(kActRelu);
   else if (act == kActLeaky) FPSG_SMALL(kActLeaky);
   else FPSG_SMALL(kActNone);
@@ -310,21 +359,21 @@ int slices_for(int N, int L) {
 }
 
 template <int MODE>
-void launch_reduce(int act, const float* x, const float* dy, const float* chan, int N, int C, int L, int S,
-                   float slope, float* part, hipStream_t s) {
+void launch_reduce(int act, const float* x, const float* dy, const float* chan, const float* pb, int N, int C, int L,
+                   int S, float slope, float* part, hipStream_t s) {
   dim3 grid(S, C);
-  if (act == kActRelu) hipLaunchKernelGGL((bn_reduce_kernel<MODE, kActRelu>), grid, dim3(kBnThreads), 0, s, x, dy, chan, N, C, L, S, slope, part);
-  else if (act == kActLeaky) hipLaunchKernelGGL((bn_reduce_kernel<MODE, kActLeaky>), grid, dim3(kBnThreads), 0, s, x, dy, chan, N, C, L, S, slope, part);
-  else hipLaunchKernelGGL((bn_reduce_kernel<MODE, kActNone>), grid, dim3(kBnThreads), 0, s, x, dy, chan, N, C, L, S, slope, part);
+  if (act == kActRelu) hipLaunchKernelGGL((bn_reduce_kernel<MODE, kActRelu>), grid, dim3(kBnThreads), 0, s, x, dy, chan, pb, N, C, L, S, slope, part);
+  else if (act == kActLeaky) hipLaunchKernelGGL((bn_reduce_kernel<MODE, kActLeaky>), grid, dim3(kBnThreads), 0, s, x, dy, chan, pb, N, C, L, S, slope, part);
+  else hipLaunchKernelGGL((bn_reduce_kernel<MODE, kActNone>), grid, dim3(kBnThreads), 0, s, x, dy, chan, pb, N, C, L, S, slope, part);
 }
 
 template <int MODE>
-void launch_apply(int act, const float* x, const float* dy, const float* chan, const float* coef, int N, int C,
-                  int L, float slope, float* out, hipStream_t s) {
+void launch_apply(int act, const float* x, const float* dy, const float* chan, const float* coef, const float* pb,
+                  int N, int C, int L, float slope, float* out, float* dxpart, hipStream_t s) {
   dim3 grid((unsigned)((size_t)N * C), (L + kBnSeg - 1) / kBnSeg);
-  if (act == kActRelu) hipLaunchKernelGGL((bn_apply_kernel<MODE, kActRelu>), grid, dim3(kBnThreads), 0, s, x, dy, chan, coef, C, L, slope, out);
-  else if (act == kActLeaky) hipLaunchKernelGGL((bn_apply_kernel<MODE, kActLeaky>), grid, dim3(kBnThreads), 0, s, x, dy, chan, coef, C, L, slope, out);
-  else hipLaunchKernelGGL((bn_apply_kernel<MODE, kActNone>), grid, dim3(kBnThreads), 0, s, x, dy, chan, coef, C, L, slope, out);
+  if (act == kActRelu) hipLaunchKernelGGL((bn_apply_kernel<MODE, kActRelu>), grid, dim3(kBnThreads), 0, s, x, dy, chan, coef, pb, C, L, slope, out, dxpart);
+  else if (act == kActLeaky) hipLaunchKernelGGL((bn_apply_kernel<MODE, kActLeaky>), grid, dim3(kBnThreads), 0, s, x, dy, chan, coef, pb, C, L, slope, out, dxpart);
+  else hipLaunchKernelGGL((bn_apply_kernel<MODE, kActNone>), grid, dim3(kBnThreads), 0, s, x, dy, chan, coef, pb, C, L, slope, out, dxpart);
 }
 
 int check_dims(const char* fn, int N, int C, int L, int act) {
@@ -339,10 +388,12 @@ int check_dims(const char* fn, int N, int C, int L, int act) {
 }  // namespace fpsg
 
 extern "C" size_t fpsg_bn_workspace_floats(int N, int C, int L) {
-  return (size_t)C * fpsg::kBnSlices * 2;
+  if (N <= 0 || C <= 0 || L <= 0) return 0;
+  const size_t segs = ((size_t)L + fpsg::kBnSeg - 1) / fpsg::kBnSeg;
+  return (size_t)C * fpsg::kBnSlices * 2 + (size_t)N * C * segs;     // channel partials + sum(dx) partials
 }
 
-extern "C" int fpsg_bn_act_fwd(const float* x, const float* gamma, const float* beta,
+extern "C" int fpsg_bn_act_fwd(const float* x, const float* pre_bias, const float* gamma, const float* beta,
                                const float* running_mean, const float* running_var, int N, int C, int L,
                                int training, float eps, int act, float slope, float* y, float* chan,
                                float* batch_mean, float* batch_var_unbiased, float* ws, fpsg_stream_t stream) {
@@ -360,14 +411,14 @@ extern "C" int fpsg_bn_act_fwd(const float* x, const float* gamma, const float* 
                          gamma, beta, C, eps, chan);
       if ((rc = launch_status("fpsg_bn_act_fwd(eval)"))) return rc;
     }
-    launch_small<0>(act, x, nullptr, gamma, beta, N, C, L, training, eps, slope, y, chan, batch_mean,
-                    batch_var_unbiased, nullptr, nullptr, s);
+    launch_small<0>(act, x, nullptr, gamma, beta, pre_bias, N, C, L, training, eps, slope, y, chan, batch_mean,
+                    batch_var_unbiased, nullptr, nullptr, nullptr, s);
     return launch_status("fpsg_bn_act_fwd(small)");
   }
   if (training) {
     FPSG_REQUIRE_PTR(ws);
     const int S = slices_for(N, L);
-    launch_reduce<0>(kActNone, x, nullptr, nullptr, N, C, L, S, 0.0f, ws, s);
+    launch_reduce<0>(kActNone, x, nullptr, nullptr, pre_bias, N, C, L, S, 0.0f, ws, s);
     if ((rc = launch_status("fpsg_bn_act_fwd(stats)"))) return rc;
     hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, ws, gamma, beta, C, S,
                        (double)N * (double)L, eps, chan, batch_mean, batch_var_unbiased);
@@ -377,13 +428,13 @@ extern "C" int fpsg_bn_act_fwd(const float* x, const float* gamma, const float* 
                        gamma, beta, C, eps, chan);
     if ((rc = launch_status("fpsg_bn_act_fwd(eval)"))) return rc;
   }
-  launch_apply<0>(act, x, nullptr, chan, nullptr, N, C, L, slope, y, s);
+  launch_apply<0>(act, x, nullptr, chan, nullptr, pre_bias, N, C, L, slope, y, nullptr, s);
   return launch_status("fpsg_bn_act_fwd(apply)");
 }
 
-extern "C" int fpsg_bn_act_bwd(const float* x, const float* dy, const float* chan, int N, int C, int L,
-                               int training, int act, float slope, float* dx, float* dgamma, float* dbeta,
-                               float* coef, float* ws, fpsg_stream_t stream) {
+extern "C" int fpsg_bn_act_bwd(const float* x, const float* pre_bias, const float* dy, const float* chan, int N,
+                               int C, int L, int training, int act, float slope, float* dx, float* dgamma,
+                               float* dbeta, float* dpre_bias, float* coef, float* ws, fpsg_stream_t stream) {
   using namespace fpsg;
   int rc = check_dims("fpsg_bn_act_bwd", N, C, L, act);
   if (rc) return rc;
@@ -393,16 +444,22 @@ extern "C" int fpsg_bn_act_bwd(const float* x, const float* dy, const float* cha
                FPSG_E_ALIGN, "fpsg_bn_act_bwd: x, dy and dx must be 16-byte aligned");
   hipStream_t s = static_cast<hipStream_t>(stream);
   if ((long)N * L <= kBnSmallMax) {
-    launch_small<1>(act, x, dy, nullptr, nullptr, N, C, L, training, 0.0f, slope, dx, const_cast<float*>(chan),
-                    nullptr, nullptr, dgamma, dbeta, s);
+    launch_small<1>(act, x, dy, nullptr, nullptr, pre_bias, N, C, L, training, 0.0f, slope, dx,
+                    const_cast<float*>(chan), nullptr, nullptr, dgamma, dbeta, dpre_bias, s);
     return launch_status("fpsg_bn_act_bwd(small)");
   }
   const int S = slices_for(N, L);
-  launch_reduce<1>(act, x, dy, chan, N, C, L, S, slope, ws, s);
+  launch_reduce<1>(act, x, dy, chan, pre_bias, N, C, L, S, slope, ws, s);
   if ((rc = launch_status("fpsg_bn_act_bwd(reduce)"))) return rc;
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, ws, chan, C, S,
                      (double)N * (double)L, training, dgamma, dbeta, coef);
   if ((rc = launch_status("fpsg_bn_act_bwd(finalize)"))) return rc;
-  launch_apply<1>(act, x, dy, chan, coef, N, C, L, slope, dx, s);
-  return launch_status("fpsg_bn_act_bwd(apply)");
+  float* dxpart = dpre_bias ? ws + (size_t)C * kBnSlices * 2 : nullptr;
+  launch_apply<1>(act, x, dy, chan, coef, pre_bias, N, C, L, slope, dx, dxpart, s);
+  if ((rc = launch_status("fpsg_bn_act_bwd(apply)"))) return rc;
+  if (dpre_bias) {
+    hipLaunchKernelGGL(bn_dxsum_kernel, dim3(C), dim3(64), 0, s, dxpart, N, C, (L + kBnSeg - 1) / kBnSeg, dpre_bias);
+    return launch_status("fpsg_bn_act_bwd(dpre_bias)");
+  }
+  return 0;
 }

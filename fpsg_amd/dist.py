@@ -6,12 +6,16 @@ The reference is single-process / single-GPU (no ``torch.distributed`` anywhere,
   * a global optimizer step consists of ``E`` independent episodes; rank ``r`` of ``W``
     runs episodes ``r, r+W, ...`` one after the other (BatchNorm statistics stay
     per-episode -- no SyncBN, as in the reference) and accumulates their gradients;
-  * every parameter's ``.grad`` is a view into ONE flat fp32 buffer (77 M elements =
-    310 MB for the full model), cut into a few large buckets.  During the LAST local
-    episode's backward, a bucket's ``all_reduce(SUM)`` is launched asynchronously as soon
-    as all of its gradients have been accumulated (decoder first, VGG last), overlapping
-    the collective with the rest of backward; xGMI is point-to-point, so few large
-    messages are what keep each link busy;
+  * the step's gradient lives in ONE flat fp32 buffer (77 M elements = 310 MB for the full
+    model), cut into a few large buckets.  An episode's backward writes fresh ``.grad``
+    tensors which a handful of multi-tensor launches copy / add into the flat buffer
+    (``absorb``) -- autograd's own accumulation would be one small add kernel per parameter
+    per episode, ~600 launches.  With more than one rank the LAST local episode instead
+    accumulates in place into views of the flat buffer (``attach``), and a bucket's
+    ``all_reduce(SUM)`` is launched asynchronously from the autograd hooks as soon as all of
+    its gradients are complete (decoder first, VGG last), overlapping the collective with the
+    rest of backward; xGMI is point-to-point, so few large messages are what keep each link
+    busy;
   * the summed gradient is divided by ``E`` (mean over the step's episodes), so a step has
     the gradient scale of the reference's one-episode step and ``--lr`` keeps its meaning.
 
@@ -79,11 +83,12 @@ class FlatGradBuckets:
         self._bucket_of: dict[int, int] = {}
         self._bucket_size: list[int] = []
         off, start, count = 0, 0, 0
+        self.views: dict[int, torch.Tensor] = {}
         for p in reversed(params):
             n = p.numel()
             # same memory format as the parameter (e.g. channels_last conv weights): the fused
             # optimizer requires param and grad layouts to match
-            p.grad = self.flat[off:off + n].as_strided(p.size(), p.stride())
+            self.views[id(p)] = self.flat[off:off + n].as_strided(p.size(), p.stride())
             self._bucket_of[id(p)] = len(self.buckets)
             off += n
             count += 1
@@ -99,6 +104,7 @@ class FlatGradBuckets:
         self._armed = False
         self._streams: dict = {}     # every stream a gradient was produced on in this backward
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in params]
+        self.attach()
 
     # -- bookkeeping ---------------------------------------------------------------
     @property
@@ -110,8 +116,39 @@ class FlatGradBuckets:
         return dist.is_initialized()
 
     def zero(self) -> None:
-        """Replaces ``optimizer.zero_grad()``: grads must stay views of the flat buffer."""
+        """Replaces ``optimizer.zero_grad()``: the flat buffer is the step's gradient."""
         self.flat.zero_()
+
+    def attach(self) -> None:
+        """``p.grad`` = the parameter's view of the flat buffer: backward accumulates in place
+        (the armed, overlapped episode) and the optimizer reads the step's gradient."""
+        for p in self.params:
+            p.grad = self.views[id(p)]
+
+    def detach(self) -> None:
+        """``p.grad = None``: the next backward leaves fresh gradient tensors (no add kernels)."""
+        for p in self.params:
+            p.grad = None
+
+    def absorb(self, first: bool = False) -> None:
+        """Adds the gradients a backward left in ``p.grad`` into the flat buffer with
+        multi-tensor launches; ``first`` overwrites instead (no ``zero()`` needed).  The sums
+        are the same fp32 adds, in the same order over episodes, as in-place accumulation."""
+        dst, src, missing = [], [], []
+        for p in self.params:
+            if p.grad is None:
+                missing.append(self.views[id(p)])
+            else:
+                dst.append(self.views[id(p)])
+                src.append(p.grad)
+        with torch.no_grad():
+            if first:
+                if dst:
+                    torch._foreach_copy_(dst, src)
+                if missing:
+                    torch._foreach_zero_(missing)
+            elif dst:
+                torch._foreach_add_(dst, src)
 
     def arm(self) -> None:
         """Call before the backward of the LAST local episode of a step: buckets are

@@ -76,9 +76,10 @@ class TrainStep:
     ``graph=True`` (GPU only): the forward + backward of an episode is captured once per
     episode shape into a hipGraph and replayed -- an episode is ~1300 kernel launches, many of
     them a few microseconds long, and the eager step is partly host-bound.  Inputs are copied
-    into the graph's static buffers; gradients accumulate in place into the flat buffer.  With
-    more than one rank the LAST local episode of a step always runs eagerly, so that its
-    backward can launch the bucketed all-reduce from the autograd hooks."""
+    into the graph's static buffers; the captured sequence ends with the multi-tensor adds of
+    the episode's gradients into the flat buffer (``FlatGradBuckets.absorb``).  With more than
+    one rank the LAST local episode of a step always runs eagerly, so that its backward can
+    launch the bucketed all-reduce from the autograd hooks."""
 
     def __init__(self, model, optimizer, world: int = 1, bucket_mb: float = 80.0, graph: bool = False):
         self.model, self.optimizer, self.world = model, optimizer, world
@@ -90,34 +91,45 @@ class TrainStep:
     # ------------------------------------------------------------------ graph plumbing
     _KEYS = ("xs", "xq", "xad", "pcs", "pcq", "pcad")
 
-    def _shape_key(self, sample):
-        return tuple((k, tuple(sample[k].shape)) for k in self._KEYS)
+    def _shape_key(self, sample, first):
+        return tuple((k, tuple(sample[k].shape)) for k in self._KEYS) + (bool(first),)
 
-    def _episode(self, sample):
+    def _episode(self, sample, first=False):
+        """Forward + backward of one episode into fresh gradient tensors, then their
+        multi-tensor copy (``first``) / add into the flat buffer."""
+        self.buckets.detach()
+        out = self.model.loss(sample)
+        out["ttl_loss"].sum().backward()
+        self.buckets.absorb(first)
+        return {n: v.detach() for n, v in out.items()}
+
+    def _episode_in_place(self, sample):
+        """The overlapped form: gradients accumulate in place into the flat buffer's views
+        and the armed hooks launch each bucket's all-reduce when it is complete."""
+        self.buckets.attach()
         out = self.model.loss(sample)
         out["ttl_loss"].sum().backward()
         return {n: v.detach() for n, v in out.items()}
 
-    def _capture(self, sample):
+    def _capture(self, sample, first):
         static = {k: sample[k].clone() for k in self._KEYS}
         g = torch.cuda.CUDAGraph()
         # thread_local: an RCCL watchdog thread may query events while this thread captures
         with torch.cuda.graph(g, capture_error_mode="thread_local"):
-            static_out = self._episode(static)
+            static_out = self._episode(static, first)
+        self.buckets.detach()           # the captured gradient tensors belong to the graph's pool
         return g, static, static_out
 
-    def _run_graphed(self, sample):
-        key = self._shape_key(sample)
+    def _run_graphed(self, sample, first):
+        key = self._shape_key(sample, first)
         if key not in self._graphs:
             # the first eager runs of a shape let MIOpen / hipBLASLt pick their kernels and
             # warm the allocator; capture happens on the third use
             n = self._eager_runs.get(key, 0)
             if n < 2:
                 self._eager_runs[key] = n + 1
-                return self._episode(sample)
-            keep = self.buckets.flat.clone()      # the capture pass also accumulates gradients
-            self._graphs[key] = self._capture(sample)
-            self.buckets.flat.copy_(keep)
+                return self._episode(sample, first)
+            self._graphs[key] = self._capture(sample, first)   # records only; replayed below
         g, static, static_out = self._graphs[key]
         for k in self._KEYS:
             static[k].copy_(sample[k], non_blocking=True)
@@ -130,19 +142,24 @@ class TrainStep:
         timed path).  ``n_episodes_global`` defaults to ``len(local) * world``."""
         if n_episodes_global is None:
             n_episodes_global = len(local_episodes) * self.world
-        self.buckets.zero()
         results = []
+        multi = self.buckets.world_initialised()
         if not local_episodes:  # still take part in the step's collectives
+            self.buckets.zero()
             self.buckets.arm()
         last = len(local_episodes) - 1
         for k, sample in enumerate(local_episodes):
-            final = k == last
-            if final:
+            first, final = k == 0, k == last
+            if final and multi:
+                if first:
+                    self.buckets.zero()
                 self.buckets.arm()
-            if self.use_graph and not (final and self.buckets.world_initialised()):
-                results.append(self._run_graphed(sample))
+                results.append(self._episode_in_place(sample))
+            elif self.use_graph:
+                results.append(self._run_graphed(sample, first))
             else:
-                results.append(self._episode(sample))
+                results.append(self._episode(sample, first))
         self.buckets.finish(n_episodes_global)
+        self.buckets.attach()           # the optimizer reads the step's gradient from the flat buffer
         self.optimizer.step()
         return results

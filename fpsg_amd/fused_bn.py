@@ -8,6 +8,11 @@ only ``x`` saved); otherwise (CPU tensors of the CPU port, ``nn.Linear`` outputs
 PyTorch modules run -- that is device dispatch of host plumbing, not a fallback for a missing
 library: on a GPU tensor a missing ``libfpsg_hip.so`` raises.
 
+``conv_bn_act(conv, bn, x, act)`` is ``act(bn(conv(x)))`` for the Conv + BatchNorm + activation
+triples: on the fused path the convolution runs WITHOUT its bias, which K5 adds in registers
+(``pre_bias``), and the bias gradient comes out of K5's dx pass -- the library path spends a
+broadcast-add kernel (read + write of the activation tensor) and a full reduction of dx on it.
+
 ``FPSG_FUSED_BN=0`` switches the fused op off (A/B measurements).
 """
 from __future__ import annotations
@@ -36,7 +41,8 @@ def _parse_act(act):
 
 class _BNAct(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, running_mean, running_var, training, eps, act_code, slope, want_stats):
+    def forward(ctx, x, weight, bias, running_mean, running_var, training, eps, act_code, slope, want_stats,
+                pre_bias=None):
         N, C = x.shape[0], x.shape[1]
         L = x.numel() // (N * C)
         lib = _hip.load()
@@ -48,7 +54,8 @@ class _BNAct(torch.autograd.Function):
         bvar = torch.empty((C,), dtype=torch.float32, device=dev) if (training and want_stats) else None
         with torch.cuda.device(dev):
             rc = lib.fpsg_bn_act_fwd(
-                _hip.ptr(x), _hip.ptr(weight) if weight is not None else None,
+                _hip.ptr(x), _hip.ptr(pre_bias) if pre_bias is not None else None,
+                _hip.ptr(weight) if weight is not None else None,
                 _hip.ptr(bias) if bias is not None else None,
                 _hip.ptr(running_mean) if running_mean is not None else None,
                 _hip.ptr(running_var) if running_var is not None else None,
@@ -56,7 +63,7 @@ class _BNAct(torch.autograd.Function):
                 _hip.ptr(bmean) if bmean is not None else None, _hip.ptr(bvar) if bvar is not None else None,
                 _hip.ptr(ws), _hip.stream_of(x))
         _hip.check(rc, "fpsg_bn_act_fwd")
-        ctx.save_for_backward(x, chan)
+        ctx.save_for_backward(x, chan, pre_bias)
         ctx.cfg = (N, C, L, training, act_code, slope, weight is not None, bias is not None)
         ctx.mark_non_differentiable(*(t for t in (bmean, bvar) if t is not None))
         if training and want_stats:
@@ -65,22 +72,27 @@ class _BNAct(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gy, _gm, _gv):
-        x, chan = ctx.saved_tensors
+        x, chan, pre_bias = ctx.saved_tensors
         N, C, L, training, act_code, slope, has_w, has_b = ctx.cfg
+        want_dpb = pre_bias is not None and ctx.needs_input_grad[10]
         lib = _hip.load()
         dev = x.device
         gy = gy.contiguous()
         dx = torch.empty_like(x)
         dgamma = torch.empty((C,), dtype=torch.float32, device=dev)
         dbeta = torch.empty((C,), dtype=torch.float32, device=dev)
+        dpb = torch.empty((C,), dtype=torch.float32, device=dev) if want_dpb else None
         coef = torch.empty((3, C), dtype=torch.float32, device=dev)
         ws = torch.empty((lib.fpsg_bn_workspace_floats(N, C, L),), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
-            rc = lib.fpsg_bn_act_bwd(_hip.ptr(x), _hip.ptr(gy), _hip.ptr(chan), N, C, L, 1 if training else 0,
+            rc = lib.fpsg_bn_act_bwd(_hip.ptr(x), _hip.ptr(pre_bias) if pre_bias is not None else None,
+                                     _hip.ptr(gy), _hip.ptr(chan), N, C, L, 1 if training else 0,
                                      act_code, float(slope), _hip.ptr(dx), _hip.ptr(dgamma), _hip.ptr(dbeta),
-                                     _hip.ptr(coef), _hip.ptr(ws), _hip.stream_of(x))
+                                     _hip.ptr(dpb) if want_dpb else None, _hip.ptr(coef), _hip.ptr(ws),
+                                     _hip.stream_of(x))
         _hip.check(rc, "fpsg_bn_act_bwd")
-        return dx, (dgamma if has_w else None), (dbeta if has_b else None), None, None, None, None, None, None, None
+        return (dx, (dgamma if has_w else None), (dbeta if has_b else None), None, None, None, None, None, None,
+                None, dpb)
 
 
 def _eligible(x: torch.Tensor) -> bool:
@@ -99,21 +111,23 @@ def _plain_act(y, act_code, slope):
 
 
 def batch_norm_act(x, weight, bias, running_mean, running_var, training, momentum, eps, act=None,
-                   return_stats: bool = False):
-    """Functional form: ``act(F.batch_norm(x, ...))``.  With ``return_stats`` (training only) also
-    returns the batch mean and the UNBIASED batch variance instead of touching the running
-    buffers (the caller applies its own update rule)."""
+                   return_stats: bool = False, pre_bias=None):
+    """Functional form: ``act(F.batch_norm(x [+ pre_bias per channel], ...))``.  With
+    ``return_stats`` (training only) also returns the batch mean and the UNBIASED batch variance
+    instead of touching the running buffers (the caller applies its own update rule)."""
     act_code, slope = _parse_act(act)
     if _eligible(x):
         xc = x.contiguous()
         y, bmean, bvar = _BNAct.apply(xc, weight, bias, running_mean, running_var, bool(training), eps,
-                                      act_code, slope, bool(training))
+                                      act_code, slope, bool(training), pre_bias)
         if training and not return_stats and running_mean is not None:
             with torch.no_grad():
                 m = 0.1 if momentum is None else momentum
                 running_mean.mul_(1 - m).add_(bmean, alpha=m)
                 running_var.mul_(1 - m).add_(bvar, alpha=m)
         return (y, bmean, bvar) if return_stats else y
+    if pre_bias is not None:
+        x = x + pre_bias.view(1, -1, *([1] * (x.dim() - 2)))
     if return_stats:
         C = x.shape[1]
         mean = torch.zeros(C, dtype=x.dtype, device=x.device)
@@ -124,12 +138,26 @@ def batch_norm_act(x, weight, bias, running_mean, running_var, training, momentu
     return _plain_act(y, act_code, slope)
 
 
-def bn_act(bn: nn.modules.batchnorm._BatchNorm, x: torch.Tensor, act=None) -> torch.Tensor:
-    """``act(bn(x))`` with the module's parameters, buffers, mode and momentum."""
+def bn_act(bn: nn.modules.batchnorm._BatchNorm, x: torch.Tensor, act=None, pre_bias=None) -> torch.Tensor:
+    """``act(bn(x [+ pre_bias]))`` with the module's parameters, buffers, mode and momentum."""
     if not _eligible(x) or not bn.track_running_stats:
+        if pre_bias is not None:
+            x = x + pre_bias.view(1, -1, *([1] * (x.dim() - 2)))
         return _plain_act(bn(x), *_parse_act(act))
     training = bn.training
     if training and bn.num_batches_tracked is not None:
         bn.num_batches_tracked += 1
     return batch_norm_act(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, bn.momentum,
-                          bn.eps, act)
+                          bn.eps, act, pre_bias=pre_bias)
+
+
+def conv_bn_act(conv: nn.modules.conv._ConvNd, bn: nn.modules.batchnorm._BatchNorm, x: torch.Tensor,
+                act=None) -> torch.Tensor:
+    """``act(bn(conv(x)))`` for ``nn.Conv1d/2d`` + BatchNorm (+ ReLU / LeakyReLU) triples."""
+    if conv.bias is None or not (x.is_cuda and x.dtype == torch.float32 and fused_enabled()
+                                 and bn.track_running_stats and conv.padding_mode == "zeros"):
+        return bn_act(bn, conv(x), act)
+    y = conv._conv_forward(x, conv.weight, None)           # bias joins inside K5
+    if not _eligible(y):
+        return bn_act(bn, y + conv.bias.view(1, -1, *([1] * (y.dim() - 2))), act)
+    return bn_act(bn, y, act, pre_bias=conv.bias)

@@ -16,7 +16,7 @@ import os
 import torch
 import torch.nn as nn
 
-from .fused_bn import bn_act
+from .fused_bn import bn_act, conv_bn_act
 
 # VGG-16 ("configuration D"): channel widths, 'P' = 2x2 max-pool
 _VGG16_PLAN = (64, 64, "P", 128, 128, "P", 256, 256, 256, "P", 512, 512, 512, "P", 512, 512,
@@ -76,7 +76,12 @@ class ImageEncoderWarpper(nn.Module):
         i = 0
         while i < len(layers):
             layer = layers[i]
-            if isinstance(layer, nn.BatchNorm2d) and i + 1 < len(layers) and isinstance(layers[i + 1], nn.ReLU):
+            if (isinstance(layer, nn.Conv2d) and i + 2 < len(layers) and isinstance(layers[i + 1], nn.BatchNorm2d)
+                    and isinstance(layers[i + 2], nn.ReLU)):
+                # conv (bias-free) -> K5: bias + BatchNorm + ReLU in one pass, bias gradient from its dx pass
+                x = conv_bn_act(layer, layers[i + 1], x, "relu")
+                i += 3
+            elif isinstance(layer, nn.BatchNorm2d) and i + 1 < len(layers) and isinstance(layers[i + 1], nn.ReLU):
                 x = bn_act(layer, x, "relu")     # BatchNorm + ReLU as one pass (K5) on the GPU
                 i += 2
             else:

@@ -17,7 +17,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .fused_bn import bn_act
+from .fused_bn import bn_act, conv_bn_act
 
 
 class _PointTrunk(nn.Module):
@@ -46,9 +46,9 @@ class STN3d(_PointTrunk):
         self.bn5 = nn.BatchNorm1d(256)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        h = bn_act(self.bn1, self.conv1(x), "relu")
-        h = bn_act(self.bn2, self.conv2(h), "relu")
-        h = bn_act(self.bn3, self.conv3(h), "relu")
+        h = conv_bn_act(self.conv1, self.bn1, x, "relu")
+        h = conv_bn_act(self.conv2, self.bn2, h, "relu")
+        h = conv_bn_act(self.conv3, self.bn3, h, "relu")
         h = h.max(dim=2)[0]
         h = F.relu(self.bn4(self.fc1(h)))
         h = F.relu(self.bn5(self.fc2(h)))
@@ -75,7 +75,7 @@ class PointNetfeat(_PointTrunk):
         trans = self.stn(x)
         # (x^T @ trans)^T == trans^T @ x : one small batched GEMM, no transposed copies
         h = torch.bmm(trans.transpose(1, 2), x)
-        h = bn_act(self.bn1, self.conv1(h), "relu")
-        h = bn_act(self.bn2, self.conv2(h), "relu")
-        h = bn_act(self.bn3, self.conv3(h), None)
+        h = conv_bn_act(self.conv1, self.bn1, h, "relu")
+        h = conv_bn_act(self.conv2, self.bn2, h, "relu")
+        h = conv_bn_act(self.conv3, self.bn3, h, None)
         return h.max(dim=2)[0], trans, None

@@ -150,16 +150,21 @@ int fpsg_softmin(const float* x, const float* y, const float* h, int B, int N, i
  *        optional outputs for the caller's running-statistics update), else running_mean/var.
  *   bwd: dx [N,C,L], dgamma [C], dbeta [C] from x, dy and chan (the activation mask is
  *        re-derived from x); coef [3][C] scratch.
+ * pre_bias [C] (optional, NULL = none): the bias of the convolution in front of the BatchNorm
+ * (the Conv2d/Conv1d + BatchNorm + ReLU triples of image_net.py:14, pointnet/model.py:30-44);
+ * x is then the bias-free convolution output and the op is act(BN(x + pre_bias[c])), with
+ * fl(x + pre_bias) formed in registers; bwd additionally returns dpre_bias[c] = sum over (n,l)
+ * of dx (optional, NULL = skip) -- the bias gradient autograd would reduce from dx.
  * ws: fpsg_bn_workspace_floats(N,C,L) floats.  x, y, dy, dx 16-byte aligned.  Deterministic.
  */
 size_t fpsg_bn_workspace_floats(int N, int C, int L);
-int fpsg_bn_act_fwd(const float* x, const float* gamma, const float* beta, const float* running_mean,
-                    const float* running_var, int N, int C, int L, int training, float eps, int act,
-                    float slope, float* y, float* chan, float* batch_mean, float* batch_var_unbiased,
-                    float* ws, fpsg_stream_t stream);
-int fpsg_bn_act_bwd(const float* x, const float* dy, const float* chan, int N, int C, int L, int training,
-                    int act, float slope, float* dx, float* dgamma, float* dbeta, float* coef, float* ws,
-                    fpsg_stream_t stream);
+int fpsg_bn_act_fwd(const float* x, const float* pre_bias, const float* gamma, const float* beta,
+                    const float* running_mean, const float* running_var, int N, int C, int L, int training,
+                    float eps, int act, float slope, float* y, float* chan, float* batch_mean,
+                    float* batch_var_unbiased, float* ws, fpsg_stream_t stream);
+int fpsg_bn_act_bwd(const float* x, const float* pre_bias, const float* dy, const float* chan, int N, int C,
+                    int L, int training, int act, float slope, float* dx, float* dgamma, float* dbeta,
+                    float* dpre_bias, float* coef, float* ws, fpsg_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -92,3 +92,78 @@ def test_deterministic(gpu):
         y.square().sum().backward()
         outs.append((y.detach().clone(), xi.grad.clone()))
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
+@pytest.mark.parametrize("shape,act", [((4, 64, 56, 56), "relu"), ((37, 16, 56, 56), "relu"), ((6, 128, 2048), None),
+                                       ((24, 32, 2048), "relu"), ((2, 7, 4096 + 64), ("leaky", 0.2))])
+@pytest.mark.parametrize("mode", ["train", "eval"])
+def test_pre_bias_is_the_broadcast_add(gpu, shape, act, mode):
+    """pre_bias: act(BN(x + b[c])) with the add done in registers -- the forward is BIT-equal to
+    feeding the materialised x + b, dx likewise, and dpre_bias is the sum of dx (fp64 yardstick)."""
+    from fpsg_amd.fused_bn import bn_act
+    import copy
+    torch.manual_seed(sum(shape) + 1)
+    C = shape[1]
+    bn = (nn.BatchNorm2d if len(shape) == 4 else nn.BatchNorm1d)(C).to(gpu)
+    with torch.no_grad():
+        bn.weight.copy_(torch.randn(C) * 0.5 + 1)
+        bn.bias.copy_(torch.randn(C) * 0.3)
+    bn2 = copy.deepcopy(bn)
+    bn.train(mode == "train"); bn2.train(mode == "train")
+    x = torch.randn(*shape, device=gpu) * 1.3
+    b = (torch.randn(C, device=gpu) * 0.5).requires_grad_()
+    x1 = x.clone().requires_grad_()
+    x2 = (x + b.detach().view(1, C, *([1] * (len(shape) - 2)))).requires_grad_()
+    y1 = bn_act(bn, x1, act, pre_bias=b)
+    y2 = bn_act(bn2, x2, act)
+    assert torch.equal(y1, y2)
+    g = torch.randn_like(y1)
+    y1.backward(g); y2.backward(g)
+    assert torch.equal(x1.grad, x2.grad)
+    assert torch.equal(bn.weight.grad, bn2.weight.grad) and torch.equal(bn.bias.grad, bn2.bias.grad)
+    assert torch.equal(bn.running_mean, bn2.running_mean) and torch.equal(bn.running_var, bn2.running_var)
+    dims = [0] + list(range(2, len(shape)))
+    want = x2.grad.double().sum(dim=dims)
+    mass = x2.grad.double().abs().sum(dim=dims)
+    assert float(((b.grad.double() - want).abs() / (mass * 1e-6 + 1e-12)).max()) <= 1.0
+    if mode == "eval":       # a real gradient there (in training mode BatchNorm cancels the bias: sum(dx) ~ 0)
+        assert float(want.abs().max()) > 1e-3
+
+
+@pytest.mark.parametrize("kind", ["conv2d", "conv1d"])
+def test_conv_bn_act_matches_module_chain(gpu, kind):
+    from fpsg_amd.fused_bn import conv_bn_act
+    import copy
+    torch.manual_seed(11)
+    if kind == "conv2d":
+        conv, bn, x = nn.Conv2d(16, 32, 3, padding=1), nn.BatchNorm2d(32), torch.randn(5, 16, 40, 40)
+    else:
+        conv, bn, x = nn.Conv1d(64, 128, 1), nn.BatchNorm1d(128), torch.randn(6, 64, 2048)
+    conv, bn, x = conv.to(gpu), bn.to(gpu).train(), x.to(gpu)
+    with torch.no_grad():
+        conv.bias.copy_(torch.randn_like(conv.bias) * 0.3)
+    conv2, bn2 = copy.deepcopy(conv), copy.deepcopy(bn)
+    x1, x2 = x.clone().requires_grad_(), x.clone().requires_grad_()
+    y1 = conv_bn_act(conv, bn, x1, "relu")
+    y2 = torch.relu(bn2(conv2(x2)))
+    assert torch.allclose(y1, y2, rtol=1e-4, atol=1e-5)
+    g = torch.randn_like(y1)
+    y1.backward(g); y2.backward(g)
+    # an output within fp32 round-off of the ReLU kink may fall on either side in the two chains; each
+    # such element perturbs one column of the input gradient and one row of the weight gradient
+    flips = int(((y1 > 0) != (y2 > 0)).sum())
+    assert flips <= 4
+    fan = conv.weight[0].numel()
+    bad = (x1.grad - x2.grad).abs() > 3e-4 * float(x2.grad.abs().max()) + 1e-5
+    assert int(bad.sum()) <= flips * fan
+    slack = flips * 8.0 * float(g.abs().max()) * float(x.abs().max())
+    for a, r in ((conv.weight.grad, conv2.weight.grad), (bn.weight.grad, bn2.weight.grad),
+                 (bn.bias.grad, bn2.bias.grad)):
+        assert float((a - r).abs().max()) <= 3e-4 * float(r.abs().max()) + 1e-5 + slack
+    # the convolution bias in front of a training-mode BatchNorm has a mathematically zero gradient;
+    # both implementations return round-off of the size of eps * sum|dx|
+    assert conv.bias.grad is not None and conv.bias.grad.shape == conv2.bias.grad.shape
+    floor = 1e-5 * float(g.abs().sum() / g.shape[1])
+    assert float(conv.bias.grad.abs().max()) <= floor and float(conv2.bias.grad.abs().max()) <= floor
+    assert torch.allclose(bn.running_mean, bn2.running_mean, rtol=1e-5, atol=1e-6)
+    assert torch.allclose(bn.running_var, bn2.running_var, rtol=1e-4, atol=1e-6)
