@@ -376,6 +376,193 @@ void launch_apply(int act, const float* x, const float* dy, const float* chan, c
   else hipLaunchKernelGGL((bn_apply_kernel<MODE, kActNone>), grid, dim3(kBnThreads), 0, s, x, dy, chan, coef, pb, C, L, slope, out, dxpart);
 }
 
+// ---- pooled variants: act(BN(x + pb)) followed by MaxPool2d(kernel 2, stride 2) -------------
+// The VGG16-BN trunk ends 5 of its 13 conv+BN+ReLU groups with a 2x2 max-pool
+// (image_net.py:14).  Unfused, the full-resolution activation is written, read back by the
+// pool (which also stores an int64 index per window), and in the backward the pool scatters
+// a full-resolution, mostly-zero gradient that BatchNorm's backward then reads twice.  Here
+// the forward writes ONLY the pooled tensor and the backward re-derives, per 2x2 window, the
+// activation values and their arg-max from x (scan order (h, w), first strictly greater or
+// NaN wins -- the rule of at::native::max_pool_forward_nchw), so that neither the
+// full-resolution output, nor the indices, nor the scattered gradient ever exist in HBM.
+// x [N,C,H,W] with H, W even; pooled tensors [N,C,H/2,W/2].
+// Work item = RP consecutive row pairs of one (n, c) plane (about kBnSeg floats).
+// MODE 0: pooled forward.  MODE 1: backward sums of dz, dz*xhat.  MODE 2: backward dx.
+// VW = windows per thread (2: 16-byte loads, needs W % 4 == 0; 1: 8-byte loads).
+template <int VW> struct PoolVec;
+template <> struct PoolVec<2> { typedef v4f in_t; typedef v2f out_t; };
+template <> struct PoolVec<1> { typedef v2f in_t; typedef float out_t; };
+
+template <int ACT>
+__device__ __forceinline__ int window_argmax(const float (&z)[4], float slope, float& ymax) {
+  float m = -INFINITY;
+  int sel = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float y = act_fwd<ACT>(z[k], slope);
+    if (y > m || y != y) { m = y; sel = k; }
+  }
+  ymax = m;
+  return sel;
+}
+
+template <int MODE, int ACT, int VW>
+__device__ __forceinline__ void pool_item(const float* __restrict__ xpl, const float* __restrict__ gpl,
+                                          float* __restrict__ opl, int W, int r0, int r1, float b, float sc,
+                                          float sh, float mu, float rs, float k1, float k2, float k3, float slope,
+                                          float& a0, float& a1) {
+  typedef typename PoolVec<VW>::in_t in_t;
+  typedef typename PoolVec<VW>::out_t out_t;
+  const int Wp = W >> 1;
+  const int vpr = Wp / VW;                 // vectors per pooled row
+  const int nvec = (r1 - r0) * vpr;
+  for (int e = threadIdx.x; e < nvec; e += kBnThreads) {
+    const int rr = e / vpr, v = e - rr * vpr;
+    const int r = r0 + rr;
+    const size_t o0 = (size_t)(2 * r) * W + 2 * VW * v;
+    const in_t t0 = *reinterpret_cast<const in_t*>(xpl + o0);
+    const in_t t1 = *reinterpret_cast<const in_t*>(xpl + o0 + W);
+    float x0[2 * VW], x1[2 * VW];
+#pragma unroll
+    for (int u = 0; u < 2 * VW; ++u) { x0[u] = t0[u] + b; x1[u] = t1[u] + b; }
+    float po[VW];
+    float d0[2 * VW], d1[2 * VW];
+#pragma unroll
+    for (int w = 0; w < VW; ++w) {
+      const float xb[4] = {x0[2 * w], x0[2 * w + 1], x1[2 * w], x1[2 * w + 1]};
+      const float z[4] = {fma_rn(xb[0], sc, sh), fma_rn(xb[1], sc, sh), fma_rn(xb[2], sc, sh), fma_rn(xb[3], sc, sh)};
+      float ymax;
+      const int sel = window_argmax<ACT>(z, slope, ymax);
+      if (MODE == 0) {
+        po[w] = ymax;
+      } else {
+        const float g = gpl[(size_t)r * Wp + VW * v + w];
+        const float zs = sel == 0 ? z[0] : sel == 1 ? z[1] : sel == 2 ? z[2] : z[3];
+        const float dz = g * act_grad<ACT>(zs, slope);
+        if (MODE == 1) {
+          const float xs = sel == 0 ? xb[0] : sel == 1 ? xb[1] : sel == 2 ? xb[2] : xb[3];
+          a0 += dz;
+          a1 = fma_rn(dz, (xs - mu) * rs, a1);
+        } else {
+          float rk[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) rk[k] = fma_rn(k1, (k == sel ? dz : 0.0f), fma_rn(k2, xb[k], k3));
+          d0[2 * w] = rk[0]; d0[2 * w + 1] = rk[1]; d1[2 * w] = rk[2]; d1[2 * w + 1] = rk[3];
+          a0 += (rk[0] + rk[1]) + (rk[2] + rk[3]);
+        }
+      }
+    }
+    if (MODE == 0) {
+      out_t ov;
+      if constexpr (VW == 2) { ov[0] = po[0]; ov[1] = po[1]; } else { ov = po[0]; }
+      *reinterpret_cast<out_t*>(opl + (size_t)r * Wp + VW * v) = ov;
+    } else if (MODE == 2) {
+      in_t o0v, o1v;
+#pragma unroll
+      for (int u = 0; u < 2 * VW; ++u) { o0v[u] = d0[u]; o1v[u] = d1[u]; }
+      *reinterpret_cast<in_t*>(opl + o0) = o0v;
+      *reinterpret_cast<in_t*>(opl + o0 + W) = o1v;
+    }
+  }
+}
+
+// MODE 0 / 2: grid (N*C planes, items of a plane).  `out`: pooled y (MODE 0) or dx (MODE 2).
+template <int MODE, int ACT, int VW>
+__global__ __launch_bounds__(kBnThreads) void bn_pool_apply_kernel(
+    const float* __restrict__ x, const float* __restrict__ dyp, const float* __restrict__ chan,
+    const float* __restrict__ coef, const float* __restrict__ pb, int C, int H, int W, int RP, float slope,
+    float* __restrict__ out, float* __restrict__ dxpart) {
+  __shared__ float red[8];
+  const int plane = blockIdx.x, c = plane % C, it = blockIdx.y;
+  const int Hp = H >> 1, Wp = W >> 1;
+  const int r0 = it * RP, r1 = (r0 + RP) < Hp ? (r0 + RP) : Hp;
+  const float b = pb ? pb[c] : 0.0f;
+  const float sc = chan[c], sh = chan[C + c];
+  float k1 = 0.0f, k2 = 0.0f, k3 = 0.0f;
+  if (MODE == 2) { k1 = coef[c]; k2 = coef[C + c]; k3 = coef[2 * C + c]; }
+  float acc = 0.0f, unused = 0.0f;
+  const float* xpl = x + (size_t)plane * H * W;
+  const float* gpl = MODE == 2 ? dyp + (size_t)plane * Hp * Wp : nullptr;
+  float* opl = MODE == 0 ? out + (size_t)plane * Hp * Wp : out + (size_t)plane * H * W;
+  pool_item<MODE, ACT, VW>(xpl, gpl, opl, W, r0, r1, b, sc, sh, 0.0f, 0.0f, k1, k2, k3, slope, acc, unused);
+  if (MODE == 2 && dxpart) {
+    block_reduce2(acc, unused, red);
+    if (threadIdx.x == 0) dxpart[(size_t)plane * gridDim.y + it] = acc;
+  }
+}
+
+// backward sums: grid (S slices, C channels); block (s, c) takes items s, s + S, ... of channel c
+template <int ACT, int VW>
+__global__ __launch_bounds__(kBnThreads) void bn_pool_reduce_kernel(
+    const float* __restrict__ x, const float* __restrict__ dyp, const float* __restrict__ chan,
+    const float* __restrict__ pb, int N, int C, int H, int W, int RP, int S, float slope,
+    float* __restrict__ part /*[C][S][2]*/) {
+  __shared__ float red[8];
+  const int c = blockIdx.y, s = blockIdx.x;
+  const int Hp = H >> 1, Wp = W >> 1;
+  const int per_plane = (Hp + RP - 1) / RP;
+  const int items = N * per_plane;
+  const float b = pb ? pb[c] : 0.0f;
+  const float sc = chan[c], sh = chan[C + c], mu = chan[2 * C + c], rs = chan[3 * C + c];
+  float a0 = 0.0f, a1 = 0.0f;
+  for (int item = s; item < items; item += S) {
+    const int n = item / per_plane, it = item - n * per_plane;
+    const int r0 = it * RP, r1 = (r0 + RP) < Hp ? (r0 + RP) : Hp;
+    const size_t plane = (size_t)n * C + c;
+    pool_item<1, ACT, VW>(x + plane * H * W, dyp + plane * Hp * Wp, nullptr, W, r0, r1, b, sc, sh, mu, rs, 0.0f, 0.0f,
+                          0.0f, slope, a0, a1);
+  }
+  block_reduce2(a0, a1, red);
+  if (threadIdx.x == 0) {
+    part[((size_t)c * S + s) * 2 + 0] = a0;
+    part[((size_t)c * S + s) * 2 + 1] = a1;
+  }
+}
+
+int pool_rows_per_item(int W) {
+  const int rp = kBnSeg / (2 * W);
+  return rp < 1 ? 1 : rp;
+}
+
+template <int MODE>
+void launch_pool_apply(int act, const float* x, const float* dyp, const float* chan, const float* coef,
+                       const float* pb, int N, int C, int H, int W, float slope, float* out, float* dxpart,
+                       hipStream_t s) {
+  const int RP = pool_rows_per_item(W);
+  dim3 grid((unsigned)((size_t)N * C), (H / 2 + RP - 1) / RP);
+#define FPSG_PA(A, V) hipLaunchKernelGGL((bn_pool_apply_kernel<MODE, A, V>), grid, dim3(kBnThreads), 0, s, x, dyp, chan, \
+                                         coef, pb, C, H, W, RP, slope, out, dxpart)
+  if ((W & 3) == 0) {
+    if (act == kActRelu) FPSG_PA(kActRelu, 2); else if (act == kActLeaky) FPSG_PA(kActLeaky, 2); else FPSG_PA(kActNone, 2);
+  } else {
+    if (act == kActRelu) FPSG_PA(kActRelu, 1); else if (act == kActLeaky) FPSG_PA(kActLeaky, 1); else FPSG_PA(kActNone, 1);
+  }
+#undef FPSG_PA
+}
+
+void launch_pool_reduce(int act, const float* x, const float* dyp, const float* chan, const float* pb, int N, int C,
+                        int H, int W, int S, float slope, float* part, hipStream_t s) {
+  const int RP = pool_rows_per_item(W);
+  dim3 grid(S, C);
+#define FPSG_PR(A, V) hipLaunchKernelGGL((bn_pool_reduce_kernel<A, V>), grid, dim3(kBnThreads), 0, s, x, dyp, chan, pb, \
+                                         N, C, H, W, RP, S, slope, part)
+  if ((W & 3) == 0) {
+    if (act == kActRelu) FPSG_PR(kActRelu, 2); else if (act == kActLeaky) FPSG_PR(kActLeaky, 2); else FPSG_PR(kActNone, 2);
+  } else {
+    if (act == kActRelu) FPSG_PR(kActRelu, 1); else if (act == kActLeaky) FPSG_PR(kActLeaky, 1); else FPSG_PR(kActNone, 1);
+  }
+#undef FPSG_PR
+}
+
+int check_pool_dims(const char* fn, int N, int C, int H, int W, int act) {
+  FPSG_REQUIRE(N > 0 && C > 0 && H > 0 && W > 0 && (H & 1) == 0 && (W & 1) == 0, FPSG_E_SHAPE,
+               "%s: N,C positive and H,W positive and even (got %d,%d,%d,%d)", fn, N, C, H, W);
+  FPSG_REQUIRE(act >= 0 && act <= 2, FPSG_E_SHAPE, "%s: act must be 0 (none), 1 (relu) or 2 (leaky)", fn);
+  FPSG_REQUIRE(C <= 65535 && (long)N * C < (1L << 31) && (long)H * W < (1L << 30) && H / 2 <= 65535, FPSG_E_LIMIT,
+               "%s: C=%d, H*W=%ld or N*C=%ld beyond the grid limits", fn, C, (long)H * W, (long)N * C);
+  return 0;
+}
+
 int check_dims(const char* fn, int N, int C, int L, int act) {
   FPSG_REQUIRE(N > 0 && C > 0 && L > 0, FPSG_E_SHAPE, "%s: N,C,L must be positive (got %d,%d,%d)", fn, N, C, L);
   FPSG_REQUIRE(act >= 0 && act <= 2, FPSG_E_SHAPE, "%s: act must be 0 (none), 1 (relu) or 2 (leaky)", fn);
@@ -460,6 +647,74 @@ extern "C" int fpsg_bn_act_bwd(const float* x, const float* pre_bias, const floa
   if (dpre_bias) {
     hipLaunchKernelGGL(bn_dxsum_kernel, dim3(C), dim3(64), 0, s, dxpart, N, C, (L + kBnSeg - 1) / kBnSeg, dpre_bias);
     return launch_status("fpsg_bn_act_bwd(dpre_bias)");
+  }
+  return 0;
+}
+
+extern "C" size_t fpsg_bn_pool_workspace_floats(int N, int C, int H, int W) {
+  if (N <= 0 || C <= 0 || H <= 1 || W <= 1) return 0;
+  const int RP = fpsg::pool_rows_per_item(W);
+  const size_t items = (size_t)(H / 2 + RP - 1) / RP;
+  return (size_t)C * fpsg::kBnSlices * 2 + (size_t)N * C * items;
+}
+
+extern "C" int fpsg_bn_act_pool_fwd(const float* x, const float* pre_bias, const float* gamma, const float* beta,
+                                    const float* running_mean, const float* running_var, int N, int C, int H, int W,
+                                    int training, float eps, int act, float slope, float* y_pooled, float* chan,
+                                    float* batch_mean, float* batch_var_unbiased, float* ws, fpsg_stream_t stream) {
+  using namespace fpsg;
+  int rc = check_pool_dims("fpsg_bn_act_pool_fwd", N, C, H, W, act);
+  if (rc) return rc;
+  FPSG_REQUIRE_PTR(x); FPSG_REQUIRE_PTR(y_pooled); FPSG_REQUIRE_PTR(chan);
+  FPSG_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y_pooled)) & 15) == 0, FPSG_E_ALIGN,
+               "fpsg_bn_act_pool_fwd: x and y_pooled must be 16-byte aligned");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int L = H * W;
+  if (training) {
+    FPSG_REQUIRE_PTR(ws);
+    const int S = slices_for(N, L);
+    launch_reduce<0>(kActNone, x, nullptr, nullptr, pre_bias, N, C, L, S, 0.0f, ws, s);
+    if ((rc = launch_status("fpsg_bn_act_pool_fwd(stats)"))) return rc;
+    hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, ws, gamma, beta, C, S,
+                       (double)N * (double)L, eps, chan, batch_mean, batch_var_unbiased);
+    if ((rc = launch_status("fpsg_bn_act_pool_fwd(finalize)"))) return rc;
+  } else {
+    FPSG_REQUIRE_PTR(running_mean); FPSG_REQUIRE_PTR(running_var);
+    hipLaunchKernelGGL(bn_eval_chan_kernel, dim3((C + 255) / 256), dim3(256), 0, s, running_mean, running_var,
+                       gamma, beta, C, eps, chan);
+    if ((rc = launch_status("fpsg_bn_act_pool_fwd(eval)"))) return rc;
+  }
+  launch_pool_apply<0>(act, x, nullptr, chan, nullptr, pre_bias, N, C, H, W, slope, y_pooled, nullptr, s);
+  return launch_status("fpsg_bn_act_pool_fwd(apply)");
+}
+
+extern "C" int fpsg_bn_act_pool_bwd(const float* x, const float* pre_bias, const float* dy_pooled, const float* chan,
+                                    int N, int C, int H, int W, int training, int act, float slope, float* dx,
+                                    float* dgamma, float* dbeta, float* dpre_bias, float* coef, float* ws,
+                                    fpsg_stream_t stream) {
+  using namespace fpsg;
+  int rc = check_pool_dims("fpsg_bn_act_pool_bwd", N, C, H, W, act);
+  if (rc) return rc;
+  FPSG_REQUIRE_PTR(x); FPSG_REQUIRE_PTR(dy_pooled); FPSG_REQUIRE_PTR(chan); FPSG_REQUIRE_PTR(dx);
+  FPSG_REQUIRE_PTR(dgamma); FPSG_REQUIRE_PTR(dbeta); FPSG_REQUIRE_PTR(coef); FPSG_REQUIRE_PTR(ws);
+  FPSG_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy_pooled) | reinterpret_cast<uintptr_t>(dx)) & 15) == 0,
+               FPSG_E_ALIGN, "fpsg_bn_act_pool_bwd: x, dy_pooled and dx must be 16-byte aligned");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int RP = pool_rows_per_item(W);
+  const int per_plane = (H / 2 + RP - 1) / RP;
+  const long items = (long)N * per_plane;
+  const int S = items < kBnSlices ? (int)items : kBnSlices;
+  launch_pool_reduce(act, x, dy_pooled, chan, pre_bias, N, C, H, W, S, slope, ws, s);
+  if ((rc = launch_status("fpsg_bn_act_pool_bwd(reduce)"))) return rc;
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, ws, chan, C, S,
+                     (double)N * (double)H * (double)W, training, dgamma, dbeta, coef);
+  if ((rc = launch_status("fpsg_bn_act_pool_bwd(finalize)"))) return rc;
+  float* dxpart = dpre_bias ? ws + (size_t)C * kBnSlices * 2 : nullptr;
+  launch_pool_apply<2>(act, x, dy_pooled, chan, coef, pre_bias, N, C, H, W, slope, dx, dxpart, s);
+  if ((rc = launch_status("fpsg_bn_act_pool_bwd(apply)"))) return rc;
+  if (dpre_bias) {
+    hipLaunchKernelGGL(bn_dxsum_kernel, dim3(C), dim3(64), 0, s, dxpart, N, C, per_plane, dpre_bias);
+    return launch_status("fpsg_bn_act_pool_bwd(dpre_bias)");
   }
   return 0;
 }

@@ -83,11 +83,22 @@ class ImgPCProtoNet(nn.Module):
             pc_z = self.pc_encoder(pc_corpus)
         return img_z[:n_support], img_z[n_support:], pc_z[:n_support], pc_z[n_support:]
 
-    def _decode_queries(self, img_zq, pc_z_proto):
+    def _decode_queries(self, img_zq, pc_z_proto, pack=None):
         """Class prototype = mean of the support features, broadcast to every query
         (reference :104-107)."""
         proto = pc_z_proto.mean(0, keepdim=True).expand(img_zq.size(0), -1)
-        return self.pc_decoder(torch.cat([img_zq, proto], dim=1))
+        return self._decode(torch.cat([img_zq, proto], dim=1), pack)
+
+    def _decode(self, hidden, pack=None):
+        if pack is not None:
+            return self.pc_decoder(hidden, pack=pack)
+        return self.pc_decoder(hidden)
+
+    def _decoder_pack(self):
+        """Stacked decoder parameters shared by the episode's two decodes (PCDecoder.pack_parameters);
+        None for a decoder without the batched form."""
+        fn = getattr(self.pc_decoder, "pack_parameters", None)
+        return fn() if fn is not None else None
 
     # ------------------------------------------------------------------------ training
     def loss(self, sample):
@@ -96,10 +107,11 @@ class ImgPCProtoNet(nn.Module):
 
     def _loss_single_class(self, img_s, img_q, img_ad, pc_s, pc_q, pc_ad):
         img_zad, img_zq, pc_z_proto, pc_z_ad = self._encode(img_s, img_q, img_ad, pc_s, pc_ad)
-        syn_q = self._decode_queries(img_zq, pc_z_proto)
+        pack = self._decoder_pack() if self.intra_flag else None
+        syn_q = self._decode_queries(img_zq, pc_z_proto, pack)
         ref_q = pc_q.squeeze(0).contiguous()
         if self.intra_flag:
-            syn_s = self.pc_decoder(torch.cat([img_zad, pc_z_ad], dim=1))
+            syn_s = self._decode(torch.cat([img_zad, pc_z_ad], dim=1), pack)
             ref_s = pc_ad.squeeze(0).contiguous()
             if self.pc_metric is chamfer_distance and syn_q.shape[1:] == syn_s.shape[1:] \
                     and ref_q.shape[1:] == ref_s.shape[1:]:

@@ -95,6 +95,56 @@ class _BNAct(torch.autograd.Function):
                 None, dpb)
 
 
+class _BNActPool(torch.autograd.Function):
+    """``max_pool2d(act(BN(x + pre_bias)), 2)`` as one op (K5 pooled variants): the forward writes
+    only the pooled tensor, the backward re-derives the windows' arg-max from ``x``."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, training, eps, act_code, slope, pre_bias):
+        N, C, H, W = x.shape
+        lib = _hip.load()
+        dev = x.device
+        yp = torch.empty((N, C, H // 2, W // 2), dtype=torch.float32, device=dev)
+        chan = torch.empty((4, C), dtype=torch.float32, device=dev)
+        ws = torch.empty((lib.fpsg_bn_pool_workspace_floats(N, C, H, W),), dtype=torch.float32, device=dev)
+        bmean = torch.empty((C,), dtype=torch.float32, device=dev) if training else None
+        bvar = torch.empty((C,), dtype=torch.float32, device=dev) if training else None
+        opt = lambda t: _hip.ptr(t) if t is not None else None
+        with torch.cuda.device(dev):
+            rc = lib.fpsg_bn_act_pool_fwd(_hip.ptr(x), opt(pre_bias), opt(weight), opt(bias), opt(running_mean),
+                                          opt(running_var), N, C, H, W, 1 if training else 0, float(eps), act_code,
+                                          float(slope), _hip.ptr(yp), _hip.ptr(chan), opt(bmean), opt(bvar),
+                                          _hip.ptr(ws), _hip.stream_of(x))
+        _hip.check(rc, "fpsg_bn_act_pool_fwd")
+        ctx.save_for_backward(x, chan, pre_bias)
+        ctx.cfg = (N, C, H, W, training, act_code, slope, weight is not None, bias is not None)
+        ctx.mark_non_differentiable(*(t for t in (bmean, bvar) if t is not None))
+        return yp, bmean, bvar
+
+    @staticmethod
+    def backward(ctx, gyp, _gm, _gv):
+        x, chan, pre_bias = ctx.saved_tensors
+        N, C, H, W, training, act_code, slope, has_w, has_b = ctx.cfg
+        want_dpb = pre_bias is not None and ctx.needs_input_grad[9]
+        lib = _hip.load()
+        dev = x.device
+        gyp = gyp.contiguous()
+        dx = torch.empty_like(x)
+        dgamma = torch.empty((C,), dtype=torch.float32, device=dev)
+        dbeta = torch.empty((C,), dtype=torch.float32, device=dev)
+        dpb = torch.empty((C,), dtype=torch.float32, device=dev) if want_dpb else None
+        coef = torch.empty((3, C), dtype=torch.float32, device=dev)
+        ws = torch.empty((lib.fpsg_bn_pool_workspace_floats(N, C, H, W),), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            rc = lib.fpsg_bn_act_pool_bwd(_hip.ptr(x), _hip.ptr(pre_bias) if pre_bias is not None else None,
+                                          _hip.ptr(gyp), _hip.ptr(chan), N, C, H, W, 1 if training else 0, act_code,
+                                          float(slope), _hip.ptr(dx), _hip.ptr(dgamma), _hip.ptr(dbeta),
+                                          _hip.ptr(dpb) if want_dpb else None, _hip.ptr(coef), _hip.ptr(ws),
+                                          _hip.stream_of(x))
+        _hip.check(rc, "fpsg_bn_act_pool_bwd")
+        return dx, (dgamma if has_w else None), (dbeta if has_b else None), None, None, None, None, None, None, dpb
+
+
 def _eligible(x: torch.Tensor) -> bool:
     if not (x.is_cuda and x.dtype == torch.float32 and x.dim() >= 3 and fused_enabled()):
         return False
@@ -161,3 +211,37 @@ def conv_bn_act(conv: nn.modules.conv._ConvNd, bn: nn.modules.batchnorm._BatchNo
     if not _eligible(y):
         return bn_act(bn, y + conv.bias.view(1, -1, *([1] * (y.dim() - 2))), act)
     return bn_act(bn, y, act, pre_bias=conv.bias)
+
+
+def _pool_eligible(y: torch.Tensor, pool: nn.MaxPool2d) -> bool:
+    def two(v):
+        return v == 2 or v == (2, 2)
+    return (_eligible(y) and y.dim() == 4 and y.shape[2] % 2 == 0 and y.shape[3] % 2 == 0
+            and two(pool.kernel_size) and two(pool.stride) and pool.padding in (0, (0, 0))
+            and pool.dilation in (1, (1, 1)) and not pool.return_indices
+            and y.shape[0] * y.shape[2] * y.shape[3] > 16384)      # small planes: the one-launch K5 + torch's pool
+
+
+def conv_bn_act_pool(conv: nn.Conv2d, bn: nn.BatchNorm2d, pool: nn.MaxPool2d, x: torch.Tensor, act=None):
+    """``pool(act(bn(conv(x))))`` for the groups that end a VGG stage (2x2 / stride-2 max-pool)."""
+    fused_conv = (conv.bias is not None and x.is_cuda and x.dtype == torch.float32 and fused_enabled()
+                  and bn.track_running_stats and conv.padding_mode == "zeros")
+    if not fused_conv:
+        return pool(conv_bn_act(conv, bn, x, act))
+    y = conv._conv_forward(x, conv.weight, None)
+    if not _pool_eligible(y, pool):
+        if not _eligible(y):
+            return pool(bn_act(bn, y + conv.bias.view(1, -1, 1, 1), act))
+        return pool(bn_act(bn, y, act, pre_bias=conv.bias))
+    training = bn.training
+    if training and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked += 1
+    act_code, slope = _parse_act(act)
+    yp, bmean, bvar = _BNActPool.apply(y.contiguous(), bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                                       bool(training), bn.eps, act_code, slope, conv.bias)
+    if training:
+        with torch.no_grad():
+            m = 0.1 if bn.momentum is None else bn.momentum
+            bn.running_mean.mul_(1 - m).add_(bmean, alpha=m)
+            bn.running_var.mul_(1 - m).add_(bvar, alpha=m)
+    return yp

@@ -16,7 +16,7 @@ import os
 import torch
 import torch.nn as nn
 
-from .fused_bn import bn_act, conv_bn_act
+from .fused_bn import bn_act, conv_bn_act, conv_bn_act_pool
 
 # VGG-16 ("configuration D"): channel widths, 'P' = 2x2 max-pool
 _VGG16_PLAN = (64, 64, "P", 128, 128, "P", 256, 256, 256, "P", 512, 512, 512, "P", 512, 512,
@@ -78,9 +78,14 @@ class ImageEncoderWarpper(nn.Module):
             layer = layers[i]
             if (isinstance(layer, nn.Conv2d) and i + 2 < len(layers) and isinstance(layers[i + 1], nn.BatchNorm2d)
                     and isinstance(layers[i + 2], nn.ReLU)):
-                # conv (bias-free) -> K5: bias + BatchNorm + ReLU in one pass, bias gradient from its dx pass
-                x = conv_bn_act(layer, layers[i + 1], x, "relu")
-                i += 3
+                # conv (bias-free) -> K5: bias + BatchNorm + ReLU in one pass, bias gradient from its dx
+                # pass; a stage's closing 2x2 max-pool joins the same pass
+                if i + 3 < len(layers) and isinstance(layers[i + 3], nn.MaxPool2d):
+                    x = conv_bn_act_pool(layer, layers[i + 1], layers[i + 3], x, "relu")
+                    i += 4
+                else:
+                    x = conv_bn_act(layer, layers[i + 1], x, "relu")
+                    i += 3
             elif isinstance(layer, nn.BatchNorm2d) and i + 1 < len(layers) and isinstance(layers[i + 1], nn.ReLU):
                 x = bn_act(layer, x, "relu")     # BatchNorm + ReLU as one pass (K5) on the GPU
                 i += 2

@@ -163,7 +163,14 @@ class PrimitiveCluster(nn.Module):
         return torch.cat(outs, dim=2)
 
 
-def _group_batch_norm(h, bns, calls_per_bn, act):
+def _stack_affine(bns, calls_per_bn):
+    """gamma / beta of ``bns`` stacked to ``[G*C]`` for ``_group_batch_norm``."""
+    gamma = torch.stack([b.weight for b in bns]).repeat_interleave(calls_per_bn, dim=0).reshape(-1)
+    beta = torch.stack([b.bias for b in bns]).repeat_interleave(calls_per_bn, dim=0).reshape(-1)
+    return gamma, beta
+
+
+def _group_batch_norm(h, bns, calls_per_bn, act, affine=None):
     """BatchNorm over the last axis of ``h [G, C, M]`` with an independent set of statistics
     per group ``g`` (one reference ``BatchNorm1d`` call each), then ``act``.
 
@@ -173,8 +180,7 @@ def _group_batch_norm(h, bns, calls_per_bn, act):
     its running statistics receive that many sequential momentum updates."""
     G, C, M = h.shape
     r = calls_per_bn
-    gamma = torch.stack([b.weight for b in bns]).repeat_interleave(r, dim=0).reshape(G * C)
-    beta = torch.stack([b.bias for b in bns]).repeat_interleave(r, dim=0).reshape(G * C)
+    gamma, beta = affine if affine is not None else _stack_affine(bns, r)
     x = h.reshape(1, G * C, M)
     fuse = "relu" if act is F.relu else None       # BatchNorm + ReLU as one pass (K5) on the GPU
     post = (lambda t: t) if act is F.relu else act
@@ -231,11 +237,42 @@ class PCDecoder(nn.Module):
         """Nested list ``[cluster][node] -> [B, ori_dim, P]`` drawn in the reference's order."""
         return [c.sample_grids(batch, device, generator) for c in self.cluster_pool]
 
-    def forward(self, hidden_feat, grid=None, generator=None):
-        """``grid`` (optional): nested list ``[cluster][node] -> [B, ori_dim, P]``."""
+    def forward(self, hidden_feat, grid=None, generator=None, pack=None):
+        """``grid`` (optional): nested list ``[cluster][node] -> [B, ori_dim, P]``.
+        ``pack`` (optional, batched form): the result of ``pack_parameters()``, shared by the
+        decodes of one episode."""
         if self.batched:
-            return self._forward_batched(hidden_feat, grid, generator)
+            return self._forward_batched(hidden_feat, grid, generator, pack)
         return self._forward_looped(hidden_feat, grid, generator)
+
+    def pack_parameters(self):
+        """The per-patch weights / biases / BatchNorm affine parameters stacked for the batched
+        form.  An episode with intra-reconstruction decodes twice (queries, supports): stacking
+        once and passing the pack to both calls halves the stacking copies and, in the backward,
+        sums the two decodes' gradients on the 24 stacked tensors instead of leaving autograd a
+        second, accumulating gradient for each of the 264 per-patch parameters."""
+        if not self.batched:
+            return None
+        clusters = list(self.cluster_pool)
+        R = self.num_nodes
+        defs = [c.deformer for c in clusters]
+        nodes = [n for c in clusters for n in c.node_pool]
+
+        def stack_w(mods, name, repeat=1):
+            w = torch.stack([getattr(m, name).weight.squeeze(-1) for m in mods])       # [n,out,in]
+            b = torch.stack([getattr(m, name).bias for m in mods])                     # [n,out]
+            if repeat > 1:
+                w = w.repeat_interleave(repeat, dim=0)
+                b = b.repeat_interleave(repeat, dim=0)
+            return w, b.unsqueeze(-1)
+
+        pack = {f"d{i}": stack_w(defs, f"conv{i}", R) for i in (1, 2, 3)}
+        pack.update({f"n{i}": stack_w(nodes, f"conv{i}") for i in (1, 2, 3, 4)})
+        pack["dbn1"] = _stack_affine([d.bn1 for d in defs], R)
+        pack["dbn2"] = _stack_affine([d.bn2 for d in defs], R)
+        for i in (1, 2, 3):
+            pack[f"nbn{i}"] = _stack_affine([getattr(n, f"bn{i}") for n in nodes], 1)
+        return pack
 
     def _forward_looped(self, hidden_feat, grid=None, generator=None):
         outs = []
@@ -243,7 +280,9 @@ class PCDecoder(nn.Module):
             outs.append(cluster(hidden_feat, None if grid is None else grid[ci], generator))
         return torch.cat(outs, dim=2).transpose(1, 2).contiguous()
 
-    def _forward_batched(self, x, grid=None, generator=None):
+    def _forward_batched(self, x, grid=None, generator=None, pack=None):
+        if pack is None:
+            pack = self.pack_parameters()
         clusters = list(self.cluster_pool)
         K, R = len(clusters), self.num_nodes
         G = K * R
@@ -260,34 +299,26 @@ class PCDecoder(nn.Module):
             g = torch.stack([t for per_cluster in grid for t in per_cluster])          # [G,B,dim,P]
         h = g.permute(0, 2, 1, 3).reshape(G, g.size(2), B * P)                          # [G,dim,B*P]
 
-        def stack_w(mods, name, repeat=1):
-            w = torch.stack([getattr(m, name).weight.squeeze(-1) for m in mods])       # [n,out,in]
-            b = torch.stack([getattr(m, name).bias for m in mods])                     # [n,out]
-            if repeat > 1:
-                w = w.repeat_interleave(repeat, dim=0)
-                b = b.repeat_interleave(repeat, dim=0)
-            return w, b.unsqueeze(-1)
-
         # ---- per-cluster deformers, applied to each of the cluster's R patches
         defs = [c.deformer for c in clusters]
-        w, b = stack_w(defs, "conv1", R)
-        h = _group_batch_norm(torch.baddbmm(b, w, h), [d.bn1 for d in defs], R, act)
-        w, b = stack_w(defs, "conv2", R)
-        h = _group_batch_norm(torch.baddbmm(b, w, h), [d.bn2 for d in defs], R, act)
-        w, b = stack_w(defs, "conv3", R)
+        w, b = pack["d1"]
+        h = _group_batch_norm(torch.baddbmm(b, w, h), [d.bn1 for d in defs], R, act, pack["dbn1"])
+        w, b = pack["d2"]
+        h = _group_batch_norm(torch.baddbmm(b, w, h), [d.bn2 for d in defs], R, act, pack["dbn2"])
+        w, b = pack["d3"]
         pts = torch.tanh(torch.baddbmm(b, w, h))                                        # [G,raw,B*P]
 
         # ---- the G patch MLPs; first layer split into latent and point parts
         nodes = [n for c in clusters for n in c.node_pool]
-        w, b = stack_w(nodes, "conv1")                                                  # [G,D,D]
+        w, b = pack["n1"]                                                               # [G,D,D]
         D = w.size(1)
         h_lat = torch.matmul(w[:, :, :L], x.t()) + b                                    # [G,D,B]
         h = torch.bmm(w[:, :, L:], pts).view(G, D, B, P) + h_lat.unsqueeze(-1)
-        h = _group_batch_norm(h.view(G, D, B * P), [n.bn1 for n in nodes], 1, act)
-        w, b = stack_w(nodes, "conv2")
-        h = _group_batch_norm(torch.baddbmm(b, w, h), [n.bn2 for n in nodes], 1, act)
-        w, b = stack_w(nodes, "conv3")
-        h = _group_batch_norm(torch.baddbmm(b, w, h), [n.bn3 for n in nodes], 1, act)
-        w, b = stack_w(nodes, "conv4")
+        h = _group_batch_norm(h.view(G, D, B * P), [n.bn1 for n in nodes], 1, act, pack["nbn1"])
+        w, b = pack["n2"]
+        h = _group_batch_norm(torch.baddbmm(b, w, h), [n.bn2 for n in nodes], 1, act, pack["nbn2"])
+        w, b = pack["n3"]
+        h = _group_batch_norm(torch.baddbmm(b, w, h), [n.bn3 for n in nodes], 1, act, pack["nbn3"])
+        w, b = pack["n4"]
         out = torch.tanh(torch.baddbmm(b, w, h))                                        # [G,3,B*P]
         return out.view(G, 3, B, P).permute(2, 0, 3, 1).reshape(B, G * P, 3).contiguous()

@@ -166,6 +166,24 @@ int fpsg_bn_act_bwd(const float* x, const float* pre_bias, const float* dy, cons
                     int L, int training, int act, float slope, float* dx, float* dgamma, float* dbeta,
                     float* dpre_bias, float* coef, float* ws, fpsg_stream_t stream);
 
+/* K5 followed by MaxPool2d(kernel 2, stride 2): the conv + BatchNorm + ReLU + max-pool groups
+ * that end the five stages of the VGG16-BN trunk (src/models/image_net.py:14).  x [N,C,H,W]
+ * (H, W even), y_pooled / dy_pooled [N,C,H/2,W/2].  The forward writes only the pooled
+ * tensor; the backward re-derives each window's activations and arg-max from x (scan order
+ * (h,w), first strictly greater or NaN wins, as torch's max_pool2d), so neither the
+ * full-resolution activation, nor pooling indices, nor the scattered gradient exist in HBM.
+ * Other arguments as fpsg_bn_act_fwd / _bwd; ws: fpsg_bn_pool_workspace_floats(N,C,H,W).
+ */
+size_t fpsg_bn_pool_workspace_floats(int N, int C, int H, int W);
+int fpsg_bn_act_pool_fwd(const float* x, const float* pre_bias, const float* gamma, const float* beta,
+                         const float* running_mean, const float* running_var, int N, int C, int H, int W,
+                         int training, float eps, int act, float slope, float* y_pooled, float* chan,
+                         float* batch_mean, float* batch_var_unbiased, float* ws, fpsg_stream_t stream);
+int fpsg_bn_act_pool_bwd(const float* x, const float* pre_bias, const float* dy_pooled, const float* chan,
+                         int N, int C, int H, int W, int training, int act, float slope, float* dx,
+                         float* dgamma, float* dbeta, float* dpre_bias, float* coef, float* ws,
+                         fpsg_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

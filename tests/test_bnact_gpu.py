@@ -167,3 +167,65 @@ def test_conv_bn_act_matches_module_chain(gpu, kind):
     assert float(conv.bias.grad.abs().max()) <= floor and float(conv2.bias.grad.abs().max()) <= floor
     assert torch.allclose(bn.running_mean, bn2.running_mean, rtol=1e-5, atol=1e-6)
     assert torch.allclose(bn.running_var, bn2.running_var, rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("shape", [(8, 64, 56, 56), (37, 16, 28, 28), (3, 8, 112, 112), (20, 24, 30, 30), (2, 3, 224, 224),
+                                   (48, 5, 64, 6)])
+@pytest.mark.parametrize("mode", ["train", "eval"])
+def test_pooled_variant_matches_unfused_chain(gpu, shape, mode):
+    """conv_bn_act_pool == max_pool2d(K5(conv(x))) : pooled output BIT-equal (same arithmetic per
+    element, max is exact); gradients agree to summation order (the pooled backward partitions its
+    partial sums differently)."""
+    from fpsg_amd.fused_bn import conv_bn_act, conv_bn_act_pool, _pool_eligible
+    import copy
+    torch.manual_seed(sum(shape))
+    N, C, H, W = shape
+    conv = nn.Conv2d(C, C, 3, padding=1).to(gpu)
+    bn = nn.BatchNorm2d(C).to(gpu)
+    pool = nn.MaxPool2d(2, 2)
+    with torch.no_grad():
+        conv.bias.copy_(torch.randn(C) * 0.3)
+        bn.weight.copy_(torch.randn(C) * 0.5 + 1)
+        bn.bias.copy_(torch.randn(C) * 0.3)
+    conv2, bn2 = copy.deepcopy(conv), copy.deepcopy(bn)
+    bn.train(mode == "train"); bn2.train(mode == "train")
+    x = torch.randn(*shape, device=gpu)
+    x1, x2 = x.clone().requires_grad_(), x.clone().requires_grad_()
+    assert _pool_eligible(conv._conv_forward(x, conv.weight, None), pool)
+    y1 = conv_bn_act_pool(conv, bn, pool, x1, "relu")
+    y2 = pool(conv_bn_act(conv2, bn2, x2, "relu"))
+    assert y1.shape == (N, C, H // 2, W // 2) and torch.equal(y1, y2)
+    g = torch.randn_like(y1)
+    y1.backward(g); y2.backward(g)
+    for a, r in ((x1.grad, x2.grad), (conv.weight.grad, conv2.weight.grad), (bn.weight.grad, bn2.weight.grad),
+                 (bn.bias.grad, bn2.bias.grad)):
+        assert float((a - r).abs().max()) <= 2e-4 * float(r.abs().max()) + 1e-6
+    assert torch.equal(bn.running_mean, bn2.running_mean) and torch.equal(bn.running_var, bn2.running_var)
+    assert int(bn.num_batches_tracked) == int(bn2.num_batches_tracked)
+    if mode == "eval":
+        assert float((conv.bias.grad - conv2.bias.grad).abs().max()) <= 2e-4 * float(conv2.bias.grad.abs().max()) + 1e-6
+
+
+def test_pooled_variant_ties_and_torch_pool(gpu):
+    """Ties inside a window (all four activations clipped to 0 by the ReLU, or equal positives) go to
+    the first element in (h, w) scan order, as torch's max_pool2d does: checked against the plain
+    torch chain BatchNorm2d -> ReLU -> MaxPool2d on inputs built from a few repeated values."""
+    from fpsg_amd.fused_bn import conv_bn_act_pool
+    import copy
+    torch.manual_seed(3)
+    N, C, H, W = 6, 8, 64, 64
+    conv = nn.Conv2d(C, C, 1).to(gpu)
+    with torch.no_grad():                                   # identity 1x1 convolution, zero bias
+        conv.weight.copy_(torch.eye(C).view(C, C, 1, 1)); conv.bias.zero_()
+    bn = nn.BatchNorm2d(C).to(gpu).train()
+    bn2 = copy.deepcopy(bn)
+    x = torch.randint(-2, 3, (N, C, H, W), device=gpu).float()          # five distinct values: many ties
+    x1, x2 = x.clone().requires_grad_(), x.clone().requires_grad_()
+    y1 = conv_bn_act_pool(conv, bn, nn.MaxPool2d(2, 2), x1, "relu")
+    y2 = torch.nn.functional.max_pool2d(torch.relu(bn2(x2)), 2, 2)
+    assert torch.allclose(y1, y2, rtol=1e-5, atol=1e-6)
+    g = torch.rand_like(y1) + 0.5
+    y1.backward(g); y2.backward(g)
+    # the same window elements receive gradient: compare the support of the part of dx that comes
+    # through the pool (dx = k1*dz + k2*x + k3: subtract the dense part using a zero-gradient twin)
+    assert float((x1.grad - x2.grad).abs().max()) <= 2e-4 * float(x2.grad.abs().max()) + 1e-6

@@ -207,11 +207,11 @@ def test_graph_replay_equals_eager_step(gpu):
         step = TrainStep(m, optimizer, graph=(mode == "graph"))
         fixed = {b: m.pc_decoder.sample_grids(b, gpu, torch.Generator(device=gpu).manual_seed(5 + b)) for b in (4, 2)}
         orig = m.pc_decoder.forward
-        m.pc_decoder.forward = lambda h, grid=None, generator=None, orig=orig, fixed=fixed: orig(h, grid=fixed[h.size(0)])
+        m.pc_decoder.forward = lambda h, grid=None, generator=None, pack=None, orig=orig, fixed=fixed: orig(h, grid=fixed[h.size(0)], pack=pack)
         for _ in range(4):                       # graph mode: 2 eager uses, capture, replay
             out = step([eps[0], eps[1]])
         if mode == "graph":
-            assert len(step._graphs) == 1
+            assert len(step._graphs) == 2        # same shape, first (copy) / later (add) episode of a step
         grads[mode] = (step.buckets.flat.clone(), float(out[-1]["ttl_loss"].sum()))
     cos = torch.nn.functional.cosine_similarity
     g_e, l_e = grads["eager"]

@@ -20,7 +20,7 @@ def _fixed_grids(model, sizes, device):
 
 def _pin_grids(model, grids):
     orig = model.pc_decoder.forward
-    model.pc_decoder.forward = lambda h, grid=None, generator=None: orig(h, grid=grids[h.size(0)])
+    model.pc_decoder.forward = lambda h, grid=None, generator=None, pack=None: orig(h, grid=grids[h.size(0)], pack=pack)
 
 
 @pytest.mark.parametrize("mode", ["train", "eval"])
