@@ -23,7 +23,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import _hip
+from . import _hip, winograd
 
 _ACT_CODES = {None: 0, "none": 0, "relu": 1, "leaky": 2}
 _MIN_ROW = 64
@@ -201,13 +201,21 @@ def bn_act(bn: nn.modules.batchnorm._BatchNorm, x: torch.Tensor, act=None, pre_b
                           bn.eps, act, pre_bias=pre_bias)
 
 
+def _conv_without_bias(conv, x):
+    """The convolution of ``conv`` without its bias: K6 (Winograd transforms + MFMA batched GEMM)
+    for the deep 3x3 layers, the library convolution otherwise."""
+    if isinstance(conv, nn.Conv2d) and winograd.eligible(x, conv):
+        return winograd.conv3x3(x, conv.weight)
+    return conv._conv_forward(x, conv.weight, None)
+
+
 def conv_bn_act(conv: nn.modules.conv._ConvNd, bn: nn.modules.batchnorm._BatchNorm, x: torch.Tensor,
                 act=None) -> torch.Tensor:
     """``act(bn(conv(x)))`` for ``nn.Conv1d/2d`` + BatchNorm (+ ReLU / LeakyReLU) triples."""
     if conv.bias is None or not (x.is_cuda and x.dtype == torch.float32 and fused_enabled()
                                  and bn.track_running_stats and conv.padding_mode == "zeros"):
         return bn_act(bn, conv(x), act)
-    y = conv._conv_forward(x, conv.weight, None)           # bias joins inside K5
+    y = _conv_without_bias(conv, x)                        # bias joins inside K5
     if not _eligible(y):
         return bn_act(bn, y + conv.bias.view(1, -1, *([1] * (y.dim() - 2))), act)
     return bn_act(bn, y, act, pre_bias=conv.bias)
@@ -228,7 +236,7 @@ def conv_bn_act_pool(conv: nn.Conv2d, bn: nn.BatchNorm2d, pool: nn.MaxPool2d, x:
                   and bn.track_running_stats and conv.padding_mode == "zeros")
     if not fused_conv:
         return pool(conv_bn_act(conv, bn, x, act))
-    y = conv._conv_forward(x, conv.weight, None)
+    y = _conv_without_bias(conv, x)
     if not _pool_eligible(y, pool):
         if not _eligible(y):
             return pool(bn_act(bn, y + conv.bias.view(1, -1, 1, 1), act))

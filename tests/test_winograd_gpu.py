@@ -1,0 +1,80 @@
+"""K6 (Winograd F(2x2,3x3) transforms through the C ABI + fp32 batched GEMM) against the
+reference's own operator, torch.nn.functional.conv2d (Conv2d 3x3 / padding 1 of vgg16_bn,
+src/models/image_net.py:14): forward, data gradient, weight gradient.  Yardstick: the same
+convolution in float64 on the CPU; tolerance 1e-4 of the tensor's scale (north_star), and the
+Winograd result must not be worse than a few times the error of the library's own fp32 result."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [  # N, C, K, H, W
+    (2, 8, 5, 4, 6), (1, 3, 7, 2, 2), (3, 16, 16, 14, 14), (2, 32, 24, 28, 30), (5, 64, 48, 56, 56), (37, 40, 32, 14, 14),
+]
+
+
+def _errs(a, ref64):
+    scale = float(ref64.abs().max()) + 1e-30
+    return float((a.double().cpu() - ref64).abs().max()) / scale
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+def test_forward_and_gradients_match_conv2d(gpu, shape):
+    from fpsg_amd.winograd import conv3x3
+    N, C, K, H, W = shape
+    torch.manual_seed(N * 1000 + C)
+    x = torch.randn(N, C, H, W)
+    w = torch.randn(K, C, 3, 3) * (2.0 / (9 * C)) ** 0.5
+    g = torch.randn(N, K, H, W)
+    x64, w64 = x.double().requires_grad_(), w.double().requires_grad_()
+    y64 = F.conv2d(x64, w64, None, 1, 1)
+    y64.backward(g.double())
+    xg, wg = x.to(gpu).requires_grad_(), w.to(gpu).requires_grad_()
+    y = conv3x3(xg, wg)
+    y.backward(g.to(gpu))
+    xl, wl = x.to(gpu).requires_grad_(), w.to(gpu).requires_grad_()
+    yl = F.conv2d(xl, wl, None, 1, 1)
+    yl.backward(g.to(gpu))
+    for ours, lib, ref in ((y, yl, y64), (xg.grad, xl.grad, x64.grad), (wg.grad, wl.grad, w64.grad)):
+        e_ours, e_lib = _errs(ours.detach(), ref.detach()), _errs(lib.detach(), ref.detach())
+        assert e_ours <= 1e-4, (shape, e_ours)
+        assert e_ours <= max(8 * e_lib, 5e-6), (shape, e_ours, e_lib)
+
+
+def test_only_requested_gradients(gpu):
+    from fpsg_amd.winograd import conv3x3
+    x = torch.randn(2, 4, 8, 8, device=gpu)
+    w = torch.randn(6, 4, 3, 3, device=gpu, requires_grad=True)
+    conv3x3(x, w).sum().backward()          # first layer of a network: no data gradient
+    assert w.grad is not None and x.grad is None
+    x2 = torch.randn(2, 4, 8, 8, device=gpu, requires_grad=True)
+    conv3x3(x2, w.detach()).sum().backward()
+    assert x2.grad is not None
+
+
+def test_argument_checks(gpu):
+    from fpsg_amd.winograd import conv3x3
+    from fpsg_amd import _hip
+    with pytest.raises(ValueError):
+        conv3x3(torch.randn(1, 4, 7, 8, device=gpu), torch.randn(4, 4, 3, 3, device=gpu))      # odd H
+    with pytest.raises(ValueError):
+        conv3x3(torch.randn(1, 4, 8, 8, device=gpu), torch.randn(4, 5, 3, 3, device=gpu))      # channel mismatch
+    lib = _hip.load()
+    assert lib.fpsg_wino_input_transform(None, 1, 1, 2, 2, None, None) != 0
+    assert b"null" in lib.fpsg_last_error()
+    x = torch.randn(1, 1, 3, 4, device=gpu)
+    assert lib.fpsg_wino_input_transform(_hip.ptr(x), 1, 1, 3, 4, _hip.ptr(x), None) != 0                 # odd H
+
+
+def test_deterministic(gpu):
+    from fpsg_amd.winograd import conv3x3
+    x = torch.randn(3, 32, 28, 28, device=gpu)
+    w = torch.randn(32, 32, 3, 3, device=gpu)
+    outs = []
+    for _ in range(2):
+        xi, wi = x.clone().requires_grad_(), w.clone().requires_grad_()
+        y = conv3x3(xi, wi)
+        y.square().sum().backward()
+        outs.append((y.detach().clone(), xi.grad.clone(), wi.grad.clone()))
+    assert all(torch.equal(a, b) for a, b in zip(*outs))
