@@ -51,11 +51,11 @@ SIGNATURES = {
                              _c_f32p, _c_stream],
     "fpsg_bn_act_pool_bwd": [_c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
                              ctypes.c_float, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_stream],
-    "fpsg_wino_input_transform": [_c_f32p, _c_int, _c_int, _c_int, _c_int, _c_f32p, _c_stream],
-    "fpsg_wino_output_transform": [_c_f32p, _c_int, _c_int, _c_int, _c_int, _c_f32p, _c_stream],
-    "fpsg_wino_grad_output_transform": [_c_f32p, _c_int, _c_int, _c_int, _c_int, _c_f32p, _c_stream],
-    "fpsg_wino_filter_transform": [_c_f32p, _c_int, _c_int, _c_int, _c_f32p, _c_stream],
-    "fpsg_wino_filter_grad_transform": [_c_f32p, _c_int, _c_int, _c_f32p, _c_stream],
+    "fpsg_wino_input_transform": [_c_int, _c_f32p, _c_int, _c_int, _c_int, _c_int, _c_f32p, _c_stream],
+    "fpsg_wino_output_transform": [_c_int, _c_f32p, _c_int, _c_int, _c_int, _c_int, _c_f32p, _c_stream],
+    "fpsg_wino_grad_output_transform": [_c_int, _c_f32p, _c_int, _c_int, _c_int, _c_int, _c_f32p, _c_stream],
+    "fpsg_wino_filter_transform": [_c_int, _c_f32p, _c_int, _c_int, _c_int, _c_f32p, _c_stream],
+    "fpsg_wino_filter_grad_transform": [_c_int, _c_f32p, _c_int, _c_int, _c_f32p, _c_stream],
     "fpsg_emd_workspace_floats": [_c_int, _c_int, _c_int],
     "fpsg_emd_approx": [_c_f32p, _c_f32p, _c_int, _c_int, _c_int, _c_f32p, _c_f32p, _c_f32p, _c_f32p,
                         _c_stream],

@@ -1,23 +1,24 @@
-// winograd.hip -- K6: Winograd F(2x2, 3x3) transforms for the deep 3x3 convolutions of the
+// winograd.hip -- K6: Winograd F(m x m, 3x3) transforms, m = 2 or 4, for the deep 3x3 convolutions of the
 // VGG16-BN trunk (reference src/models/image_net.py:14, torchvision vgg16_bn.features: thirteen
 // Conv2d(3x3, padding 1, stride 1); here the ones with >= 256 channels), gfx950.
 //
-// conv(x, w)[n,k] = sum_c x[n,c] * w[k,c] (3x3, pad 1) is evaluated per 2x2 output tile as
-//     Y = A^T [ sum_c (G g G^T) .* (B^T d B) ] A ,   d = the 4x4 input tile at stride 2
-// i.e. 16 independent GEMMs  M[xi] = U[xi] (K x C)  *  V[xi] (C x P)   over the P = N*(H/2)*(W/2)
-// tiles, with 2.25x fewer multiplications than the direct form.  The GEMMs are plain, large fp32
+// conv(x, w)[n,k] = sum_c x[n,c] * w[k,c] (3x3, pad 1) is evaluated per m x m output tile as
+//     Y = A^T [ sum_c (G g G^T) .* (B^T d B) ] A ,   d = the (m+2)x(m+2) input tile at stride m
+// i.e. (m+2)^2 independent GEMMs  M[xi] = U[xi] (K x C)  *  V[xi] (C x P)  over the
+// P = N*(H/m)*(W/m) tiles, with 2.25x (m=2) or 4x (m=4) fewer multiplications than the direct
+// form; the transform-domain tensors are 4x (m=2) or 2.25x (m=4) the image tensors.  The GEMMs are plain, large fp32
 // matrix products and run on the MFMA pipes through the caller's BLAS (hipBLASLt via torch.bmm:
 // 110-120 TFLOP/s at these shapes); this file holds the data-movement halves, which are pure HBM
 // streams:
-//   input transform   x  [N,C,H,W]   -> V  [16,C,P]     (reads 1x, writes 4x the tensor)
-//   output transform  M  [16,K,P]    -> y  [N,K,H,W]    (reads 4x, writes 1x)
-//   filter transform  w  [K,C,3,3]   -> U  [16,K,C]     (or, for the data gradient, the
+//   input transform   x  [N,C,H,W]   -> V  [A*A,C,P]    (A = m+2)
+//   output transform  M  [A*A,K,P]   -> y  [N,K,H,W]
+//   filter transform  w  [K,C,3,3]   -> U  [A*A,K,C]    (or, for the data gradient, the
 //                                                        180-degree-rotated, transposed filter)
 // and, for the weight gradient  dU[xi] = dM[xi] (K x P) * V[xi]^T (P x C):
-//   grad-output transform  dy [N,K,H,W] -> dM [16,K,P]  (dM = A dY A^T per tile)
-//   filter-grad transform  dU [16,K,C]  -> dw [K,C,3,3] (dw = G^T dU G)
-// Tile p = (n*Th + th)*Tw + tw covers output rows 2th..2th+1, cols 2tw..2tw+1 and input rows
-// 2th-1..2th+2, cols 2tw-1..2tw+2 (zero outside the image).  Threads run along p, so every
+//   grad-output transform  dy [N,K,H,W] -> dM [A*A,K,P] (dM = A dY A^T per tile)
+//   filter-grad transform  dU [A*A,K,C] -> dw [K,C,3,3] (dw = G^T dU G)
+// Tile p = (n*Th + th)*Tw + tw covers output rows m*th..m*th+m-1, cols m*tw..m*tw+m-1 and input
+// rows m*th-1..m*th+m, cols m*tw-1..m*tw+m (zero outside the image).  Threads run along p, so every
 // transform-domain access is a coalesced 4-byte stream and the image-side accesses of a wave
 // cover contiguous row segments.  Deterministic (no atomics).
 #include "fpsg_common.h"
@@ -27,173 +28,282 @@ namespace {
 
 constexpr int kWinoThreads = 256;
 
+// One-dimensional transforms of F(m, 3), m = 2 and 4 (interpolation points 0, +-1 [, +-2], inf;
+// the matrices of Lavin & Gray, "Fast Algorithms for Convolutional Neural Networks").  A = m + 2.
+//   in  : B^T d      (A -> A)      out : A^T m     (A -> m)
+//   flt : G g        (3 -> A)      gout: A y       (m -> A)      fgrad: G^T u    (A -> 3)
+template <int M> struct Wino;
+
+template <> struct Wino<2> {
+  static constexpr int A = 4;
+  static __device__ __forceinline__ void in(const float (&d)[4], float (&t)[4]) {
+    t[0] = d[0] - d[2]; t[1] = d[1] + d[2]; t[2] = d[2] - d[1]; t[3] = d[1] - d[3];
+  }
+  static __device__ __forceinline__ void out(const float (&m)[4], float (&s)[2]) {
+    s[0] = (m[0] + m[1]) + m[2]; s[1] = (m[1] - m[2]) - m[3];
+  }
+  static __device__ __forceinline__ void flt(const float (&g)[3], float (&u)[4]) {
+    u[0] = g[0]; u[1] = 0.5f * ((g[0] + g[1]) + g[2]); u[2] = 0.5f * ((g[0] - g[1]) + g[2]); u[3] = g[2];
+  }
+  static __device__ __forceinline__ void gout(const float (&y)[2], float (&r)[4]) {
+    r[0] = y[0]; r[1] = y[0] + y[1]; r[2] = y[0] - y[1]; r[3] = -y[1];
+  }
+  static __device__ __forceinline__ void fgrad(const float (&u)[4], float (&a)[3]) {
+    a[0] = u[0] + 0.5f * (u[1] + u[2]); a[1] = 0.5f * (u[1] - u[2]); a[2] = 0.5f * (u[1] + u[2]) + u[3];
+  }
+};
+
+template <> struct Wino<4> {
+  static constexpr int A = 6;
+  static __device__ __forceinline__ void in(const float (&d)[6], float (&t)[6]) {
+    t[0] = fma_rn(4.0f, d[0], fma_rn(-5.0f, d[2], d[4]));
+    t[1] = fma_rn(-4.0f, d[1] + d[2], d[3] + d[4]);
+    t[2] = fma_rn(4.0f, d[1] - d[2], d[4] - d[3]);
+    t[3] = fma_rn(2.0f, d[3] - d[1], d[4] - d[2]);
+    t[4] = fma_rn(2.0f, d[1] - d[3], d[4] - d[2]);
+    t[5] = fma_rn(4.0f, d[1], fma_rn(-5.0f, d[3], d[5]));
+  }
+  static __device__ __forceinline__ void out(const float (&m)[6], float (&s)[4]) {
+    const float p12 = m[1] + m[2], m12 = m[1] - m[2], p34 = m[3] + m[4], m34 = m[3] - m[4];
+    s[0] = (m[0] + p12) + p34;
+    s[1] = fma_rn(2.0f, m34, m12);
+    s[2] = fma_rn(4.0f, p34, p12);
+    s[3] = fma_rn(8.0f, m34, m12) + m[5];
+  }
+  static __device__ __forceinline__ void flt(const float (&g)[3], float (&u)[6]) {
+    const float e = g[0] + g[2];
+    u[0] = 0.25f * g[0];
+    u[1] = (-1.0f / 6.0f) * (e + g[1]);
+    u[2] = (-1.0f / 6.0f) * (e - g[1]);
+    const float f = fma_rn(1.0f / 24.0f, g[0], (1.0f / 6.0f) * g[2]);
+    u[3] = fma_rn(1.0f / 12.0f, g[1], f);
+    u[4] = fma_rn(-1.0f / 12.0f, g[1], f);
+    u[5] = g[2];
+  }
+  static __device__ __forceinline__ void gout(const float (&y)[4], float (&r)[6]) {
+    const float e = y[0] + y[2], o = y[1] + y[3];
+    r[0] = y[0];
+    r[1] = e + o;
+    r[2] = e - o;
+    const float e4 = fma_rn(4.0f, y[2], y[0]), o4 = fma_rn(8.0f, y[3], 2.0f * y[1]);
+    r[3] = e4 + o4;
+    r[4] = e4 - o4;
+    r[5] = y[3];
+  }
+  static __device__ __forceinline__ void fgrad(const float (&u)[6], float (&a)[3]) {
+    const float p12 = u[1] + u[2], m12 = u[1] - u[2], p34 = u[3] + u[4], m34 = u[3] - u[4];
+    a[0] = fma_rn(0.25f, u[0], fma_rn(-1.0f / 6.0f, p12, (1.0f / 24.0f) * p34));
+    a[1] = fma_rn(-1.0f / 6.0f, m12, (1.0f / 12.0f) * m34);
+    a[2] = fma_rn(-1.0f / 6.0f, p12, fma_rn(1.0f / 6.0f, p34, u[5]));
+  }
+};
+
+struct TileIndex { long n; int th, tw; };
+__device__ __forceinline__ TileIndex tile_of(long p, int Th, int Tw) {
+  TileIndex t;
+  t.tw = (int)(p % Tw);
+  const long q = p / Tw;
+  t.th = (int)(q % Th);
+  t.n = q / Th;
+  return t;
+}
+
+// Each thread loads the M interior columns of its tile's rows as ONE aligned vector (a wave reads a
+// contiguous row segment) and takes the two halo columns from the neighbouring lanes' vectors;
+// only lanes at a wave edge inside an image row fetch their halo from memory.
+template <int M>
 __global__ __launch_bounds__(kWinoThreads) void wino_input_kernel(const float* __restrict__ x, int C, int H, int W,
                                                                    int Th, int Tw, long P, float* __restrict__ V) {
-  const long p = (long)blockIdx.x * kWinoThreads + threadIdx.x;
-  if (p >= P) return;
+  constexpr int A = Wino<M>::A;
+  typedef float vin __attribute__((ext_vector_type(M)));
+  const long p_raw = (long)blockIdx.x * kWinoThreads + threadIdx.x;
+  const bool live = p_raw < P;
+  const long p = live ? p_raw : P - 1;          // dead lanes shadow the last tile: every lane shuffles
   const int c = blockIdx.y;
-  const int tw = (int)(p % Tw);
-  const long q = p / Tw;
-  const int th = (int)(q % Th);
-  const long n = q / Th;
-  const float* xp = x + ((size_t)n * C + c) * H * W;
-  const int r0 = 2 * th - 1, c0 = 2 * tw - 1;
-  float d[4][4];
+  const TileIndex ti = tile_of(p, Th, Tw);
+  const float* xp = x + ((size_t)ti.n * C + c) * H * W;
+  const int r0 = M * ti.th - 1, c0 = M * ti.tw;
+  const int lane = threadIdx.x & (kWave - 1);
+  const bool has_left = ti.tw > 0, has_right = ti.tw < Tw - 1;
+  const bool left_lane = has_left && lane > 0;              // lane-1 holds tile (th, tw-1)
+  const bool right_lane = has_right && lane < kWave - 1;    // lane+1 holds tile (th, tw+1)
+  float d[A][A];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < A; ++i) {
     const int r = r0 + i;
     const bool rin = r >= 0 && r < H;
+    const float* rp = xp + (size_t)(rin ? r : 0) * W + c0;
+    vin mid;
+    if (rin) mid = *reinterpret_cast<const vin*>(rp);
+    else
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int cc = c0 + j;
-      d[i][j] = (rin && cc >= 0 && cc < W) ? xp[(size_t)r * W + cc] : 0.0f;
-    }
-  }
-  float t[4][4];
+      for (int j = 0; j < M; ++j) mid[j] = 0.0f;
+    float lft = __shfl_up(mid[M - 1], 1, kWave);
+    float rgt = __shfl_down(mid[0], 1, kWave);
+    if (!left_lane) lft = (has_left && rin) ? rp[-1] : 0.0f;
+    if (!right_lane) rgt = (has_right && rin) ? rp[M] : 0.0f;
+    d[i][0] = lft;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    t[0][j] = d[0][j] - d[2][j];
-    t[1][j] = d[1][j] + d[2][j];
-    t[2][j] = d[2][j] - d[1][j];
-    t[3][j] = d[1][j] - d[3][j];
+    for (int j = 0; j < M; ++j) d[i][1 + j] = mid[j];
+    d[i][A - 1] = rgt;
   }
+  float t[A][A];        // t[j][i]: column j of the tile after the transform along rows
+#pragma unroll
+  for (int j = 0; j < A; ++j) {
+    float col[A];
+#pragma unroll
+    for (int i = 0; i < A; ++i) col[i] = d[i][j];
+    Wino<M>::in(col, t[j]);
+  }
+  if (!live) return;
   const size_t plane = (size_t)C * P;
   float* vp = V + (size_t)c * P + p;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    vp[(size_t)(4 * i + 0) * plane] = t[i][0] - t[i][2];
-    vp[(size_t)(4 * i + 1) * plane] = t[i][1] + t[i][2];
-    vp[(size_t)(4 * i + 2) * plane] = t[i][2] - t[i][1];
-    vp[(size_t)(4 * i + 3) * plane] = t[i][1] - t[i][3];
+  for (int i = 0; i < A; ++i) {
+    float row[A], v[A];
+#pragma unroll
+    for (int j = 0; j < A; ++j) row[j] = t[j][i];
+    Wino<M>::in(row, v);
+#pragma unroll
+    for (int j = 0; j < A; ++j) vp[(size_t)(A * i + j) * plane] = v[j];
   }
 }
 
-__global__ __launch_bounds__(kWinoThreads) void wino_output_kernel(const float* __restrict__ M, int K, int H, int W,
+template <int M>
+__global__ __launch_bounds__(kWinoThreads) void wino_output_kernel(const float* __restrict__ Mt, int K, int H, int W,
                                                                     int Th, int Tw, long P, float* __restrict__ y) {
+  constexpr int A = Wino<M>::A;
+  typedef float vout __attribute__((ext_vector_type(M)));
   const long p = (long)blockIdx.x * kWinoThreads + threadIdx.x;
   if (p >= P) return;
   const int k = blockIdx.y;
-  const int tw = (int)(p % Tw);
-  const long q = p / Tw;
-  const int th = (int)(q % Th);
-  const long n = q / Th;
+  const TileIndex ti = tile_of(p, Th, Tw);
   const size_t plane = (size_t)K * P;
-  const float* mp = M + (size_t)k * P + p;
-  float m[4][4];
+  const float* mp = Mt + (size_t)k * P + p;
+  float s[A][M];        // s[j][i]: column j after the transform along rows
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int j = 0; j < A; ++j) {
+    float m[A];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) m[i][j] = mp[(size_t)(4 * i + j) * plane];
-  float s[2][4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    s[0][j] = (m[0][j] + m[1][j]) + m[2][j];
-    s[1][j] = (m[1][j] - m[2][j]) - m[3][j];
+    for (int i = 0; i < A; ++i) m[i] = mp[(size_t)(A * i + j) * plane];
+    Wino<M>::out(m, s[j]);
   }
-  float* yp = y + (((size_t)n * K + k) * H + 2 * th) * W + 2 * tw;
-  v2f o0, o1;
-  o0[0] = (s[0][0] + s[0][1]) + s[0][2];
-  o0[1] = (s[0][1] - s[0][2]) - s[0][3];
-  o1[0] = (s[1][0] + s[1][1]) + s[1][2];
-  o1[1] = (s[1][1] - s[1][2]) - s[1][3];
-  *reinterpret_cast<v2f*>(yp) = o0;
-  *reinterpret_cast<v2f*>(yp + W) = o1;
+  float* yp = y + (((size_t)ti.n * K + k) * H + M * ti.th) * W + M * ti.tw;
+#pragma unroll
+  for (int i = 0; i < M; ++i) {
+    float row[A], o[M];
+#pragma unroll
+    for (int j = 0; j < A; ++j) row[j] = s[j][i];
+    Wino<M>::out(row, o);
+    vout ov;
+#pragma unroll
+    for (int j = 0; j < M; ++j) ov[j] = o[j];
+    *reinterpret_cast<vout*>(yp + (size_t)i * W) = ov;
+  }
 }
 
-// dM = A dY A^T, A = [[1,0],[1,1],[1,-1],[0,-1]]
+// dM = A dY A^T per tile
+template <int M>
 __global__ __launch_bounds__(kWinoThreads) void wino_grad_output_kernel(const float* __restrict__ dy, int K, int H,
                                                                          int W, int Th, int Tw, long P,
                                                                          float* __restrict__ dM) {
+  constexpr int A = Wino<M>::A;
+  typedef float vin __attribute__((ext_vector_type(M)));
   const long p = (long)blockIdx.x * kWinoThreads + threadIdx.x;
   if (p >= P) return;
   const int k = blockIdx.y;
-  const int tw = (int)(p % Tw);
-  const long q = p / Tw;
-  const int th = (int)(q % Th);
-  const long n = q / Th;
-  const float* yp = dy + (((size_t)n * K + k) * H + 2 * th) * W + 2 * tw;
-  const v2f y0 = *reinterpret_cast<const v2f*>(yp);
-  const v2f y1 = *reinterpret_cast<const v2f*>(yp + W);
-  float r[4][2];
+  const TileIndex ti = tile_of(p, Th, Tw);
+  const float* yp = dy + (((size_t)ti.n * K + k) * H + M * ti.th) * W + M * ti.tw;
+  float yv[M][M];
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    r[0][j] = y0[j];
-    r[1][j] = y0[j] + y1[j];
-    r[2][j] = y0[j] - y1[j];
-    r[3][j] = -y1[j];
+  for (int i = 0; i < M; ++i) {
+    const vin v = *reinterpret_cast<const vin*>(yp + (size_t)i * W);
+#pragma unroll
+    for (int j = 0; j < M; ++j) yv[i][j] = v[j];
+  }
+  float r[M][A];        // r[j][i]: column j after the transform along rows
+#pragma unroll
+  for (int j = 0; j < M; ++j) {
+    float col[M];
+#pragma unroll
+    for (int i = 0; i < M; ++i) col[i] = yv[i][j];
+    Wino<M>::gout(col, r[j]);
   }
   const size_t plane = (size_t)K * P;
   float* mp = dM + (size_t)k * P + p;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    mp[(size_t)(4 * i + 0) * plane] = r[i][0];
-    mp[(size_t)(4 * i + 1) * plane] = r[i][0] + r[i][1];
-    mp[(size_t)(4 * i + 2) * plane] = r[i][0] - r[i][1];
-    mp[(size_t)(4 * i + 3) * plane] = -r[i][1];
+  for (int i = 0; i < A; ++i) {
+    float row[M], o[A];
+#pragma unroll
+    for (int j = 0; j < M; ++j) row[j] = r[j][i];
+    Wino<M>::gout(row, o);
+#pragma unroll
+    for (int j = 0; j < A; ++j) mp[(size_t)(A * i + j) * plane] = o[j];
   }
 }
 
 // U = G g G^T per (k, c); flip != 0: the filter of the data gradient, g'[c][k] = rot180(g[k][c]),
-// written as U [16, C, K].
+// written as U [A*A, C, K].
+template <int M>
 __global__ void wino_filter_kernel(const float* __restrict__ w, int K, int C, int flip, float* __restrict__ U) {
+  constexpr int A = Wino<M>::A;
   const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= (long)K * C) return;
   const int k = (int)(e / C), c = (int)(e % C);
   const float* g = w + (size_t)e * 9;
-  float a[3][3];
-#pragma unroll
-  for (int i = 0; i < 3; ++i)
-#pragma unroll
-    for (int j = 0; j < 3; ++j) a[i][j] = flip ? g[(2 - i) * 3 + (2 - j)] : g[i * 3 + j];
-  float t[4][3];
+  float t[3][A];        // t[j][i]: column j after the transform along rows
 #pragma unroll
   for (int j = 0; j < 3; ++j) {
-    t[0][j] = a[0][j];
-    t[1][j] = 0.5f * ((a[0][j] + a[1][j]) + a[2][j]);
-    t[2][j] = 0.5f * ((a[0][j] - a[1][j]) + a[2][j]);
-    t[3][j] = a[2][j];
+    float col[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) col[i] = flip ? g[(2 - i) * 3 + (2 - j)] : g[i * 3 + j];
+    Wino<M>::flt(col, t[j]);
   }
   const size_t plane = (size_t)K * C;
   float* up = U + (flip ? (size_t)c * K + k : (size_t)k * C + c);
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    up[(size_t)(4 * i + 0) * plane] = t[i][0];
-    up[(size_t)(4 * i + 1) * plane] = 0.5f * ((t[i][0] + t[i][1]) + t[i][2]);
-    up[(size_t)(4 * i + 2) * plane] = 0.5f * ((t[i][0] - t[i][1]) + t[i][2]);
-    up[(size_t)(4 * i + 3) * plane] = t[i][2];
+  for (int i = 0; i < A; ++i) {
+    float row[3], o[A];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) row[j] = t[j][i];
+    Wino<M>::flt(row, o);
+#pragma unroll
+    for (int j = 0; j < A; ++j) up[(size_t)(A * i + j) * plane] = o[j];
   }
 }
 
 // dw = G^T dU G per (k, c)
+template <int M>
 __global__ void wino_filter_grad_kernel(const float* __restrict__ dU, int K, int C, float* __restrict__ dw) {
+  constexpr int A = Wino<M>::A;
   const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= (long)K * C) return;
   const size_t plane = (size_t)K * C;
-  float u[4][4];
+  float a[A][3];        // a[j][i]: column j after the transform along rows
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int j = 0; j < A; ++j) {
+    float col[A];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) u[i][j] = dU[(size_t)(4 * i + j) * plane + e];
-  float a[3][4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    a[0][j] = u[0][j] + 0.5f * (u[1][j] + u[2][j]);
-    a[1][j] = 0.5f * (u[1][j] - u[2][j]);
-    a[2][j] = 0.5f * (u[1][j] + u[2][j]) + u[3][j];
+    for (int i = 0; i < A; ++i) col[i] = dU[(size_t)(A * i + j) * plane + e];
+    Wino<M>::fgrad(col, a[j]);
   }
   float* g = dw + (size_t)e * 9;
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
-    g[i * 3 + 0] = a[i][0] + 0.5f * (a[i][1] + a[i][2]);
-    g[i * 3 + 1] = 0.5f * (a[i][1] - a[i][2]);
-    g[i * 3 + 2] = 0.5f * (a[i][1] + a[i][2]) + a[i][3];
+    float row[A], o[3];
+#pragma unroll
+    for (int j = 0; j < A; ++j) row[j] = a[j][i];
+    Wino<M>::fgrad(row, o);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) g[i * 3 + j] = o[j];
   }
 }
 
-int check_image(const char* fn, int N, int C, int H, int W) {
-  FPSG_REQUIRE(N > 0 && C > 0 && H > 0 && W > 0 && (H & 1) == 0 && (W & 1) == 0, FPSG_E_SHAPE,
-               "%s: N,C positive and H,W positive and even (got %d,%d,%d,%d)", fn, N, C, H, W);
-  const long P = (long)N * (H / 2) * (W / 2);
+int check_image(const char* fn, int m, int N, int C, int H, int W) {
+  FPSG_REQUIRE(m == 2 || m == 4, FPSG_E_SHAPE, "%s: m must be 2 or 4 (got %d)", fn, m);
+  FPSG_REQUIRE(N > 0 && C > 0 && H > 0 && W > 0 && H % m == 0 && W % m == 0, FPSG_E_SHAPE,
+               "%s: N,C positive and H,W positive multiples of m=%d (got %d,%d,%d,%d)", fn, m, N, C, H, W);
+  const long P = (long)N * (H / m) * (W / m);
   FPSG_REQUIRE(C <= 65535 && (P + kWinoThreads - 1) / kWinoThreads < (1L << 31), FPSG_E_LIMIT,
                "%s: C=%d or tile count %ld beyond the grid limits", fn, C, P);
   return 0;
@@ -202,62 +312,66 @@ int check_image(const char* fn, int N, int C, int H, int W) {
 }  // namespace
 }  // namespace fpsg
 
-extern "C" int fpsg_wino_input_transform(const float* x, int N, int C, int H, int W, float* V, fpsg_stream_t stream) {
+#define FPSG_WINO_IMAGE_LAUNCH(KERNEL, CH, ...)                                                              \
+  const long P = (long)N * (H / m) * (W / m);                                                                \
+  dim3 grid((unsigned)((P + kWinoThreads - 1) / kWinoThreads), CH);                                          \
+  if (m == 2) hipLaunchKernelGGL((KERNEL<2>), grid, dim3(kWinoThreads), 0, static_cast<hipStream_t>(stream), __VA_ARGS__); \
+  else hipLaunchKernelGGL((KERNEL<4>), grid, dim3(kWinoThreads), 0, static_cast<hipStream_t>(stream), __VA_ARGS__)
+
+extern "C" int fpsg_wino_input_transform(int m, const float* x, int N, int C, int H, int W, float* V,
+                                         fpsg_stream_t stream) {
   using namespace fpsg;
-  int rc = check_image("fpsg_wino_input_transform", N, C, H, W);
+  int rc = check_image("fpsg_wino_input_transform", m, N, C, H, W);
   if (rc) return rc;
   FPSG_REQUIRE_PTR(x); FPSG_REQUIRE_PTR(V);
-  const long P = (long)N * (H / 2) * (W / 2);
-  dim3 grid((unsigned)((P + kWinoThreads - 1) / kWinoThreads), C);
-  hipLaunchKernelGGL(wino_input_kernel, grid, dim3(kWinoThreads), 0, static_cast<hipStream_t>(stream), x, C, H, W,
-                     H / 2, W / 2, P, V);
+  FPSG_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0, FPSG_E_ALIGN, "fpsg_wino_input_transform: x must be 16-byte aligned");
+  FPSG_WINO_IMAGE_LAUNCH(wino_input_kernel, C, x, C, H, W, H / m, W / m, P, V);
   return launch_status("fpsg_wino_input_transform");
 }
 
-extern "C" int fpsg_wino_output_transform(const float* M, int N, int K, int H, int W, float* y, fpsg_stream_t stream) {
+extern "C" int fpsg_wino_output_transform(int m, const float* M, int N, int K, int H, int W, float* y,
+                                          fpsg_stream_t stream) {
   using namespace fpsg;
-  int rc = check_image("fpsg_wino_output_transform", N, K, H, W);
+  int rc = check_image("fpsg_wino_output_transform", m, N, K, H, W);
   if (rc) return rc;
   FPSG_REQUIRE_PTR(M); FPSG_REQUIRE_PTR(y);
-  FPSG_REQUIRE((reinterpret_cast<uintptr_t>(y) & 7) == 0, FPSG_E_ALIGN, "fpsg_wino_output_transform: y must be 8-byte aligned");
-  const long P = (long)N * (H / 2) * (W / 2);
-  dim3 grid((unsigned)((P + kWinoThreads - 1) / kWinoThreads), K);
-  hipLaunchKernelGGL(wino_output_kernel, grid, dim3(kWinoThreads), 0, static_cast<hipStream_t>(stream), M, K, H, W,
-                     H / 2, W / 2, P, y);
+  FPSG_REQUIRE((reinterpret_cast<uintptr_t>(y) & 15) == 0, FPSG_E_ALIGN, "fpsg_wino_output_transform: y must be 16-byte aligned");
+  FPSG_WINO_IMAGE_LAUNCH(wino_output_kernel, K, M, K, H, W, H / m, W / m, P, y);
   return launch_status("fpsg_wino_output_transform");
 }
 
-extern "C" int fpsg_wino_grad_output_transform(const float* dy, int N, int K, int H, int W, float* dM,
+extern "C" int fpsg_wino_grad_output_transform(int m, const float* dy, int N, int K, int H, int W, float* dM,
                                                fpsg_stream_t stream) {
   using namespace fpsg;
-  int rc = check_image("fpsg_wino_grad_output_transform", N, K, H, W);
+  int rc = check_image("fpsg_wino_grad_output_transform", m, N, K, H, W);
   if (rc) return rc;
   FPSG_REQUIRE_PTR(dy); FPSG_REQUIRE_PTR(dM);
-  FPSG_REQUIRE((reinterpret_cast<uintptr_t>(dy) & 7) == 0, FPSG_E_ALIGN, "fpsg_wino_grad_output_transform: dy must be 8-byte aligned");
-  const long P = (long)N * (H / 2) * (W / 2);
-  dim3 grid((unsigned)((P + kWinoThreads - 1) / kWinoThreads), K);
-  hipLaunchKernelGGL(wino_grad_output_kernel, grid, dim3(kWinoThreads), 0, static_cast<hipStream_t>(stream), dy, K, H,
-                     W, H / 2, W / 2, P, dM);
+  FPSG_REQUIRE((reinterpret_cast<uintptr_t>(dy) & 15) == 0, FPSG_E_ALIGN, "fpsg_wino_grad_output_transform: dy must be 16-byte aligned");
+  FPSG_WINO_IMAGE_LAUNCH(wino_grad_output_kernel, K, dy, K, H, W, H / m, W / m, P, dM);
   return launch_status("fpsg_wino_grad_output_transform");
 }
 
-extern "C" int fpsg_wino_filter_transform(const float* w, int K, int C, int flip_transpose, float* U,
+extern "C" int fpsg_wino_filter_transform(int m, const float* w, int K, int C, int flip_transpose, float* U,
                                           fpsg_stream_t stream) {
   using namespace fpsg;
+  FPSG_REQUIRE(m == 2 || m == 4, FPSG_E_SHAPE, "fpsg_wino_filter_transform: m must be 2 or 4 (got %d)", m);
   FPSG_REQUIRE(K > 0 && C > 0, FPSG_E_SHAPE, "fpsg_wino_filter_transform: K,C must be positive (got %d,%d)", K, C);
   FPSG_REQUIRE_PTR(w); FPSG_REQUIRE_PTR(U);
   const long n = (long)K * C;
-  hipLaunchKernelGGL(wino_filter_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), w, K, C, flip_transpose, U);
+  dim3 grid((unsigned)((n + 255) / 256));
+  if (m == 2) hipLaunchKernelGGL(wino_filter_kernel<2>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), w, K, C, flip_transpose, U);
+  else hipLaunchKernelGGL(wino_filter_kernel<4>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), w, K, C, flip_transpose, U);
   return launch_status("fpsg_wino_filter_transform");
 }
 
-extern "C" int fpsg_wino_filter_grad_transform(const float* dU, int K, int C, float* dw, fpsg_stream_t stream) {
+extern "C" int fpsg_wino_filter_grad_transform(int m, const float* dU, int K, int C, float* dw, fpsg_stream_t stream) {
   using namespace fpsg;
+  FPSG_REQUIRE(m == 2 || m == 4, FPSG_E_SHAPE, "fpsg_wino_filter_grad_transform: m must be 2 or 4 (got %d)", m);
   FPSG_REQUIRE(K > 0 && C > 0, FPSG_E_SHAPE, "fpsg_wino_filter_grad_transform: K,C must be positive (got %d,%d)", K, C);
   FPSG_REQUIRE_PTR(dU); FPSG_REQUIRE_PTR(dw);
   const long n = (long)K * C;
-  hipLaunchKernelGGL(wino_filter_grad_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), dU, K, C, dw);
+  dim3 grid((unsigned)((n + 255) / 256));
+  if (m == 2) hipLaunchKernelGGL(wino_filter_grad_kernel<2>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), dU, K, C, dw);
+  else hipLaunchKernelGGL(wino_filter_grad_kernel<4>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), dU, K, C, dw);
   return launch_status("fpsg_wino_filter_grad_transform");
 }

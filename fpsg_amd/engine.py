@@ -15,6 +15,7 @@ import torch
 import torch.optim as optim
 
 from . import dist as fdist
+from . import winograd
 from .few_shot import ImgPCProtoNet
 from .image_net import ImageEncoderWarpper
 from .point_cloud_net import PCDecoder, PCEncoder
@@ -148,17 +149,18 @@ class TrainStep:
             self.buckets.zero()
             self.buckets.arm()
         last = len(local_episodes) - 1
-        for k, sample in enumerate(local_episodes):
-            first, final = k == 0, k == last
-            if final and multi:
-                if first:
-                    self.buckets.zero()
-                self.buckets.arm()
-                results.append(self._episode_in_place(sample))
-            elif self.use_graph:
-                results.append(self._run_graphed(sample, first))
-            else:
-                results.append(self._episode(sample, first))
+        with winograd.weights_frozen():      # no parameter changes until optimizer.step() below
+            for k, sample in enumerate(local_episodes):
+                first, final = k == 0, k == last
+                if final and multi:
+                    if first:
+                        self.buckets.zero()
+                    self.buckets.arm()
+                    results.append(self._episode_in_place(sample))
+                elif self.use_graph:
+                    results.append(self._run_graphed(sample, first))
+                else:
+                    results.append(self._episode(sample, first))
         self.buckets.finish(n_episodes_global)
         self.buckets.attach()           # the optimizer reads the step's gradient from the flat buffer
         self.optimizer.step()

@@ -1,10 +1,13 @@
-"""3x3 convolution through Winograd F(2x2, 3x3) (K6) for the deep layers of the image trunk.
+"""3x3 convolution through Winograd F(m x m, 3x3), m = 2 or 4 (K6), for the deep layers of the image trunk.
 
 ``conv3x3(x, weight)`` is ``F.conv2d(x, weight, None, stride=1, padding=1)`` with gradients to
 both arguments.  The 16 transform-domain GEMMs are fp32 batched matrix products on the MFMA
 pipes (``torch.bmm`` = hipBLASLt); the input / output / filter transforms are the HIP kernels
-of ``csrc/winograd.hip`` through the C ABI.  2.25x fewer multiplications than the direct form;
-measured on MI355X against MIOpen's own fp32 Winograd kernel (the solver it picks for these
+of ``csrc/winograd.hip`` through the C ABI.  2.25x (m=2) / 4x (m=4) fewer multiplications than the
+direct form; ``tile_size`` picks m = 4 where the image is a multiple of 4 and at least 28 wide
+(the 56x56 and 28x28 stages), m = 2 otherwise (14x14); ``FPSG_WINOGRAD_M=2`` forces m = 2.
+fp32 error against a float64 convolution: ~1e-6 of the output scale for m = 2, ~1e-5 for m = 4
+(the library's own kernels: ~1e-6), inside the 1e-4 budget of the path.  Measured on MI355X against MIOpen's own fp32 Winograd kernel (the solver it picks for these
 layers) this is faster from 256 channels up (weight gradient: from 128), where the 4x larger transform-domain tensors are
 small next to the GEMM work (``profiles/``: wino_*).  Reference layers: the Conv2d(3x3, pad 1) of
 torchvision's ``vgg16_bn.features`` built at ``src/models/image_net.py:14``.
@@ -20,11 +23,11 @@ import torch
 
 from . import _hip
 
-# Below these widths the transforms' HBM traffic (4x the image tensors) outweighs the saved
-# multiplications (profiles/: wino_bench): min(C,K) >= 128 and max(C,K) >= 256 selects conv3_1 ...
-# conv5_3 of VGG16, nine of its thirteen layers.
+# Below these widths the transforms' HBM traffic (4x / 2.25x the image tensors) outweighs the saved
+# multiplications (profiles/: wino_bench): min(C,K) >= 128, and with 2x2 tiles also max(C,K) >= 256,
+# selects conv2_2 ... conv5_3 of VGG16, ten of its thirteen layers.
 MIN_CHANNELS = 128
-MIN_WIDE_CHANNELS = 256
+MIN_WIDE_CHANNELS_M2 = 256
 
 
 def enabled() -> bool:
@@ -38,70 +41,119 @@ def eligible(x: torch.Tensor, conv: torch.nn.Conv2d) -> bool:
             and is_(conv.kernel_size, 3) and is_(conv.stride, 1) and is_(conv.padding, 1) and is_(conv.dilation, 1)
             and conv.groups == 1 and conv.padding_mode == "zeros"
             and min(conv.in_channels, conv.out_channels) >= MIN_CHANNELS
-            and max(conv.in_channels, conv.out_channels) >= MIN_WIDE_CHANNELS
-            and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0)
+            and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0
+            and (tile_size(x.shape[2], x.shape[3]) == 4
+                 or max(conv.in_channels, conv.out_channels) >= MIN_WIDE_CHANNELS_M2))
+
+
+def tile_size(H: int, W: int) -> int:
+    forced = os.environ.get("FPSG_WINOGRAD_M")
+    if forced:
+        return int(forced)
+    return 4 if (H % 4 == 0 and W % 4 == 0 and min(H, W) >= 28) else 2
 
 
 def _call(name, *args):
     _hip.check(getattr(_hip.load(), name)(*args), name)
 
 
-def _filter(w, flip):
+_frozen_cache = None     # {(data_ptr, m, flip): U} while a ``weights_frozen`` block is active
+
+
+class weights_frozen:
+    """Context manager: the convolution weights do not change inside the block (the episodes of
+    one optimizer step), so each transformed filter is computed once and reused.  Not used while
+    a hipGraph is being captured (a replay must transform the then-current weights)."""
+
+    def __enter__(self):
+        global _frozen_cache
+        self._outer = _frozen_cache
+        _frozen_cache = {} if _frozen_cache is None else _frozen_cache
+        return self
+
+    def __exit__(self, *exc):
+        global _frozen_cache
+        _frozen_cache = self._outer
+        return False
+
+
+def _filter(m, w, flip):
+    cache = _frozen_cache
+    if cache is not None and torch.cuda.is_current_stream_capturing():
+        cache = None
+    key = (w.data_ptr(), m, bool(flip))
+    if cache is not None and key in cache:
+        return cache[key]
     K, C = w.shape[0], w.shape[1]
-    U = torch.empty((16, C, K) if flip else (16, K, C), dtype=torch.float32, device=w.device)
-    _call("fpsg_wino_filter_transform", _hip.ptr(w), K, C, 1 if flip else 0, _hip.ptr(U), _hip.stream_of(w))
+    a2 = (m + 2) ** 2
+    U = torch.empty((a2, C, K) if flip else (a2, K, C), dtype=torch.float32, device=w.device)
+    _call("fpsg_wino_filter_transform", m, _hip.ptr(w), K, C, 1 if flip else 0, _hip.ptr(U), _hip.stream_of(w))
+    if cache is not None:
+        cache[key] = U
     return U
 
 
-def _input(x):
+def _input(m, x):
     N, C, H, W = x.shape
-    V = torch.empty((16, C, N * (H // 2) * (W // 2)), dtype=torch.float32, device=x.device)
-    _call("fpsg_wino_input_transform", _hip.ptr(x), N, C, H, W, _hip.ptr(V), _hip.stream_of(x))
+    V = torch.empty(((m + 2) ** 2, C, N * (H // m) * (W // m)), dtype=torch.float32, device=x.device)
+    _call("fpsg_wino_input_transform", m, _hip.ptr(x), N, C, H, W, _hip.ptr(V), _hip.stream_of(x))
     return V
 
 
-def _output(M, N, H, W):
+def _output(m, M, N, H, W):
     K = M.shape[1]
     y = torch.empty((N, K, H, W), dtype=torch.float32, device=M.device)
-    _call("fpsg_wino_output_transform", _hip.ptr(M), N, K, H, W, _hip.ptr(y), _hip.stream_of(M))
+    _call("fpsg_wino_output_transform", m, _hip.ptr(M), N, K, H, W, _hip.ptr(y), _hip.stream_of(M))
     return y
+
+
+def _grad_output(m, gy):
+    N, K, H, W = gy.shape
+    dM = torch.empty(((m + 2) ** 2, K, N * (H // m) * (W // m)), dtype=torch.float32, device=gy.device)
+    _call("fpsg_wino_grad_output_transform", m, _hip.ptr(gy), N, K, H, W, _hip.ptr(dM), _hip.stream_of(gy))
+    return dM
+
+
+def _filter_grad(m, dU, like):
+    gw = torch.empty_like(like)
+    _call("fpsg_wino_filter_grad_transform", m, _hip.ptr(dU), like.shape[0], like.shape[1], _hip.ptr(gw),
+          _hip.stream_of(dU))
+    return gw
 
 
 class _Conv3x3(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w):
+    def forward(ctx, x, w, m):
         x, w = x.contiguous(), w.contiguous()
         N, C, H, W = x.shape
         with torch.cuda.device(x.device):
-            V = _input(x)
-            y = _output(torch.bmm(_filter(w, False), V), N, H, W)
+            V = _input(m, x)
+            y = _output(m, torch.bmm(_filter(m, w, False), V), N, H, W)
         ctx.save_for_backward(V if ctx.needs_input_grad[1] else None, w)
-        ctx.dims = (N, C, H, W)
+        ctx.dims = (N, C, H, W, m)
         return y
 
     @staticmethod
     def backward(ctx, gy):
         V, w = ctx.saved_tensors
-        N, C, H, W = ctx.dims
-        K = w.shape[0]
+        N, C, H, W, m = ctx.dims
         gy = gy.contiguous()
         gx = gw = None
         with torch.cuda.device(gy.device):
             if ctx.needs_input_grad[0]:
-                gx = _output(torch.bmm(_filter(w, True), _input(gy)), N, H, W)
+                gx = _output(m, torch.bmm(_filter(m, w, True), _input(m, gy)), N, H, W)
             if ctx.needs_input_grad[1]:
-                dM = torch.empty((16, K, V.shape[2]), dtype=torch.float32, device=gy.device)
-                _call("fpsg_wino_grad_output_transform", _hip.ptr(gy), N, K, H, W, _hip.ptr(dM), _hip.stream_of(gy))
-                dU = torch.bmm(dM, V.transpose(1, 2))
-                gw = torch.empty_like(w)
-                _call("fpsg_wino_filter_grad_transform", _hip.ptr(dU), K, C, _hip.ptr(gw), _hip.stream_of(gy))
-        return gx, gw
+                gw = _filter_grad(m, torch.bmm(_grad_output(m, gy), V.transpose(1, 2)), w)
+        return gx, gw, None
 
 
-def conv3x3(x: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
-    """``F.conv2d(x, weight, None, 1, 1)`` for ``x [N,C,H,W]`` (H, W even), ``weight [K,C,3,3]``."""
+def conv3x3(x: torch.Tensor, weight: torch.Tensor, m: int | None = None) -> torch.Tensor:
+    """``F.conv2d(x, weight, None, 1, 1)`` for ``x [N,C,H,W]`` (H, W even), ``weight [K,C,3,3]``;
+    ``m``: output tile size 2 or 4 (default: ``tile_size(H, W)``)."""
     if x.dim() != 4 or weight.dim() != 4 or tuple(weight.shape[2:]) != (3, 3) or weight.shape[1] != x.shape[1]:
         raise ValueError(f"conv3x3: x {tuple(x.shape)} / weight {tuple(weight.shape)}")
-    if x.shape[2] % 2 or x.shape[3] % 2:
-        raise ValueError("conv3x3: H and W must be even")
-    return _Conv3x3.apply(x, weight)
+    if m is None:
+        m = tile_size(x.shape[2], x.shape[3])
+    if m not in (2, 4) or x.shape[2] % m or x.shape[3] % m:
+        raise ValueError(f"conv3x3: H and W must be multiples of the tile size m={m} (2 or 4)")
+    return _Conv3x3.apply(x, weight, m)

@@ -184,24 +184,29 @@ int fpsg_bn_act_pool_bwd(const float* x, const float* pre_bias, const float* dy_
                          float* dgamma, float* dbeta, float* dpre_bias, float* coef, float* ws,
                          fpsg_stream_t stream);
 
-/* ---- K6: Winograd F(2x2,3x3) transforms for the deep 3x3 convolutions of the image trunk ----
+/* ---- K6: Winograd F(m x m, 3x3) transforms (m = 2 or 4) for the deep 3x3 convolutions -------
  * Replaces, together with the caller's fp32 batched GEMM (hipBLASLt, MFMA), the library
  * convolution under the Conv2d(3x3, padding 1) layers of torchvision's vgg16_bn.features that
  * src/models/image_net.py:14 instantiates (forward :21-24, full backward: SURVEY.md F9).
- *   y  = conv(x, w):         U = filter(w, flip 0) [16,K,C];  V = input(x) [16,C,P];
- *                            M[xi] = U[xi] V[xi] [16,K,P];     y = output(M)
- *   dx = conv(dy, rot180 w^T): U' = filter(w, flip 1) [16,C,K]; V' = input(dy) [16,K,P];
- *                            M'[xi] = U'[xi] V'[xi] [16,C,P];  dx = output(M')
- *   dw:                      dM = grad_output(dy) [16,K,P];    dU[xi] = dM[xi] V[xi]^T [16,K,C];
- *                            dw = filter_grad(dU)
- * P = N*(H/2)*(W/2) tiles, tile p = (n*(H/2) + th)*(W/2) + tw; H, W even.  All tensors fp32,
- * contiguous, caller-allocated; image tensors 8-byte aligned.  Deterministic.
+ * With A = m + 2 and P = N*(H/m)*(W/m) tiles (tile p = (n*(H/m) + th)*(W/m) + tw; H, W multiples
+ * of m):
+ *   y  = conv(x, w):           U = filter(w, flip 0) [A*A,K,C];  V = input(x) [A*A,C,P];
+ *                              M[xi] = U[xi] V[xi] [A*A,K,P];     y = output(M)
+ *   dx = conv(dy, rot180 w^T): U' = filter(w, flip 1) [A*A,C,K]; V' = input(dy) [A*A,K,P];
+ *                              M'[xi] = U'[xi] V'[xi] [A*A,C,P]; dx = output(M')
+ *   dw:                        dM = grad_output(dy) [A*A,K,P];   dU[xi] = dM[xi] V[xi]^T [A*A,K,C];
+ *                              dw = filter_grad(dU)
+ * m = 2: 2.25x fewer multiplications than the direct form, fp32 error a few ulp; m = 4: 4x fewer,
+ * error ~1e-5 of the output scale (transform constants up to 8 and 1/24).  All tensors fp32,
+ * contiguous, caller-allocated; image tensors 16-byte aligned.  Deterministic.
  */
-int fpsg_wino_input_transform(const float* x, int N, int C, int H, int W, float* V, fpsg_stream_t stream);
-int fpsg_wino_output_transform(const float* M, int N, int K, int H, int W, float* y, fpsg_stream_t stream);
-int fpsg_wino_grad_output_transform(const float* dy, int N, int K, int H, int W, float* dM, fpsg_stream_t stream);
-int fpsg_wino_filter_transform(const float* w, int K, int C, int flip_transpose, float* U, fpsg_stream_t stream);
-int fpsg_wino_filter_grad_transform(const float* dU, int K, int C, float* dw, fpsg_stream_t stream);
+int fpsg_wino_input_transform(int m, const float* x, int N, int C, int H, int W, float* V, fpsg_stream_t stream);
+int fpsg_wino_output_transform(int m, const float* M, int N, int K, int H, int W, float* y, fpsg_stream_t stream);
+int fpsg_wino_grad_output_transform(int m, const float* dy, int N, int K, int H, int W, float* dM,
+                                    fpsg_stream_t stream);
+int fpsg_wino_filter_transform(int m, const float* w, int K, int C, int flip_transpose, float* U,
+                               fpsg_stream_t stream);
+int fpsg_wino_filter_grad_transform(int m, const float* dU, int K, int C, float* dw, fpsg_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -29,23 +29,16 @@ for (C, K, H) in [(64, 64, 224), (64, 128, 112), (128, 128, 112), (128, 256, 56)
     l_f = timeit(lambda: F.conv2d(x, w, None, 1, 1))
     l_dx = timeit(lambda: torch.nn.grad.conv2d_input(x.shape, w, gy, padding=1))
     l_dw = timeit(lambda: torch.nn.grad.conv2d_weight(x, w.shape, gy, padding=1))
-    w_f = timeit(lambda: wg._output(torch.bmm(wg._filter(w, False), wg._input(x)), N, H, H))
-    w_dx = timeit(lambda: wg._output(torch.bmm(wg._filter(w, True), wg._input(gy)), N, H, H))
-    V = wg._input(x)
-    P = V.shape[2]
-
-    def dw():
-        dM = torch.empty((16, K, P), device=dev)
-        wg._call("fpsg_wino_grad_output_transform", wg._hip.ptr(gy), N, K, H, H, wg._hip.ptr(dM), None)
-        dU = torch.bmm(dM, V.transpose(1, 2))
-        out = torch.empty_like(w)
-        wg._call("fpsg_wino_filter_grad_transform", wg._hip.ptr(dU), K, C, wg._hip.ptr(out), None)
-        return out
-    w_dw = timeit(dw)
-    U = wg._filter(w, False)
-    t_in = timeit(lambda: wg._input(x)); t_g = timeit(lambda: torch.bmm(U, V)); M = torch.bmm(U, V)
-    t_out = timeit(lambda: wg._output(M, N, H, H))
-    print(f"{C:4d}->{K:4d} @{H:3d}x{H:<3d}       {l_f:8.3f} {w_f:9.3f} | {l_dx:8.3f} {w_dx:8.3f} | {l_dw:8.3f} {w_dw:8.3f} | "
-          f"{t_in:.3f} ({(x.numel()+V.numel())*4/t_in/1e9:.1f} TB/s), {t_g:.3f} ({2*16*K*C*P/t_g/1e9:.0f} TF/s), "
-          f"{t_out:.3f} ({(M.numel()+gy.numel())*4/t_out/1e9:.1f} TB/s)", flush=True)
-    del V, M
+    for m in ((2, 4) if H % 4 == 0 else (2,)):
+        w_f = timeit(lambda: wg._output(m, torch.bmm(wg._filter(m, w, False), wg._input(m, x)), N, H, H))
+        w_dx = timeit(lambda: wg._output(m, torch.bmm(wg._filter(m, w, True), wg._input(m, gy)), N, H, H))
+        V = wg._input(m, x)
+        P = V.shape[2]
+        w_dw = timeit(lambda: wg._filter_grad(m, torch.bmm(wg._grad_output(m, gy), V.transpose(1, 2)), w))
+        U = wg._filter(m, w, False)
+        t_in = timeit(lambda: wg._input(m, x)); t_g = timeit(lambda: torch.bmm(U, V)); M = torch.bmm(U, V)
+        t_out = timeit(lambda: wg._output(m, M, N, H, H))
+        print(f"{C:4d}->{K:4d} @{H:3d}x{H:<3d} m={m}   {l_f:8.3f} {w_f:9.3f} | {l_dx:8.3f} {w_dx:8.3f} | {l_dw:8.3f} {w_dw:8.3f} | "
+              f"{t_in:.3f} ({(x.numel()+V.numel())*4/t_in/1e9:.1f} TB/s), {t_g:.3f} ({2*(m+2)**2*K*C*P/t_g/1e9:.0f} TF/s), "
+              f"{t_out:.3f} ({(M.numel()+gy.numel())*4/t_out/1e9:.1f} TB/s)", flush=True)
+        del V, M
