@@ -249,8 +249,10 @@ __global__ void wino_filter_kernel(const float* __restrict__ w, int K, int C, in
   constexpr int A = Wino<M>::A;
   const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= (long)K * C) return;
-  const int k = (int)(e / C), c = (int)(e % C);
-  const float* g = w + (size_t)e * 9;
+  // threads run along the fastest axis of the OUTPUT (c, or k when transposing) so that the A*A
+  // plane writes are coalesced; the transposing form then reads its 36-byte filters K*36 bytes apart
+  const int k = flip ? (int)(e % K) : (int)(e / C), c = flip ? (int)(e / K) : (int)(e % C);
+  const float* g = w + ((size_t)k * C + c) * 9;
   float t[3][A];        // t[j][i]: column j after the transform along rows
 #pragma unroll
   for (int j = 0; j < 3; ++j) {

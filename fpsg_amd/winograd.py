@@ -8,7 +8,7 @@ direct form; ``tile_size`` picks m = 4 where the image is a multiple of 4 and at
 (the 56x56 and 28x28 stages), m = 2 otherwise (14x14); ``FPSG_WINOGRAD_M=2`` forces m = 2.
 fp32 error against a float64 convolution: ~1e-6 of the output scale for m = 2, ~1e-5 for m = 4
 (the library's own kernels: ~1e-6), inside the 1e-4 budget of the path.  Measured on MI355X against MIOpen's own fp32 Winograd kernel (the solver it picks for these
-layers) this is faster from 256 channels up (weight gradient: from 128), where the 4x larger transform-domain tensors are
+layers) this is faster from 64 channels up with 4x4 tiles, where the 4x larger transform-domain tensors are
 small next to the GEMM work (``profiles/``: wino_*).  Reference layers: the Conv2d(3x3, pad 1) of
 torchvision's ``vgg16_bn.features`` built at ``src/models/image_net.py:14``.
 
@@ -24,9 +24,11 @@ import torch
 from . import _hip
 
 # Below these widths the transforms' HBM traffic (4x / 2.25x the image tensors) outweighs the saved
-# multiplications (profiles/: wino_bench): min(C,K) >= 128, and with 2x2 tiles also max(C,K) >= 256,
-# selects conv2_2 ... conv5_3 of VGG16, ten of its thirteen layers.
-MIN_CHANNELS = 128
+# multiplications (profiles/: wino_bench): 4x4 tiles pay off from 64 channels (conv1_2 ... conv4_3 of
+# VGG16), 2x2 tiles (the 14x14 stage) from min(C,K) >= 128 and max(C,K) >= 256; conv1_1 (3 input
+# channels) stays with the library.
+MIN_CHANNELS_M4 = 64
+MIN_CHANNELS_M2 = 128
 MIN_WIDE_CHANNELS_M2 = 256
 
 
@@ -40,10 +42,8 @@ def eligible(x: torch.Tensor, conv: torch.nn.Conv2d) -> bool:
     return (enabled() and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4
             and is_(conv.kernel_size, 3) and is_(conv.stride, 1) and is_(conv.padding, 1) and is_(conv.dilation, 1)
             and conv.groups == 1 and conv.padding_mode == "zeros"
-            and min(conv.in_channels, conv.out_channels) >= MIN_CHANNELS
             and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0
-            and (tile_size(x.shape[2], x.shape[3]) == 4
-                 or max(conv.in_channels, conv.out_channels) >= MIN_WIDE_CHANNELS_M2))
+            and _wide_enough(conv.in_channels, conv.out_channels, tile_size(x.shape[2], x.shape[3])))
 
 
 def tile_size(H: int, W: int) -> int:
@@ -51,6 +51,11 @@ def tile_size(H: int, W: int) -> int:
     if forced:
         return int(forced)
     return 4 if (H % 4 == 0 and W % 4 == 0 and min(H, W) >= 28) else 2
+
+
+def _wide_enough(c_in: int, c_out: int, m: int) -> bool:
+    lo, hi = min(c_in, c_out), max(c_in, c_out)
+    return lo >= MIN_CHANNELS_M4 if m == 4 else (lo >= MIN_CHANNELS_M2 and hi >= MIN_WIDE_CHANNELS_M2)
 
 
 def _call(name, *args):
