@@ -32,6 +32,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from fpsg_amd import dist as fdist  # noqa: E402
+from fpsg_amd import gemm_tuning  # noqa: E402
 from fpsg_amd import metrics  # noqa: E402
 from fpsg_amd.engine import TrainStep, build_model, build_optimizer, default_options  # noqa: E402
 from fpsg_amd.episodes import synthetic_episode  # noqa: E402
@@ -187,6 +188,11 @@ def main():
     ap.add_argument("--no-graph", dest="graph", action="store_false")
     ap.add_argument("--overlap", dest="overlap", action="store_true", default=False,
                     help="run the point encoder on a second stream beside the image trunk (+2.5%% on c3)")
+    ap.add_argument("--gemm-tuning", choices=["file", "off", "tune"], default=None,
+                    help="library GEMM kernel selection (fpsg_amd.gemm_tuning): recorded choices from "
+                         "fpsg_amd/tuning/gemm_gfx950.csv [default], the libraries' heuristic, or time "
+                         "unknown shapes now and append them to --gemm-records")
+    ap.add_argument("--gemm-records", default=None, help="records file for --gemm-tuning tune / file")
     ap.add_argument("--channels-last", action="store_true", help="experiment: NHWC image trunk")
     ap.add_argument("--miopen-benchmark", action="store_true", help="experiment: MIOpen find mode")
     args = ap.parse_args()
@@ -209,6 +215,9 @@ def main():
     if args.graph:
         warmup = max(warmup, 1 if epr >= 4 else 4)   # 2 eager uses + the capture before timing
     torch.backends.cudnn.benchmark = bool(args.miopen_benchmark)
+    if args.gemm_tuning is not None:
+        os.environ["FPSG_GEMM_TUNING"] = {"off": "0"}.get(args.gemm_tuning, args.gemm_tuning)
+    gemm_info = gemm_tuning.enable(path=args.gemm_records)
     opt = default_options(device="cuda", intra_recon=intra, pc_encoder=encoder, n_shot=S, n_query=Q)
     torch.manual_seed(0)                      # identical initial weights on every rank
     model = build_model(opt).to(device)
@@ -278,7 +287,7 @@ def main():
                        "intra_recon": intra, "pc_encoder": encoder, "episodes_per_rank_per_step": epr,
                        "episodes_per_step_global": epr * world, "parallelism": f"dp{world}",
                        "params": sum(p.numel() for p in model.parameters()),
-                       "hip_graph": bool(args.graph)},
+                       "hip_graph": bool(args.graph), **gemm_info},
             "final_loss": loss,
         }
         if n_l:

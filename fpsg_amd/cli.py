@@ -131,4 +131,8 @@ def pick_device(opt) -> torch.device:
     if opt.device.startswith("cuda") and not torch.cuda.is_available():
         raise SystemExit("--device cuda requested but no ROCm GPU is visible "
                          "(the Chamfer / EMD / kNN ops are HIP kernels; there is no CPU fallback)")
-    return torch.device(opt.device)
+    device = torch.device(opt.device)
+    if device.type == "cuda":
+        from . import gemm_tuning
+        gemm_tuning.enable()          # recorded library-GEMM kernel choices for this path's shapes
+    return device

@@ -49,3 +49,28 @@ def test_dgcnn_encoder_and_ae_mode(gpu, tmp_path):
     pre = _run(["trainPointAE.py", "--synthetic", "--core", "dgcnn", "--epoch", "1", "--n_pts", "256",
                 "--batch_size", "16", "--model_path", str(tmp_path), "--name", "pre"])
     assert os.path.exists(os.path.join(str(tmp_path), "pre", "pre_dgcnn.pt")) and "Running CrossEntropy" in pre
+
+
+def test_gemm_tuning_records_load_and_keep_results(gpu):
+    """fpsg_amd.gemm_tuning: the committed records file loads (validators match this image) and a
+    GEMM of a recorded shape still equals the float64 product; disable() restores the default."""
+    import os
+    import torch
+    from fpsg_amd import gemm_tuning
+    assert os.path.exists(gemm_tuning.DEFAULT_FILE)
+    info = gemm_tuning.enable()
+    try:
+        assert info["gemm_tuning"] == "file" and info["gemm_records_loaded"] is True
+        import torch.cuda.tunable as tunable
+        assert tunable.is_enabled() and not tunable.tuning_is_enabled()
+        assert len(tunable.get_results()) > 50
+        torch.manual_seed(0)
+        U = torch.randn(36, 512, 512, device=gpu)
+        V = torch.randn(36, 512, 1813, device=gpu)          # conv4_2 of the c5 workload, F(4x4,3x3)
+        M = torch.bmm(U, V)
+        ref = torch.bmm(U[:2].double(), V[:2].double())
+        assert float((M[:2].double() - ref).abs().max()) <= 1e-4 * float(ref.abs().max())
+    finally:
+        gemm_tuning.disable()
+    import torch.cuda.tunable as tunable
+    assert not tunable.is_enabled()

@@ -50,6 +50,9 @@ def main(opt):
     rank, world, device = fdist.init_distributed("cuda" if opt.device.startswith("cuda") else "cpu")
     if world == 1:
         device = cli.pick_device(opt)
+    elif device.type == "cuda":
+        from fpsg_amd import gemm_tuning
+        gemm_tuning.enable()
     is_main = rank == 0
 
     timestamp = time.strftime("%m_%d_%H_%M")
