@@ -35,12 +35,23 @@ def enable(path: str | None = None, tune: bool | None = None) -> dict:
     if not tune and not os.path.exists(path):
         return {"gemm_tuning": "off (no records file)"}
     tunable.enable(True)
-    tunable.set_filename(path, insert_device_ordinal=False)
+    records = path
+    if not tune:
+        # TunableOp may rewrite its file when the process ends; the ranks of a job share the
+        # committed records, so each process works on a private copy
+        import shutil
+        import tempfile
+        fd, records = tempfile.mkstemp(prefix="fpsg_gemm_records_", suffix=".csv")
+        os.close(fd)
+        shutil.copyfile(path, records)
+        import atexit
+        atexit.register(lambda p=records: os.path.exists(p) and os.remove(p))
+    tunable.set_filename(records, insert_device_ordinal=False)
     tunable.tuning_enable(bool(tune))
     if tune:
         tunable.set_max_tuning_duration(30)
         tunable.set_max_tuning_iterations(10)
-    loaded = bool(os.path.exists(path) and tunable.read_file(path))
+    loaded = bool(os.path.exists(records) and tunable.read_file(records))
     return {"gemm_tuning": "tune" if tune else "file", "gemm_records": os.path.basename(path),
             "gemm_records_loaded": loaded}
 
