@@ -51,6 +51,12 @@ SIGNATURES = {
                              _c_f32p, _c_stream],
     "fpsg_bn_act_pool_bwd": [_c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
                              ctypes.c_float, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_stream],
+    "fpsg_bn_max_workspace_floats": [_c_int, _c_int, _c_int],
+    "fpsg_bn_act_max_fwd": [_c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_int, _c_int, _c_int, _c_int,
+                            ctypes.c_float, _c_int, ctypes.c_float, _c_f32p, _c_i32p, _c_f32p, _c_f32p, _c_f32p,
+                            _c_f32p, _c_stream],
+    "fpsg_bn_act_max_bwd": [_c_f32p, _c_f32p, _c_f32p, _c_i32p, _c_f32p, _c_int, _c_int, _c_int, _c_int, _c_int,
+                            ctypes.c_float, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_stream],
     "fpsg_wino_input_transform": [_c_int, _c_f32p, _c_int, _c_int, _c_int, _c_int, _c_f32p, _c_stream],
     "fpsg_wino_output_transform": [_c_int, _c_f32p, _c_int, _c_int, _c_int, _c_int, _c_f32p, _c_stream],
     "fpsg_wino_grad_output_transform": [_c_int, _c_f32p, _c_int, _c_int, _c_int, _c_int, _c_f32p, _c_stream],
@@ -61,7 +67,7 @@ SIGNATURES = {
                         _c_stream],
 }
 _RESTYPES = {"fpsg_last_error": ctypes.c_char_p, "fpsg_chamfer_set_config": None,
-             "fpsg_bn_workspace_floats": ctypes.c_size_t, "fpsg_bn_pool_workspace_floats": ctypes.c_size_t, "fpsg_emd_workspace_floats": ctypes.c_size_t}
+             "fpsg_bn_workspace_floats": ctypes.c_size_t, "fpsg_bn_pool_workspace_floats": ctypes.c_size_t, "fpsg_bn_max_workspace_floats": ctypes.c_size_t, "fpsg_emd_workspace_floats": ctypes.c_size_t}
 
 _lib = None
 _lock = threading.Lock()

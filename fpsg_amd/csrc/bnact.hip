@@ -563,6 +563,193 @@ int check_pool_dims(const char* fn, int N, int C, int H, int W, int act) {
   return 0;
 }
 
+// ---- max-over-the-row variants: max_l act(BN(x + pb))[n, c, l] ---------------------------------
+// PointNet ends its shared MLP with BatchNorm (+ReLU in the T-Net) and a max over the N points
+// (src/pointnet/model.py:35-37, 222-224) on a [B,1024,N] tensor (537 MB at B=64, N=2048).
+// z -> act(z) and x -> x*scale+shift are monotone, so
+//     max_l act(BN(x_l)) = act(BN(x_sel)),  x_sel = max_l x_l if scale >= 0 else min_l x_l,
+// bit-equal to the max of the individually normalised values.  The statistics pass therefore also
+// tracks each row's extremes (first index on ties) and the normalised tensor is never written:
+// forward 1 read (library chain: BN 2R+1W, ReLU, max 1R); backward: the incoming gradient is
+// [N, C] and lands on one element per row, so the sums of dz and dz*xhat are over N values per
+// channel and dx = k1*dz*[l = sel] + k2*x + k3 is 1 read + 1 write (library chain: scatter 1W, ReLU
+// backward, BN backward 4R+1W).  The gradient goes to the FIRST arg-extreme of x in the row; the
+// library's max picks among equal OUTPUTS, which only differs where distinct inputs round to the
+// same output (same gradient value on a numerically equal neighbour) or are clipped by the ReLU
+// (zero gradient either way).
+struct RowExt { float vmax, vmin; int imax, imin; };
+
+__device__ __forceinline__ void ext_merge(float& vmax, int& imax, float& vmin, int& imin, float omax, int oimax,
+                                          float omin, int oimin) {
+  if (omax > vmax || (omax == vmax && oimax < imax)) { vmax = omax; imax = oimax; }
+  if (omin < vmin || (omin == vmin && oimin < imin)) { vmin = omin; imin = oimin; }
+}
+
+// grid (S, C): block (s, c) takes the (n, seg) items s, s + S, ... of channel c; per item it also
+// writes the extremes of the segment.  STATS = 0 (eval mode): extremes only.
+template <int STATS>
+__global__ __launch_bounds__(kBnThreads) void bn_reduce_ext_kernel(const float* __restrict__ x,
+                                                                   const float* __restrict__ pb, int N, int C, int L,
+                                                                   int S, float* __restrict__ part /*[C][S][2]*/,
+                                                                   RowExt* __restrict__ ext /*[N*C][segs]*/) {
+  __shared__ float red[8];
+  __shared__ float smax[4], smin[4];
+  __shared__ int simax[4], simin[4];
+  const int c = blockIdx.y, s = blockIdx.x;
+  const int segs = (L + kBnSeg - 1) / kBnSeg;
+  const int items = N * segs;
+  const float b = pb ? pb[c] : 0.0f;
+  float a0 = 0.0f, a1 = 0.0f;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int it = s; it < items; it += S) {
+    const int n = it / segs, seg = it - n * segs;
+    const size_t base = ((size_t)n * C + c) * L + (size_t)seg * kBnSeg;
+    const int len = (L - seg * kBnSeg) < kBnSeg ? (L - seg * kBnSeg) : kBnSeg;
+    float vmax = -INFINITY, vmin = INFINITY;
+    int imax = 0x7fffffff, imin = 0x7fffffff;
+    // ascending positions per thread: strict compares keep the first occurrence
+    if ((L & 3) == 0) {
+      const v4f* __restrict__ xp = reinterpret_cast<const v4f*>(x + base);
+      for (int e = threadIdx.x; e < len / 4; e += kBnThreads) {
+        const v4f q = xp[e];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const float xv = q[u] + b;
+          if (STATS) { a0 += xv; a1 = fma_rn(xv, xv, a1); }
+          if (xv > vmax) { vmax = xv; imax = seg * kBnSeg + 4 * e + u; }
+          if (xv < vmin) { vmin = xv; imin = seg * kBnSeg + 4 * e + u; }
+        }
+      }
+    } else {
+      for (int e = threadIdx.x; e < len; e += kBnThreads) {
+        const float xv = x[base + e] + b;
+        if (STATS) { a0 += xv; a1 = fma_rn(xv, xv, a1); }
+        if (xv > vmax) { vmax = xv; imax = seg * kBnSeg + e; }
+        if (xv < vmin) { vmin = xv; imin = seg * kBnSeg + e; }
+      }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1)
+      ext_merge(vmax, imax, vmin, imin, __shfl_down(vmax, off, 64), __shfl_down(imax, off, 64),
+                __shfl_down(vmin, off, 64), __shfl_down(imin, off, 64));
+    __syncthreads();                                             // the previous item's reads of smax[] are done
+    if (lane == 0) { smax[wave] = vmax; simax[wave] = imax; smin[wave] = vmin; simin[wave] = imin; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+      for (int w = 1; w < 4; ++w) ext_merge(vmax, imax, vmin, imin, smax[w], simax[w], smin[w], simin[w]);
+      RowExt r; r.vmax = vmax; r.vmin = vmin; r.imax = imax; r.imin = imin;
+      ext[((size_t)n * C + c) * segs + seg] = r;
+    }
+  }
+  if (STATS) {
+    __syncthreads();
+    block_reduce2(a0, a1, red);
+    if (threadIdx.x == 0) {
+      part[((size_t)c * S + s) * 2 + 0] = a0;
+      part[((size_t)c * S + s) * 2 + 1] = a1;
+    }
+  }
+}
+
+// one thread per (n, c) row: combine the segments' extremes, pick by the sign of scale, emit
+// out = act(x_sel*scale + shift) and the selected index
+template <int ACT>
+__global__ void bn_max_out_kernel(const RowExt* __restrict__ ext, const float* __restrict__ chan, int rows, int C,
+                                  int segs, float slope, float* __restrict__ out, int* __restrict__ idx) {
+  const int row = blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= rows) return;
+  const int c = row % C;
+  RowExt r = ext[(size_t)row * segs];
+  for (int sgi = 1; sgi < segs; ++sgi) {
+    const RowExt o = ext[(size_t)row * segs + sgi];
+    ext_merge(r.vmax, r.imax, r.vmin, r.imin, o.vmax, o.imax, o.vmin, o.imin);
+  }
+  const float sc = chan[c], sh = chan[C + c];
+  const bool up = sc >= 0.0f;
+  out[row] = act_fwd<ACT>(fma_rn(up ? r.vmax : r.vmin, sc, sh), slope);
+  idx[row] = sc == 0.0f ? 0 : (up ? r.imax : r.imin);
+}
+
+// backward, per channel (one wave): dz[n] = g[n,c] * act'(z_sel), sums over n in a fixed order,
+// dgamma / dbeta / coefficients as bn_bwd_finalize_kernel, dz stored for the dx pass
+template <int ACT>
+__global__ __launch_bounds__(64) void bn_max_bwd_coef_kernel(const float* __restrict__ x, const float* __restrict__ pb,
+                                                             const float* __restrict__ g, const int* __restrict__ idx,
+                                                             const float* __restrict__ chan, int N, int C, int L,
+                                                             int training, float slope, float* __restrict__ dz,
+                                                             float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                             float* __restrict__ coef) {
+  const int c = blockIdx.x;
+  const float b = pb ? pb[c] : 0.0f;
+  const float sc = chan[c], sh = chan[C + c], mu = chan[2 * C + c], rs = chan[3 * C + c];
+  double s0 = 0.0, s1 = 0.0;
+  for (int n = threadIdx.x; n < N; n += 64) {
+    const size_t row = (size_t)n * C + c;
+    const float xs = x[row * L + idx[row]] + b;
+    const float d = g[row] * act_grad<ACT>(fma_rn(xs, sc, sh), slope);
+    dz[row] = d;
+    s0 += (double)d;
+    s1 += (double)(d * ((xs - mu) * rs));
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) { s0 += __shfl_down(s0, off, 64); s1 += __shfl_down(s1, off, 64); }
+  if (threadIdx.x == 0) {
+    dbeta[c] = (float)s0;
+    dgamma[c] = (float)s1;
+    const double count = (double)N * (double)L;
+    coef[c] = sc;
+    if (training) {
+      const double k2 = -(double)sc * s1 * (double)rs / count;
+      coef[C + c] = (float)k2;
+      coef[2 * C + c] = (float)(-(double)sc * s0 / count - k2 * (double)mu);
+    } else {
+      coef[C + c] = 0.0f;
+      coef[2 * C + c] = 0.0f;
+    }
+  }
+}
+
+// dx = k1*dz*[l == sel] + k2*(x+b) + k3 ; grid (N*C rows, segments)
+__global__ __launch_bounds__(kBnThreads) void bn_max_apply_kernel(const float* __restrict__ x,
+                                                                  const float* __restrict__ pb,
+                                                                  const float* __restrict__ dz,
+                                                                  const int* __restrict__ idx,
+                                                                  const float* __restrict__ coef, int C, int L,
+                                                                  float* __restrict__ dx, float* __restrict__ dxpart) {
+  __shared__ float red[8];
+  const int row = blockIdx.x, c = row % C, seg = blockIdx.y;
+  const size_t base = (size_t)row * L + (size_t)seg * kBnSeg;
+  const int len = (L - seg * kBnSeg) < kBnSeg ? (L - seg * kBnSeg) : kBnSeg;
+  const float b = pb ? pb[c] : 0.0f;
+  const float k1 = coef[c], k2 = coef[C + c], k3 = coef[2 * C + c];
+  const float d = dz[row];
+  const int sel = idx[row] - seg * kBnSeg;
+  float acc = 0.0f, unused = 0.0f;
+  if ((L & 3) == 0) {
+    const v4f* __restrict__ xp = reinterpret_cast<const v4f*>(x + base);
+    v4f* __restrict__ op = reinterpret_cast<v4f*>(dx + base);
+    for (int e = threadIdx.x; e < len / 4; e += kBnThreads) {
+      const v4f xv = xp[e];
+      v4f r;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) r[u] = fma_rn(k1, (4 * e + u == sel) ? d : 0.0f, fma_rn(k2, xv[u] + b, k3));
+      acc += (r[0] + r[1]) + (r[2] + r[3]);
+      op[e] = r;
+    }
+  } else {
+    for (int e = threadIdx.x; e < len; e += kBnThreads) {
+      const float r = fma_rn(k1, (e == sel) ? d : 0.0f, fma_rn(k2, x[base + e] + b, k3));
+      acc += r;
+      dx[base + e] = r;
+    }
+  }
+  if (dxpart) {
+    block_reduce2(acc, unused, red);
+    if (threadIdx.x == 0) dxpart[(size_t)row * gridDim.y + seg] = acc;
+  }
+}
+
 int check_dims(const char* fn, int N, int C, int L, int act) {
   FPSG_REQUIRE(N > 0 && C > 0 && L > 0, FPSG_E_SHAPE, "%s: N,C,L must be positive (got %d,%d,%d)", fn, N, C, L);
   FPSG_REQUIRE(act >= 0 && act <= 2, FPSG_E_SHAPE, "%s: act must be 0 (none), 1 (relu) or 2 (leaky)", fn);
@@ -715,6 +902,80 @@ extern "C" int fpsg_bn_act_pool_bwd(const float* x, const float* pre_bias, const
   if (dpre_bias) {
     hipLaunchKernelGGL(bn_dxsum_kernel, dim3(C), dim3(64), 0, s, dxpart, N, C, per_plane, dpre_bias);
     return launch_status("fpsg_bn_act_pool_bwd(dpre_bias)");
+  }
+  return 0;
+}
+
+extern "C" size_t fpsg_bn_max_workspace_floats(int N, int C, int L) {
+  if (N <= 0 || C <= 0 || L <= 0) return 0;
+  const size_t segs = ((size_t)L + fpsg::kBnSeg - 1) / fpsg::kBnSeg;
+  // channel partials + per-(row, segment) extremes (4 words) / sum(dx) partials + dz [N*C]
+  return (size_t)C * fpsg::kBnSlices * 2 + (size_t)N * C * segs * 4 + (size_t)N * C;
+}
+
+extern "C" int fpsg_bn_act_max_fwd(const float* x, const float* pre_bias, const float* gamma, const float* beta,
+                                   const float* running_mean, const float* running_var, int N, int C, int L,
+                                   int training, float eps, int act, float slope, float* out, int32_t* idx,
+                                   float* chan, float* batch_mean, float* batch_var_unbiased, float* ws,
+                                   fpsg_stream_t stream) {
+  using namespace fpsg;
+  int rc = check_dims("fpsg_bn_act_max_fwd", N, C, L, act);
+  if (rc) return rc;
+  FPSG_REQUIRE_PTR(x); FPSG_REQUIRE_PTR(out); FPSG_REQUIRE_PTR(idx); FPSG_REQUIRE_PTR(chan); FPSG_REQUIRE_PTR(ws);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int segs = (L + kBnSeg - 1) / kBnSeg;
+  const int S = slices_for(N, L);
+  RowExt* ext = reinterpret_cast<RowExt*>(ws + (size_t)C * kBnSlices * 2);
+  dim3 grid(S, C);
+  if (training) {
+    hipLaunchKernelGGL(bn_reduce_ext_kernel<1>, grid, dim3(kBnThreads), 0, s, x, pre_bias, N, C, L, S, ws, ext);
+    if ((rc = launch_status("fpsg_bn_act_max_fwd(stats)"))) return rc;
+    hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, ws, gamma, beta, C, S,
+                       (double)N * (double)L, eps, chan, batch_mean, batch_var_unbiased);
+    if ((rc = launch_status("fpsg_bn_act_max_fwd(finalize)"))) return rc;
+  } else {
+    FPSG_REQUIRE_PTR(running_mean); FPSG_REQUIRE_PTR(running_var);
+    hipLaunchKernelGGL(bn_reduce_ext_kernel<0>, grid, dim3(kBnThreads), 0, s, x, pre_bias, N, C, L, S, ws, ext);
+    if ((rc = launch_status("fpsg_bn_act_max_fwd(extremes)"))) return rc;
+    hipLaunchKernelGGL(bn_eval_chan_kernel, dim3((C + 255) / 256), dim3(256), 0, s, running_mean, running_var,
+                       gamma, beta, C, eps, chan);
+    if ((rc = launch_status("fpsg_bn_act_max_fwd(eval)"))) return rc;
+  }
+  const int rows = N * C;
+  dim3 og((rows + 255) / 256);
+  if (act == kActRelu) hipLaunchKernelGGL(bn_max_out_kernel<kActRelu>, og, dim3(256), 0, s, ext, chan, rows, C, segs, slope, out, idx);
+  else if (act == kActLeaky) hipLaunchKernelGGL(bn_max_out_kernel<kActLeaky>, og, dim3(256), 0, s, ext, chan, rows, C, segs, slope, out, idx);
+  else hipLaunchKernelGGL(bn_max_out_kernel<kActNone>, og, dim3(256), 0, s, ext, chan, rows, C, segs, slope, out, idx);
+  return launch_status("fpsg_bn_act_max_fwd(out)");
+}
+
+extern "C" int fpsg_bn_act_max_bwd(const float* x, const float* pre_bias, const float* gout, const int32_t* idx,
+                                   const float* chan, int N, int C, int L, int training, int act, float slope,
+                                   float* dx, float* dgamma, float* dbeta, float* dpre_bias, float* coef, float* ws,
+                                   fpsg_stream_t stream) {
+  using namespace fpsg;
+  int rc = check_dims("fpsg_bn_act_max_bwd", N, C, L, act);
+  if (rc) return rc;
+  FPSG_REQUIRE_PTR(x); FPSG_REQUIRE_PTR(gout); FPSG_REQUIRE_PTR(idx); FPSG_REQUIRE_PTR(chan); FPSG_REQUIRE_PTR(dx);
+  FPSG_REQUIRE_PTR(dgamma); FPSG_REQUIRE_PTR(dbeta); FPSG_REQUIRE_PTR(coef); FPSG_REQUIRE_PTR(ws);
+  FPSG_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dx)) & 15) == 0, FPSG_E_ALIGN,
+               "fpsg_bn_act_max_bwd: x and dx must be 16-byte aligned");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int segs = (L + kBnSeg - 1) / kBnSeg;
+  float* dxpart = ws + (size_t)C * kBnSlices * 2;
+  float* dz = dxpart + (size_t)N * C * segs * 4;
+#define FPSG_MAXB(A) hipLaunchKernelGGL(bn_max_bwd_coef_kernel<A>, dim3(C), dim3(64), 0, s, x, pre_bias, gout, idx, chan, \
+                                        N, C, L, training, slope, dz, dgamma, dbeta, coef)
+  if (act == kActRelu) FPSG_MAXB(kActRelu); else if (act == kActLeaky) FPSG_MAXB(kActLeaky); else FPSG_MAXB(kActNone);
+#undef FPSG_MAXB
+  if ((rc = launch_status("fpsg_bn_act_max_bwd(coef)"))) return rc;
+  dim3 grid((unsigned)((size_t)N * C), segs);
+  hipLaunchKernelGGL(bn_max_apply_kernel, grid, dim3(kBnThreads), 0, s, x, pre_bias, dz, idx, coef, C, L, dx,
+                     dpre_bias ? dxpart : nullptr);
+  if ((rc = launch_status("fpsg_bn_act_max_bwd(apply)"))) return rc;
+  if (dpre_bias) {
+    hipLaunchKernelGGL(bn_dxsum_kernel, dim3(C), dim3(64), 0, s, dxpart, N, C, segs, dpre_bias);
+    return launch_status("fpsg_bn_act_max_bwd(dpre_bias)");
   }
   return 0;
 }

@@ -145,6 +145,57 @@ class _BNActPool(torch.autograd.Function):
         return dx, (dgamma if has_w else None), (dbeta if has_b else None), None, None, None, None, None, None, dpb
 
 
+class _BNActMax(torch.autograd.Function):
+    """``act(BN(x + pre_bias)).max(dim=2)[0]`` for ``x [N, C, L]`` as one op (K5 max variants): only
+    each row's extreme of ``x`` is normalised; the backward scatters the ``[N, C]`` gradient."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, training, eps, act_code, slope, pre_bias):
+        N, C, L = x.shape
+        lib = _hip.load()
+        dev = x.device
+        out = torch.empty((N, C), dtype=torch.float32, device=dev)
+        idx = torch.empty((N, C), dtype=torch.int32, device=dev)
+        chan = torch.empty((4, C), dtype=torch.float32, device=dev)
+        ws = torch.empty((lib.fpsg_bn_max_workspace_floats(N, C, L),), dtype=torch.float32, device=dev)
+        bmean = torch.empty((C,), dtype=torch.float32, device=dev) if training else None
+        bvar = torch.empty((C,), dtype=torch.float32, device=dev) if training else None
+        opt = lambda t: _hip.ptr(t) if t is not None else None
+        with torch.cuda.device(dev):
+            rc = lib.fpsg_bn_act_max_fwd(_hip.ptr(x), opt(pre_bias), opt(weight), opt(bias), opt(running_mean),
+                                         opt(running_var), N, C, L, 1 if training else 0, float(eps), act_code,
+                                         float(slope), _hip.ptr(out), _hip.ptr(idx), _hip.ptr(chan), opt(bmean),
+                                         opt(bvar), _hip.ptr(ws), _hip.stream_of(x))
+        _hip.check(rc, "fpsg_bn_act_max_fwd")
+        ctx.save_for_backward(x, chan, idx, pre_bias)
+        ctx.cfg = (N, C, L, training, act_code, slope, weight is not None, bias is not None)
+        ctx.mark_non_differentiable(*(t for t in (bmean, bvar) if t is not None))
+        return out, bmean, bvar
+
+    @staticmethod
+    def backward(ctx, gout, _gm, _gv):
+        x, chan, idx, pre_bias = ctx.saved_tensors
+        N, C, L, training, act_code, slope, has_w, has_b = ctx.cfg
+        want_dpb = pre_bias is not None and ctx.needs_input_grad[9]
+        lib = _hip.load()
+        dev = x.device
+        gout = gout.contiguous()
+        dx = torch.empty_like(x)
+        dgamma = torch.empty((C,), dtype=torch.float32, device=dev)
+        dbeta = torch.empty((C,), dtype=torch.float32, device=dev)
+        dpb = torch.empty((C,), dtype=torch.float32, device=dev) if want_dpb else None
+        coef = torch.empty((3, C), dtype=torch.float32, device=dev)
+        ws = torch.empty((lib.fpsg_bn_max_workspace_floats(N, C, L),), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            rc = lib.fpsg_bn_act_max_bwd(_hip.ptr(x), _hip.ptr(pre_bias) if pre_bias is not None else None,
+                                         _hip.ptr(gout), _hip.ptr(idx), _hip.ptr(chan), N, C, L,
+                                         1 if training else 0, act_code, float(slope), _hip.ptr(dx),
+                                         _hip.ptr(dgamma), _hip.ptr(dbeta), _hip.ptr(dpb) if want_dpb else None,
+                                         _hip.ptr(coef), _hip.ptr(ws), _hip.stream_of(x))
+        _hip.check(rc, "fpsg_bn_act_max_bwd")
+        return dx, (dgamma if has_w else None), (dbeta if has_b else None), None, None, None, None, None, None, dpb
+
+
 def _eligible(x: torch.Tensor) -> bool:
     if not (x.is_cuda and x.dtype == torch.float32 and x.dim() >= 3 and fused_enabled()):
         return False
@@ -253,3 +304,27 @@ def conv_bn_act_pool(conv: nn.Conv2d, bn: nn.BatchNorm2d, pool: nn.MaxPool2d, x:
             bn.running_mean.mul_(1 - m).add_(bmean, alpha=m)
             bn.running_var.mul_(1 - m).add_(bvar, alpha=m)
     return yp
+
+
+def conv_bn_act_max(conv: nn.Conv1d, bn: nn.BatchNorm1d, x: torch.Tensor, act=None) -> torch.Tensor:
+    """``act(bn(conv(x))).max(dim=2)[0]`` -> ``[N, C]``: the tail of PointNet's shared MLPs
+    (``pointnet/model.py:35-37, 222-224``)."""
+    fused = (conv.bias is not None and x.is_cuda and x.dtype == torch.float32 and fused_enabled()
+             and bn.track_running_stats and conv.padding_mode == "zeros")
+    if fused:
+        y = conv._conv_forward(x, conv.weight, None)
+        fused = y.dim() == 3 and _eligible(y)
+    if not fused:
+        return conv_bn_act(conv, bn, x, act).max(dim=2)[0]
+    training = bn.training
+    if training and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked += 1
+    act_code, slope = _parse_act(act)
+    out, bmean, bvar = _BNActMax.apply(y.contiguous(), bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                                       bool(training), bn.eps, act_code, slope, conv.bias)
+    if training:
+        with torch.no_grad():
+            m = 0.1 if bn.momentum is None else bn.momentum
+            bn.running_mean.mul_(1 - m).add_(bmean, alpha=m)
+            bn.running_var.mul_(1 - m).add_(bvar, alpha=m)
+    return out

@@ -17,7 +17,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .fused_bn import bn_act, conv_bn_act
+from .fused_bn import bn_act, conv_bn_act, conv_bn_act_max
 
 
 class _PointTrunk(nn.Module):
@@ -48,8 +48,7 @@ class STN3d(_PointTrunk):
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         h = conv_bn_act(self.conv1, self.bn1, x, "relu")
         h = conv_bn_act(self.conv2, self.bn2, h, "relu")
-        h = conv_bn_act(self.conv3, self.bn3, h, "relu")
-        h = h.max(dim=2)[0]
+        h = conv_bn_act_max(self.conv3, self.bn3, h, "relu")     # BatchNorm + ReLU + max over points (K5)
         h = F.relu(self.bn4(self.fc1(h)))
         h = F.relu(self.bn5(self.fc2(h)))
         h = self.fc3(h)
@@ -77,5 +76,5 @@ class PointNetfeat(_PointTrunk):
         h = torch.bmm(trans.transpose(1, 2), x)
         h = conv_bn_act(self.conv1, self.bn1, h, "relu")
         h = conv_bn_act(self.conv2, self.bn2, h, "relu")
-        h = conv_bn_act(self.conv3, self.bn3, h, None)
-        return h.max(dim=2)[0], trans, None
+        h = conv_bn_act_max(self.conv3, self.bn3, h, None)       # BatchNorm + max over points (K5)
+        return h, trans, None

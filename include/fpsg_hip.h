@@ -184,6 +184,23 @@ int fpsg_bn_act_pool_bwd(const float* x, const float* pre_bias, const float* dy_
                          float* dgamma, float* dbeta, float* dpre_bias, float* coef, float* ws,
                          fpsg_stream_t stream);
 
+/* K5 followed by the max over the row: max_l act(BN(x + pre_bias))[n,c,l] -> out [N,C], the
+ * BatchNorm (+ReLU) + torch.max(x, 2) tails of PointNet's shared MLPs (src/pointnet/model.py:35-37,
+ * 222-224).  act and BN are monotone, so only each row's extreme of x is normalised: the forward
+ * is one read of x (no normalised tensor is written), idx [N,C] receives the selected position
+ * (first arg-max of x where scale >= 0, first arg-min otherwise); the backward takes gout [N,C],
+ * and is one read + one write (dx).  Other arguments as fpsg_bn_act_fwd / _bwd;
+ * ws: fpsg_bn_max_workspace_floats(N,C,L).
+ */
+size_t fpsg_bn_max_workspace_floats(int N, int C, int L);
+int fpsg_bn_act_max_fwd(const float* x, const float* pre_bias, const float* gamma, const float* beta,
+                        const float* running_mean, const float* running_var, int N, int C, int L, int training,
+                        float eps, int act, float slope, float* out, int32_t* idx, float* chan, float* batch_mean,
+                        float* batch_var_unbiased, float* ws, fpsg_stream_t stream);
+int fpsg_bn_act_max_bwd(const float* x, const float* pre_bias, const float* gout, const int32_t* idx,
+                        const float* chan, int N, int C, int L, int training, int act, float slope, float* dx,
+                        float* dgamma, float* dbeta, float* dpre_bias, float* coef, float* ws, fpsg_stream_t stream);
+
 /* ---- K6: Winograd F(m x m, 3x3) transforms (m = 2 or 4) for the deep 3x3 convolutions -------
  * Replaces, together with the caller's fp32 batched GEMM (hipBLASLt, MFMA), the library
  * convolution under the Conv2d(3x3, padding 1) layers of torchvision's vgg16_bn.features that

@@ -229,3 +229,70 @@ def test_pooled_variant_ties_and_torch_pool(gpu):
     # the same window elements receive gradient: compare the support of the part of dx that comes
     # through the pool (dx = k1*dz + k2*x + k3: subtract the dense part using a zero-gradient twin)
     assert float((x1.grad - x2.grad).abs().max()) <= 2e-4 * float(x2.grad.abs().max()) + 1e-6
+
+
+@pytest.mark.parametrize("shape,act", [((6, 128, 2048), "relu"), ((64, 32, 2048), None), ((3, 16, 4096 + 640), ("leaky", 0.2)),
+                                       ((5, 24, 1000), "relu"), ((2, 8, 9000), None)])
+@pytest.mark.parametrize("mode", ["train", "eval"])
+def test_max_variant_matches_unfused_chain(gpu, shape, act, mode):
+    """conv_bn_act_max == conv_bn_act(...).max(dim=2)[0]: outputs BIT-equal (monotone maps commute with
+    max), running statistics equal, gradients to summation order.  gamma has both signs (arg-max and
+    arg-min rows)."""
+    from fpsg_amd.fused_bn import conv_bn_act, conv_bn_act_max
+    import copy
+    torch.manual_seed(sum(shape) + 7)
+    N, C, L = shape
+    conv = nn.Conv1d(16, C, 1).to(gpu)
+    bn = nn.BatchNorm1d(C).to(gpu)
+    with torch.no_grad():
+        conv.bias.copy_(torch.randn(C) * 0.3)
+        bn.weight.copy_(torch.randn(C))            # both signs
+        bn.weight[0] = 0.0                         # a constant channel
+        bn.bias.copy_(torch.randn(C) * 0.3)
+    conv2, bn2 = copy.deepcopy(conv), copy.deepcopy(bn)
+    bn.train(mode == "train"); bn2.train(mode == "train")
+    x = torch.randn(N, 16, L, device=gpu)
+    x1, x2 = x.clone().requires_grad_(), x.clone().requires_grad_()
+    y1 = conv_bn_act_max(conv, bn, x1, act)
+    y2 = conv_bn_act(conv2, bn2, x2, act).max(dim=2)[0]
+    assert y1.shape == (N, C)
+    # same statistics arithmetic as the sliced K5 path (N*L > 16384); the one-launch small path of
+    # the unfused op sums in another order
+    same_stats = mode == "eval" or N * L > 16384
+    if same_stats:
+        assert torch.equal(y1, y2)
+        assert torch.equal(bn.running_mean, bn2.running_mean) and torch.equal(bn.running_var, bn2.running_var)
+    else:
+        assert torch.allclose(y1, y2, rtol=1e-5, atol=1e-6)
+        assert torch.allclose(bn.running_mean, bn2.running_mean, rtol=1e-5, atol=1e-7)
+        assert torch.allclose(bn.running_var, bn2.running_var, rtol=1e-5, atol=1e-7)
+    g = torch.randn_like(y1)
+    y1.backward(g); y2.backward(g)
+    for a, r in ((x1.grad, x2.grad), (conv.weight.grad, conv2.weight.grad), (bn.weight.grad, bn2.weight.grad),
+                 (bn.bias.grad, bn2.bias.grad)):
+        assert float((a - r).abs().max()) <= 2e-4 * float(r.abs().max()) + 1e-6
+    assert int(bn.num_batches_tracked) == int(bn2.num_batches_tracked)
+
+
+def test_max_variant_selected_index(gpu):
+    """The C ABI's idx output: first arg-max of x where gamma >= 0, first arg-min where gamma < 0."""
+    from fpsg_amd import _hip
+    torch.manual_seed(5)
+    N, C, L = 4, 6, 5000
+    x = torch.randint(-50, 50, (N, C, L), device=gpu).float()            # many ties
+    gamma = torch.tensor([1.0, -1.0, 0.5, -2.0, 1.5, -0.1], device=gpu)
+    beta = torch.zeros(C, device=gpu)
+    lib = _hip.load()
+    out = torch.empty(N, C, device=gpu); idx = torch.empty(N, C, dtype=torch.int32, device=gpu)
+    chan = torch.empty(4, C, device=gpu)
+    ws = torch.empty(lib.fpsg_bn_max_workspace_floats(N, C, L), device=gpu)
+    rc = lib.fpsg_bn_act_max_fwd(_hip.ptr(x), None, _hip.ptr(gamma), _hip.ptr(beta), None, None, N, C, L, 1, 1e-5, 0, 0.0,
+                                 _hip.ptr(out), _hip.ptr(idx), _hip.ptr(chan), None, None, _hip.ptr(ws), None)
+    assert rc == 0
+    torch.cuda.synchronize()
+    xc = x.cpu()
+    for n in range(N):
+        for c in range(C):
+            row = xc[n, c]
+            want = int((row == (row.max() if gamma[c] >= 0 else row.min())).nonzero()[0])
+            assert int(idx[n, c]) == want, (n, c)

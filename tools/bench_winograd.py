@@ -22,7 +22,7 @@ def timeit(fn, n=20):
 
 print(f"# N={N}; ms per call; lib = F.conv2d / torch.nn.grad (MIOpen), wino = K6 transforms + torch.bmm")
 print(f"# {'layer':22s} {'lib fwd':>8s} {'wino fwd':>9s} | {'lib dx':>8s} {'wino dx':>8s} | {'lib dw':>8s} {'wino dw':>8s} | parts: in-T, gemm, out-T")
-for (C, K, H) in [(64, 64, 224), (64, 128, 112), (128, 128, 112), (128, 256, 56), (256, 256, 56), (256, 512, 28), (512, 512, 28), (512, 512, 14)]:
+for (C, K, H) in [(3, 64, 224), (64, 64, 224), (64, 128, 112), (128, 128, 112), (128, 256, 56), (256, 256, 56), (256, 512, 28), (512, 512, 28), (512, 512, 14)]:
     x = torch.randn(N, C, H, H, device=dev)
     w = torch.randn(K, C, 3, 3, device=dev) * 0.05
     gy = torch.randn(N, K, H, H, device=dev)
