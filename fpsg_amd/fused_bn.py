@@ -252,11 +252,22 @@ def bn_act(bn: nn.modules.batchnorm._BatchNorm, x: torch.Tensor, act=None, pre_b
                           bn.eps, act, pre_bias=pre_bias)
 
 
+def _is_pointwise(conv) -> bool:
+    return (isinstance(conv, nn.Conv1d) and conv.kernel_size == (1,) and conv.stride == (1,)
+            and conv.padding == (0,) and conv.dilation == (1,) and conv.groups == 1)
+
+
 def _conv_without_bias(conv, x):
     """The convolution of ``conv`` without its bias: K6 (Winograd transforms + MFMA batched GEMM)
-    for the deep 3x3 layers, the library convolution otherwise."""
+    for the 3x3 layers; a batched GEMM for the 1x1 ``Conv1d`` of the shared MLPs (the library
+    convolution wraps the same product in NHWC transposes of ``[B,1024,N]`` tensors for its
+    weight gradient, and its GEMM kernel is not covered by the recorded kernel choices); the
+    library convolution otherwise."""
     if isinstance(conv, nn.Conv2d) and winograd.eligible(x, conv):
         return winograd.conv3x3(x, conv.weight)
+    if _is_pointwise(conv) and x.is_cuda and x.dim() == 3 and conv.in_channels >= 32:
+        w = conv.weight.squeeze(-1)                               # [K, C]
+        return torch.bmm(w.unsqueeze(0).expand(x.shape[0], -1, -1), x)
     return conv._conv_forward(x, conv.weight, None)
 
 
@@ -312,7 +323,7 @@ def conv_bn_act_max(conv: nn.Conv1d, bn: nn.BatchNorm1d, x: torch.Tensor, act=No
     fused = (conv.bias is not None and x.is_cuda and x.dtype == torch.float32 and fused_enabled()
              and bn.track_running_stats and conv.padding_mode == "zeros")
     if fused:
-        y = conv._conv_forward(x, conv.weight, None)
+        y = _conv_without_bias(conv, x)
         fused = y.dim() == 3 and _eligible(y)
     if not fused:
         return conv_bn_act(conv, bn, x, act).max(dim=2)[0]

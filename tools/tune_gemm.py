@@ -13,6 +13,10 @@ import sys
 out = os.path.abspath(sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/gemm_gfx950.csv")
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 os.makedirs(os.path.dirname(out), exist_ok=True)
+seed = os.path.join(root, "fpsg_amd", "tuning", "gemm_gfx950.csv")
+if not os.path.exists(out) and os.path.exists(seed) and "--fresh" not in sys.argv:
+    import shutil
+    shutil.copyfile(seed, out)          # keep the existing records, time only shapes that are new
 for wl, extra in (("c5", []), ("c4", []), ("c2", ["--no-graph"]), ("c3", [])):
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--workload", wl, "--gemm-tuning", "tune", "--gemm-records", out,
            "--no-cpu-baseline", "--steps", "1", "--warmup", "1"] + extra
