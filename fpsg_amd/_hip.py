@@ -40,19 +40,19 @@ SIGNATURES = {
                           _c_int, _c_int, _c_f32p, _c_stream],
     "fpsg_softmin": [_c_f32p, _c_f32p, _c_f32p, _c_int, _c_int, _c_int, ctypes.c_float, _c_f32p, _c_stream],
     "fpsg_bn_workspace_floats": [_c_int, _c_int, _c_int],
-    "fpsg_bn_act_fwd": [_c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_int, _c_int, _c_int, _c_int,
+    "fpsg_bn_act_fwd": [_c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, ctypes.c_float, _c_int, _c_int, _c_int, _c_int,
                         ctypes.c_float, _c_int, ctypes.c_float, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p,
                         _c_stream],
     "fpsg_bn_act_bwd": [_c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_int, _c_int, _c_int, _c_int, _c_int,
                         ctypes.c_float, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_stream],
     "fpsg_bn_pool_workspace_floats": [_c_int, _c_int, _c_int, _c_int],
-    "fpsg_bn_act_pool_fwd": [_c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_int, _c_int, _c_int, _c_int,
+    "fpsg_bn_act_pool_fwd": [_c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, ctypes.c_float, _c_int, _c_int, _c_int, _c_int,
                              _c_int, ctypes.c_float, _c_int, ctypes.c_float, _c_f32p, _c_f32p, _c_f32p, _c_f32p,
                              _c_f32p, _c_stream],
     "fpsg_bn_act_pool_bwd": [_c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
                              ctypes.c_float, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_stream],
     "fpsg_bn_max_workspace_floats": [_c_int, _c_int, _c_int],
-    "fpsg_bn_act_max_fwd": [_c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_int, _c_int, _c_int, _c_int,
+    "fpsg_bn_act_max_fwd": [_c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, ctypes.c_float, _c_int, _c_int, _c_int, _c_int,
                             ctypes.c_float, _c_int, ctypes.c_float, _c_f32p, _c_i32p, _c_f32p, _c_f32p, _c_f32p,
                             _c_f32p, _c_stream],
     "fpsg_bn_act_max_bwd": [_c_f32p, _c_f32p, _c_f32p, _c_i32p, _c_f32p, _c_int, _c_int, _c_int, _c_int, _c_int,

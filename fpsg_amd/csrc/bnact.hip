@@ -126,7 +126,8 @@ __global__ __launch_bounds__(kBnThreads) void bn_reduce_kernel(
 __global__ void bn_fwd_finalize_kernel(const float* __restrict__ part, const float* __restrict__ gamma,
                                        const float* __restrict__ beta, int C, int S, double count, float eps,
                                        float* __restrict__ chan, float* __restrict__ batch_mean,
-                                       float* __restrict__ batch_var_unbiased) {
+                                       float* __restrict__ batch_var_unbiased, float* __restrict__ run_mean,
+                                       float* __restrict__ run_var, float momentum) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   double s0 = 0.0, s1 = 0.0;
@@ -141,8 +142,13 @@ __global__ void bn_fwd_finalize_kernel(const float* __restrict__ part, const flo
   chan[C + c] = b - (float)mean * scale;
   chan[2 * C + c] = (float)mean;
   chan[3 * C + c] = rstd;
+  const float unbiased = (float)(count > 1.0 ? var * count / (count - 1.0) : var);
   if (batch_mean) batch_mean[c] = (float)mean;
-  if (batch_var_unbiased) batch_var_unbiased[c] = (float)(count > 1.0 ? var * count / (count - 1.0) : var);
+  if (batch_var_unbiased) batch_var_unbiased[c] = unbiased;
+  if (run_mean && momentum >= 0.0f) {       // running <- (1 - m) * running + m * batch (torch's rule)
+    run_mean[c] = fma_rn(momentum, (float)mean, (1.0f - momentum) * run_mean[c]);
+    run_var[c] = fma_rn(momentum, unbiased, (1.0f - momentum) * run_var[c]);
+  }
 }
 
 // eval mode: chan from running statistics
@@ -270,7 +276,7 @@ __global__ __launch_bounds__(kBnThreads) void bn_small_kernel(
     const float* __restrict__ beta, const float* __restrict__ pb, int N, int C, int L, int training, float eps,
     float slope, float* __restrict__ out, float* __restrict__ chan, float* __restrict__ batch_mean,
     float* __restrict__ batch_var_unbiased, float* __restrict__ dgamma, float* __restrict__ dbeta,
-    float* __restrict__ dpb) {
+    float* __restrict__ dpb, float* __restrict__ run_mean, float* __restrict__ run_var, float momentum) {
   __shared__ float red[8];
   __shared__ float bc[4];
   const int c = blockIdx.x;
@@ -302,8 +308,13 @@ __global__ __launch_bounds__(kBnThreads) void bn_small_kernel(
         const float g = gamma ? gamma[c] : 1.0f, b = beta ? beta[c] : 0.0f;
         bc[0] = g * rstd; bc[1] = b - (float)mean * g * rstd; bc[2] = (float)mean; bc[3] = rstd;
         chan[c] = bc[0]; chan[C + c] = bc[1]; chan[2 * C + c] = bc[2]; chan[3 * C + c] = bc[3];
+        const float unbiased = (float)(count > 1.0 ? var * count / (count - 1.0) : var);
         if (batch_mean) batch_mean[c] = (float)mean;
-        if (batch_var_unbiased) batch_var_unbiased[c] = (float)(count > 1.0 ? var * count / (count - 1.0) : var);
+        if (batch_var_unbiased) batch_var_unbiased[c] = unbiased;
+        if (run_mean && momentum >= 0.0f) {
+          run_mean[c] = fma_rn(momentum, (float)mean, (1.0f - momentum) * run_mean[c]);
+          run_var[c] = fma_rn(momentum, unbiased, (1.0f - momentum) * run_var[c]);
+        }
       } else {
         dbeta[c] = a0; dgamma[c] = a1;
         const double k2 = training ? -(double)sc * a1 * rs / count : 0.0;
@@ -343,10 +354,12 @@ __global__ __launch_bounds__(kBnThreads) void bn_small_kernel(
 template <int MODE>
 void launch_small(int act, const float* x, const float* dy, const float* gamma, const float* beta, const float* pb,
                   int N, int C, int L, int training, float eps, float slope, float* out, float* chan, float* bm,
-                  float* bv, float* dgamma, float* dbeta, float* dpb, hipStream_t s) {
+                  float* bv, float* dgamma, float* dbeta, float* dpb, float* rmean, float* rvar, float momentum,
+                  hipStream_t s) {
   dim3 grid(C);
 #define FPSG_SMALL(A) hipLaunchKernelGGL((bn_small_kernel<MODE, A>), grid, dim3(kBnThreads), 0, s, x, dy, gamma, beta, \
-                                         pb, N, C, L, training, eps, slope, out, chan, bm, bv, dgamma, dbeta, dpb)
+                                         pb, N, C, L, training, eps, slope, out, chan, bm, bv, dgamma, dbeta, dpb, rmean, \
+                                         rvar, momentum)
   if (act == kActRelu) FPSG_SMALL(kActRelu);
   else if (act == kActLeaky) FPSG_SMALL(kActLeaky);
   else FPSG_SMALL(kActNone);
@@ -768,7 +781,7 @@ extern "C" size_t fpsg_bn_workspace_floats(int N, int C, int L) {
 }
 
 extern "C" int fpsg_bn_act_fwd(const float* x, const float* pre_bias, const float* gamma, const float* beta,
-                               const float* running_mean, const float* running_var, int N, int C, int L,
+                               float* running_mean, float* running_var, float momentum, int N, int C, int L,
                                int training, float eps, int act, float slope, float* y, float* chan,
                                float* batch_mean, float* batch_var_unbiased, float* ws, fpsg_stream_t stream) {
   using namespace fpsg;
@@ -786,7 +799,7 @@ extern "C" int fpsg_bn_act_fwd(const float* x, const float* pre_bias, const floa
       if ((rc = launch_status("fpsg_bn_act_fwd(eval)"))) return rc;
     }
     launch_small<0>(act, x, nullptr, gamma, beta, pre_bias, N, C, L, training, eps, slope, y, chan, batch_mean,
-                    batch_var_unbiased, nullptr, nullptr, nullptr, s);
+                    batch_var_unbiased, nullptr, nullptr, nullptr, running_mean, running_var, momentum, s);
     return launch_status("fpsg_bn_act_fwd(small)");
   }
   if (training) {
@@ -795,7 +808,8 @@ extern "C" int fpsg_bn_act_fwd(const float* x, const float* pre_bias, const floa
     launch_reduce<0>(kActNone, x, nullptr, nullptr, pre_bias, N, C, L, S, 0.0f, ws, s);
     if ((rc = launch_status("fpsg_bn_act_fwd(stats)"))) return rc;
     hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, ws, gamma, beta, C, S,
-                       (double)N * (double)L, eps, chan, batch_mean, batch_var_unbiased);
+                       (double)N * (double)L, eps, chan, batch_mean, batch_var_unbiased, running_mean, running_var,
+                       momentum);
     if ((rc = launch_status("fpsg_bn_act_fwd(finalize)"))) return rc;
   } else {
     hipLaunchKernelGGL(bn_eval_chan_kernel, dim3((C + 255) / 256), dim3(256), 0, s, running_mean, running_var,
@@ -819,7 +833,7 @@ extern "C" int fpsg_bn_act_bwd(const float* x, const float* pre_bias, const floa
   hipStream_t s = static_cast<hipStream_t>(stream);
   if ((long)N * L <= kBnSmallMax) {
     launch_small<1>(act, x, dy, nullptr, nullptr, pre_bias, N, C, L, training, 0.0f, slope, dx,
-                    const_cast<float*>(chan), nullptr, nullptr, dgamma, dbeta, dpre_bias, s);
+                    const_cast<float*>(chan), nullptr, nullptr, dgamma, dbeta, dpre_bias, nullptr, nullptr, -1.0f, s);
     return launch_status("fpsg_bn_act_bwd(small)");
   }
   const int S = slices_for(N, L);
@@ -846,7 +860,7 @@ extern "C" size_t fpsg_bn_pool_workspace_floats(int N, int C, int H, int W) {
 }
 
 extern "C" int fpsg_bn_act_pool_fwd(const float* x, const float* pre_bias, const float* gamma, const float* beta,
-                                    const float* running_mean, const float* running_var, int N, int C, int H, int W,
+                                    float* running_mean, float* running_var, float momentum, int N, int C, int H, int W,
                                     int training, float eps, int act, float slope, float* y_pooled, float* chan,
                                     float* batch_mean, float* batch_var_unbiased, float* ws, fpsg_stream_t stream) {
   using namespace fpsg;
@@ -863,7 +877,8 @@ extern "C" int fpsg_bn_act_pool_fwd(const float* x, const float* pre_bias, const
     launch_reduce<0>(kActNone, x, nullptr, nullptr, pre_bias, N, C, L, S, 0.0f, ws, s);
     if ((rc = launch_status("fpsg_bn_act_pool_fwd(stats)"))) return rc;
     hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, ws, gamma, beta, C, S,
-                       (double)N * (double)L, eps, chan, batch_mean, batch_var_unbiased);
+                       (double)N * (double)L, eps, chan, batch_mean, batch_var_unbiased, running_mean, running_var,
+                       momentum);
     if ((rc = launch_status("fpsg_bn_act_pool_fwd(finalize)"))) return rc;
   } else {
     FPSG_REQUIRE_PTR(running_mean); FPSG_REQUIRE_PTR(running_var);
@@ -914,7 +929,7 @@ extern "C" size_t fpsg_bn_max_workspace_floats(int N, int C, int L) {
 }
 
 extern "C" int fpsg_bn_act_max_fwd(const float* x, const float* pre_bias, const float* gamma, const float* beta,
-                                   const float* running_mean, const float* running_var, int N, int C, int L,
+                                   float* running_mean, float* running_var, float momentum, int N, int C, int L,
                                    int training, float eps, int act, float slope, float* out, int32_t* idx,
                                    float* chan, float* batch_mean, float* batch_var_unbiased, float* ws,
                                    fpsg_stream_t stream) {
@@ -931,7 +946,8 @@ extern "C" int fpsg_bn_act_max_fwd(const float* x, const float* pre_bias, const 
     hipLaunchKernelGGL(bn_reduce_ext_kernel<1>, grid, dim3(kBnThreads), 0, s, x, pre_bias, N, C, L, S, ws, ext);
     if ((rc = launch_status("fpsg_bn_act_max_fwd(stats)"))) return rc;
     hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, ws, gamma, beta, C, S,
-                       (double)N * (double)L, eps, chan, batch_mean, batch_var_unbiased);
+                       (double)N * (double)L, eps, chan, batch_mean, batch_var_unbiased, running_mean, running_var,
+                       momentum);
     if ((rc = launch_status("fpsg_bn_act_max_fwd(finalize)"))) return rc;
   } else {
     FPSG_REQUIRE_PTR(running_mean); FPSG_REQUIRE_PTR(running_var);

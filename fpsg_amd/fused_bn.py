@@ -42,7 +42,7 @@ def _parse_act(act):
 class _BNAct(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, running_mean, running_var, training, eps, act_code, slope, want_stats,
-                pre_bias=None):
+                pre_bias=None, momentum=-1.0):
         N, C = x.shape[0], x.shape[1]
         L = x.numel() // (N * C)
         lib = _hip.load()
@@ -58,7 +58,7 @@ class _BNAct(torch.autograd.Function):
                 _hip.ptr(weight) if weight is not None else None,
                 _hip.ptr(bias) if bias is not None else None,
                 _hip.ptr(running_mean) if running_mean is not None else None,
-                _hip.ptr(running_var) if running_var is not None else None,
+                _hip.ptr(running_var) if running_var is not None else None, float(momentum),
                 N, C, L, 1 if training else 0, float(eps), act_code, float(slope), _hip.ptr(y), _hip.ptr(chan),
                 _hip.ptr(bmean) if bmean is not None else None, _hip.ptr(bvar) if bvar is not None else None,
                 _hip.ptr(ws), _hip.stream_of(x))
@@ -92,7 +92,7 @@ class _BNAct(torch.autograd.Function):
                                      _hip.stream_of(x))
         _hip.check(rc, "fpsg_bn_act_bwd")
         return (dx, (dgamma if has_w else None), (dbeta if has_b else None), None, None, None, None, None, None,
-                None, dpb)
+                None, dpb, None)
 
 
 class _BNActPool(torch.autograd.Function):
@@ -100,29 +100,27 @@ class _BNActPool(torch.autograd.Function):
     only the pooled tensor, the backward re-derives the windows' arg-max from ``x``."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, running_mean, running_var, training, eps, act_code, slope, pre_bias):
+    def forward(ctx, x, weight, bias, running_mean, running_var, training, eps, act_code, slope, pre_bias,
+                momentum=-1.0):
         N, C, H, W = x.shape
         lib = _hip.load()
         dev = x.device
         yp = torch.empty((N, C, H // 2, W // 2), dtype=torch.float32, device=dev)
         chan = torch.empty((4, C), dtype=torch.float32, device=dev)
         ws = torch.empty((lib.fpsg_bn_pool_workspace_floats(N, C, H, W),), dtype=torch.float32, device=dev)
-        bmean = torch.empty((C,), dtype=torch.float32, device=dev) if training else None
-        bvar = torch.empty((C,), dtype=torch.float32, device=dev) if training else None
         opt = lambda t: _hip.ptr(t) if t is not None else None
         with torch.cuda.device(dev):
             rc = lib.fpsg_bn_act_pool_fwd(_hip.ptr(x), opt(pre_bias), opt(weight), opt(bias), opt(running_mean),
-                                          opt(running_var), N, C, H, W, 1 if training else 0, float(eps), act_code,
-                                          float(slope), _hip.ptr(yp), _hip.ptr(chan), opt(bmean), opt(bvar),
+                                          opt(running_var), float(momentum), N, C, H, W, 1 if training else 0,
+                                          float(eps), act_code, float(slope), _hip.ptr(yp), _hip.ptr(chan), None, None,
                                           _hip.ptr(ws), _hip.stream_of(x))
         _hip.check(rc, "fpsg_bn_act_pool_fwd")
         ctx.save_for_backward(x, chan, pre_bias)
         ctx.cfg = (N, C, H, W, training, act_code, slope, weight is not None, bias is not None)
-        ctx.mark_non_differentiable(*(t for t in (bmean, bvar) if t is not None))
-        return yp, bmean, bvar
+        return yp
 
     @staticmethod
-    def backward(ctx, gyp, _gm, _gv):
+    def backward(ctx, gyp):
         x, chan, pre_bias = ctx.saved_tensors
         N, C, H, W, training, act_code, slope, has_w, has_b = ctx.cfg
         want_dpb = pre_bias is not None and ctx.needs_input_grad[9]
@@ -142,7 +140,7 @@ class _BNActPool(torch.autograd.Function):
                                           _hip.ptr(dpb) if want_dpb else None, _hip.ptr(coef), _hip.ptr(ws),
                                           _hip.stream_of(x))
         _hip.check(rc, "fpsg_bn_act_pool_bwd")
-        return dx, (dgamma if has_w else None), (dbeta if has_b else None), None, None, None, None, None, None, dpb
+        return dx, (dgamma if has_w else None), (dbeta if has_b else None), None, None, None, None, None, None, dpb, None
 
 
 class _BNActMax(torch.autograd.Function):
@@ -150,7 +148,8 @@ class _BNActMax(torch.autograd.Function):
     each row's extreme of ``x`` is normalised; the backward scatters the ``[N, C]`` gradient."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, running_mean, running_var, training, eps, act_code, slope, pre_bias):
+    def forward(ctx, x, weight, bias, running_mean, running_var, training, eps, act_code, slope, pre_bias,
+                momentum=-1.0):
         N, C, L = x.shape
         lib = _hip.load()
         dev = x.device
@@ -158,22 +157,19 @@ class _BNActMax(torch.autograd.Function):
         idx = torch.empty((N, C), dtype=torch.int32, device=dev)
         chan = torch.empty((4, C), dtype=torch.float32, device=dev)
         ws = torch.empty((lib.fpsg_bn_max_workspace_floats(N, C, L),), dtype=torch.float32, device=dev)
-        bmean = torch.empty((C,), dtype=torch.float32, device=dev) if training else None
-        bvar = torch.empty((C,), dtype=torch.float32, device=dev) if training else None
         opt = lambda t: _hip.ptr(t) if t is not None else None
         with torch.cuda.device(dev):
             rc = lib.fpsg_bn_act_max_fwd(_hip.ptr(x), opt(pre_bias), opt(weight), opt(bias), opt(running_mean),
-                                         opt(running_var), N, C, L, 1 if training else 0, float(eps), act_code,
-                                         float(slope), _hip.ptr(out), _hip.ptr(idx), _hip.ptr(chan), opt(bmean),
-                                         opt(bvar), _hip.ptr(ws), _hip.stream_of(x))
+                                         opt(running_var), float(momentum), N, C, L, 1 if training else 0, float(eps),
+                                         act_code, float(slope), _hip.ptr(out), _hip.ptr(idx), _hip.ptr(chan), None,
+                                         None, _hip.ptr(ws), _hip.stream_of(x))
         _hip.check(rc, "fpsg_bn_act_max_fwd")
         ctx.save_for_backward(x, chan, idx, pre_bias)
         ctx.cfg = (N, C, L, training, act_code, slope, weight is not None, bias is not None)
-        ctx.mark_non_differentiable(*(t for t in (bmean, bvar) if t is not None))
-        return out, bmean, bvar
+        return out
 
     @staticmethod
-    def backward(ctx, gout, _gm, _gv):
+    def backward(ctx, gout):
         x, chan, idx, pre_bias = ctx.saved_tensors
         N, C, L, training, act_code, slope, has_w, has_b = ctx.cfg
         want_dpb = pre_bias is not None and ctx.needs_input_grad[9]
@@ -193,7 +189,7 @@ class _BNActMax(torch.autograd.Function):
                                          _hip.ptr(dgamma), _hip.ptr(dbeta), _hip.ptr(dpb) if want_dpb else None,
                                          _hip.ptr(coef), _hip.ptr(ws), _hip.stream_of(x))
         _hip.check(rc, "fpsg_bn_act_max_bwd")
-        return dx, (dgamma if has_w else None), (dbeta if has_b else None), None, None, None, None, None, None, dpb
+        return dx, (dgamma if has_w else None), (dbeta if has_b else None), None, None, None, None, None, None, dpb, None
 
 
 def _eligible(x: torch.Tensor) -> bool:
@@ -219,13 +215,12 @@ def batch_norm_act(x, weight, bias, running_mean, running_var, training, momentu
     act_code, slope = _parse_act(act)
     if _eligible(x):
         xc = x.contiguous()
+        # training without return_stats: the kernel's finalize step also applies the momentum update
+        # of the running statistics (no separate elementwise launches)
+        update = training and not return_stats and running_mean is not None
+        m = (0.1 if momentum is None else float(momentum)) if update else -1.0
         y, bmean, bvar = _BNAct.apply(xc, weight, bias, running_mean, running_var, bool(training), eps,
-                                      act_code, slope, bool(training), pre_bias)
-        if training and not return_stats and running_mean is not None:
-            with torch.no_grad():
-                m = 0.1 if momentum is None else momentum
-                running_mean.mul_(1 - m).add_(bmean, alpha=m)
-                running_var.mul_(1 - m).add_(bvar, alpha=m)
+                                      act_code, slope, bool(training and return_stats), pre_bias, m)
         return (y, bmean, bvar) if return_stats else y
     if pre_bias is not None:
         x = x + pre_bias.view(1, -1, *([1] * (x.dim() - 2)))
@@ -307,14 +302,9 @@ def conv_bn_act_pool(conv: nn.Conv2d, bn: nn.BatchNorm2d, pool: nn.MaxPool2d, x:
     if training and bn.num_batches_tracked is not None:
         bn.num_batches_tracked += 1
     act_code, slope = _parse_act(act)
-    yp, bmean, bvar = _BNActPool.apply(y.contiguous(), bn.weight, bn.bias, bn.running_mean, bn.running_var,
-                                       bool(training), bn.eps, act_code, slope, conv.bias)
-    if training:
-        with torch.no_grad():
-            m = 0.1 if bn.momentum is None else bn.momentum
-            bn.running_mean.mul_(1 - m).add_(bmean, alpha=m)
-            bn.running_var.mul_(1 - m).add_(bvar, alpha=m)
-    return yp
+    m = (0.1 if bn.momentum is None else float(bn.momentum)) if training else -1.0
+    return _BNActPool.apply(y.contiguous(), bn.weight, bn.bias, bn.running_mean, bn.running_var, bool(training),
+                            bn.eps, act_code, slope, conv.bias, m)
 
 
 def conv_bn_act_max(conv: nn.Conv1d, bn: nn.BatchNorm1d, x: torch.Tensor, act=None) -> torch.Tensor:
@@ -331,11 +321,6 @@ def conv_bn_act_max(conv: nn.Conv1d, bn: nn.BatchNorm1d, x: torch.Tensor, act=No
     if training and bn.num_batches_tracked is not None:
         bn.num_batches_tracked += 1
     act_code, slope = _parse_act(act)
-    out, bmean, bvar = _BNActMax.apply(y.contiguous(), bn.weight, bn.bias, bn.running_mean, bn.running_var,
-                                       bool(training), bn.eps, act_code, slope, conv.bias)
-    if training:
-        with torch.no_grad():
-            m = 0.1 if bn.momentum is None else bn.momentum
-            bn.running_mean.mul_(1 - m).add_(bmean, alpha=m)
-            bn.running_var.mul_(1 - m).add_(bvar, alpha=m)
-    return out
+    m = (0.1 if bn.momentum is None else float(bn.momentum)) if training else -1.0
+    return _BNActMax.apply(y.contiguous(), bn.weight, bn.bias, bn.running_mean, bn.running_var, bool(training),
+                           bn.eps, act_code, slope, conv.bias, m)

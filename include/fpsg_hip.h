@@ -146,8 +146,10 @@ int fpsg_softmin(const float* x, const float* y, const float* h, int B, int N, i
  * src/models/point_cloud_net.py:52-54,76-79) on [N,C,L]-contiguous fp32 tensors; statistics
  * per channel over (N,L).  act: 0 none, 1 ReLU, 2 LeakyReLU(slope).
  *   fwd: y = act((x-mean)*rstd*gamma+beta); chan [4][C] receives (scale, shift, mean, rstd) for
- *        the backward; training != 0: batch statistics (batch_mean / batch_var_unbiased [C] are
- *        optional outputs for the caller's running-statistics update), else running_mean/var.
+ *        the backward; training != 0: batch statistics; running_mean / running_var [C] (optional)
+ *        are then updated in place, running <- (1-momentum)*running + momentum*batch (unbiased
+ *        variance), unless momentum < 0; batch_mean / batch_var_unbiased [C] are optional outputs
+ *        for a caller with its own update rule.  training == 0: running_mean/var are the statistics.
  *   bwd: dx [N,C,L], dgamma [C], dbeta [C] from x, dy and chan (the activation mask is
  *        re-derived from x); coef [3][C] scratch.
  * pre_bias [C] (optional, NULL = none): the bias of the convolution in front of the BatchNorm
@@ -159,7 +161,7 @@ int fpsg_softmin(const float* x, const float* y, const float* h, int B, int N, i
  */
 size_t fpsg_bn_workspace_floats(int N, int C, int L);
 int fpsg_bn_act_fwd(const float* x, const float* pre_bias, const float* gamma, const float* beta,
-                    const float* running_mean, const float* running_var, int N, int C, int L, int training,
+                    float* running_mean, float* running_var, float momentum, int N, int C, int L, int training,
                     float eps, int act, float slope, float* y, float* chan, float* batch_mean,
                     float* batch_var_unbiased, float* ws, fpsg_stream_t stream);
 int fpsg_bn_act_bwd(const float* x, const float* pre_bias, const float* dy, const float* chan, int N, int C,
@@ -176,7 +178,7 @@ int fpsg_bn_act_bwd(const float* x, const float* pre_bias, const float* dy, cons
  */
 size_t fpsg_bn_pool_workspace_floats(int N, int C, int H, int W);
 int fpsg_bn_act_pool_fwd(const float* x, const float* pre_bias, const float* gamma, const float* beta,
-                         const float* running_mean, const float* running_var, int N, int C, int H, int W,
+                         float* running_mean, float* running_var, float momentum, int N, int C, int H, int W,
                          int training, float eps, int act, float slope, float* y_pooled, float* chan,
                          float* batch_mean, float* batch_var_unbiased, float* ws, fpsg_stream_t stream);
 int fpsg_bn_act_pool_bwd(const float* x, const float* pre_bias, const float* dy_pooled, const float* chan,
@@ -194,7 +196,7 @@ int fpsg_bn_act_pool_bwd(const float* x, const float* pre_bias, const float* dy_
  */
 size_t fpsg_bn_max_workspace_floats(int N, int C, int L);
 int fpsg_bn_act_max_fwd(const float* x, const float* pre_bias, const float* gamma, const float* beta,
-                        const float* running_mean, const float* running_var, int N, int C, int L, int training,
+                        float* running_mean, float* running_var, float momentum, int N, int C, int L, int training,
                         float eps, int act, float slope, float* out, int32_t* idx, float* chan, float* batch_mean,
                         float* batch_var_unbiased, float* ws, fpsg_stream_t stream);
 int fpsg_bn_act_max_bwd(const float* x, const float* pre_bias, const float* gout, const int32_t* idx,

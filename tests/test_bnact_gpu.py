@@ -286,7 +286,7 @@ def test_max_variant_selected_index(gpu):
     out = torch.empty(N, C, device=gpu); idx = torch.empty(N, C, dtype=torch.int32, device=gpu)
     chan = torch.empty(4, C, device=gpu)
     ws = torch.empty(lib.fpsg_bn_max_workspace_floats(N, C, L), device=gpu)
-    rc = lib.fpsg_bn_act_max_fwd(_hip.ptr(x), None, _hip.ptr(gamma), _hip.ptr(beta), None, None, N, C, L, 1, 1e-5, 0, 0.0,
+    rc = lib.fpsg_bn_act_max_fwd(_hip.ptr(x), None, _hip.ptr(gamma), _hip.ptr(beta), None, None, -1.0, N, C, L, 1, 1e-5, 0, 0.0,
                                  _hip.ptr(out), _hip.ptr(idx), _hip.ptr(chan), None, None, _hip.ptr(ws), None)
     assert rc == 0
     torch.cuda.synchronize()
