@@ -123,15 +123,23 @@ __global__ __launch_bounds__(kBnThreads) void bn_reduce_kernel(
 
 // forward finalize: mean / biased var -> chan = (scale, shift, mean, rstd); optional outputs of
 // the batch mean and UNBIASED variance (what running statistics are updated with).
-__global__ void bn_fwd_finalize_kernel(const float* __restrict__ part, const float* __restrict__ gamma,
+// One wave per channel: lane s holds slice s of the channel's partial sums (S <= 64), fixed
+// shuffle tree in fp64.
+__device__ __forceinline__ void wave_sum2(double& a, double& b) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) { a += __shfl_down(a, off, 64); b += __shfl_down(b, off, 64); }
+}
+
+__global__ __launch_bounds__(64) void bn_fwd_finalize_kernel(const float* __restrict__ part, const float* __restrict__ gamma,
                                        const float* __restrict__ beta, int C, int S, double count, float eps,
                                        float* __restrict__ chan, float* __restrict__ batch_mean,
                                        float* __restrict__ batch_var_unbiased, float* __restrict__ run_mean,
                                        float* __restrict__ run_var, float momentum) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+  const int c = blockIdx.x, lane = threadIdx.x;
   double s0 = 0.0, s1 = 0.0;
-  for (int s = 0; s < S; ++s) { s0 += part[((size_t)c * S + s) * 2]; s1 += part[((size_t)c * S + s) * 2 + 1]; }
+  if (lane < S) { s0 = part[((size_t)c * S + lane) * 2]; s1 = part[((size_t)c * S + lane) * 2 + 1]; }
+  wave_sum2(s0, s1);
+  if (lane != 0) return;
   const double mean = s0 / count;
   double var = s1 / count - mean * mean;
   var = var > 0.0 ? var : 0.0;
@@ -166,13 +174,14 @@ __global__ void bn_eval_chan_kernel(const float* __restrict__ rmean, const float
 }
 
 // backward finalize: dgamma, dbeta and the coefficients of dx = k1*dz + k2*x + k3
-__global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, const float* __restrict__ chan, int C,
+__global__ __launch_bounds__(64) void bn_bwd_finalize_kernel(const float* __restrict__ part, const float* __restrict__ chan, int C,
                                        int S, double count, int training, float* __restrict__ dgamma,
                                        float* __restrict__ dbeta, float* __restrict__ coef /*[3][C]*/) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+  const int c = blockIdx.x, lane = threadIdx.x;
   double s0 = 0.0, s1 = 0.0;
-  for (int s = 0; s < S; ++s) { s0 += part[((size_t)c * S + s) * 2]; s1 += part[((size_t)c * S + s) * 2 + 1]; }
+  if (lane < S) { s0 = part[((size_t)c * S + lane) * 2]; s1 = part[((size_t)c * S + lane) * 2 + 1]; }
+  wave_sum2(s0, s1);
+  if (lane != 0) return;
   dbeta[c] = (float)s0;
   dgamma[c] = (float)s1;
   const double scale = chan[c], mean = chan[2 * C + c], rstd = chan[3 * C + c];
@@ -807,7 +816,7 @@ extern "C" int fpsg_bn_act_fwd(const float* x, const float* pre_bias, const floa
     const int S = slices_for(N, L);
     launch_reduce<0>(kActNone, x, nullptr, nullptr, pre_bias, N, C, L, S, 0.0f, ws, s);
     if ((rc = launch_status("fpsg_bn_act_fwd(stats)"))) return rc;
-    hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, ws, gamma, beta, C, S,
+    hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3(C), dim3(64), 0, s, ws, gamma, beta, C, S,
                        (double)N * (double)L, eps, chan, batch_mean, batch_var_unbiased, running_mean, running_var,
                        momentum);
     if ((rc = launch_status("fpsg_bn_act_fwd(finalize)"))) return rc;
@@ -839,7 +848,7 @@ extern "C" int fpsg_bn_act_bwd(const float* x, const float* pre_bias, const floa
   const int S = slices_for(N, L);
   launch_reduce<1>(act, x, dy, chan, pre_bias, N, C, L, S, slope, ws, s);
   if ((rc = launch_status("fpsg_bn_act_bwd(reduce)"))) return rc;
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, ws, chan, C, S,
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, s, ws, chan, C, S,
                      (double)N * (double)L, training, dgamma, dbeta, coef);
   if ((rc = launch_status("fpsg_bn_act_bwd(finalize)"))) return rc;
   float* dxpart = dpre_bias ? ws + (size_t)C * kBnSlices * 2 : nullptr;
@@ -876,7 +885,7 @@ extern "C" int fpsg_bn_act_pool_fwd(const float* x, const float* pre_bias, const
     const int S = slices_for(N, L);
     launch_reduce<0>(kActNone, x, nullptr, nullptr, pre_bias, N, C, L, S, 0.0f, ws, s);
     if ((rc = launch_status("fpsg_bn_act_pool_fwd(stats)"))) return rc;
-    hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, ws, gamma, beta, C, S,
+    hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3(C), dim3(64), 0, s, ws, gamma, beta, C, S,
                        (double)N * (double)L, eps, chan, batch_mean, batch_var_unbiased, running_mean, running_var,
                        momentum);
     if ((rc = launch_status("fpsg_bn_act_pool_fwd(finalize)"))) return rc;
@@ -908,7 +917,7 @@ extern "C" int fpsg_bn_act_pool_bwd(const float* x, const float* pre_bias, const
   const int S = items < kBnSlices ? (int)items : kBnSlices;
   launch_pool_reduce(act, x, dy_pooled, chan, pre_bias, N, C, H, W, S, slope, ws, s);
   if ((rc = launch_status("fpsg_bn_act_pool_bwd(reduce)"))) return rc;
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, ws, chan, C, S,
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, s, ws, chan, C, S,
                      (double)N * (double)H * (double)W, training, dgamma, dbeta, coef);
   if ((rc = launch_status("fpsg_bn_act_pool_bwd(finalize)"))) return rc;
   float* dxpart = dpre_bias ? ws + (size_t)C * kBnSlices * 2 : nullptr;
@@ -945,7 +954,7 @@ extern "C" int fpsg_bn_act_max_fwd(const float* x, const float* pre_bias, const 
   if (training) {
     hipLaunchKernelGGL(bn_reduce_ext_kernel<1>, grid, dim3(kBnThreads), 0, s, x, pre_bias, N, C, L, S, ws, ext);
     if ((rc = launch_status("fpsg_bn_act_max_fwd(stats)"))) return rc;
-    hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, ws, gamma, beta, C, S,
+    hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3(C), dim3(64), 0, s, ws, gamma, beta, C, S,
                        (double)N * (double)L, eps, chan, batch_mean, batch_var_unbiased, running_mean, running_var,
                        momentum);
     if ((rc = launch_status("fpsg_bn_act_max_fwd(finalize)"))) return rc;
