@@ -227,6 +227,15 @@ int fpsg_wino_filter_transform(int m, const float* w, int K, int C, int flip_tra
                                fpsg_stream_t stream);
 int fpsg_wino_filter_grad_transform(int m, const float* dU, int K, int C, float* dw, fpsg_stream_t stream);
 
+/* K6 in one kernel for 64 input channels (F(4x4,3x3); conv1_2 / conv2_1 of the trunk and their data
+ * gradients): y [N,K,H,W] = conv(x [N,64,H,W], w) from U = fpsg_wino_filter_transform(4, w, ...)
+ * [36,K,64]; input transform, the 36 MFMA products and the output transform stay on chip -- with 64
+ * channels the separate GEMM is bound by the traffic of V and M (2 x 2.25 x the image tensor each
+ * way).  C must be 64, K a multiple of 16, H and W multiples of 4; x, y 16-byte aligned.
+ */
+int fpsg_wino_conv_fused(const float* x, const float* U, int N, int C, int K, int H, int W, float* y,
+                         fpsg_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

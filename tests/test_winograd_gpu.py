@@ -93,3 +93,38 @@ def test_deterministic(gpu, m):
 def test_tile_size_rule():
     from fpsg_amd.winograd import tile_size
     assert tile_size(56, 56) == 4 and tile_size(28, 28) == 4 and tile_size(14, 14) == 2 and tile_size(30, 28) == 2
+
+
+@pytest.mark.parametrize("shape", [(3, 64, 64, 32, 32), (2, 64, 128, 28, 36), (5, 64, 16, 8, 12), (1, 64, 64, 4, 4),
+                                   (37, 64, 64, 56, 56)])
+def test_fused_kernel_matches_three_kernel_form(gpu, shape, monkeypatch):
+    """K6f (fpsg_wino_conv_fused): same transforms, channel sum in the MFMA's k order -> agrees with
+    transform + GEMM + transform to fp32 round-off, forward and (where the output has 64 channels)
+    data gradient; the weight gradient rebuilds V from x."""
+    from fpsg_amd import winograd as wg
+    N, C, K, H, W = shape
+    torch.manual_seed(N + K)
+    x = torch.randn(N, C, H, W, device=gpu)
+    w = torch.randn(K, C, 3, 3, device=gpu) * (2.0 / (9 * C)) ** 0.5
+    g = torch.randn(N, K, H, W, device=gpu)
+    outs = {}
+    for fused in ("0", "1"):
+        monkeypatch.setenv("FPSG_WINOGRAD_FUSED", fused)
+        xi, wi = x.clone().requires_grad_(), w.clone().requires_grad_()
+        y = wg.conv3x3(xi, wi, 4)
+        y.backward(g)
+        outs[fused] = (y.detach(), xi.grad, wi.grad)
+    for a, b in zip(outs["0"], outs["1"]):
+        assert float((a - b).abs().max()) <= 2e-5 * float(a.abs().max()) + 1e-7
+    x64 = F.conv2d(x.double().cpu(), w.double().cpu(), None, 1, 1)
+    assert float((outs["1"][0].double().cpu() - x64).abs().max()) <= 4e-5 * float(x64.abs().max())
+
+
+def test_fused_kernel_argument_checks(gpu):
+    from fpsg_amd import _hip
+    lib = _hip.load()
+    x = torch.randn(1, 32, 8, 8, device=gpu)
+    U = torch.randn(36, 16, 32, device=gpu)
+    y = torch.empty(1, 16, 8, 8, device=gpu)
+    assert lib.fpsg_wino_conv_fused(_hip.ptr(x), _hip.ptr(U), 1, 32, 16, 8, 8, _hip.ptr(y), None) != 0      # C != 64
+    assert b"C must be 64" in lib.fpsg_last_error()
