@@ -1,0 +1,86 @@
+"""Host-side selection logic that needs no GPU: Winograd eligibility / tile-size rules, the
+transformed-filter cache's lifetime, GEMM-records plumbing, fused BatchNorm dispatch on CPU tensors."""
+import os
+
+import pytest
+import torch
+import torch.nn as nn
+
+
+def test_winograd_tile_and_width_rules(monkeypatch):
+    from fpsg_amd import winograd as wg
+    monkeypatch.delenv("FPSG_WINOGRAD_M", raising=False)
+    assert [wg.tile_size(s, s) for s in (224, 112, 56, 28, 14, 24, 30)] == [4, 4, 4, 4, 2, 2, 2]
+    monkeypatch.setenv("FPSG_WINOGRAD_M", "2")
+    assert wg.tile_size(224, 224) == 2
+    monkeypatch.delenv("FPSG_WINOGRAD_M")
+    # VGG16 at 224x224: every layer but conv1_1 (3 input channels) qualifies
+    plan = [(3, 64, 224), (64, 64, 224), (64, 128, 112), (128, 128, 112), (128, 256, 56), (256, 256, 56),
+            (256, 512, 28), (512, 512, 28), (512, 512, 14)]
+    got = [wg._wide_enough(c, k, wg.tile_size(h, h)) for c, k, h in plan]
+    assert got == [False] + [True] * 8
+    assert not wg._wide_enough(64, 128, 2) and wg._wide_enough(128, 256, 2)      # 2x2 tiles need wider layers
+
+
+def test_winograd_eligibility_needs_gpu_fp32_3x3(monkeypatch):
+    from fpsg_amd import winograd as wg
+    conv = nn.Conv2d(64, 64, 3, padding=1)
+    assert not wg.eligible(torch.randn(1, 64, 8, 8), conv)                        # CPU tensor
+    monkeypatch.setenv("FPSG_WINOGRAD", "0")
+    assert not wg.enabled()
+    monkeypatch.delenv("FPSG_WINOGRAD")
+    assert wg.enabled()
+    with pytest.raises(ValueError):
+        wg.conv3x3(torch.randn(1, 4, 8, 8), torch.randn(4, 5, 3, 3))
+    with pytest.raises(ValueError):
+        wg.conv3x3(torch.randn(1, 4, 6, 8), torch.randn(4, 4, 3, 3), 4)
+    monkeypatch.setenv("FPSG_WINOGRAD_FUSED", "0")
+    assert not wg._can_fuse(4, 64, 64)
+    monkeypatch.delenv("FPSG_WINOGRAD_FUSED")
+    assert wg._can_fuse(4, 64, 128) and not wg._can_fuse(4, 128, 64) and not wg._can_fuse(2, 64, 64)
+
+
+def test_filter_cache_lives_only_inside_weights_frozen():
+    from fpsg_amd import winograd as wg
+    assert wg._frozen_cache is None
+    with wg.weights_frozen():
+        assert wg._frozen_cache == {}
+        wg._frozen_cache["k"] = 1
+        with wg.weights_frozen():                       # nested: same cache
+            assert wg._frozen_cache == {"k": 1}
+        assert wg._frozen_cache == {"k": 1}
+    assert wg._frozen_cache is None
+
+
+def test_gemm_tuning_is_off_without_gpu_and_records_are_well_formed():
+    from fpsg_amd import gemm_tuning
+    if not torch.cuda.is_available():
+        assert gemm_tuning.enable() == {"gemm_tuning": "off"}
+    lines = open(gemm_tuning.DEFAULT_FILE).read().strip().splitlines()
+    validators = [l for l in lines if l.startswith("Validator,")]
+    records = [l for l in lines if not l.startswith("Validator,")]
+    assert {v.split(",")[1] for v in validators} >= {"PT_VERSION", "HIPBLASLT_VERSION", "ROCBLAS_VERSION", "GCN_ARCH_NAME"}
+    assert any("gfx950" in v for v in validators)
+    assert len(records) > 100
+    for r in records:
+        op, shape, solution = r.split(",")[:3]
+        assert op.startswith("Gemm") and "_" in shape
+        assert solution.startswith(("Gemm_Rocblas_", "Gemm_Hipblaslt_", "Default"))
+
+
+def test_fused_bn_helpers_run_the_plain_modules_on_cpu():
+    """CPU tensors (the CPU port used by the parity tests) take PyTorch's own modules: same values as
+    the module chain, including the max-over-points and pooled forms."""
+    from fpsg_amd.fused_bn import conv_bn_act, conv_bn_act_max, conv_bn_act_pool
+    torch.manual_seed(0)
+    conv1, bn1 = nn.Conv1d(8, 16, 1), nn.BatchNorm1d(16)
+    x = torch.randn(3, 8, 128)
+    import copy
+    c2, b2 = copy.deepcopy(conv1), copy.deepcopy(bn1)
+    assert torch.equal(conv_bn_act_max(conv1, bn1, x, "relu"), torch.relu(b2(c2(x))).max(dim=2)[0])
+    conv2, bn2, pool = nn.Conv2d(4, 6, 3, padding=1), nn.BatchNorm2d(6), nn.MaxPool2d(2, 2)
+    c3, b3 = copy.deepcopy(conv2), copy.deepcopy(bn2)
+    img = torch.randn(2, 4, 8, 8)
+    assert torch.equal(conv_bn_act_pool(conv2, bn2, pool, img, "relu"), pool(torch.relu(b3(c3(img)))))
+    c4, b4 = copy.deepcopy(c3), copy.deepcopy(b3)
+    assert torch.equal(conv_bn_act(c3, b3, img, ("leaky", 0.2)), torch.nn.functional.leaky_relu(b4(c4(img)), 0.2))
