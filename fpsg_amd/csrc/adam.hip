@@ -1,0 +1,83 @@
+// adam.hip -- K7: the optimizer step of the train loop as ONE HBM stream, for gfx950.
+//
+// Reference: torch.optim.Adam(lr, betas=(.9,.999)) stepped once per episode, src/trainNetwork.py:
+// 118-123 and 144 ("optimizer over 77 M params -- elementwise, HBM-bound").
+// The library's fused Adam is a multi-tensor launch over the model's ~600 separate parameter
+// tensors (10 chunked launches, 2.2 TB/s); with parameters, gradients and both moments each living
+// in one flat fp32 buffer (fpsg_amd/optim.py) the step is a single float4 grid-stride stream:
+//   g  = grad * grad_scale            (the mean over the step's episodes, folded in: no separate
+//                                      pass over the 310 MB gradient buffer)
+//   m  = m + (1-b1) * (g - m)         (torch: exp_avg.lerp_(grad, 1-b1))
+//   v  = b2 * v + (1-b2) * g * g
+//   p -= (lr / (1-b1^t)) * m / (sqrt(v) / sqrt(1-b2^t) + eps)
+// 4 reads + 3 writes of the buffer = 28 B per parameter (2.17 GB for the 77.4 M of the full model).
+#include "fpsg_common.h"
+
+namespace fpsg {
+namespace {
+
+constexpr int kAdamThreads = 256;
+
+__global__ __launch_bounds__(kAdamThreads) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                            float* __restrict__ m, float* __restrict__ v, size_t n4,
+                                                            size_t n, float step_size, float b1, float b2, float eps,
+                                                            float inv_sqrt_bc2, float gscale) {
+  const size_t stride = (size_t)gridDim.x * kAdamThreads;
+  const float omb1 = 1.0f - b1, omb2 = 1.0f - b2;
+  for (size_t i = (size_t)blockIdx.x * kAdamThreads + threadIdx.x; i < n4; i += stride) {
+    v4f pv = reinterpret_cast<const v4f*>(p)[i];
+    const v4f gv = reinterpret_cast<const v4f*>(g)[i];
+    v4f mv = reinterpret_cast<const v4f*>(m)[i];
+    v4f vv = reinterpret_cast<const v4f*>(v)[i];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float gg = gv[u] * gscale;
+      mv[u] = fma_rn(omb1, gg - mv[u], mv[u]);
+      vv[u] = fma_rn(omb2 * gg, gg, b2 * vv[u]);
+      const float denom = fma_rn(__fsqrt_rn(vv[u]), inv_sqrt_bc2, eps);
+      pv[u] = fma_rn(-step_size, mv[u] / denom, pv[u]);
+    }
+    reinterpret_cast<v4f*>(p)[i] = pv;
+    reinterpret_cast<v4f*>(m)[i] = mv;
+    reinterpret_cast<v4f*>(v)[i] = vv;
+  }
+  // tail (n not a multiple of 4)
+  if (blockIdx.x == 0) {
+    for (size_t i = n4 * 4 + threadIdx.x; i < n; i += kAdamThreads) {
+      const float gg = g[i] * gscale;
+      const float mm = fma_rn(omb1, gg - m[i], m[i]);
+      const float vq = fma_rn(omb2 * gg, gg, b2 * v[i]);
+      const float denom = fma_rn(__fsqrt_rn(vq), inv_sqrt_bc2, eps);
+      p[i] = fma_rn(-step_size, mm / denom, p[i]);
+      m[i] = mm;
+      v[i] = vq;
+    }
+  }
+}
+
+}  // namespace
+}  // namespace fpsg
+
+extern "C" int fpsg_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, float lr,
+                              float beta1, float beta2, float eps, int step, float grad_scale, fpsg_stream_t stream) {
+  using namespace fpsg;
+  FPSG_REQUIRE(n > 0 && step >= 1, FPSG_E_SHAPE, "fpsg_adam_step: n must be positive and step >= 1 (got %zu, %d)", n, step);
+  FPSG_REQUIRE(beta1 >= 0.0f && beta1 < 1.0f && beta2 >= 0.0f && beta2 < 1.0f && eps >= 0.0f, FPSG_E_SHAPE,
+               "fpsg_adam_step: betas must lie in [0,1) and eps be non-negative");
+  FPSG_REQUIRE_PTR(param); FPSG_REQUIRE_PTR(grad); FPSG_REQUIRE_PTR(exp_avg); FPSG_REQUIRE_PTR(exp_avg_sq);
+  FPSG_REQUIRE(((reinterpret_cast<uintptr_t>(param) | reinterpret_cast<uintptr_t>(grad) |
+                 reinterpret_cast<uintptr_t>(exp_avg) | reinterpret_cast<uintptr_t>(exp_avg_sq)) & 15) == 0,
+               FPSG_E_ALIGN, "fpsg_adam_step: the four buffers must be 16-byte aligned");
+  // bias corrections in double, as torch does for python-scalar steps
+  const double bc1 = 1.0 - pow((double)beta1, (double)step);
+  const double bc2 = 1.0 - pow((double)beta2, (double)step);
+  const float step_size = (float)((double)lr / bc1);
+  const float inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+  const size_t n4 = n / 4;
+  size_t blocks = (n4 + kAdamThreads - 1) / kAdamThreads;
+  if (blocks > 256 * 16) blocks = 256 * 16;        // grid-stride: 16 workgroups per CU
+  if (blocks == 0) blocks = 1;
+  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(kAdamThreads), 0, static_cast<hipStream_t>(stream), param,
+                     grad, exp_avg, exp_avg_sq, n4, n, step_size, beta1, beta2, eps, inv_sqrt_bc2, grad_scale);
+  return launch_status("fpsg_adam_step");
+}

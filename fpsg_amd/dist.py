@@ -84,7 +84,7 @@ class FlatGradBuckets:
         self._bucket_size: list[int] = []
         off, start, count = 0, 0, 0
         self.views: dict[int, torch.Tensor] = {}
-        for p in reversed(params):
+        for p in reversed(params):               # the layout of fpsg_amd.optim.flat_layout
             n = p.numel()
             # same memory format as the parameter (e.g. channels_last conv weights): the fused
             # optimizer requires param and grad layouts to match

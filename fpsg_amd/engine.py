@@ -18,6 +18,7 @@ from . import dist as fdist
 from . import winograd
 from .few_shot import ImgPCProtoNet
 from .image_net import ImageEncoderWarpper
+from .optim import FlatAdam
 from .point_cloud_net import PCDecoder, PCEncoder
 
 
@@ -55,8 +56,12 @@ def build_optimizer(model, opt):
     (``trainNetwork.py:118-130``)."""
     on_gpu = next(model.parameters()).is_cuda
     if not opt.SGD:
-        optimizer = optim.Adam(model.parameters(), lr=opt.lr, betas=(0.9, 0.999),
-                               **({"fused": True} if on_gpu else {}))
+        if on_gpu and os.environ.get("FPSG_FLAT_ADAM", "1") != "0":
+            # K7: parameters, gradients and moments in flat buffers, the step is one HBM stream
+            optimizer = FlatAdam(model.parameters(), lr=opt.lr, betas=(0.9, 0.999))
+        else:
+            optimizer = optim.Adam(model.parameters(), lr=opt.lr, betas=(0.9, 0.999),
+                                   **({"fused": True} if on_gpu else {}))
     else:
         optimizer = optim.SGD(model.parameters(), lr=opt.lr, weight_decay=1e-2)
     scheduler = optim.lr_scheduler.StepLR(optimizer, step_size=int(opt.lr_decay), gamma=0.5)
@@ -85,6 +90,8 @@ class TrainStep:
     def __init__(self, model, optimizer, world: int = 1, bucket_mb: float = 80.0, graph: bool = False):
         self.model, self.optimizer, self.world = model, optimizer, world
         self.buckets = fdist.FlatGradBuckets(model, bucket_mb=bucket_mb)
+        if isinstance(optimizer, FlatAdam):
+            optimizer.bind_gradients(self.buckets.flat)      # same layout: the step reads it in place
         self.use_graph = bool(graph) and next(model.parameters()).is_cuda
         self._graphs = {}
         self._eager_runs = {}

@@ -236,6 +236,17 @@ int fpsg_wino_filter_grad_transform(int m, const float* dU, int K, int C, float*
 int fpsg_wino_conv_fused(const float* x, const float* U, int N, int C, int K, int H, int W, float* y,
                          fpsg_stream_t stream);
 
+/* ---- K7: Adam step over flat buffers ---------------------------------------------------------
+ * Replaces torch.optim.Adam(lr, betas=(.9,.999)).step() of the train loop (src/trainNetwork.py:
+ * 118-123, 144) when parameters, gradients and the two moments each live in one flat fp32 buffer
+ * of n elements (fpsg_amd/optim.py): one 4-read / 3-write stream.  step = 1 for the first update
+ * (bias corrections 1 - beta^step); grad_scale multiplies the gradient first (1/E for the mean
+ * over the E episodes of a step).  amsgrad, weight decay and maximize are not part of the reference
+ * configuration and not provided.  Buffers 16-byte aligned.
+ */
+int fpsg_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, float lr,
+                   float beta1, float beta2, float eps, int step, float grad_scale, fpsg_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

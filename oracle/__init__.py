@@ -234,3 +234,17 @@ def sinkhorn_divergence(x, y, blur=0.05, scaling=0.5, softmin_fn=None):
     a_y, b_x = sm(y, x, a_log + b_x / e, e), sm(x, y, b_log + a_y / e, e)
     a_x, b_y = sm(x, x, a_log + a_x / e, e), sm(y, y, b_log + b_y / e, e)
     return ((b_x - a_x).mean(1) + (a_y - b_y).mean(1)).astype(np.float32)
+
+
+def adam_step(p, g, m, v, t, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8):
+    """One step of ``torch.optim.Adam`` as the reference configures it (``src/trainNetwork.py:118-123``:
+    ``optim.Adam(model.parameters(), lr=opt.lr, betas=(.9, .999))``, no weight decay / amsgrad), in
+    float64 numpy, following the algorithm in the class's documentation:
+    ``m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;  p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps)``.
+    ``t`` counts from 1.  Returns the new ``(p, m, v)``."""
+    p, g, m, v = (np.asarray(a, dtype=np.float64) for a in (p, g, m, v))
+    m = beta1 * m + (1.0 - beta1) * g
+    v = beta2 * v + (1.0 - beta2) * g * g
+    step_size = lr / (1.0 - beta1 ** t)
+    denom = np.sqrt(v) / np.sqrt(1.0 - beta2 ** t) + eps
+    return p - step_size * m / denom, m, v

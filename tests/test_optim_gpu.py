@@ -1,0 +1,121 @@
+"""K7 (fpsg_adam_step through fpsg_amd.optim.FlatAdam) against torch.optim.Adam -- the optimizer the
+reference constructs at src/trainNetwork.py:118-123 -- and the float64 oracle: parameters and moments
+over several steps with a StepLR decay in between, state-dict round trip, flat-buffer plumbing."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+pytestmark = pytest.mark.gpu
+
+
+def _net():
+    torch.manual_seed(0)
+    # no BatchNorm behind a biased convolution: such a bias has a round-off gradient, which Adam's
+    # normalisation turns into +-lr steps that no two runs share
+    return nn.Sequential(nn.Conv1d(3, 37, 1), nn.Tanh(), nn.Conv1d(37, 5, 1), nn.Flatten(), nn.Linear(5 * 31, 7))
+
+
+def _loss(net, x):
+    return net(x).square().mean()
+
+
+def test_matches_torch_adam_over_steps(gpu):
+    from fpsg_amd.optim import FlatAdam
+    a, b = _net().to(gpu), None
+    b = copy.deepcopy(a)
+    opt_a = FlatAdam(a.parameters(), lr=3e-3, betas=(0.9, 0.999))
+    opt_b = torch.optim.Adam(b.parameters(), lr=3e-3, betas=(0.9, 0.999))
+    sched_a = torch.optim.lr_scheduler.StepLR(opt_a, step_size=3, gamma=0.5)
+    sched_b = torch.optim.lr_scheduler.StepLR(opt_b, step_size=3, gamma=0.5)
+    # parameters now live in one flat buffer, values untouched
+    flat = opt_a.flat_param
+    for p in a.parameters():
+        assert flat.data_ptr() <= p.data_ptr() < flat.data_ptr() + flat.numel() * 4
+    for pa, pb in zip(a.parameters(), b.parameters()):
+        assert torch.equal(pa, pb)
+    torch.manual_seed(1)
+    for it in range(8):
+        x = torch.randn(16, 3, 31, device=gpu)
+        for net, opt, sched in ((a, opt_a, sched_a), (b, opt_b, sched_b)):
+            opt.zero_grad(set_to_none=True)
+            _loss(net, x).backward()
+            opt.step()
+            sched.step()
+        for pa, pb in zip(a.parameters(), b.parameters()):
+            assert torch.allclose(pa, pb, rtol=2e-5, atol=2e-7), (it, float((pa - pb).abs().max()))
+    assert opt_a.param_groups[0]["lr"] == opt_b.param_groups[0]["lr"] == 3e-3 * 0.25
+    for pa, pb in zip(a.parameters(), b.parameters()):
+        sa, sb = opt_a.state[pa], opt_b.state[pb]
+        assert float(sa["step"].detach()) == float(sb["step"].detach()) == 8
+        # eight steps of fp32 recurrences on gradients that already differ in the last digits
+        assert torch.allclose(sa["exp_avg"], sb["exp_avg"], rtol=2e-4, atol=1e-9)
+        assert torch.allclose(sa["exp_avg_sq"], sb["exp_avg_sq"], rtol=2e-4, atol=1e-12)
+
+
+def test_kernel_against_float64_oracle(gpu, oracle):
+    from fpsg_amd import _hip
+    lib = _hip.load()
+    rng = np.random.default_rng(3)
+    n = 100003                                               # not a multiple of 4: the tail path
+    p = rng.standard_normal(n).astype(np.float32); g = (rng.standard_normal(n) * 0.1).astype(np.float32)
+    m = (rng.standard_normal(n) * 0.05).astype(np.float32); v = (rng.random(n) * 0.01).astype(np.float32)
+    tp, tg, tm, tv = (torch.from_numpy(a.copy()).to(gpu) for a in (p, g, m, v))
+    for t, scale in ((1, 1.0), (7, 0.125), (1000, 1.0)):
+        rp, rm, rv = oracle.adam_step(p, g * np.float32(scale), m, v, t, lr=2e-3)
+        qp, qm, qv = tp.clone(), tm.clone(), tv.clone()
+        rc = lib.fpsg_adam_step(_hip.ptr(qp), _hip.ptr(tg), _hip.ptr(qm), _hip.ptr(qv), n, 2e-3, 0.9, 0.999, 1e-8, t,
+                                scale, None)
+        assert rc == 0
+        for got, want in ((qp, rp), (qm, rm), (qv, rv)):
+            err = np.abs(got.cpu().numpy().astype(np.float64) - want)
+            assert float(err.max()) <= 1e-6 * float(np.abs(want).max()) + 1e-9
+    assert lib.fpsg_adam_step(_hip.ptr(tp), _hip.ptr(tg), _hip.ptr(tm), _hip.ptr(tv), n, 1e-3, 0.9, 0.999, 1e-8, 0, 1.0, None) != 0
+    assert lib.fpsg_adam_step(_hip.ptr(tp), None, _hip.ptr(tm), _hip.ptr(tv), n, 1e-3, 0.9, 0.999, 1e-8, 1, 1.0, None) != 0
+
+
+def test_state_dict_round_trip_and_resume(gpu):
+    from fpsg_amd.optim import FlatAdam
+    a = _net().to(gpu)
+    opt = FlatAdam(a.parameters(), lr=1e-3)
+    x = torch.randn(8, 3, 31, device=gpu)
+    for _ in range(3):
+        opt.zero_grad(set_to_none=True); _loss(a, x).backward(); opt.step()
+    sd = copy.deepcopy(opt.state_dict())
+    weights = copy.deepcopy(a.state_dict())
+    opt.zero_grad(set_to_none=True); _loss(a, x).backward(); opt.step()
+    after = [p.detach().clone() for p in a.parameters()]
+    # a fresh model + optimizer resumed from the saved state takes the identical 4th step
+    b = _net().to(gpu)
+    b.load_state_dict(weights)
+    opt_b = FlatAdam(b.parameters(), lr=1e-3)
+    opt_b.load_state_dict(sd)
+    assert opt_b._t == 3
+    opt_b.zero_grad(set_to_none=True); _loss(b, x).backward(); opt_b.step()
+    for pa, pb in zip(after, b.parameters()):
+        assert torch.equal(pa, pb)
+    # a torch.optim.Adam state dict loads too (same per-parameter entries)
+    c = _net().to(gpu); c.load_state_dict(weights)
+    ref = torch.optim.Adam(c.parameters(), lr=1e-3)
+    ref.load_state_dict(sd)
+    assert float(ref.state[next(iter(c.parameters()))]["step"]) == 3
+
+
+def test_train_step_uses_the_flat_gradient_buffer_in_place(gpu):
+    from fpsg_amd.engine import TrainStep, build_model, build_optimizer, default_options
+    from fpsg_amd.episodes import synthetic_episode
+    from fpsg_amd.optim import FlatAdam
+    torch.manual_seed(0)
+    opt = default_options(device="cuda", intra_recon=True)
+    m = build_model(opt).to(gpu).train()
+    optimizer, _ = build_optimizer(m, opt)
+    assert isinstance(optimizer, FlatAdam)
+    step = TrainStep(m, optimizer)
+    assert optimizer._bound is step.buckets.flat
+    before = optimizer.flat_param.clone()
+    ep = synthetic_episode(2, 1, n_pts=2048, img_size=64, seed=3, device=gpu)
+    step([ep, ep])
+    assert optimizer._flat_gradient() is step.buckets.flat and optimizer._gather is None
+    assert not torch.equal(before, optimizer.flat_param) and bool(torch.isfinite(optimizer.flat_param).all())
