@@ -103,8 +103,11 @@ def _reverse_graph(idx32: torch.Tensor):
     inside a group, so the backward's summation order is fixed): ``rev [B,N*k]`` int32 and
     ``off [B,N+1]`` int32."""
     B, N, k = idx32.shape
-    vals, order = torch.sort(idx32.reshape(B, N * k), dim=1, stable=True)
-    bounds = torch.arange(N + 1, device=idx32.device, dtype=vals.dtype).expand(B, N + 1).contiguous()
+    keys = idx32.reshape(B, N * k)
+    if N < 32768:
+        keys = keys.to(torch.int16)          # two radix passes instead of four (0.17 vs 0.23 ms at 64 x 40960)
+    vals, order = torch.sort(keys, dim=1, stable=True)
+    bounds = torch.arange(N + 1, device=idx32.device, dtype=torch.int32).to(vals.dtype).expand(B, N + 1).contiguous()
     off = torch.searchsorted(vals.contiguous(), bounds)
     return order.to(torch.int32).contiguous(), off.to(torch.int32).contiguous()
 
