@@ -63,6 +63,8 @@ SIGNATURES = {
     "fpsg_wino_filter_transform": [_c_int, _c_f32p, _c_int, _c_int, _c_int, _c_f32p, _c_stream],
     "fpsg_wino_filter_grad_transform": [_c_int, _c_f32p, _c_int, _c_int, _c_f32p, _c_stream],
     "fpsg_wino_conv_fused": [_c_f32p, _c_f32p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_f32p, _c_stream],
+    "fpsg_conv_first_dw_workspace_floats": [_c_int, _c_int, _c_int],
+    "fpsg_conv_first_dw": [_c_f32p, _c_f32p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_f32p, _c_f32p, _c_stream],
     "fpsg_adam_step": [_c_f32p, _c_f32p, _c_f32p, _c_f32p, ctypes.c_size_t, ctypes.c_float, ctypes.c_float,
                        ctypes.c_float, ctypes.c_float, _c_int, ctypes.c_float, _c_stream],
     "fpsg_emd_workspace_floats": [_c_int, _c_int, _c_int],
@@ -70,7 +72,7 @@ SIGNATURES = {
                         _c_stream],
 }
 _RESTYPES = {"fpsg_last_error": ctypes.c_char_p, "fpsg_chamfer_set_config": None,
-             "fpsg_bn_workspace_floats": ctypes.c_size_t, "fpsg_bn_pool_workspace_floats": ctypes.c_size_t, "fpsg_bn_max_workspace_floats": ctypes.c_size_t, "fpsg_emd_workspace_floats": ctypes.c_size_t}
+             "fpsg_bn_workspace_floats": ctypes.c_size_t, "fpsg_bn_pool_workspace_floats": ctypes.c_size_t, "fpsg_bn_max_workspace_floats": ctypes.c_size_t, "fpsg_conv_first_dw_workspace_floats": ctypes.c_size_t, "fpsg_emd_workspace_floats": ctypes.c_size_t}
 
 _lib = None
 _lock = threading.Lock()

@@ -23,7 +23,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import _hip, winograd
+from . import _hip, conv_first, winograd
 
 _ACT_CODES = {None: 0, "none": 0, "relu": 1, "leaky": 2}
 _MIN_ROW = 64
@@ -260,6 +260,8 @@ def _conv_without_bias(conv, x):
     library convolution otherwise."""
     if isinstance(conv, nn.Conv2d) and winograd.eligible(x, conv):
         return winograd.conv3x3(x, conv.weight)
+    if isinstance(conv, nn.Conv2d) and conv_first.eligible(x, conv):
+        return conv_first.conv3x3_first(x, conv.weight)          # library forward, K8 weight gradient
     if _is_pointwise(conv) and x.is_cuda and x.dim() == 3 and conv.in_channels >= 32:
         w = conv.weight.squeeze(-1)                               # [K, C]
         return torch.bmm(w.unsqueeze(0).expand(x.shape[0], -1, -1), x)

@@ -236,6 +236,17 @@ int fpsg_wino_filter_grad_transform(int m, const float* dU, int K, int C, float*
 int fpsg_wino_conv_fused(const float* x, const float* U, int N, int C, int K, int H, int W, float* y,
                          fpsg_stream_t stream);
 
+/* ---- K8: weight gradient of the first VGG convolution (3 -> 64 channels, 3x3, padding 1) ------
+ * vgg16_bn.features[0] of src/models/image_net.py:14 in the backward of the train step:
+ * dw [64,3,3,3] = sum over (n,h,w) of dy[n,k,h,w] * x[n,c,h+a-1,w+b-1], x [N,3,H,W], dy [N,64,H,W]
+ * (W a multiple of 4, dy 16-byte aligned).  dy is read once (LDS-staged tiles feeding fp32 MFMA),
+ * the workgroups' partial sums are reduced in a fixed order: HBM-bound, deterministic.
+ * ws: fpsg_conv_first_dw_workspace_floats(N,H,W) floats.
+ */
+size_t fpsg_conv_first_dw_workspace_floats(int N, int H, int W);
+int fpsg_conv_first_dw(const float* x, const float* dy, int N, int C, int K, int H, int W, float* dw, float* ws,
+                       fpsg_stream_t stream);
+
 /* ---- K7: Adam step over flat buffers ---------------------------------------------------------
  * Replaces torch.optim.Adam(lr, betas=(.9,.999)).step() of the train loop (src/trainNetwork.py:
  * 118-123, 144) when parameters, gradients and the two moments each live in one flat fp32 buffer

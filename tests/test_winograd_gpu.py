@@ -128,3 +128,32 @@ def test_fused_kernel_argument_checks(gpu):
     y = torch.empty(1, 16, 8, 8, device=gpu)
     assert lib.fpsg_wino_conv_fused(_hip.ptr(x), _hip.ptr(U), 1, 32, 16, 8, 8, _hip.ptr(y), None) != 0      # C != 64
     assert b"C must be 64" in lib.fpsg_last_error()
+
+
+@pytest.mark.parametrize("shape", [(2, 8, 8), (3, 30, 36), (5, 64, 64), (2, 224, 224), (37, 56, 100)])
+def test_first_layer_weight_gradient(gpu, shape):
+    """K8 (fpsg_conv_first_dw): dw of the 3 -> 64 channel first convolution against conv2d's own
+    weight gradient in float64 and against the library's fp32 result."""
+    from fpsg_amd.conv_first import conv3x3_first
+    N, H, W = shape
+    torch.manual_seed(N + H)
+    x = torch.randn(N, 3, H, W)
+    w = torch.randn(64, 3, 3, 3) * 0.2
+    g = torch.randn(N, 64, H, W)
+    w64 = w.double().requires_grad_()
+    F.conv2d(x.double(), w64, None, 1, 1).backward(g.double())
+    wg = w.to(gpu).requires_grad_()
+    y = conv3x3_first(x.to(gpu), wg)
+    y.backward(g.to(gpu))
+    wl = w.to(gpu).requires_grad_()
+    yl = F.conv2d(x.to(gpu), wl, None, 1, 1)
+    yl.backward(g.to(gpu))
+    assert torch.equal(y, yl)
+    scale = float(w64.grad.abs().max())
+    e_ours = float((wg.grad.double().cpu() - w64.grad).abs().max()) / scale
+    e_lib = float((wl.grad.double().cpu() - w64.grad).abs().max()) / scale
+    assert e_ours <= 1e-5 and e_ours <= max(4 * e_lib, 2e-6), (shape, e_ours, e_lib)
+    # deterministic
+    wg2 = w.to(gpu).requires_grad_()
+    conv3x3_first(x.to(gpu), wg2).backward(g.to(gpu))
+    assert torch.equal(wg.grad, wg2.grad)
