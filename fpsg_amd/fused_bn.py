@@ -262,7 +262,7 @@ def _conv_without_bias(conv, x):
         return winograd.conv3x3(x, conv.weight)
     if isinstance(conv, nn.Conv2d) and conv_first.eligible(x, conv):
         return conv_first.conv3x3_first(x, conv.weight)          # library forward, K8 weight gradient
-    if _is_pointwise(conv) and x.is_cuda and x.dim() == 3 and conv.in_channels >= 32:
+    if _is_pointwise(conv) and x.is_cuda and x.dim() == 3:
         w = conv.weight.squeeze(-1)                               # [K, C]
         return torch.bmm(w.unsqueeze(0).expand(x.shape[0], -1, -1), x)
     return conv._conv_forward(x, conv.weight, None)
