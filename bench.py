@@ -289,6 +289,7 @@ def main():
                        "params": sum(p.numel() for p in model.parameters()),
                        "hip_graph": bool(args.graph), **gemm_info},
             "final_loss": loss,
+            "hbm_peak_allocated_gb": round(torch.cuda.max_memory_allocated(device) / 1e9, 2),
         }
         if n_l:
             achieved_flops = flops / sec
