@@ -17,7 +17,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .fused_bn import bn_act, conv_bn_act, conv_bn_act_max
+from .fused_bn import conv_bn_act, conv_bn_act_max
 
 
 class _PointTrunk(nn.Module):
