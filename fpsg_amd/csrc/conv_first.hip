@@ -87,16 +87,24 @@ __global__ __launch_bounds__(kFirstThreads) void conv_first_dw_kernel(const floa
     for (int r = 0; r < 4; ++r) pp[(16 * wave + 4 * kk + r) * 32 + 16 * nt + col] = acc[nt][r];
 }
 
-// dw[k][tap] (tap = 9c + 3a + b < 27) = sum of the workgroups' partials, fixed order, fp64
-__global__ __launch_bounds__(64) void conv_first_dw_reduce_kernel(const float* __restrict__ part, int n_part,
-                                                                  float* __restrict__ dw /*[64][27]*/) {
-  const int e = blockIdx.x;                       // one wave per output element
-  const int k = e / 27, tap = e - 27 * k;
+// dw[k][tap] (tap = 9c + 3a + b < 27) = sum of the workgroups' partials in a fixed order, fp64.
+// One workgroup per output channel k: thread (g, tap) sums the partials p = g, g+32, ... (each
+// (p, k) row of 32 taps is one 128-byte read), the 32 groups are combined through LDS in order.
+__global__ __launch_bounds__(1024) void conv_first_dw_reduce_kernel(const float* __restrict__ part, int n_part,
+                                                                    float* __restrict__ dw /*[64][27]*/) {
+  __shared__ double acc[32][32];
+  const int k = blockIdx.x, tap = threadIdx.x & 31, g = threadIdx.x >> 5;
   double a = 0.0;
-  for (int p = threadIdx.x; p < n_part; p += 64) a += (double)part[((size_t)p * 64 + k) * 32 + tap];
+#pragma unroll 8
+  for (int p = g; p < n_part; p += 32) a += (double)part[((size_t)p * 64 + k) * 32 + tap];
+  acc[g][tap] = a;
+  __syncthreads();
+  if (g == 0 && tap < 27) {
+    double t = acc[0][tap];
 #pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) a += __shfl_down(a, off, 64);
-  if (threadIdx.x == 0) dw[e] = (float)a;
+    for (int q = 1; q < 32; ++q) t += acc[q][tap];
+    dw[k * 27 + tap] = (float)t;
+  }
 }
 
 }  // namespace
@@ -104,7 +112,7 @@ __global__ __launch_bounds__(64) void conv_first_dw_reduce_kernel(const float* _
 
 extern "C" size_t fpsg_conv_first_dw_workspace_floats(int N, int H, int W) {
   if (N <= 0 || H <= 0 || W <= 0) return 0;
-  return (size_t)1024 * 64 * 32;
+  return (size_t)2048 * 64 * 32;
 }
 
 extern "C" int fpsg_conv_first_dw(const float* x, const float* dy, int N, int C, int K, int H, int W, float* dw,
@@ -118,10 +126,10 @@ extern "C" int fpsg_conv_first_dw(const float* x, const float* dy, int N, int C,
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int segs_per_row = (W + kPx - 1) / kPx;
   const long n_segs = (long)N * H * segs_per_row;
-  const int blocks = n_segs < 1024 ? (int)n_segs : 1024;
+  const int blocks = n_segs < 2048 ? (int)n_segs : 2048;   // 8 workgroups per CU: staging of one overlaps the MFMAs of others
   hipLaunchKernelGGL(conv_first_dw_kernel, dim3(blocks), dim3(kFirstThreads), 0, s, x, dy, H, W, segs_per_row, n_segs, ws);
   int rc = launch_status("fpsg_conv_first_dw(partials)");
   if (rc) return rc;
-  hipLaunchKernelGGL(conv_first_dw_reduce_kernel, dim3(64 * 27), dim3(64), 0, s, ws, blocks, dw);
+  hipLaunchKernelGGL(conv_first_dw_reduce_kernel, dim3(64), dim3(1024), 0, s, ws, blocks, dw);
   return launch_status("fpsg_conv_first_dw(reduce)");
 }
