@@ -157,3 +157,31 @@ def test_first_layer_weight_gradient(gpu, shape):
     wg2 = w.to(gpu).requires_grad_()
     conv3x3_first(x.to(gpu), wg2).backward(g.to(gpu))
     assert torch.equal(wg.grad, wg2.grad)
+
+
+@pytest.mark.parametrize("layer", [(64, 64, 224), (64, 128, 112), (128, 128, 112), (256, 256, 56), (512, 512, 28), (512, 512, 14)])
+def test_full_size_layers_against_the_library_and_linearity(gpu, layer):
+    """The VGG16 layer shapes of the BASELINE workload (37 images = 32 support + 5 query): K6 / K6f
+    forward and both gradients against the library convolution, and linearity in the input,
+    conv(a*x1 + x2) = a*conv(x1) + conv(x2) -- a size-independent property of every path."""
+    from fpsg_amd import winograd as wg
+    C, K, H = layer
+    N = 37
+    torch.manual_seed(C + H)
+    x1 = torch.randn(N, C, H, H, device=gpu)
+    x2 = torch.randn(N, C, H, H, device=gpu)
+    w = (torch.randn(K, C, 3, 3, device=gpu) * (2.0 / (9 * C)) ** 0.5)
+    xa, wa = x1.clone().requires_grad_(), w.clone().requires_grad_()
+    xb, wb = x1.clone().requires_grad_(), w.clone().requires_grad_()
+    ya = wg.conv3x3(xa, wa)
+    yb = F.conv2d(xb, wb, None, 1, 1)
+    scale = float(yb.abs().max())
+    assert float((ya - yb).abs().max()) <= 6e-5 * scale
+    g = torch.randn_like(yb)
+    ya.backward(g); yb.backward(g)
+    assert float((xa.grad - xb.grad).abs().max()) <= 6e-5 * float(xb.grad.abs().max())
+    assert float((wa.grad - wb.grad).abs().max()) <= 1e-4 * float(wb.grad.abs().max())
+    with torch.no_grad():
+        lhs = wg.conv3x3(1.5 * x1 + x2, w)
+        rhs = 1.5 * wg.conv3x3(x1, w) + wg.conv3x3(x2, w)
+    assert float((lhs - rhs).abs().max()) <= 6e-5 * float(rhs.abs().max())
