@@ -607,32 +607,32 @@ __device__ __forceinline__ void ext_merge(float& vmax, int& imax, float& vmin, i
   if (omin < vmin || (omin == vmin && oimin < imin)) { vmin = omin; imin = oimin; }
 }
 
-// grid (S, C): block (s, c) takes the (n, seg) items s, s + S, ... of channel c; per item it also
-// writes the extremes of the segment.  STATS = 0 (eval mode): extremes only.
+// grid (S, C): wave w of block (s, c) takes the (n, seg) items 4s + w, 4s + w + 4S, ... of channel c
+// (a 2048-point row is 8 KB: a wave streams it with 8 vector loads per lane and reduces the
+// extremes with shuffles, no LDS, no barrier); the block's sums go to part[c][s].
+// STATS = 0 (eval mode): extremes only.
 template <int STATS>
 __global__ __launch_bounds__(kBnThreads) void bn_reduce_ext_kernel(const float* __restrict__ x,
                                                                    const float* __restrict__ pb, int N, int C, int L,
                                                                    int S, float* __restrict__ part /*[C][S][2]*/,
                                                                    RowExt* __restrict__ ext /*[N*C][segs]*/) {
   __shared__ float red[8];
-  __shared__ float smax[4], smin[4];
-  __shared__ int simax[4], simin[4];
   const int c = blockIdx.y, s = blockIdx.x;
   const int segs = (L + kBnSeg - 1) / kBnSeg;
   const int items = N * segs;
   const float b = pb ? pb[c] : 0.0f;
   float a0 = 0.0f, a1 = 0.0f;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  for (int it = s; it < items; it += S) {
+  for (int it = 4 * s + wave; it < items; it += 4 * S) {
     const int n = it / segs, seg = it - n * segs;
     const size_t base = ((size_t)n * C + c) * L + (size_t)seg * kBnSeg;
     const int len = (L - seg * kBnSeg) < kBnSeg ? (L - seg * kBnSeg) : kBnSeg;
     float vmax = -INFINITY, vmin = INFINITY;
     int imax = 0x7fffffff, imin = 0x7fffffff;
-    // ascending positions per thread: strict compares keep the first occurrence
+    // ascending positions per lane: strict compares keep the first occurrence
     if ((L & 3) == 0) {
       const v4f* __restrict__ xp = reinterpret_cast<const v4f*>(x + base);
-      for (int e = threadIdx.x; e < len / 4; e += kBnThreads) {
+      for (int e = lane; e < len / 4; e += 64) {
         const v4f q = xp[e];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -643,7 +643,7 @@ __global__ __launch_bounds__(kBnThreads) void bn_reduce_ext_kernel(const float* 
         }
       }
     } else {
-      for (int e = threadIdx.x; e < len; e += kBnThreads) {
+      for (int e = lane; e < len; e += 64) {
         const float xv = x[base + e] + b;
         if (STATS) { a0 += xv; a1 = fma_rn(xv, xv, a1); }
         if (xv > vmax) { vmax = xv; imax = seg * kBnSeg + e; }
@@ -654,18 +654,12 @@ __global__ __launch_bounds__(kBnThreads) void bn_reduce_ext_kernel(const float* 
     for (int off = 32; off >= 1; off >>= 1)
       ext_merge(vmax, imax, vmin, imin, __shfl_down(vmax, off, 64), __shfl_down(imax, off, 64),
                 __shfl_down(vmin, off, 64), __shfl_down(imin, off, 64));
-    __syncthreads();                                             // the previous item's reads of smax[] are done
-    if (lane == 0) { smax[wave] = vmax; simax[wave] = imax; smin[wave] = vmin; simin[wave] = imin; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-#pragma unroll
-      for (int w = 1; w < 4; ++w) ext_merge(vmax, imax, vmin, imin, smax[w], simax[w], smin[w], simin[w]);
+    if (lane == 0) {
       RowExt r; r.vmax = vmax; r.vmin = vmin; r.imax = imax; r.imin = imin;
       ext[((size_t)n * C + c) * segs + seg] = r;
     }
   }
   if (STATS) {
-    __syncthreads();
     block_reduce2(a0, a1, red);
     if (threadIdx.x == 0) {
       part[((size_t)c * S + s) * 2 + 0] = a0;
@@ -948,7 +942,9 @@ extern "C" int fpsg_bn_act_max_fwd(const float* x, const float* pre_bias, const 
   FPSG_REQUIRE_PTR(x); FPSG_REQUIRE_PTR(out); FPSG_REQUIRE_PTR(idx); FPSG_REQUIRE_PTR(chan); FPSG_REQUIRE_PTR(ws);
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int segs = (L + kBnSeg - 1) / kBnSeg;
-  const int S = slices_for(N, L);
+  // one item per WAVE and pass: S workgroups of 4 waves per channel
+  const int items_max = N * segs;
+  const int S = items_max >= 4 * kBnSlices ? kBnSlices : (items_max + 3) / 4;
   RowExt* ext = reinterpret_cast<RowExt*>(ws + (size_t)C * kBnSlices * 2);
   dim3 grid(S, C);
   if (training) {

@@ -256,9 +256,9 @@ def test_max_variant_matches_unfused_chain(gpu, shape, act, mode):
     y1 = conv_bn_act_max(conv, bn, x1, act)
     y2 = conv_bn_act(conv2, bn2, x2, act).max(dim=2)[0]
     assert y1.shape == (N, C)
-    # same statistics arithmetic as the sliced K5 path (N*L > 16384); the one-launch small path of
-    # the unfused op sums in another order
-    same_stats = mode == "eval" or N * L > 16384
+    # eval mode: same statistics, bit-equal outputs; training mode: the statistics pass of the max
+    # variant groups its partial sums differently (several rows per workgroup)
+    same_stats = mode == "eval"
     if same_stats:
         assert torch.equal(y1, y2)
         assert torch.equal(bn.running_mean, bn2.running_mean) and torch.equal(bn.running_var, bn2.running_var)
