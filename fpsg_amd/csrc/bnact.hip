@@ -285,25 +285,62 @@ __global__ __launch_bounds__(kBnThreads) void bn_small_kernel(
     const float* __restrict__ beta, const float* __restrict__ pb, int N, int C, int L, int training, float eps,
     float slope, float* __restrict__ out, float* __restrict__ chan, float* __restrict__ batch_mean,
     float* __restrict__ batch_var_unbiased, float* __restrict__ dgamma, float* __restrict__ dbeta,
-    float* __restrict__ dpb, float* __restrict__ run_mean, float* __restrict__ run_var, float momentum) {
+    float* __restrict__ dpb, float* __restrict__ run_mean, float* __restrict__ run_var, float momentum,
+    int staged /* the first sweep's values are kept in LDS (dynamic: N*L floats forward, 2*N*L backward) */) {
+  // The second sweep re-reads what the first one read.  With tens of thousands of 16-64 KB channels
+  // in flight (the decoder's grouped BatchNorm: 24,624 channels) the 4 MB L2 of an XCD does not hold
+  // them -- PMC: 3.7 reads per write in the backward instead of 2 -- so each thread parks its own
+  // elements in LDS (its own slots: no barrier needed) when they fit 64 KB.
+  extern __shared__ __attribute__((aligned(16))) float stage[];
   __shared__ float red[8];
   __shared__ float bc[4];
   const int c = blockIdx.x;
   const float b = pb ? pb[c] : 0.0f;
   const double count = (double)N * (double)L;
+  const bool vec = (L & 3) == 0;
+  const int L4 = L >> 2;
+  v4f* __restrict__ sx = reinterpret_cast<v4f*>(stage);                   // x + b
+  v4f* __restrict__ sd = reinterpret_cast<v4f*>(stage) + (size_t)N * L4;  // dz (backward)
   float sc = 0.0f, sh = 0.0f, mu = 0.0f, rs = 0.0f;
   if (MODE == 1 || !training) { sc = chan[c]; sh = chan[C + c]; mu = chan[2 * C + c]; rs = chan[3 * C + c]; }
-  if (MODE == 1 || training) {
+  const bool two_sweeps = MODE == 1 || training;
+  const bool keep = staged && vec && two_sweeps;
+  if (two_sweeps) {
     float a0 = 0.0f, a1 = 0.0f;
     for (int n = 0; n < N; ++n) {
       const size_t base = ((size_t)n * C + c) * L;
-      for (int e = threadIdx.x; e < L; e += kBnThreads) {
-        const float xv = x[base + e] + b;
-        if (MODE == 0) {
-          a0 += xv; a1 = fma_rn(xv, xv, a1);
-        } else {
-          const float dz = dy[base + e] * act_grad<ACT>(fma_rn(xv, sc, sh), slope);
-          a0 += dz; a1 = fma_rn(dz, (xv - mu) * rs, a1);
+      if (vec) {
+        const v4f* __restrict__ xp = reinterpret_cast<const v4f*>(x + base);
+        const v4f* __restrict__ gp = reinterpret_cast<const v4f*>(MODE == 1 ? dy + base : x + base);
+        for (int e = threadIdx.x; e < L4; e += kBnThreads) {
+          v4f xv = xp[e];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) xv[u] += b;
+          if (MODE == 0) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { a0 += xv[u]; a1 = fma_rn(xv[u], xv[u], a1); }
+          } else {
+            const v4f gv = gp[e];
+            v4f dz;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              dz[u] = gv[u] * act_grad<ACT>(fma_rn(xv[u], sc, sh), slope);
+              a0 += dz[u];
+              a1 = fma_rn(dz[u], (xv[u] - mu) * rs, a1);
+            }
+            if (keep) sd[(size_t)n * L4 + e] = dz;
+          }
+          if (keep) sx[(size_t)n * L4 + e] = xv;
+        }
+      } else {
+        for (int e = threadIdx.x; e < L; e += kBnThreads) {
+          const float xv = x[base + e] + b;
+          if (MODE == 0) {
+            a0 += xv; a1 = fma_rn(xv, xv, a1);
+          } else {
+            const float dz = dy[base + e] * act_grad<ACT>(fma_rn(xv, sc, sh), slope);
+            a0 += dz; a1 = fma_rn(dz, (xv - mu) * rs, a1);
+          }
         }
       }
     }
@@ -314,8 +351,8 @@ __global__ __launch_bounds__(kBnThreads) void bn_small_kernel(
         double var = a1 / count - mean * mean;
         var = var > 0.0 ? var : 0.0;
         const float rstd = (float)(1.0 / sqrt(var + (double)eps));
-        const float g = gamma ? gamma[c] : 1.0f, b = beta ? beta[c] : 0.0f;
-        bc[0] = g * rstd; bc[1] = b - (float)mean * g * rstd; bc[2] = (float)mean; bc[3] = rstd;
+        const float g = gamma ? gamma[c] : 1.0f, bb = beta ? beta[c] : 0.0f;
+        bc[0] = g * rstd; bc[1] = bb - (float)mean * g * rstd; bc[2] = (float)mean; bc[3] = rstd;
         chan[c] = bc[0]; chan[C + c] = bc[1]; chan[2 * C + c] = bc[2]; chan[3 * C + c] = bc[3];
         const float unbiased = (float)(count > 1.0 ? var * count / (count - 1.0) : var);
         if (batch_mean) batch_mean[c] = (float)mean;
@@ -341,15 +378,49 @@ __global__ __launch_bounds__(kBnThreads) void bn_small_kernel(
   float acc = 0.0f, unused = 0.0f;
   for (int n = 0; n < N; ++n) {
     const size_t base = ((size_t)n * C + c) * L;
-    for (int e = threadIdx.x; e < L; e += kBnThreads) {
-      const float xv = x[base + e] + b;
-      if (MODE == 0) {
-        out[base + e] = act_fwd<ACT>(fma_rn(xv, sc, sh), slope);
-      } else {
-        const float dz = dy[base + e] * act_grad<ACT>(fma_rn(xv, sc, sh), slope);
-        const float r = fma_rn(k1, dz, fma_rn(k2, xv, k3));
-        out[base + e] = r;
-        acc += r;
+    if (vec) {
+      const v4f* __restrict__ xp = reinterpret_cast<const v4f*>(x + base);
+      const v4f* __restrict__ gp = reinterpret_cast<const v4f*>(MODE == 1 ? dy + base : x + base);
+      v4f* __restrict__ op = reinterpret_cast<v4f*>(out + base);
+      for (int e = threadIdx.x; e < L4; e += kBnThreads) {
+        v4f xv;
+        if (keep) {
+          xv = sx[(size_t)n * L4 + e];
+        } else {
+          xv = xp[e];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) xv[u] += b;
+        }
+        v4f r;
+        if (MODE == 0) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) r[u] = act_fwd<ACT>(fma_rn(xv[u], sc, sh), slope);
+        } else {
+          v4f dz;
+          if (keep) {
+            dz = sd[(size_t)n * L4 + e];
+          } else {
+            const v4f gv = gp[e];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) dz[u] = gv[u] * act_grad<ACT>(fma_rn(xv[u], sc, sh), slope);
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) r[u] = fma_rn(k1, dz[u], fma_rn(k2, xv[u], k3));
+          acc += (r[0] + r[1]) + (r[2] + r[3]);
+        }
+        op[e] = r;
+      }
+    } else {
+      for (int e = threadIdx.x; e < L; e += kBnThreads) {
+        const float xv = x[base + e] + b;
+        if (MODE == 0) {
+          out[base + e] = act_fwd<ACT>(fma_rn(xv, sc, sh), slope);
+        } else {
+          const float dz = dy[base + e] * act_grad<ACT>(fma_rn(xv, sc, sh), slope);
+          const float r = fma_rn(k1, dz, fma_rn(k2, xv, k3));
+          out[base + e] = r;
+          acc += r;
+        }
       }
     }
   }
@@ -366,9 +437,13 @@ void launch_small(int act, const float* x, const float* dy, const float* gamma, 
                   float* bv, float* dgamma, float* dbeta, float* dpb, float* rmean, float* rvar, float momentum,
                   hipStream_t s) {
   dim3 grid(C);
-#define FPSG_SMALL(A) hipLaunchKernelGGL((bn_small_kernel<MODE, A>), grid, dim3(kBnThreads), 0, s, x, dy, gamma, beta, \
+  // first-sweep values parked in LDS when they fit the default 64 KB of dynamic LDS
+  const size_t need = (size_t)N * L * sizeof(float) * (MODE == 1 ? 2 : 1);
+  const int staged = ((L & 3) == 0 && need <= 64 * 1024 && (MODE == 1 || training)) ? 1 : 0;
+  const size_t lds = staged ? need : 0;
+#define FPSG_SMALL(A) hipLaunchKernelGGL((bn_small_kernel<MODE, A>), grid, dim3(kBnThreads), lds, s, x, dy, gamma, beta, \
                                          pb, N, C, L, training, eps, slope, out, chan, bm, bv, dgamma, dbeta, dpb, rmean, \
-                                         rvar, momentum)
+                                         rvar, momentum, staged)
   if (act == kActRelu) FPSG_SMALL(kActRelu);
   else if (act == kActLeaky) FPSG_SMALL(kActLeaky);
   else FPSG_SMALL(kActNone);
