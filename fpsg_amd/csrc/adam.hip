@@ -55,8 +55,110 @@ __global__ __launch_bounds__(kAdamThreads) void adam_kernel(float* __restrict__ 
   }
 }
 
+// The same update with the gradient read from the per-parameter tensors autograd produced instead
+// of a flat copy of them: segment s of the flat buffers is [seg_off[s], seg_off[s+1]) and its
+// gradient starts at gtab[s] (null: no gradient = zero).  A step of ONE episode on one rank then
+// needs no 310 MB gather.  A vector of four elements looks its segment up by bisection (10 steps
+// over ~600 cached offsets, free next to 28 B of traffic per element); a vector that straddles
+// two segments is done element by element.
+__device__ __forceinline__ int segment_of(const long long* __restrict__ seg_off, int nseg, long long i) {
+  int lo = 0, hi = nseg;
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (seg_off[mid] <= i) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
+__global__ __launch_bounds__(kAdamThreads) void adam_ptr_kernel(float* __restrict__ p, const float* const* __restrict__ gtab,
+                                                                const long long* __restrict__ seg_off, int nseg,
+                                                                float* __restrict__ m, float* __restrict__ v, size_t n4,
+                                                                size_t n, float step_size, float b1, float b2,
+                                                                float eps, float inv_sqrt_bc2, float gscale) {
+  const size_t stride = (size_t)gridDim.x * kAdamThreads;
+  const float omb1 = 1.0f - b1, omb2 = 1.0f - b2;
+  for (size_t j = (size_t)blockIdx.x * kAdamThreads + threadIdx.x; j < n4 + 1; j += stride) {
+    const long long i = (long long)(4 * j);
+    const int cnt = j < n4 ? 4 : (int)(n - 4 * n4);          // the last "vector" is the tail
+    if (cnt == 0) break;
+    int sg = segment_of(seg_off, nseg, i);
+    float gg[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (i + cnt <= seg_off[sg + 1]) {
+      const float* g = gtab[sg];
+      if (g) {
+        const long long base = i - seg_off[sg];
+        if (cnt == 4 && ((base & 3) == 0)) {                   // the tensor starts 256-B aligned
+          const v4f q = *reinterpret_cast<const v4f*>(g + base);
+          gg[0] = q[0]; gg[1] = q[1]; gg[2] = q[2]; gg[3] = q[3];
+        } else {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) if (u < cnt) gg[u] = g[base + u];
+        }
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (u >= cnt) break;
+        while (i + u >= seg_off[sg + 1]) ++sg;
+        const float* g = gtab[sg];
+        gg[u] = g ? g[i + u - seg_off[sg]] : 0.0f;
+      }
+    }
+    if (cnt == 4) {                                            // flat buffers: aligned vectors
+      v4f pv = reinterpret_cast<const v4f*>(p)[j];
+      v4f mv = reinterpret_cast<const v4f*>(m)[j];
+      v4f vv = reinterpret_cast<const v4f*>(v)[j];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float gq = gg[u] * gscale;
+        mv[u] = fma_rn(omb1, gq - mv[u], mv[u]);
+        vv[u] = fma_rn(omb2 * gq, gq, b2 * vv[u]);
+        const float denom = fma_rn(__fsqrt_rn(vv[u]), inv_sqrt_bc2, eps);
+        pv[u] = fma_rn(-step_size, mv[u] / denom, pv[u]);
+      }
+      reinterpret_cast<v4f*>(p)[j] = pv;
+      reinterpret_cast<v4f*>(m)[j] = mv;
+      reinterpret_cast<v4f*>(v)[j] = vv;
+    } else {
+      for (int u = 0; u < cnt; ++u) {
+        const size_t e = (size_t)i + u;
+        const float gq = gg[u] * gscale;
+        const float mm = fma_rn(omb1, gq - m[e], m[e]);
+        const float vq = fma_rn(omb2 * gq, gq, b2 * v[e]);
+        const float denom = fma_rn(__fsqrt_rn(vq), inv_sqrt_bc2, eps);
+        p[e] = fma_rn(-step_size, mm / denom, p[e]);
+        m[e] = mm;
+        v[e] = vq;
+      }
+    }
+  }
+}
+
 }  // namespace
 }  // namespace fpsg
+
+extern "C" int fpsg_adam_step_segments(float* param, const float* const* grad_ptrs, const long long* seg_off, int nseg,
+                                       float* exp_avg, float* exp_avg_sq, size_t n, float lr, float beta1, float beta2,
+                                       float eps, int step, float grad_scale, fpsg_stream_t stream) {
+  using namespace fpsg;
+  FPSG_REQUIRE(n > 0 && step >= 1 && nseg > 0, FPSG_E_SHAPE,
+               "fpsg_adam_step_segments: n, nseg must be positive and step >= 1 (got %zu, %d, %d)", n, nseg, step);
+  FPSG_REQUIRE(beta1 >= 0.0f && beta1 < 1.0f && beta2 >= 0.0f && beta2 < 1.0f && eps >= 0.0f, FPSG_E_SHAPE,
+               "fpsg_adam_step_segments: betas must lie in [0,1) and eps be non-negative");
+  FPSG_REQUIRE_PTR(param); FPSG_REQUIRE_PTR(exp_avg); FPSG_REQUIRE_PTR(exp_avg_sq);
+  FPSG_REQUIRE(grad_ptrs != nullptr && seg_off != nullptr, FPSG_E_NULL, "fpsg_adam_step_segments: null table");
+  const double bc1 = 1.0 - pow((double)beta1, (double)step);
+  const double bc2 = 1.0 - pow((double)beta2, (double)step);
+  const float step_size = (float)((double)lr / bc1);
+  const float inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+  const size_t n4 = n / 4;
+  size_t blocks = (n4 + 1 + kAdamThreads - 1) / kAdamThreads;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  hipLaunchKernelGGL(adam_ptr_kernel, dim3((unsigned)blocks), dim3(kAdamThreads), 0, static_cast<hipStream_t>(stream),
+                     param, grad_ptrs, seg_off, nseg, exp_avg, exp_avg_sq, n4, n, step_size, beta1, beta2, eps,
+                     inv_sqrt_bc2, grad_scale);
+  return launch_status("fpsg_adam_step_segments");
+}
 
 extern "C" int fpsg_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, float lr,
                               float beta1, float beta2, float eps, int step, float grad_scale, fpsg_stream_t stream) {

@@ -7,8 +7,10 @@ buffer (``p.data`` becomes a view; values, ``Parameter`` objects and state-dict 
 untouched), the two moments are flat buffers of the same layout, and ``step()`` is a single
 launch of ``fpsg_adam_step`` (4 reads + 3 writes per element) instead of a multi-tensor sweep
 over ~600 tensors.  The layout is that of ``fpsg_amd.dist.FlatGradBuckets`` (``flat_layout``), so
-the step's flat gradient buffer is consumed in place; gradients that are not views of a bound
-flat buffer are first gathered with one multi-tensor copy.
+the step's flat gradient buffer is consumed in place.  Gradients that are NOT views of a bound flat
+buffer -- a step of one episode on one rank leaves them where autograd put them -- are read through
+a table of per-parameter pointers (``fpsg_adam_step_segments``: no 310 MB gather); only
+non-contiguous gradients are first gathered with one multi-tensor copy.
 
 It is a ``torch.optim.Optimizer``: ``param_groups[0]['lr']`` (StepLR), ``state_dict()`` /
 ``load_state_dict()`` (per-parameter ``step`` / ``exp_avg`` / ``exp_avg_sq`` entries, i.e. the
@@ -50,8 +52,12 @@ class FlatAdam(Optimizer):
         self.flat_param = torch.empty(total, dtype=torch.float32, device=dev)
         self.flat_exp_avg = torch.zeros(total, dtype=torch.float32, device=dev)
         self.flat_exp_avg_sq = torch.zeros(total, dtype=torch.float32, device=dev)
-        self._gather = None                    # private flat gradient buffer (unbound use)
+        self._gather = None                    # private flat gradient buffer (non-contiguous gradients)
         self._bound = None                     # the train step's flat gradient buffer
+        offs = [off for _, off, _ in self._layout] + [total]
+        self._seg_off = torch.tensor(offs, dtype=torch.int64, device=dev)
+        self._gtab = torch.zeros(len(self._layout), dtype=torch.int64, device=dev)
+        self._gtab_host = None                 # the pointers currently in _gtab
         self._t = 0
         self._step_tensor = torch.zeros((), dtype=torch.float32)       # shared by every state entry
         with torch.no_grad():
@@ -70,12 +76,37 @@ class FlatAdam(Optimizer):
             raise ValueError("FlatAdam.bind_gradients: buffer does not match the parameter layout")
         self._bound = flat_grad
 
-    def _flat_gradient(self) -> torch.Tensor:
+    def _bound_gradient(self):
         first, off0, _ = self._layout[0]
         last, off1, _ = self._layout[-1]
         b = self._bound
         if (b is not None and first.grad is not None and last.grad is not None
                 and first.grad.data_ptr() == b.data_ptr() + 4 * off0 and last.grad.data_ptr() == b.data_ptr() + 4 * off1):
+            return b
+        return None
+
+    def _pointer_table(self):
+        """Device table of the parameters' gradient pointers (0 = no gradient), or None when a
+        gradient cannot be read in place (not contiguous fp32 on the parameters' device)."""
+        dev = self.flat_param.device
+        ptrs = []
+        for p, _, n in self._layout:
+            g = p.grad
+            if g is None:
+                ptrs.append(0)
+            elif g.dtype == torch.float32 and g.device == dev and g.is_contiguous() and g.numel() == n:
+                ptrs.append(g.data_ptr())
+            else:
+                return None
+        if ptrs != self._gtab_host:
+            # a fresh pinned tensor per change: the caching host allocator keeps it until the copy ran
+            self._gtab.copy_(torch.tensor(ptrs, dtype=torch.int64).pin_memory(), non_blocking=True)
+            self._gtab_host = ptrs
+        return self._gtab
+
+    def _flat_gradient(self) -> torch.Tensor:
+        b = self._bound_gradient()
+        if b is not None:
             return b
         if self._gather is None:
             self._gather = torch.zeros_like(self.flat_param)
@@ -103,15 +134,23 @@ class FlatAdam(Optimizer):
         if first.data_ptr() != self.flat_param.data_ptr() + 4 * self._layout[0][1]:
             raise RuntimeError("FlatAdam: the parameters were moved off the flat buffer (model.to() / "
                                "a new .data after the optimizer was built); rebuild the optimizer")
-        g = self._flat_gradient()
+        g = self._bound_gradient()
+        table = self._pointer_table() if g is None else None
+        if g is None and table is None:
+            g = self._flat_gradient()
         self._t += 1
         self._step_tensor.fill_(float(self._t))
         lib = _hip.load()
+        hyper = (float(group["lr"]), float(group["betas"][0]), float(group["betas"][1]), float(group["eps"]), self._t, 1.0,
+                 _hip.stream_of(self.flat_param))
         with torch.cuda.device(self.flat_param.device):
-            rc = lib.fpsg_adam_step(_hip.ptr(self.flat_param), _hip.ptr(g), _hip.ptr(self.flat_exp_avg),
-                                    _hip.ptr(self.flat_exp_avg_sq), self.flat_param.numel(), float(group["lr"]),
-                                    float(group["betas"][0]), float(group["betas"][1]), float(group["eps"]), self._t,
-                                    1.0, _hip.stream_of(self.flat_param))
+            if g is not None:
+                rc = lib.fpsg_adam_step(_hip.ptr(self.flat_param), _hip.ptr(g), _hip.ptr(self.flat_exp_avg),
+                                        _hip.ptr(self.flat_exp_avg_sq), self.flat_param.numel(), *hyper)
+            else:
+                rc = lib.fpsg_adam_step_segments(_hip.ptr(self.flat_param), _hip.ptr(table), _hip.ptr(self._seg_off),
+                                                 len(self._layout), _hip.ptr(self.flat_exp_avg),
+                                                 _hip.ptr(self.flat_exp_avg_sq), self.flat_param.numel(), *hyper)
         _hip.check(rc, "fpsg_adam_step")
         return loss
 

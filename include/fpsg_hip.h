@@ -257,6 +257,15 @@ int fpsg_conv_first_dw(const float* x, const float* dy, int N, int C, int K, int
  */
 int fpsg_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, float lr,
                    float beta1, float beta2, float eps, int step, float grad_scale, fpsg_stream_t stream);
+/* The same step with the gradient left where autograd put it: segment s of the flat buffers is
+ * [seg_off[s], seg_off[s+1]) (seg_off: nseg+1 int64 on the device, seg_off[0] = 0, seg_off[nseg] = n)
+ * and its gradient is the contiguous fp32 tensor at grad_ptrs[s] (device array of nseg device
+ * pointers; NULL = no gradient = zero).  Saves the gather of the gradients into a flat buffer when a
+ * step is one episode on one rank (the reference's own loop, trainNetwork.py:140-148).
+ */
+int fpsg_adam_step_segments(float* param, const float* const* grad_ptrs, const long long* seg_off, int nseg,
+                            float* exp_avg, float* exp_avg_sq, size_t n, float lr, float beta1, float beta2,
+                            float eps, int step, float grad_scale, fpsg_stream_t stream);
 
 #ifdef __cplusplus
 }

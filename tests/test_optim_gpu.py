@@ -119,3 +119,51 @@ def test_train_step_uses_the_flat_gradient_buffer_in_place(gpu):
     step([ep, ep])
     assert optimizer._flat_gradient() is step.buckets.flat and optimizer._gather is None
     assert not torch.equal(before, optimizer.flat_param) and bool(torch.isfinite(optimizer.flat_param).all())
+
+
+def test_pointer_table_step_equals_flat_step(gpu):
+    """fpsg_adam_step_segments (gradients read where autograd left them) == fpsg_adam_step on a flat
+    copy of the same gradients, bit for bit; a parameter without gradient counts as zero; the
+    train step of one episode on one rank uses it and leaves the flat buffer untouched."""
+    from fpsg_amd.optim import FlatAdam, flat_layout
+    a, b = _net().to(gpu), _net().to(gpu)
+    opt_a, opt_b = FlatAdam(a.parameters(), lr=2e-3), FlatAdam(b.parameters(), lr=2e-3)
+    layout, total = flat_layout([p for p in b.parameters()])
+    flat = torch.zeros(total, device=gpu)
+    opt_b.bind_gradients(flat)
+    for p, off, n in layout:
+        p.grad = flat[off:off + n].view(p.shape)
+    torch.manual_seed(4)
+    for it in range(3):
+        x = torch.randn(8, 3, 31, device=gpu)
+        opt_a.zero_grad(set_to_none=True)
+        _loss(a, x).backward()
+        skipped = list(a.parameters())[1]
+        if it == 1:
+            skipped.grad = None                                   # a parameter without gradient
+        with torch.no_grad():                                     # the same gradients, flat, for b
+            for (pb, off, n), pa in zip(layout, reversed(list(a.parameters()))):
+                flat[off:off + n].copy_((pa.grad if pa.grad is not None else torch.zeros_like(pa)).reshape(-1))
+        assert opt_a._bound_gradient() is None and opt_a._pointer_table() is not None
+        assert opt_b._bound_gradient() is flat
+        opt_a.step(); opt_b.step()
+        for pa, pb in zip(a.parameters(), b.parameters()):
+            assert torch.equal(pa, pb), it
+    assert opt_a._gather is None
+
+
+def test_single_episode_step_reads_gradients_in_place(gpu):
+    from fpsg_amd.engine import TrainStep, build_model, build_optimizer, default_options
+    from fpsg_amd.episodes import synthetic_episode
+    torch.manual_seed(0)
+    opt = default_options(device="cuda", intra_recon=True)
+    m = build_model(opt).to(gpu).train()
+    optimizer, _ = build_optimizer(m, opt)
+    step = TrainStep(m, optimizer)
+    ep = synthetic_episode(2, 1, n_pts=2048, img_size=64, seed=3, device=gpu)
+    before = optimizer.flat_param.clone()
+    step.buckets.flat.fill_(7.0)
+    step([ep])
+    assert bool((step.buckets.flat == 7.0).all())                 # no gather happened
+    assert optimizer._gather is None and optimizer._gtab_host is not None
+    assert not torch.equal(before, optimizer.flat_param) and bool(torch.isfinite(optimizer.flat_param).all())
