@@ -11,11 +11,11 @@ The reference is single-process / single-GPU (no ``torch.distributed`` anywhere,
     tensors which a handful of multi-tensor launches copy / add into the flat buffer
     (``absorb``) -- autograd's own accumulation would be one small add kernel per parameter
     per episode, ~600 launches.  With more than one rank the LAST local episode instead
-    accumulates in place into views of the flat buffer (``attach``), and a bucket's
-    ``all_reduce(SUM)`` is launched asynchronously from the autograd hooks as soon as all of
-    its gradients are complete (decoder first, VGG last), overlapping the collective with the
-    rest of backward; xGMI is point-to-point, so few large messages are what keep each link
-    busy;
+    also leaves fresh gradient tensors; the autograd hooks count them per bucket and, as soon
+    as a bucket is complete (decoder first, VGG last), absorb ITS gradients with one
+    multi-tensor launch and start its ``all_reduce(SUM)`` asynchronously, overlapping the
+    collective with the rest of backward; xGMI is point-to-point, so few large messages are
+    what keep each link busy;
   * the summed gradient is divided by ``E`` (mean over the step's episodes), so a step has
     the gradient scale of the reference's one-episode step and ``--lr`` keeps its meaning.
 
@@ -100,8 +100,12 @@ class FlatGradBuckets:
             self.buckets.append((start, off))
             self._bucket_size.append(count)
         self._pending = [0] * len(self.buckets)
+        self._bucket_params: list[list] = [[] for _ in self.buckets]
+        for p in params:
+            self._bucket_params[self._bucket_of[id(p)]].append(p)
         self._handles: list = []
         self._armed = False
+        self._armed_first = False
         self._streams: dict = {}     # every stream a gradient was produced on in this backward
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in params]
         self.attach()
@@ -150,13 +154,32 @@ class FlatGradBuckets:
             elif dst:
                 torch._foreach_add_(dst, src)
 
-    def arm(self) -> None:
-        """Call before the backward of the LAST local episode of a step: buckets are
-        all-reduced as they complete during that backward."""
+    def arm(self, first: bool = False) -> None:
+        """Call (after ``detach()``) before the backward of the LAST local episode of a step:
+        each bucket is absorbed into the flat buffer (copied if ``first``: the step's only local
+        episode) and all-reduced as soon as its gradients are complete during that backward."""
         self._armed = dist.is_initialized()
+        self._armed_first = bool(first)
         self._pending = list(self._bucket_size)
         self._handles = []
         self._streams = {}
+
+    def _absorb_bucket(self, b: int) -> None:
+        dst, src, missing = [], [], []
+        for p in self._bucket_params[b]:
+            if p.grad is None:
+                missing.append(self.views[id(p)])
+            elif p.grad.data_ptr() != self.views[id(p)].data_ptr():
+                dst.append(self.views[id(p)])
+                src.append(p.grad)
+        with torch.no_grad():
+            if self._armed_first:
+                if dst:
+                    torch._foreach_copy_(dst, src)
+                if missing:
+                    torch._foreach_zero_(missing)
+            elif dst:
+                torch._foreach_add_(dst, src)
 
     def _on_grad(self, p: torch.Tensor) -> None:
         if not self._armed:
@@ -173,6 +196,7 @@ class FlatGradBuckets:
                 for key, st in self._streams.items():
                     if key != cur.cuda_stream:
                         cur.wait_stream(st)
+            self._absorb_bucket(b)
             s, e = self.buckets[b]
             self._handles.append(
                 dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.group,
@@ -184,6 +208,7 @@ class FlatGradBuckets:
         if self._armed:
             for b, left in enumerate(self._pending):
                 if left > 0:  # e.g. parameters unused by this step's graph
+                    self._absorb_bucket(b)
                     s, e = self.buckets[b]
                     self._handles.append(dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM,
                                                          group=self.group, async_op=True))

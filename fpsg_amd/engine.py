@@ -113,10 +113,12 @@ class TrainStep:
             self.buckets.absorb(first)
         return {n: v.detach() for n, v in out.items()}
 
-    def _episode_in_place(self, sample):
-        """The overlapped form: gradients accumulate in place into the flat buffer's views
-        and the armed hooks launch each bucket's all-reduce when it is complete."""
-        self.buckets.attach()
+    def _episode_hooked(self, sample, first):
+        """The overlapped form (last local episode of a multi-rank step): fresh gradient tensors
+        as in ``_episode``; the armed hooks absorb each bucket and launch its all-reduce as soon
+        as its gradients are complete."""
+        self.buckets.detach()
+        self.buckets.arm(first)
         out = self.model.loss(sample)
         out["ttl_loss"].sum().backward()
         return {n: v.detach() for n, v in out.items()}
@@ -166,16 +168,14 @@ class TrainStep:
                   and not multi and os.environ.get("FPSG_DIRECT_GRADS", "1") != "0")
         if not local_episodes:  # still take part in the step's collectives
             self.buckets.zero()
+            self.buckets.attach()
             self.buckets.arm()
         last = len(local_episodes) - 1
         with winograd.weights_frozen():      # no parameter changes until optimizer.step() below
             for k, sample in enumerate(local_episodes):
                 first, final = k == 0, k == last
                 if final and multi:
-                    if first:
-                        self.buckets.zero()
-                    self.buckets.arm()
-                    results.append(self._episode_in_place(sample))
+                    results.append(self._episode_hooked(sample, first))
                 elif self.use_graph:
                     results.append(self._run_graphed(sample, first, absorb=not direct))
                 else:
