@@ -55,17 +55,33 @@ __device__ __forceinline__ void store_vec(float* p, const float (&v)[VEC]) {
   *reinterpret_cast<T*>(p) = t;
 }
 
+// Workgroup -> (cloud, block of points).  The neighbour gathers of a cloud touch its whole [N, Co]
+// arrays (2 MB at Co = 256) about k times: they should come from L2, not HBM.  Workgroup ids are
+// dealt round-robin to the 8 XCDs (id % 8), each with its own 4 MB L2, so cloud b is given to XCD
+// b % 8 and an XCD works through its clouds one after the other (PMC before: 6.3 GB of HBM reads
+// for 0.6 GB of operands in the Co = 256 backward).
+struct CloudBlock { int b, bx; };
+__device__ __forceinline__ CloudBlock cloud_block(int bpc) {
+  const int id = blockIdx.x, xcd = id & 7, slot = id >> 3;
+  CloudBlock r;
+  r.b = xcd + 8 * (slot / bpc);
+  r.bx = slot % bpc;
+  return r;
+}
+
 // PQ [B,N,2*Co] (P = first Co columns, Q = last Co), idx [B,N,k], sgn [Co] (+1: take max, -1:
 // take min).  Outputs ysel [B,N,Co], jsel [B,N,Co] (uint8 neighbour slot), s1 [B,N,Co] or null,
 // part [gridDim.y*gridDim.x][2][Co] or null.
 template <int VEC>
 __global__ __launch_bounds__(kEcThreads) void edgeconv_fwd_kernel(
     const float* __restrict__ PQ, const int32_t* __restrict__ idx, const float* __restrict__ sgn,
-    int N, int k, float* __restrict__ ysel, uint8_t* __restrict__ jsel, float* __restrict__ s1,
+    int B, int N, int k, int bpc, float* __restrict__ ysel, uint8_t* __restrict__ jsel, float* __restrict__ s1,
     float* __restrict__ part) {
   constexpr int Co = 64 * VEC;
   __shared__ float red[4][2][Co];
-  const int b = blockIdx.y;
+  const CloudBlock cb = cloud_block(bpc);
+  if (cb.b >= B) return;
+  const int b = cb.b;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int c0 = lane * VEC;
@@ -75,7 +91,7 @@ __global__ __launch_bounds__(kEcThreads) void edgeconv_fwd_kernel(
 #pragma unroll
   for (int v = 0; v < VEC; ++v) { sum[v] = 0.0f; sumsq[v] = 0.0f; }
 
-  const int n_first = (blockIdx.x * 4 + wave) * kEcPtsPerWave;
+  const int n_first = (cb.bx * 4 + wave) * kEcPtsPerWave;
   for (int pp = 0; pp < kEcPtsPerWave; ++pp) {
     const int n = n_first + pp;
     if (n >= N) break;  // wave-uniform
@@ -120,7 +136,7 @@ __global__ __launch_bounds__(kEcThreads) void edgeconv_fwd_kernel(
 #pragma unroll
   for (int v = 0; v < VEC; ++v) { red[wave][0][c0 + v] = sum[v]; red[wave][1][c0 + v] = sumsq[v]; }
   __syncthreads();
-  float* dst = part + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 2 * Co;
+  float* dst = part + ((size_t)b * bpc + cb.bx) * 2 * Co;
   for (int e = threadIdx.x; e < 2 * Co; e += kEcThreads) {
     const int which = e / Co, c = e - which * Co;
     dst[e] = (red[0][which][c] + red[1][which][c]) + (red[2][which][c] + red[3][which][c]);
@@ -134,9 +150,11 @@ template <int VEC>
 __global__ __launch_bounds__(kEcThreads) void edgeconv_bwd_kernel(
     const float* __restrict__ dzs, const uint8_t* __restrict__ jsel, const float* __restrict__ PQ,
     const float* __restrict__ s1, const int32_t* __restrict__ rev, const int32_t* __restrict__ off,
-    const float* __restrict__ coef, int N, int k, int stats, float* __restrict__ dPQ) {
+    const float* __restrict__ coef, int B, int N, int k, int bpc, int stats, float* __restrict__ dPQ) {
   constexpr int Co = 64 * VEC;
-  const int b = blockIdx.y;
+  const CloudBlock cb = cloud_block(bpc);
+  if (cb.b >= B) return;
+  const int b = cb.b;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int c0 = lane * VEC;
@@ -147,7 +165,7 @@ __global__ __launch_bounds__(kEcThreads) void edgeconv_bwd_kernel(
   const float* __restrict__ pq = PQ + (size_t)b * N * 2 * Co;
   const int32_t* __restrict__ revb = rev + (size_t)b * N * k;
   const int32_t* __restrict__ offb = off + (size_t)b * (N + 1);
-  const int m_first = (blockIdx.x * 4 + wave) * kEcPtsPerWave;
+  const int m_first = (cb.bx * 4 + wave) * kEcPtsPerWave;
   for (int pp = 0; pp < kEcPtsPerWave; ++pp) {
     const int m = m_first + pp;
     if (m >= N) break;
@@ -200,8 +218,9 @@ __global__ __launch_bounds__(kEcThreads) void edgeconv_bwd_kernel(
   }
 }
 
-inline dim3 ec_grid(int B, int N) {
-  return dim3((N + 4 * kEcPtsPerWave - 1) / (4 * kEcPtsPerWave), B);
+inline int ec_blocks_per_cloud(int N) { return (N + 4 * kEcPtsPerWave - 1) / (4 * kEcPtsPerWave); }
+inline dim3 ec_grid(int B, int N) {          // 8 * ceil(B/8) clouds' worth of workgroups, see cloud_block
+  return dim3((unsigned)(8 * ((B + 7) / 8) * ec_blocks_per_cloud(N)));
 }
 
 }  // namespace
@@ -227,9 +246,10 @@ extern "C" int fpsg_edgeconv_fwd(const float* PQ, const int32_t* idx, const floa
                FPSG_E_ALIGN, "fpsg_edgeconv_fwd: PQ/ysel/s1 must be 16-byte and jsel 4-byte aligned");
   hipStream_t s = static_cast<hipStream_t>(stream);
   const dim3 grid = ec_grid(B, N);
-  if (Co == 64) hipLaunchKernelGGL(edgeconv_fwd_kernel<1>, grid, dim3(kEcThreads), 0, s, PQ, idx, sgn, N, k, ysel, jsel, s1, part);
-  else if (Co == 128) hipLaunchKernelGGL(edgeconv_fwd_kernel<2>, grid, dim3(kEcThreads), 0, s, PQ, idx, sgn, N, k, ysel, jsel, s1, part);
-  else hipLaunchKernelGGL(edgeconv_fwd_kernel<4>, grid, dim3(kEcThreads), 0, s, PQ, idx, sgn, N, k, ysel, jsel, s1, part);
+  const int bpc = ec_blocks_per_cloud(N);
+  if (Co == 64) hipLaunchKernelGGL(edgeconv_fwd_kernel<1>, grid, dim3(kEcThreads), 0, s, PQ, idx, sgn, B, N, k, bpc, ysel, jsel, s1, part);
+  else if (Co == 128) hipLaunchKernelGGL(edgeconv_fwd_kernel<2>, grid, dim3(kEcThreads), 0, s, PQ, idx, sgn, B, N, k, bpc, ysel, jsel, s1, part);
+  else hipLaunchKernelGGL(edgeconv_fwd_kernel<4>, grid, dim3(kEcThreads), 0, s, PQ, idx, sgn, B, N, k, bpc, ysel, jsel, s1, part);
   return launch_status("fpsg_edgeconv_fwd");
 }
 
@@ -251,9 +271,10 @@ extern "C" int fpsg_edgeconv_bwd(const float* dzs, const uint8_t* jsel, const fl
                FPSG_E_ALIGN, "fpsg_edgeconv_bwd: float buffers must be 16-byte aligned");
   hipStream_t s = static_cast<hipStream_t>(stream);
   const dim3 grid = ec_grid(B, N);
+  const int bpc = ec_blocks_per_cloud(N);
   const int stats = s1 != nullptr;
-  if (Co == 64) hipLaunchKernelGGL(edgeconv_bwd_kernel<1>, grid, dim3(kEcThreads), 0, s, dzs, jsel, PQ, s1, rev, off, coef, N, k, stats, dPQ);
-  else if (Co == 128) hipLaunchKernelGGL(edgeconv_bwd_kernel<2>, grid, dim3(kEcThreads), 0, s, dzs, jsel, PQ, s1, rev, off, coef, N, k, stats, dPQ);
-  else hipLaunchKernelGGL(edgeconv_bwd_kernel<4>, grid, dim3(kEcThreads), 0, s, dzs, jsel, PQ, s1, rev, off, coef, N, k, stats, dPQ);
+  if (Co == 64) hipLaunchKernelGGL(edgeconv_bwd_kernel<1>, grid, dim3(kEcThreads), 0, s, dzs, jsel, PQ, s1, rev, off, coef, B, N, k, bpc, stats, dPQ);
+  else if (Co == 128) hipLaunchKernelGGL(edgeconv_bwd_kernel<2>, grid, dim3(kEcThreads), 0, s, dzs, jsel, PQ, s1, rev, off, coef, B, N, k, bpc, stats, dPQ);
+  else hipLaunchKernelGGL(edgeconv_bwd_kernel<4>, grid, dim3(kEcThreads), 0, s, dzs, jsel, PQ, s1, rev, off, coef, B, N, k, bpc, stats, dPQ);
   return launch_status("fpsg_edgeconv_bwd");
 }
