@@ -163,6 +163,34 @@ class PrimitiveCluster(nn.Module):
         return torch.cat(outs, dim=2)
 
 
+class _SplitLast(torch.autograd.Function):
+    """``(w[..., :L], w[..., L:])`` as views; the backward writes the two gradients into ONE new
+    tensor.  Autograd's own slicing gives each slice a zero-filled full-size gradient and adds the
+    two: for the stacked first-layer weight ``[16, 1539, 1539]`` (152 MB) that is five extra passes."""
+
+    @staticmethod
+    def forward(ctx, w, L):
+        ctx.L = L
+        return w[..., :L], w[..., L:]
+
+    @staticmethod
+    def backward(ctx, g_lat, g_pts):
+        L = ctx.L
+        shape = list(g_lat.shape if g_lat is not None else g_pts.shape)
+        shape[-1] = (g_lat.shape[-1] if g_lat is not None else L) + (g_pts.shape[-1] if g_pts is not None else 0)
+        ref = g_lat if g_lat is not None else g_pts
+        gw = torch.empty(shape, dtype=ref.dtype, device=ref.device)
+        if g_lat is not None:
+            gw[..., :L].copy_(g_lat)
+        else:
+            gw[..., :L].zero_()
+        if g_pts is not None:
+            gw[..., L:].copy_(g_pts)
+        else:
+            gw[..., L:].zero_()
+        return gw, None
+
+
 def _stack_affine(bns, calls_per_bn):
     """gamma / beta of ``bns`` stacked to ``[G*C]`` for ``_group_batch_norm``."""
     gamma = torch.stack([b.weight for b in bns]).repeat_interleave(calls_per_bn, dim=0).reshape(-1)
@@ -268,6 +296,10 @@ class PCDecoder(nn.Module):
 
         pack = {f"d{i}": stack_w(defs, f"conv{i}", R) for i in (1, 2, 3)}
         pack.update({f"n{i}": stack_w(nodes, f"conv{i}") for i in (1, 2, 3, 4)})
+        # first node layer: latent and point columns of the stacked weight, split once per pack
+        w1, b1 = pack["n1"]
+        L = w1.size(2) - self.conf.raw_dim
+        pack["n1_split"] = _SplitLast.apply(w1, L) + (b1,)
         pack["dbn1"] = _stack_affine([d.bn1 for d in defs], R)
         pack["dbn2"] = _stack_affine([d.bn2 for d in defs], R)
         for i in (1, 2, 3):
@@ -310,10 +342,12 @@ class PCDecoder(nn.Module):
 
         # ---- the G patch MLPs; first layer split into latent and point parts
         nodes = [n for c in clusters for n in c.node_pool]
-        w, b = pack["n1"]                                                               # [G,D,D]
-        D = w.size(1)
-        h_lat = torch.matmul(w[:, :, :L], x.t()) + b                                    # [G,D,B]
-        h = torch.bmm(w[:, :, L:], pts).view(G, D, B, P) + h_lat.unsqueeze(-1)
+        w_lat, w_pts, b = pack["n1_split"]                                              # [G,D,L], [G,D,raw]
+        if w_lat.size(2) != L:
+            raise ValueError(f"PCDecoder: hidden size {L} does not match the first layer ({w_lat.size(2)} latent columns)")
+        D = w_lat.size(1)
+        h_lat = torch.matmul(w_lat, x.t()) + b                                          # [G,D,B]
+        h = torch.bmm(w_pts, pts).view(G, D, B, P) + h_lat.unsqueeze(-1)
         h = _group_batch_norm(h.view(G, D, B * P), [n.bn1 for n in nodes], 1, act, pack["nbn1"])
         w, b = pack["n2"]
         h = _group_batch_norm(torch.baddbmm(b, w, h), [n.bn2 for n in nodes], 1, act, pack["nbn2"])
