@@ -3,6 +3,7 @@ src/datasets/utils.py) and the sample-dict contract."""
 import os
 
 import numpy as np
+import pytest
 import torch
 
 from conftest import GOLDEN
@@ -57,3 +58,20 @@ def test_episode_sharding_is_world_size_independent():
     e = synthetic_episode(2, 1, n_pts=32, img_size=32, seed=5)
     f = synthetic_episode(2, 1, n_pts=32, img_size=32, seed=5)
     assert torch.equal(e["pcs"], f["pcs"]) and torch.equal(e["xq"], f["xq"])
+
+
+def test_prefetcher_yields_the_same_episodes_in_order():
+    from fpsg_amd.episodes import EpisodePrefetcher, synthetic_episode
+    eps = [synthetic_episode(2, 1, n_pts=64, img_size=8, seed=s) for s in range(5)]
+    got = list(EpisodePrefetcher(iter(eps), "cpu", depth=2))
+    assert len(got) == 5
+    for a, b in zip(eps, got):
+        assert all(torch.equal(a[k], b[k]) for k in ("xs", "xq", "xad", "pcs", "pcq", "pcad"))
+
+    def broken():
+        yield eps[0]
+        raise RuntimeError("loader failed")
+    it = EpisodePrefetcher(broken(), "cpu")
+    next(it)
+    with pytest.raises(RuntimeError, match="loader failed"):
+        next(it)

@@ -23,6 +23,7 @@ import torch
 from fpsg_amd import cli
 from fpsg_amd import dist as fdist
 from fpsg_amd.engine import TrainStep, build_model, build_optimizer, to_device
+from fpsg_amd.episodes import EpisodePrefetcher
 
 
 def evaluate(model, dl_test, n_query, n_shot, device, log):
@@ -103,7 +104,7 @@ def main(opt):
         # every rank draws its own episodes; different seeds per (epoch, rank)
         torch.manual_seed(1000003 * epoch + rank)
         sums = torch.zeros(2, dtype=torch.float64, device=device)
-        it = iter(dl)
+        it = EpisodePrefetcher(iter(dl), device)      # next episodes drawn and uploaded behind the step
         n_steps = max(1, opt.n_episode // eps_per_step)
         t0 = time.perf_counter()
         for _ in range(n_steps):
@@ -111,6 +112,7 @@ def main(opt):
             for out in step(local, n_episodes_global=eps_per_step):
                 sums[0] += out["query_rec_loss"].sum() / n_query
                 sums[1] += out["support_rec_loss"].sum() / opt.n_shot
+        it.close()
         q_sum, s_sum = fdist.all_reduce_scalars(sums.tolist(), device)   # one host sync per epoch
         done = n_steps * eps_per_step
         dt = time.perf_counter() - t0
