@@ -141,7 +141,56 @@ def episode_goldens():
     print("episode_streams.npz", {k: v.shape for k, v in out.items()})
 
 
+def _rows(t):
+    """Large gradients are stored as their first 64 rows (fixtures stay small)."""
+    return t[:64] if t.numel() > 65536 else t
+
+
+def gradient_goldens():
+    """Backward passes of the reference modules (training mode, CPU autograd): gradients of
+    ``sum(feat * w)`` with respect to the input and to a spread of parameters -- what the
+    HIP path's fused BatchNorm+max / EdgeConv backward kernels must reproduce."""
+    out = {}
+    ckpt = os.path.join(REF, "checkpoint/pretrain_pointnet/pretrained_pcencoder_pointnet.pt")
+    sd = torch.load(ckpt, map_location="cpu", weights_only=True)
+    pref = "pc_encoder.pointnet_feat_extractor."
+    inner = {k[len(pref):]: v for k, v in sd.items()}
+    for tag, shape in (("a", (4, 3, 256)), ("b", (2, 3, 2048))):
+        g = torch.Generator().manual_seed(100 + len(tag) + shape[2])
+        x = (torch.randn(*shape, generator=g) * 0.5).requires_grad_()     # same inputs as pointnet_goldens
+        w = torch.randn(shape[0], 1024, generator=g)
+        out[f"pn_w_{tag}"] = w.numpy()
+        m = PointNetfeat()
+        m.load_state_dict(inner)
+        m.train()
+        feat, _, _ = m(x)
+        (feat * w).sum().backward()
+        out[f"pn_gx_{tag}"] = x.grad.numpy()
+        for name, p in m.named_parameters():
+            out[f"pn_g_{tag}_{name}"] = _rows(p.grad).numpy()
+    dgm.torch = _TorchOnCPU()
+    try:
+        net = dgm.DGCNNfeat()
+        net.load_state_dict(torch.load(os.path.join(OUT, "dgcnn_state.pt"), weights_only=True))
+        net.train()
+        g = torch.Generator().manual_seed(22)
+        pts = torch.randn(3, 3, 160, generator=g)
+        pts = (pts / pts.norm(dim=1, keepdim=True).amax(dim=2, keepdim=True)).requires_grad_()   # = dgcnn_x
+        w = torch.randn(3, 1024, generator=g)
+        out["dg_w"] = w.numpy()
+        feat = net(pts)
+        (feat * w).sum().backward()
+        out["dg_gx"] = pts.grad.numpy()
+        for name, p in net.named_parameters():
+            out[f"dg_g_{name}"] = _rows(p.grad).numpy()
+    finally:
+        dgm.torch = torch
+    np.savez_compressed(os.path.join(OUT, "gradient_goldens.npz"), **out)
+    print("gradient_goldens.npz", {k: v.shape for k, v in out.items()})
+
+
 if __name__ == "__main__":
     pointnet_goldens()
     dgcnn_goldens()
     episode_goldens()
+    gradient_goldens()

@@ -23,33 +23,95 @@ def _pin_grids(model, grids):
     model.pc_decoder.forward = lambda h, grid=None, generator=None, pack=None: orig(h, grid=grids[h.size(0)], pack=pack)
 
 
+def _record(name, payload):
+    """Measured deviations are printed and, on the GPU box, left under gpurun_out/ for DESIGN.md."""
+    import json
+    import os
+    print(name, json.dumps(payload))
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(out):
+        with open(os.path.join(out, "parity_deviation.jsonl"), "a") as f:
+            f.write(json.dumps({"test": name, **payload}) + "\n")
+
+
+def _chamfer64(p1, p2, w1=1.0, w2=1.0):
+    """Kaolin's chamfer_distance semantics (few_shot.py:57,110) in float64 torch, differentiable
+    through the arg-min: the 'truth' metric of the float64 run."""
+    d = (p1.unsqueeze(2) - p2.unsqueeze(1)).square().sum(-1)          # [B,N,M]
+    return w1 * d.min(dim=2)[0].mean(dim=1) + w2 * d.min(dim=1)[0].mean(dim=1)
+
+
+# Loss bounds (relative, against the fp32 CPU port = reference arithmetic + C-oracle Chamfer), ~3x what was
+# measured on MI355X at 224x224 images (gpurun_out/parity_deviation.jsonl, DESIGN.md section 5): with
+# F(2x2,3x3) tiles everywhere every loss is within north_star's 1e-4; with the default F(4x4,3x3) tiles
+# the total loss is, the 2-query loss of this small training-mode episode reaches 2.5e-4.
+LOSS_TOL = {"4": {"ttl_loss": 1e-4, "query_rec_loss": 8e-4, "support_rec_loss": 1e-4},
+            "2": {"ttl_loss": 1e-4, "query_rec_loss": 1e-4, "support_rec_loss": 1e-4}}
+
+
+@pytest.mark.parametrize("wino_m", ["4", "2"])
 @pytest.mark.parametrize("mode", ["train", "eval"])
-def test_pointnet_episode_loss_and_gradients(gpu, oracle, mode):
+def test_pointnet_episode_loss_and_gradients(gpu, oracle, monkeypatch, mode, wino_m):
+    from _gradcheck import assert_like_yardstick
     from fpsg_amd.engine import build_model, default_options
     from fpsg_amd.episodes import synthetic_episode
+    if wino_m == "2":
+        monkeypatch.setenv("FPSG_WINOGRAD_M", "2")
     torch.manual_seed(1)
     S, Q = 4, 2
     cpu = build_model(default_options(device="cpu", intra_recon=True)).train(mode == "train")
     dev = copy.deepcopy(cpu).to(gpu)
+    cpu64 = copy.deepcopy(cpu).double()
     cpu.pc_metric = oracle.make_torch_chamfer()
-    ep = synthetic_episode(S, Q, n_pts=2048, img_size=96, seed=3)
+    cpu64.pc_metric = _chamfer64
+    ep = synthetic_episode(S, Q, n_pts=2048, img_size=224, seed=3)         # the real image size: F(4x4) on 4 stages
     ep_gpu = {k: (v.to(gpu) if torch.is_tensor(v) else v) for k, v in ep.items()}
+    ep64 = {k: (v.double() if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in ep.items()}
     grids_cpu = _fixed_grids(cpu, (S, Q), "cpu")
     grids_gpu = {b: [[t.to(gpu) for t in c] for c in g] for b, g in grids_cpu.items()}
+    grids_64 = {b: [[t.double() for t in c] for c in g] for b, g in grids_cpu.items()}
     _pin_grids(cpu, grids_cpu)
     _pin_grids(dev, grids_gpu)
+    _pin_grids(cpu64, grids_64)
     out_c = cpu.loss(ep)
     out_g = dev.loss(ep_gpu)
+    out_t = cpu64.loss(ep64)
+    measured = {"mode": mode, "wino_m": wino_m}
     for key in ("query_rec_loss", "support_rec_loss", "ttl_loss"):
-        a, b = float(out_c[key].detach().sum()), float(out_g[key].detach().sum())
-        assert abs(a - b) <= 2e-3 * abs(a), (mode, key, a, b)
+        a, b, t = (float(o[key].detach().sum()) for o in (out_c, out_g, out_t))
+        measured[key] = abs(a - b) / abs(a)
+        measured[key + "_hip_vs_f64"] = abs(b - t) / abs(t)
+        measured[key + "_cpu32_vs_f64"] = abs(a - t) / abs(t)
+    stats = None
     if mode == "train":
         out_c["ttl_loss"].sum().backward()
         out_g["ttl_loss"].sum().backward()
-        gc = torch.cat([p.grad.reshape(-1) for p in cpu.parameters()])
-        gg = torch.cat([p.grad.reshape(-1) for p in dev.parameters()]).cpu()
-        cos = float(torch.nn.functional.cosine_similarity(gc, gg, dim=0))
-        assert cos > 0.995 and abs(float(gg.norm() / gc.norm()) - 1) < 2e-2, (cos, float(gg.norm() / gc.norm()))
+        out_t["ttl_loss"].sum().backward()
+        named = lambda m: {n: p.grad for n, p in m.named_parameters()}
+        # every parameter tensor's gradient: HIP path vs float64, with the fp32 CPU port (the reference's
+        # arithmetic) as the yardstick -- tests/_gradcheck.py
+        # per module group: relative L2 distance from the float64 gradient, HIP path and fp32 CPU port
+        for top in ("img_encoder", "pc_encoder", "pc_decoder"):
+            cat = lambda m: torch.cat([p.grad.reshape(-1).double().cpu() for n, p in m.named_parameters() if n.startswith(top)])
+            t64 = cat(cpu64)
+            measured[f"grad_l2[{top}]_hip_vs_f64"] = float((cat(dev) - t64).norm() / t64.norm())
+            measured[f"grad_l2[{top}]_cpu32_vs_f64"] = float((cat(cpu) - t64).norm() / t64.norm())
+        _record("episode_parity_groups", measured)
+        # every parameter tensor's gradient: HIP path vs float64, with the fp32 CPU port (the reference's
+        # arithmetic) as the yardstick -- tests/_gradcheck.py.  A 6-image training-mode BatchNorm network is
+        # chaotic at the percent level in fp32 whatever the arithmetic (the CPU port itself: median 1 %, worst
+        # tensor 8 % from float64), so this end-to-end bound is statistical; the per-module tests
+        # (test_pointnet_gpu, test_decoder_gpu, test_dgcnn_size_gpu, test_winograd_gpu, test_bnact_gpu) are tight.
+        stats = assert_like_yardstick(named(dev), named(cpu), named(cpu64), f"episode train m={wino_m}",
+                                      factor=5.0, hard_max=0.5, cancelled_max=5e-2)
+        measured["grad_dev_hip"], measured["grad_dev_cpu32"] = stats
+        for top in ("img_encoder", "pc_encoder", "pc_decoder"):
+            assert measured[f"grad_l2[{top}]_hip_vs_f64"] <= 5 * measured[f"grad_l2[{top}]_cpu32_vs_f64"] + 1e-3, measured
+    _record("episode_parity", measured)
+    for key, tol in LOSS_TOL[wino_m].items():
+        assert measured[key] <= tol, measured
+        # and no further from the float64 run than the reference arithmetic is, within the same bound
+        assert measured[key + "_hip_vs_f64"] <= measured[key + "_cpu32_vs_f64"] + tol, measured
 
 
 def test_evaluation_dict_with_emd(gpu, oracle):

@@ -57,3 +57,19 @@ def test_encoder_wrapper_returns_feature_only(gold):
         out = enc(torch.from_numpy(gold["x_a"]))
     assert out.shape == (4, 1024)
     np.testing.assert_allclose(out.numpy(), gold["feat_a_eval"], rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_training_gradients_match_reference(gold, tag):
+    """Host port against the reference module's own autograd (gradient_goldens.npz)."""
+    gg = np.load(os.path.join(GOLDEN, "gradient_goldens.npz"))
+    enc = _encoder().train()
+    net = enc.pc_encoder.pointnet_feat_extractor
+    x = torch.from_numpy(gold[f"x_{tag}"]).requires_grad_()
+    feat, _, _ = net(x)
+    (feat * torch.from_numpy(gg[f"pn_w_{tag}"])).sum().backward()
+    np.testing.assert_allclose(x.grad.numpy(), gg[f"pn_gx_{tag}"], rtol=1e-3, atol=1e-5 * np.abs(gg[f"pn_gx_{tag}"]).max())
+    for name, p in net.named_parameters():
+        ref = gg[f"pn_g_{tag}_{name}"]
+        got = (p.grad[:64] if p.grad.numel() > 65536 else p.grad).numpy()
+        assert np.abs(got - ref).max() <= 1e-3 * np.abs(ref).max() + 1e-6, name
