@@ -29,7 +29,16 @@ SIGNATURES = {
                          _c_f32p, _c_i32p, _c_f32p, _c_i32p, _c_stream],
     "fpsg_chamfer_bwd": [_c_f32p, _c_f32p, _c_i32p, _c_i32p, _c_f32p, _c_f32p,
                          _c_int, _c_int, _c_int, _c_f32p, _c_f32p, _c_stream],
-    "fpsg_chamfer_set_config": [_c_int],
+    "fpsg_chamfer_fwd_variant": [_c_f32p, _c_f32p, _c_int, _c_int, _c_int,
+                                 _c_f32p, _c_i32p, _c_f32p, _c_i32p, _c_int, _c_stream],
+    "fpsg_chamfer_workspace_bytes": [_c_int, _c_int, _c_int, _c_int],
+    "fpsg_chamfer_fwd_tiled": [_c_f32p, _c_f32p, _c_int, _c_int, _c_int,
+                               _c_f32p, _c_i32p, _c_f32p, _c_i32p, ctypes.c_void_p, ctypes.c_size_t, _c_int,
+                               _c_stream],
+    "fpsg_chamfer_bwd_sorted": [_c_f32p, _c_f32p, _c_i32p, _c_i32p, _c_f32p, _c_f32p,
+                                _c_int, _c_int, _c_int, _c_f32p, _c_f32p, _c_stream],
+    "fpsg_chamfer_bwd_scan": [_c_f32p, _c_f32p, _c_i32p, _c_i32p, _c_f32p, _c_f32p,
+                              _c_int, _c_int, _c_int, _c_f32p, _c_f32p, _c_stream],
     "fpsg_knn": [_c_f32p, _c_int, _c_int, _c_int, _c_int, _c_i32p, _c_f32p, _c_stream],
     "fpsg_edge_feature_fwd": [_c_f32p, _c_i32p, _c_int, _c_int, _c_int, _c_int, _c_f32p, _c_stream],
     "fpsg_edge_feature_bwd": [_c_f32p, _c_i32p, _c_int, _c_int, _c_int, _c_int, _c_f32p, _c_stream],
@@ -39,6 +48,9 @@ SIGNATURES = {
     "fpsg_edgeconv_bwd": [_c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_i32p, _c_i32p, _c_f32p, _c_int, _c_int,
                           _c_int, _c_int, _c_f32p, _c_stream],
     "fpsg_softmin": [_c_f32p, _c_f32p, _c_f32p, _c_int, _c_int, _c_int, ctypes.c_float, _c_f32p, _c_stream],
+    "fpsg_sinkhorn_workspace_floats": [_c_int, _c_int, _c_int],
+    "fpsg_sinkhorn_divergence": [_c_f32p, _c_f32p, _c_int, _c_int, _c_int, ctypes.c_void_p, _c_int, _c_f32p, _c_f32p,
+                                 _c_stream],
     "fpsg_bn_workspace_floats": [_c_int, _c_int, _c_int],
     "fpsg_bn_act_fwd": [_c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, ctypes.c_float, _c_int, _c_int, _c_int, _c_int,
                         ctypes.c_float, _c_int, ctypes.c_float, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p,
@@ -74,7 +86,8 @@ SIGNATURES = {
     "fpsg_emd_approx": [_c_f32p, _c_f32p, _c_int, _c_int, _c_int, _c_f32p, _c_f32p, _c_f32p, _c_f32p,
                         _c_stream],
 }
-_RESTYPES = {"fpsg_last_error": ctypes.c_char_p, "fpsg_chamfer_set_config": None,
+_RESTYPES = {"fpsg_last_error": ctypes.c_char_p, "fpsg_chamfer_workspace_bytes": ctypes.c_size_t,
+             "fpsg_sinkhorn_workspace_floats": ctypes.c_size_t,
              "fpsg_bn_workspace_floats": ctypes.c_size_t, "fpsg_bn_pool_workspace_floats": ctypes.c_size_t, "fpsg_bn_max_workspace_floats": ctypes.c_size_t, "fpsg_conv_first_dw_workspace_floats": ctypes.c_size_t, "fpsg_emd_workspace_floats": ctypes.c_size_t}
 
 _lib = None

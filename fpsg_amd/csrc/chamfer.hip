@@ -239,8 +239,8 @@ int launch_fwd(const float* xyz1, const float* xyz2, int B, int N, int M, float*
 // list in LDS (integer LDS atomics only hand out slots; the ORDER of accumulation does not
 // depend on them).  Pass 2: each thread walks its list in ascending j (selection by "smallest
 // j greater than the previous one"), so the fp32 sums are bit-identical to the oracle's
-// sequential loop.  Targets chosen by more than kBwdCap sources are summed by the whole wave in
-// a fixed hierarchical order (see below), which the oracle follows too.
+// blocked order (also for targets chosen by more than kBwdCap sources, see below).  This scanning kernel
+// serves clouds of more than 4096 points; smaller ones take chamfer_bwd_sorted_kernel (chamfer_tiled.hip).
 constexpr int kBwdThreads = 256;
 constexpr int kBwdCap = 16;
 constexpr int kBwdStage = 4096;
@@ -304,7 +304,11 @@ __global__ __launch_bounds__(kBwdThreads) void chamfer_bwd_kernel(
     ay = t * (py - Bc[3 * j + 1]);
     az = t * (pz - Bc[3 * j + 2]);
   }
+  // Summation order (see chamfer_tiled.hip): sources in ascending j, blocks of 32 summed from +0, the
+  // block sums added to the own term in block order.
   const int n = live ? cnt[tid] : 0;
+  float sx = 0.0f, sy = 0.0f, sz = 0.0f;
+  int filled = 0;
   if (n <= kBwdCap) {
     int prev = -1;
     for (int s = 0; s < n; ++s) {
@@ -315,44 +319,29 @@ __global__ __launch_bounds__(kBwdThreads) void chamfer_bwd_kernel(
       }
       prev = j;
       const float t = 2.0f * gb_up[j];
-      ax = fma_rn(t, px - Bc[3 * j + 0], ax);
-      ay = fma_rn(t, py - Bc[3 * j + 1], ay);
-      az = fma_rn(t, pz - Bc[3 * j + 2], az);
+      sx = fma_rn(t, px - Bc[3 * j + 0], sx);
+      sy = fma_rn(t, py - Bc[3 * j + 1], sy);
+      sz = fma_rn(t, pz - Bc[3 * j + 2], sz);
     }
-  }
-  // Targets chosen by more than kBwdCap sources (routine early in training, when the generated
-  // cloud is a small blob): the whole wave serves them one at a time.  Lane t sums the sources
-  // j = t (mod 64) in ascending order, the 64 partial sums are folded by a fixed shuffle tree
-  // (32,16,..,1) and added to the own term -- the same fixed order as the oracle.
-  const int lane = tid & 63;
-  unsigned long long heavy = __ballot(n > kBwdCap);
-  while (heavy) {
-    const int L = __builtin_ctzll(heavy);
-    heavy &= heavy - 1;
-    const int tgt = __builtin_amdgcn_readlane(i, L);
-    const float qx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(px), L));
-    const float qy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(py), L));
-    const float qz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pz), L));
-    float sx = 0.0f, sy = 0.0f, sz = 0.0f;
-    for (int j = lane; j < nb; j += 64) {
-      if ((staged ? sib[j] : ib[j]) == tgt) {
+    filled = n;
+  } else {
+    // more sources than slots: the thread scans the whole list in ascending j (slow, but this kernel only
+    // serves clouds beyond the sorted kernel's 4096 points)
+    for (int j = 0; j < nb; ++j) {
+      if ((staged ? sib[j] : ib[j]) == i) {
         const float t = 2.0f * gb_up[j];
-        sx = fma_rn(t, qx - Bc[3 * j + 0], sx);
-        sy = fma_rn(t, qy - Bc[3 * j + 1], sy);
-        sz = fma_rn(t, qz - Bc[3 * j + 2], sz);
+        sx = fma_rn(t, px - Bc[3 * j + 0], sx);
+        sy = fma_rn(t, py - Bc[3 * j + 1], sy);
+        sz = fma_rn(t, pz - Bc[3 * j + 2], sz);
+        if (++filled == 32) {
+          ax += sx; ay += sy; az += sz;
+          sx = 0.0f; sy = 0.0f; sz = 0.0f;
+          filled = 0;
+        }
       }
     }
-#pragma unroll
-    for (int sft = 32; sft >= 1; sft >>= 1) {
-      sx += __shfl_down(sx, sft, 64);
-      sy += __shfl_down(sy, sft, 64);
-      sz += __shfl_down(sz, sft, 64);
-    }
-    const float tx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sx), 0));
-    const float ty = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sy), 0));
-    const float tz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sz), 0));
-    if (lane == L) { ax += tx; ay += ty; az += tz; }
   }
+  if (filled) { ax += sx; ay += sy; az += sz; }
   if (live) {
     out[3 * i + 0] = ax;
     out[3 * i + 1] = ay;
@@ -363,22 +352,19 @@ __global__ __launch_bounds__(kBwdThreads) void chamfer_bwd_kernel(
 }  // namespace
 }  // namespace fpsg
 
-// tuning hook (tools/bench_chamfer.py): -1 = automatic choice of (R, W)
-static int fpsg_chamfer_cfg_override = -1;
-
-extern "C" int fpsg_chamfer_fwd(const float* xyz1, const float* xyz2, int B, int N, int M,
-                                float* dist1, int32_t* idx1, float* dist2, int32_t* idx2,
-                                fpsg_stream_t stream) {
+extern "C" int fpsg_chamfer_fwd_variant(const float* xyz1, const float* xyz2, int B, int N, int M,
+                                        float* dist1, int32_t* idx1, float* dist2, int32_t* idx2,
+                                        int cfg, fpsg_stream_t stream) {
   using namespace fpsg;
   FPSG_REQUIRE(B > 0 && N > 0 && M > 0, FPSG_E_SHAPE,
                "fpsg_chamfer_fwd: B,N,M must be positive (got %d,%d,%d)", B, N, M);
   FPSG_REQUIRE((long)B * ((N > M ? N : M) / 64 + 1) * 2 < (1L << 31), FPSG_E_LIMIT,
                "fpsg_chamfer_fwd: B=%d x N=%d exceeds the grid limit", B, N > M ? N : M);
+  FPSG_REQUIRE(cfg >= -1 && cfg <= 6, FPSG_E_SHAPE, "fpsg_chamfer_fwd_variant: cfg %d not in [-1, 6]", cfg);
   FPSG_REQUIRE_PTR(xyz1); FPSG_REQUIRE_PTR(xyz2);
   FPSG_REQUIRE_PTR(dist1); FPSG_REQUIRE_PTR(idx1);
   FPSG_REQUIRE_PTR(dist2); FPSG_REQUIRE_PTR(idx2);
   hipStream_t s = static_cast<hipStream_t>(stream);
-  int cfg = fpsg_chamfer_cfg_override;
   if (cfg < 0) {
     // Queries per lane R and waves per workgroup W, from a sweep on MI355X at N = M = 2048
     // (profiles/r01/chamfer_microbench_v4_config_sweep.txt): the launch time is
@@ -399,12 +385,16 @@ extern "C" int fpsg_chamfer_fwd(const float* xyz1, const float* xyz2, int B, int
   }
 }
 
-extern "C" void fpsg_chamfer_set_config(int cfg) { fpsg_chamfer_cfg_override = cfg; }
-
-extern "C" int fpsg_chamfer_bwd(const float* xyz1, const float* xyz2, const int32_t* idx1,
-                                const int32_t* idx2, const float* g1, const float* g2, int B,
-                                int N, int M, float* gxyz1, float* gxyz2,
+extern "C" int fpsg_chamfer_fwd(const float* xyz1, const float* xyz2, int B, int N, int M,
+                                float* dist1, int32_t* idx1, float* dist2, int32_t* idx2,
                                 fpsg_stream_t stream) {
+  return fpsg_chamfer_fwd_variant(xyz1, xyz2, B, N, M, dist1, idx1, dist2, idx2, -1, stream);
+}
+
+extern "C" int fpsg_chamfer_bwd_scan(const float* xyz1, const float* xyz2, const int32_t* idx1,
+                                     const int32_t* idx2, const float* g1, const float* g2, int B,
+                                     int N, int M, float* gxyz1, float* gxyz2,
+                                     fpsg_stream_t stream) {
   using namespace fpsg;
   FPSG_REQUIRE(B > 0 && N > 0 && M > 0, FPSG_E_SHAPE,
                "fpsg_chamfer_bwd: B,N,M must be positive (got %d,%d,%d)", B, N, M);
@@ -418,4 +408,13 @@ extern "C" int fpsg_chamfer_bwd(const float* xyz1, const float* xyz2, const int3
                      static_cast<hipStream_t>(stream), xyz1, xyz2, idx1, idx2, g1, g2, N, M, tiles,
                      gxyz1, gxyz2);
   return launch_status("fpsg_chamfer_bwd");
+}
+
+extern "C" int fpsg_chamfer_bwd(const float* xyz1, const float* xyz2, const int32_t* idx1,
+                                const int32_t* idx2, const float* g1, const float* g2, int B,
+                                int N, int M, float* gxyz1, float* gxyz2,
+                                fpsg_stream_t stream) {
+  if (N > 0 && M > 0 && N <= 4096 && M <= 4096)
+    return fpsg_chamfer_bwd_sorted(xyz1, xyz2, idx1, idx2, g1, g2, B, N, M, gxyz1, gxyz2, stream);
+  return fpsg_chamfer_bwd_scan(xyz1, xyz2, idx1, idx2, g1, g2, B, N, M, gxyz1, gxyz2, stream);
 }

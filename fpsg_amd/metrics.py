@@ -33,6 +33,12 @@ def _probe(kind, B, N, M):
     return _NoProbe() if _launch_probe is None else _launch_probe(kind, B, N, M)
 
 
+def _tiled_enabled() -> bool:
+    """``FPSG_CHAMFER_TILED=0`` selects the two-pass forward kernel (A/B measurements)."""
+    import os
+    return os.environ.get("FPSG_CHAMFER_TILED", "1") != "0"
+
+
 def _check_clouds(p1: torch.Tensor, p2: torch.Tensor):
     if p1.dim() != 3 or p2.dim() != 3 or p1.size(2) != 3 or p2.size(2) != 3:
         raise ValueError(f"expected [B,N,3] and [B,M,3] clouds, got {tuple(p1.shape)} and "
@@ -61,10 +67,19 @@ class _SidedPair(torch.autograd.Function):
         dist2 = torch.empty((B, M), dtype=torch.float32, device=p1.device)
         idx1 = torch.empty((B, N), dtype=torch.int32, device=p1.device)
         idx2 = torch.empty((B, M), dtype=torch.int32, device=p1.device)
+        # one-pass tiled form (every d(i,j) evaluated once) for clouds of at most 4096 points; the
+        # two-pass kernel (no workspace) otherwise.  Bit-identical results.
+        ws_bytes = lib.fpsg_chamfer_workspace_bytes(B, N, M, -1) if _tiled_enabled() else 0
         with torch.cuda.device(p1.device), _probe("chamfer_fwd", B, N, M):
-            rc = lib.fpsg_chamfer_fwd(_hip.ptr(p1), _hip.ptr(p2), B, N, M, _hip.ptr(dist1),
-                                      _hip.ptr(idx1), _hip.ptr(dist2), _hip.ptr(idx2),
-                                      _hip.stream_of(p1))
+            if ws_bytes:
+                ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=p1.device)
+                rc = lib.fpsg_chamfer_fwd_tiled(_hip.ptr(p1), _hip.ptr(p2), B, N, M, _hip.ptr(dist1),
+                                                _hip.ptr(idx1), _hip.ptr(dist2), _hip.ptr(idx2),
+                                                _hip.ptr(ws), ws_bytes, -1, _hip.stream_of(p1))
+            else:
+                rc = lib.fpsg_chamfer_fwd(_hip.ptr(p1), _hip.ptr(p2), B, N, M, _hip.ptr(dist1),
+                                          _hip.ptr(idx1), _hip.ptr(dist2), _hip.ptr(idx2),
+                                          _hip.stream_of(p1))
         _hip.check(rc, "fpsg_chamfer_fwd")
         ctx.save_for_backward(p1, p2, idx1, idx2)
         ctx.mark_non_differentiable(idx1, idx2)
@@ -180,34 +195,37 @@ def sinkhorn_divergence(p1: torch.Tensor, p2: torch.Tensor, blur: float = 0.05, 
     Forward value only (the reference uses it in evaluation, ``few_shot.py:168``); the geomloss
     package is absent from the reference tree and unpinned, so parity is UNPINNED."""
     _check_clouds(p1, p2)
-    import math
     B, N, _ = p1.shape
     M = p2.size(1)
     x, y = p1.detach(), p2.detach()
     if diameter is None:     # one host sync; pass `diameter` to stay asynchronous
         pts = torch.cat([x.reshape(-1, 3), y.reshape(-1, 3)])
         diameter = float((pts.amax(0) - pts.amin(0)).norm())
+    eps_s = sinkhorn_epsilons(diameter, blur, scaling)
+    # the loop itself (four soft-mins per schedule entry, symmetric averaging, final extrapolation)
+    # runs inside the library: one launch per entry (K2b)
+    import ctypes
+    lib = _hip.load()
+    eps_arr = (ctypes.c_float * len(eps_s))(*eps_s)
+    out = torch.empty((B,), dtype=torch.float32, device=x.device)
+    ws = torch.empty((lib.fpsg_sinkhorn_workspace_floats(B, N, M),), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device), _probe("sinkhorn", B, N, M):
+        rc = lib.fpsg_sinkhorn_divergence(_hip.ptr(x), _hip.ptr(y), B, N, M, eps_arr, len(eps_s), _hip.ptr(out),
+                                          _hip.ptr(ws), _hip.stream_of(x))
+    _hip.check(rc, "fpsg_sinkhorn_divergence")
+    return out
+
+
+def sinkhorn_epsilons(diameter: float, blur: float = 0.05, scaling: float = 0.5):
+    """geomloss' ``epsilon_schedule(p=2, diameter, blur, scaling)``."""
+    import math
     eps_s = [diameter ** 2]
     e = 2 * math.log(diameter)
     while e > 2 * math.log(blur):
         eps_s.append(math.exp(e))
         e += 2 * math.log(scaling)
     eps_s.append(blur ** 2)
-    a_log = torch.full((B, N), -math.log(N), dtype=torch.float32, device=x.device)
-    b_log = torch.full((B, M), -math.log(M), dtype=torch.float32, device=x.device)
-    e = eps_s[0]
-    a_x, b_y = softmin(x, x, a_log, e), softmin(y, y, b_log, e)
-    a_y, b_x = softmin(y, x, a_log, e), softmin(x, y, b_log, e)
-    for e in eps_s:
-        at_y = softmin(y, x, a_log + b_x / e, e)
-        bt_x = softmin(x, y, b_log + a_y / e, e)
-        at_x = softmin(x, x, a_log + a_x / e, e)
-        bt_y = softmin(y, y, b_log + b_y / e, e)
-        a_y, b_x = 0.5 * (a_y + at_y), 0.5 * (b_x + bt_x)
-        a_x, b_y = 0.5 * (a_x + at_x), 0.5 * (b_y + bt_y)
-    a_y, b_x = softmin(y, x, a_log + b_x / e, e), softmin(x, y, b_log + a_y / e, e)
-    a_x, b_y = softmin(x, x, a_log + a_x / e, e), softmin(y, y, b_log + b_y / e, e)
-    return (b_x - a_x).mean(dim=1) + (a_y - b_y).mean(dim=1)
+    return eps_s
 
 
 def emd_loss(p1: torch.Tensor, p2: torch.Tensor, reduce: str = "mean", sinkhorn: bool = False):

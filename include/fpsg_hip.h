@@ -11,7 +11,8 @@
  *   - a call only enqueues work on `stream` and returns (asynchronous);
  *   - return value 0 = success; >0 = hipError_t from the launch; <0 = argument check
  *     (FPSG_E_*); fpsg_last_error() gives a thread-local message for the last failure;
- *   - no C++ exception crosses the boundary; no global state besides that message.
+ *   - no C++ exception crosses the boundary; no global state besides that message (tuning variants
+ *     are explicit arguments, never process-wide settings).
  *   - index outputs are int32 (the Python mirror widens to int64 where the reference
  *     API exposes int64).
  */
@@ -52,24 +53,54 @@ int fpsg_chamfer_fwd(const float* xyz1, const float* xyz2, int B, int N, int M,
                      float* dist1, int32_t* idx1, float* dist2, int32_t* idx2,
                      fpsg_stream_t stream);
 
-/* Tuning hook for micro-benchmarks: force the forward kernel's (queries per lane, waves per
- * workgroup) variant: 0=(1,16) 1=(2,16) 2=(4,8) 3=(8,4) 4=(4,4) 5=(2,8) 6=(2,4); -1 (default) =
- * automatic.  Results do
+/* The same with an explicit kernel variant (micro-benchmarks, tests): (queries per lane, waves per
+ * workgroup) 0=(1,16) 1=(2,16) 2=(4,8) 3=(8,4) 4=(4,4) 5=(2,8) 6=(2,4); -1 = automatic.  Results do
  * not depend on it. */
-void fpsg_chamfer_set_config(int cfg);
+int fpsg_chamfer_fwd_variant(const float* xyz1, const float* xyz2, int B, int N, int M,
+                             float* dist1, int32_t* idx1, float* dist2, int32_t* idx2,
+                             int cfg, fpsg_stream_t stream);
+
+/* One-pass form of the same op (the default of the Python mirror for clouds of at most 4096 points):
+ * every d(i,j) is evaluated once and serves both directions (d is bit-symmetric); 2-D tiles of
+ * 64*R rows x W*cpw*16 candidates leave 64-bit partial keys in the caller's workspace, a second
+ * launch merges them and recovers the exact indices.  Bit-identical results to fpsg_chamfer_fwd.
+ * ws: fpsg_chamfer_workspace_bytes(B,N,M,variant) bytes, 8-byte aligned.  variant: -1 automatic,
+ * else (R==8 ? 100 : 0) + 10*W + cpw with R in {4,8}, W in {1,2,4}, cpw in 1..9.  The workspace size
+ * is 0 when this form does not apply: N or M > 4096, or (variant -1) fewer than ~7 pairs of
+ * 2048-point clouds, where fpsg_chamfer_fwd's small workgroups fill the chip better. */
+size_t fpsg_chamfer_workspace_bytes(int B, int N, int M, int variant);
+int fpsg_chamfer_fwd_tiled(const float* xyz1, const float* xyz2, int B, int N, int M,
+                           float* dist1, int32_t* idx1, float* dist2, int32_t* idx2,
+                           void* ws, size_t ws_bytes, int variant, fpsg_stream_t stream);
 
 /* Backward of the two sided distances w.r.t. both clouds (Kaolin's
  * sided_distance backward, reached through autograd from
  * src/trainNetwork.py:144 `ttl_loss.backward()`).
  * g1 [B,N], g2 [B,M] are the upstream gradients of dist1/dist2.
- * gxyz1 [B,N,3], gxyz2 [B,M,3] are fully overwritten.  Deterministic: every output
- * element is summed by one thread in ascending source-index order (no float atomics).
- */
+ * gxyz1 [B,N,3], gxyz2 [B,M,3] are fully overwritten.  Deterministic (Kaolin scatters with float
+ * atomics, i.e. in no defined order).  Order fixed here, per output point i of cloud a:
+ *   own term   ga_i = (2 g_a[i]) (a_i - b[idx_a[i]]);
+ *   the sources j with idx_b[j] == i, in ascending j, are cut into blocks of 32; block k is summed
+ *   from +0 by S_k = fma(2 g_b[j], a_i - b_j, S_k); then ga_i += S_0, += S_1, ... in block order.
+ * fpsg_chamfer_bwd picks between the two kernels below (same results):
+ *   _sorted: N, M <= 4096; one workgroup per (pair, side) inverts the argmin list by sorting
+ *            (target, source) keys in LDS -- time independent of how many sources share a target;
+ *   _scan  : any size; every 256-point tile scans the other side's argmin list. */
 int fpsg_chamfer_bwd(const float* xyz1, const float* xyz2,
                      const int32_t* idx1, const int32_t* idx2,
                      const float* g1, const float* g2,
                      int B, int N, int M,
                      float* gxyz1, float* gxyz2, fpsg_stream_t stream);
+int fpsg_chamfer_bwd_sorted(const float* xyz1, const float* xyz2,
+                            const int32_t* idx1, const int32_t* idx2,
+                            const float* g1, const float* g2,
+                            int B, int N, int M,
+                            float* gxyz1, float* gxyz2, fpsg_stream_t stream);
+int fpsg_chamfer_bwd_scan(const float* xyz1, const float* xyz2,
+                          const int32_t* idx1, const int32_t* idx2,
+                          const float* g1, const float* g2,
+                          int B, int N, int M,
+                          float* gxyz1, float* gxyz2, fpsg_stream_t stream);
 
 /* ---- K3: kNN graph ----------------------------------------------------------------
  * Replaces `knn(x, k)` of src/dgcnn/model.py:13-20 (torch.matmul into a [B,N,N] matrix +
@@ -139,6 +170,20 @@ int fpsg_edgeconv_bwd(const float* dzs, const uint8_t* jsel, const float* PQ, co
  */
 int fpsg_softmin(const float* x, const float* y, const float* h, int B, int N, int M, float eps,
                  float* out, fpsg_stream_t stream);
+
+/* The whole divergence of emd_wrapper (src/models/utils.py:12-13): the symmetric, annealed, debiased
+ * Sinkhorn loop of geomloss.SamplesLoss("sinkhorn", p=2) between uniform clouds x [B,N,3], y [B,M,3]:
+ *   duals a_x, b_x [N], a_y, b_y [M] start as the soft-mins of the log-weights at eps[0]; for every
+ *   eps of the schedule the four soft-mins (h = log-weight + dual * (1/eps)) are evaluated from the
+ *   previous duals and averaged in, new = (old + softmin)/2; one last un-averaged evaluation at
+ *   eps[n-1];  out[b] = mean_i (b_x - a_x) + mean_j (a_y - b_y).
+ * ONE launch per schedule entry (the four soft-mins side by side), n_eps + 3 launches in all.
+ * eps_host: the schedule as n_eps HOST floats (geomloss: diameter^2, then diameter^2 * scaling^2k
+ * down to blur^2, then blur^2); ws: fpsg_sinkhorn_workspace_floats(B,N,M) device floats.  Deterministic. */
+size_t fpsg_sinkhorn_workspace_floats(int B, int N, int M);
+int fpsg_sinkhorn_divergence(const float* x, const float* y, int B, int N, int M,
+                             const float* eps_host, int n_eps, float* out, float* ws,
+                             fpsg_stream_t stream);
 
 /* ---- K5: BatchNorm fused with its activation (training and eval mode) -------------------
  * Replaces the BatchNorm{1,2}d + ReLU / LeakyReLU module pairs of the reference networks

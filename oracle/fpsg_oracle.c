@@ -69,19 +69,17 @@ void oracle_chamfer_fwd(const float* xyz1, const float* xyz2, int B, int N, int 
  *   own term      : ga[i]  = (2*g_a[i]) * (a_i - b[idx_a[i]])
  *   scatter terms : + (2*g_b[j]) * (a_i - b_j)   for every j with idx_b[j]==i
  *                   (d(b_j, a_i) = |b_j - a_i|^2, d/da_i = 2 (a_i - b_j))
- * Kaolin accumulates these with atomicAdd, i.e. in no defined order; the order is fixed here
- * (and followed bit for bit by the HIP kernel):
- *   - a point chosen by at most 16 sources: own term, then the sources in ascending j, each
- *     component accumulated with fmaf(t, diff, acc), t = 2*g;
- *   - a point chosen by more than 16 sources: 64 partial sums, partial t taking the sources
- *     j = t (mod 64) in ascending j (fmaf chain from +0), folded pairwise p[t] += p[t+s] for
- *     s = 32,16,8,4,2,1, then  own + p[0].                                               */
-#define ORACLE_BWD_CAP 16
+ * Kaolin accumulates the scatter terms with atomicAdd, i.e. in no defined order.  The order fixed
+ * here (and in include/fpsg_hip.h): the sources j with idx_b[j] == i, in ascending j, are cut into
+ * blocks of 32; block k is summed from +0 by S_k = fmaf(2*g_b[j], a_i - b_j, S_k) in ascending j;
+ * ga_i = own term, then ga_i += S_0, += S_1, ...  (A point with at most 32 sources is therefore a
+ * plain sequential sum; blocks make a point chosen by hundreds of sources summable in parallel.)   */
+#define ORACLE_BWD_BLOCK 32
 static void grad_one_cloud(const float* a, const float* b, const int32_t* idx_a,
                            const int32_t* idx_b, const float* g_a, const float* g_b,
                            int Na, int Nb, float* ga) {
-  int* deg = (int*)calloc((size_t)Na, sizeof(int));
-  for (int j = 0; j < Nb; ++j) deg[idx_b[j]]++;
+  float* part = (float*)calloc((size_t)Na * 3, sizeof(float));   /* the open block of every point */
+  int* fill = (int*)calloc((size_t)Na, sizeof(int));             /* sources in the open block */
   for (int i = 0; i < Na; ++i) {
     const float* p = a + 3 * i;
     const float* q = b + 3 * idx_a[i];
@@ -90,36 +88,25 @@ static void grad_one_cloud(const float* a, const float* b, const int32_t* idx_a,
     ga[3 * i + 1] = t * (p[1] - q[1]);
     ga[3 * i + 2] = t * (p[2] - q[2]);
   }
-  for (int j = 0; j < Nb; ++j) {          /* light targets: ascending j */
+  for (int j = 0; j < Nb; ++j) {
     int i = idx_b[j];
-    if (deg[i] > ORACLE_BWD_CAP) continue;
     const float* p = a + 3 * i;
     const float* q = b + 3 * j;
     float t = 2.0f * g_b[j];
-    ga[3 * i + 0] = fmaf(t, p[0] - q[0], ga[3 * i + 0]);
-    ga[3 * i + 1] = fmaf(t, p[1] - q[1], ga[3 * i + 1]);
-    ga[3 * i + 2] = fmaf(t, p[2] - q[2], ga[3 * i + 2]);
-  }
-  for (int i = 0; i < Na; ++i) {          /* heavy targets: 64 strided partials + fixed tree */
-    if (deg[i] <= ORACLE_BWD_CAP) continue;
-    float part[64][3];
-    memset(part, 0, sizeof(part));
-    const float* p = a + 3 * i;
-    for (int j = 0; j < Nb; ++j) {
-      if (idx_b[j] != i) continue;
-      const float* q = b + 3 * j;
-      float t = 2.0f * g_b[j];
-      float* s = part[j & 63];
-      s[0] = fmaf(t, p[0] - q[0], s[0]);
-      s[1] = fmaf(t, p[1] - q[1], s[1]);
-      s[2] = fmaf(t, p[2] - q[2], s[2]);
+    float* s = part + 3 * i;
+    s[0] = fmaf(t, p[0] - q[0], s[0]);
+    s[1] = fmaf(t, p[1] - q[1], s[1]);
+    s[2] = fmaf(t, p[2] - q[2], s[2]);
+    if (++fill[i] == ORACLE_BWD_BLOCK) {                         /* block complete: add it, open the next */
+      for (int c = 0; c < 3; ++c) { ga[3 * i + c] += s[c]; s[c] = 0.0f; }
+      fill[i] = 0;
     }
-    for (int sft = 32; sft >= 1; sft >>= 1)
-      for (int t = 0; t < sft; ++t)
-        for (int c = 0; c < 3; ++c) part[t][c] += part[t + sft][c];
-    for (int c = 0; c < 3; ++c) ga[3 * i + c] += part[0][c];
   }
-  free(deg);
+  for (int i = 0; i < Na; ++i)
+    if (fill[i])
+      for (int c = 0; c < 3; ++c) ga[3 * i + c] += part[3 * i + c];
+  free(part);
+  free(fill);
 }
 
 void oracle_chamfer_bwd(const float* xyz1, const float* xyz2, const int32_t* idx1,

@@ -39,24 +39,87 @@ def test_fwd_bit_exact_vs_oracle(gpu, oracle, B, N, M):
     assert np.array_equal(d2.view(np.uint32), od2.view(np.uint32))
 
 
+def _call_fwd(lib, name, p1, p2, dev, *extra):
+    B, N, M = p1.shape[0], p1.shape[1], p2.shape[1]
+    t1, t2 = torch.from_numpy(p1).to(dev), torch.from_numpy(p2).to(dev)
+    d1 = torch.empty((B, N), device=dev); d2 = torch.empty((B, M), device=dev)
+    i1 = torch.empty((B, N), device=dev, dtype=torch.int32); i2 = torch.empty((B, M), device=dev, dtype=torch.int32)
+    rc = getattr(lib, name)(t1.data_ptr(), t2.data_ptr(), B, N, M, d1.data_ptr(), i1.data_ptr(), d2.data_ptr(),
+                            i2.data_ptr(), *extra, torch.cuda.current_stream().cuda_stream)
+    assert rc == 0, lib.fpsg_last_error()
+    return d1.cpu().numpy(), i1.cpu().numpy(), d2.cpu().numpy(), i2.cpu().numpy()
+
+
+def _assert_fwd_equal(got, exp):
+    d1, i1, d2, i2 = got
+    od1, oi1, od2, oi2 = exp
+    assert np.array_equal(i1, oi1) and np.array_equal(i2, oi2)
+    assert np.array_equal(d1.view(np.uint32), od1.view(np.uint32))
+    assert np.array_equal(d2.view(np.uint32), od2.view(np.uint32))
+
+
 @pytest.mark.parametrize("cfg", range(7))
-def test_every_kernel_variant_is_bit_exact(gpu, oracle, cfg):
-    """All (queries per lane, waves per workgroup) variants of the forward kernel, forced
-    through the tuning hook, on ragged sizes (tail lanes, partial chunks, N != M)."""
+def test_every_two_pass_variant_is_bit_exact(gpu, oracle, cfg):
+    """All (queries per lane, waves per workgroup) variants of the two-pass forward kernel, selected by
+    explicit argument, on ragged sizes (tail lanes, partial chunks, N != M)."""
     from fpsg_amd import _hip
     rng = np.random.default_rng(100 + cfg)
     p1 = unit_ball_clouds(rng, 3, 1000)
     p2 = np.tanh(rng.standard_normal((3, 777, 3))).astype(np.float32)
+    _assert_fwd_equal(_call_fwd(_hip.load(), "fpsg_chamfer_fwd_variant", p1, p2, gpu, cfg), oracle.chamfer_fwd(p1, p2))
+
+
+# (R==8 ? 100 : 0) + 10 * W + cpw: every template instance, several tile widths
+TILED_VARIANTS = [111, 121, 141, 144, 148, 122, 11, 21, 41, 44, 49, 14]
+
+
+@pytest.mark.parametrize("variant", TILED_VARIANTS)
+@pytest.mark.parametrize("B,N,M", [(3, 1000, 777), (2, 2048, 2048), (2, 1, 50), (2, 50, 1), (1, 4096, 3000), (2, 129, 4096)])
+def test_every_tiled_variant_is_bit_exact(gpu, oracle, variant, B, N, M):
+    """The one-pass tiled forward (each d(i,j) evaluated once, both directions served) for every tile
+    shape: ragged rows / candidates, N != M, single points, the 4096-point limit."""
+    from fpsg_amd import _hip
     lib = _hip.load()
-    lib.fpsg_chamfer_set_config(cfg)
-    try:
-        d1, i1, d2, i2 = _run_fwd(p1, p2, gpu)
-    finally:
-        lib.fpsg_chamfer_set_config(-1)
-    od1, oi1, od2, oi2 = oracle.chamfer_fwd(p1, p2)
-    assert np.array_equal(i1, oi1) and np.array_equal(i2, oi2)
-    assert np.array_equal(d1.view(np.uint32), od1.view(np.uint32))
-    assert np.array_equal(d2.view(np.uint32), od2.view(np.uint32))
+    rng = np.random.default_rng(variant * 7 + N + M)
+    p1 = unit_ball_clouds(rng, B, N)
+    p2 = np.tanh(rng.standard_normal((B, M, 3))).astype(np.float32)
+    nbytes = lib.fpsg_chamfer_workspace_bytes(B, N, M, variant)
+    assert nbytes > 0
+    ws = torch.empty((nbytes,), dtype=torch.uint8, device=gpu)
+    got = _call_fwd(lib, "fpsg_chamfer_fwd_tiled", p1, p2, gpu, ws.data_ptr(), nbytes, variant)
+    _assert_fwd_equal(got, oracle.chamfer_fwd(p1, p2))
+
+
+def test_tiled_ties_and_duplicates(gpu, oracle):
+    """Exact ties across lanes, segments, tiles and workgroups: lattice points and repeats
+    (src/datasets/modelnet.py:61-64 pads short clouds with repeats) -- the lowest index must win on
+    both sides in every tile shape."""
+    from fpsg_amd import _hip
+    lib = _hip.load()
+    rng = np.random.default_rng(17)
+    base = rng.integers(-3, 4, size=(3, 700, 3)).astype(np.float32)
+    p1 = np.concatenate([base, base[:, :500], base[:, 100:300]], axis=1)      # 1400 with repeats
+    p2 = np.concatenate([base[:, ::-1], base[:, :333]], axis=1)               # 1033
+    exp = oracle.chamfer_fwd(p1, p2)
+    for variant in (141, 144, 41, 11, 122):
+        nbytes = lib.fpsg_chamfer_workspace_bytes(3, 1400, 1033, variant)
+        ws = torch.empty((nbytes,), dtype=torch.uint8, device=gpu)
+        _assert_fwd_equal(_call_fwd(lib, "fpsg_chamfer_fwd_tiled", p1, p2, gpu, ws.data_ptr(), nbytes, variant), exp)
+
+
+def test_tiled_refuses_what_it_cannot_do(gpu):
+    from fpsg_amd import _hip
+    lib = _hip.load()
+    assert lib.fpsg_chamfer_workspace_bytes(2, 5000, 100, -1) == 0          # beyond 4096 points: two-pass kernel
+    assert lib.fpsg_chamfer_workspace_bytes(2, 2048, 2048, -1) == 0         # few pairs: the two-pass kernel is faster
+    assert lib.fpsg_chamfer_workspace_bytes(37, 2048, 2048, -1) > 0
+    assert lib.fpsg_chamfer_workspace_bytes(2, 100, 100, 131) == 0           # W = 3 is not a variant
+    p = torch.rand(2, 64, 3, device=gpu)
+    d = torch.empty(2, 64, device=gpu); i = torch.empty(2, 64, device=gpu, dtype=torch.int32)
+    ws = torch.empty(8, dtype=torch.uint8, device=gpu)
+    rc = lib.fpsg_chamfer_fwd_tiled(p.data_ptr(), p.data_ptr(), 2, 64, 64, d.data_ptr(), i.data_ptr(), d.data_ptr(),
+                                    i.data_ptr(), ws.data_ptr(), 8, 141, None)
+    assert rc == -4 and b"workspace" in lib.fpsg_last_error()
 
 
 def test_ties_pick_lowest_index(gpu, oracle):
@@ -81,44 +144,92 @@ def test_kaolin_docstring_known_answer(gpu):
     np.testing.assert_allclose(out, np.array(kat["expected"]), rtol=1e-4)  # north_star tol
 
 
-@pytest.mark.parametrize("B,N,M", [(1, 2048, 2048), (5, 2048, 2048), (3, 333, 1000),
-                                   (2, 4097, 5000), (2, 1, 50)])
-def test_bwd_bit_exact_vs_oracle(gpu, oracle, B, N, M):
-    from fpsg_amd.metrics import _SidedPair
+def _call_bwd(lib, name, p1, p2, i1, i2, g1, g2, dev):
+    B, N, M = p1.shape[0], p1.shape[1], p2.shape[1]
+    t = lambda a, dt=None: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    tp1, tp2, ti1, ti2, tg1, tg2 = t(p1), t(p2), t(i1.astype(np.int32)), t(i2.astype(np.int32)), t(g1), t(g2)
+    gx1, gx2 = torch.empty_like(tp1), torch.empty_like(tp2)
+    rc = getattr(lib, name)(tp1.data_ptr(), tp2.data_ptr(), ti1.data_ptr(), ti2.data_ptr(), tg1.data_ptr(),
+                            tg2.data_ptr(), B, N, M, gx1.data_ptr(), gx2.data_ptr(),
+                            torch.cuda.current_stream().cuda_stream)
+    assert rc == 0, lib.fpsg_last_error()
+    return gx1.cpu().numpy(), gx2.cpu().numpy()
+
+
+@pytest.mark.parametrize("kernel", ["fpsg_chamfer_bwd", "fpsg_chamfer_bwd_sorted", "fpsg_chamfer_bwd_scan"])
+@pytest.mark.parametrize("B,N,M", [(1, 2048, 2048), (5, 2048, 2048), (3, 333, 1000), (2, 4096, 3000),
+                                   (2, 4097, 5000), (2, 1, 50), (3, 50, 1)])
+def test_bwd_bit_exact_vs_oracle(gpu, oracle, kernel, B, N, M):
+    """Both backward kernels (sorted inversion for clouds up to 4096 points, tile scan for any size) against
+    the oracle's sequential order: own term, then the sources in ascending index."""
+    from fpsg_amd import _hip
+    if kernel == "fpsg_chamfer_bwd_sorted" and max(N, M) > 4096:
+        pytest.skip("the sorted kernel serves clouds of at most 4096 points")
     rng = np.random.default_rng(B + N + M)
     p1 = unit_ball_clouds(rng, B, N)
     p2 = np.tanh(rng.standard_normal((B, M, 3))).astype(np.float32)
     g1 = rng.standard_normal((B, N)).astype(np.float32)
     g2 = rng.standard_normal((B, M)).astype(np.float32)
+    _, oi1, _, oi2 = oracle.chamfer_fwd(p1, p2)
+    gx1, gx2 = _call_bwd(_hip.load(), kernel, p1, p2, oi1, oi2, g1, g2, gpu)
+    ogx1, ogx2 = oracle.chamfer_bwd(p1, p2, oi1, oi2, g1, g2)
+    assert np.array_equal(gx1.view(np.uint32), ogx1.view(np.uint32))
+    assert np.array_equal(gx2.view(np.uint32), ogx2.view(np.uint32))
+
+
+def test_autograd_path_is_bit_exact(gpu, oracle):
+    from fpsg_amd.metrics import _SidedPair
+    rng = np.random.default_rng(9)
+    p1 = unit_ball_clouds(rng, 5, 2048)
+    p2 = np.tanh(rng.standard_normal((5, 2048, 3))).astype(np.float32)
+    g1 = rng.standard_normal((5, 2048)).astype(np.float32)
+    g2 = rng.standard_normal((5, 2048)).astype(np.float32)
     t1 = torch.from_numpy(p1).to(gpu).requires_grad_()
     t2 = torch.from_numpy(p2).to(gpu).requires_grad_()
     d1, d2, i1, i2 = _SidedPair.apply(t1, t2)
     torch.autograd.backward([d1, d2], [torch.from_numpy(g1).to(gpu), torch.from_numpy(g2).to(gpu)])
-    _, oi1, _, oi2 = oracle.chamfer_fwd(p1, p2)
+    od1, oi1, od2, oi2 = oracle.chamfer_fwd(p1, p2)
+    assert np.array_equal(i1.cpu().numpy(), oi1) and np.array_equal(d2.detach().cpu().numpy(), od2)
     ogx1, ogx2 = oracle.chamfer_bwd(p1, p2, oi1, oi2, g1, g2)
     assert np.array_equal(t1.grad.cpu().numpy().view(np.uint32), ogx1.view(np.uint32))
     assert np.array_equal(t2.grad.cpu().numpy().view(np.uint32), ogx2.view(np.uint32))
 
 
-def test_bwd_many_sources_per_target(gpu, oracle):
-    """Duplicate-heavy clouds: some points are the nearest neighbour of hundreds of others
-    (more than the 16 in-edge slots kept in LDS), which takes the backward's overflow path."""
-    from fpsg_amd.metrics import _SidedPair
+@pytest.mark.parametrize("kernel", ["fpsg_chamfer_bwd_sorted", "fpsg_chamfer_bwd_scan"])
+def test_bwd_many_sources_per_target(gpu, oracle, kernel):
+    """Duplicate-heavy clouds: some points are the nearest neighbour of hundreds of others (routine early in
+    training, when the generated cloud is a small blob)."""
+    from fpsg_amd import _hip
     rng = np.random.default_rng(21)
     base = rng.integers(-2, 3, size=(3, 40, 3)).astype(np.float32)
     p1 = np.repeat(base, 30, axis=1)[:, :1100]                        # 30 copies of each point
     p2 = np.concatenate([base[:, :7], rng.standard_normal((3, 900, 3)).astype(np.float32) * 5], axis=1)
     g1 = rng.standard_normal(p1.shape[:2]).astype(np.float32)
     g2 = rng.standard_normal(p2.shape[:2]).astype(np.float32)
-    t1 = torch.from_numpy(p1).to(gpu).requires_grad_()
-    t2 = torch.from_numpy(p2).to(gpu).requires_grad_()
-    d1, d2, i1, i2 = _SidedPair.apply(t1, t2)
-    torch.autograd.backward([d1, d2], [torch.from_numpy(g1).to(gpu), torch.from_numpy(g2).to(gpu)])
     _, oi1, _, oi2 = oracle.chamfer_fwd(p1, p2)
     assert np.bincount(oi1.reshape(-1)).max() > 100                    # really many-to-one
+    gx1, gx2 = _call_bwd(_hip.load(), kernel, p1, p2, oi1, oi2, g1, g2, gpu)
     ogx1, ogx2 = oracle.chamfer_bwd(p1, p2, oi1, oi2, g1, g2)
-    assert np.array_equal(t1.grad.cpu().numpy().view(np.uint32), ogx1.view(np.uint32))
-    assert np.array_equal(t2.grad.cpu().numpy().view(np.uint32), ogx2.view(np.uint32))
+    assert np.array_equal(gx1.view(np.uint32), ogx1.view(np.uint32))
+    assert np.array_equal(gx2.view(np.uint32), ogx2.view(np.uint32))
+
+
+def test_bwd_all_sources_on_one_target(gpu, oracle):
+    """The extreme: every point of one cloud chooses the same target (a collapsed generated cloud)."""
+    from fpsg_amd import _hip
+    rng = np.random.default_rng(22)
+    p1 = unit_ball_clouds(rng, 2, 2048)
+    p2 = np.zeros((2, 2048, 3), np.float32) + 5.0
+    p2[:, 77] = 0.0                                                    # the one point near cloud 1
+    g1 = rng.standard_normal((2, 2048)).astype(np.float32)
+    g2 = rng.standard_normal((2, 2048)).astype(np.float32)
+    _, oi1, _, oi2 = oracle.chamfer_fwd(p1, p2)
+    assert (oi1 == 77).all()
+    ogx1, ogx2 = oracle.chamfer_bwd(p1, p2, oi1, oi2, g1, g2)
+    for kernel in ("fpsg_chamfer_bwd_sorted", "fpsg_chamfer_bwd_scan"):
+        gx1, gx2 = _call_bwd(_hip.load(), kernel, p1, p2, oi1, oi2, g1, g2, gpu)
+        assert np.array_equal(gx1.view(np.uint32), ogx1.view(np.uint32))
+        assert np.array_equal(gx2.view(np.uint32), ogx2.view(np.uint32))
 
 
 def test_chamfer_value_and_grad_vs_float64(gpu):

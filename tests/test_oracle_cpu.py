@@ -81,3 +81,20 @@ def test_oracle_properties_hypothesis(oracle):
         np.testing.assert_allclose(((a - nb) ** 2).sum(-1), d1, rtol=1e-5, atol=1e-7)
 
     check()
+
+
+def test_sinkhorn_restatement_vs_independent_float64(oracle):
+    """The float32 / O(N+M) restatement used as the HIP kernels' checker against an independent float64
+    restatement of the same published geomloss loop with explicit [N,M] matrices (oracle/sinkhorn_f64.py)."""
+    from oracle.sinkhorn_f64 import epsilon_schedule, sinkhorn_divergence_f64
+    rng = np.random.default_rng(8)
+    x = unit_ball_clouds(rng, 2, 300)
+    y = (unit_ball_clouds(rng, 2, 400) * 0.7 + 0.2).astype(np.float32)
+    a = oracle.sinkhorn_divergence(x, y)
+    b = sinkhorn_divergence_f64(x, y)
+    np.testing.assert_allclose(a, b, rtol=1e-5)
+    assert np.allclose(oracle.sinkhorn_epsilons(x, y), epsilon_schedule(2, np.linalg.norm(
+        np.concatenate([x.reshape(-1, 3), y.reshape(-1, 3)]).max(0) - np.concatenate([x.reshape(-1, 3), y.reshape(-1, 3)]).min(0)), 0.05, 0.5))
+    # the divergence of a cloud with itself is zero, and it is symmetric
+    assert abs(sinkhorn_divergence_f64(x, x)).max() < 1e-12
+    np.testing.assert_allclose(sinkhorn_divergence_f64(x, y), sinkhorn_divergence_f64(y, x), rtol=1e-10)

@@ -1,5 +1,6 @@
-"""K1 micro-benchmark: N=M=2048, several batch sizes, fwd and bwd.
-Usage (GPU box): python tools/bench_chamfer.py [--reps 200]"""
+"""K1 micro-benchmark: N=M=2048, several batch sizes; the two-pass forward, the
+one-pass tiled forward (tiles + finalize, timed together as one op), both backward kernels.
+Usage (GPU box): python tools/bench_chamfer.py [--reps 200] [--sweep] [--blob]"""
 import argparse
 import os
 import sys
@@ -14,42 +15,61 @@ BWD_BYTES = 131072
 PAIRS = 2 * 2048 * 2048
 PEAK_HBM = 8.0e12
 PEAK_F32 = 157.3e12
+TILED = [148, 144, 142, 141, 124, 122, 114, 112, 48, 44, 42, 24, 18]
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reps", type=int, default=200)
     ap.add_argument("--n", type=int, default=2048)
-    ap.add_argument("--sweep", action="store_true", help="time every (R,W) variant of the forward kernel")
+    ap.add_argument("--sweep", action="store_true", help="time every variant of the forward kernels")
+    ap.add_argument("--blob", action="store_true", help="second cloud collapsed to a small blob (early training)")
+    ap.add_argument("--batches", type=str, default="")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     lib = _hip.load()
     N = M = args.n
     scale = (N / 2048.0)
-    for B in ((1, 2, 3, 5, 8, 12, 16, 24, 32, 37, 48, 64, 96, 128, 256) if args.sweep else (1, 5, 32, 37, 64, 256, 1024)):
+    batches = [int(b) for b in args.batches.split(",")] if args.batches else \
+        ((1, 2, 5, 8, 16, 32, 37, 64, 128, 256) if args.sweep else (1, 5, 32, 37, 64, 256, 1024))
+    # bring the chip to its working clock before anything is timed
+    warm = torch.randn(4096, 4096, device=dev)
+    t_end = torch.cuda.Event(enable_timing=True)
+    for _ in range(200):
+        warm = torch.tanh(warm)
+    torch.cuda.synchronize()
+    for B in batches:
         p1 = torch.rand(B, N, 3, device=dev) * 2 - 1
-        p2 = torch.tanh(torch.randn(B, M, 3, device=dev))
+        p2 = torch.tanh(torch.randn(B, M, 3, device=dev) * (0.02 if args.blob else 1.0))
         d1 = torch.empty(B, N, device=dev); d2 = torch.empty(B, M, device=dev)
         i1 = torch.empty(B, N, device=dev, dtype=torch.int32); i2 = torch.empty(B, M, device=dev, dtype=torch.int32)
         g1 = torch.randn(B, N, device=dev); g2 = torch.randn(B, M, device=dev)
         gx1 = torch.empty_like(p1); gx2 = torch.empty_like(p2)
         s = torch.cuda.current_stream().cuda_stream
+        ws_max = max(lib.fpsg_chamfer_workspace_bytes(B, N, M, v) for v in [-1] + TILED)
+        ws = torch.empty(max(ws_max, 8), dtype=torch.uint8, device=dev)
 
-        def fwd():
-            return lib.fpsg_chamfer_fwd(p1.data_ptr(), p2.data_ptr(), B, N, M, d1.data_ptr(), i1.data_ptr(),
-                                        d2.data_ptr(), i2.data_ptr(), s)
+        def two_pass(cfg):
+            return lambda: lib.fpsg_chamfer_fwd_variant(p1.data_ptr(), p2.data_ptr(), B, N, M, d1.data_ptr(), i1.data_ptr(),
+                                                        d2.data_ptr(), i2.data_ptr(), cfg, s)
 
-        def bwd():
-            return lib.fpsg_chamfer_bwd(p1.data_ptr(), p2.data_ptr(), i1.data_ptr(), i2.data_ptr(), g1.data_ptr(),
-                                        g2.data_ptr(), B, N, M, gx1.data_ptr(), gx2.data_ptr(), s)
+        def tiled(variant):
+            nb = lib.fpsg_chamfer_workspace_bytes(B, N, M, variant)
+            return lambda: lib.fpsg_chamfer_fwd_tiled(p1.data_ptr(), p2.data_ptr(), B, N, M, d1.data_ptr(), i1.data_ptr(),
+                                                      d2.data_ptr(), i2.data_ptr(), ws.data_ptr(), nb, variant, s)
 
-        runs = [("fwd", fwd, FWD_BYTES, -1), ("bwd", bwd, BWD_BYTES, -1)]
+        def bwd(name):
+            return lambda: getattr(lib, name)(p1.data_ptr(), p2.data_ptr(), i1.data_ptr(), i2.data_ptr(), g1.data_ptr(),
+                                              g2.data_ptr(), B, N, M, gx1.data_ptr(), gx2.data_ptr(), s)
+
+        runs = [("fwd two-pass", two_pass(-1), FWD_BYTES), ("fwd tiled", tiled(-1), FWD_BYTES)]
         if args.sweep:
-            runs = [(f"fwd[cfg{c}]", fwd, FWD_BYTES, c) for c in range(7)] + runs
-        for name, fn, nbytes, cfg in runs:
-            lib.fpsg_chamfer_set_config(cfg)
-            for _ in range(20):
-                assert fn() == 0
+            runs += [(f"fwd two-pass[cfg{c}]", two_pass(c), FWD_BYTES) for c in range(7)]
+            runs += [(f"fwd tiled[{v}]", tiled(v), FWD_BYTES) for v in TILED]
+        runs += [("bwd sorted", bwd("fpsg_chamfer_bwd_sorted"), BWD_BYTES), ("bwd scan", bwd("fpsg_chamfer_bwd_scan"), BWD_BYTES)]
+        for name, fn, nbytes in runs:
+            for _ in range(50):
+                assert fn() == 0, lib.fpsg_last_error()
             torch.cuda.synchronize()
             e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -58,10 +78,10 @@ def main():
             e1.record(); torch.cuda.synchronize()
             t = e0.elapsed_time(e1) * 1e-3 / args.reps
             gbps = B * nbytes * scale / t / 1e9
-            line = f"{name} B={B:5d} N={N}: {t*1e6:9.2f} us  {gbps:8.1f} GB/s ({gbps*1e9/PEAK_HBM*100:5.2f}% HBM)"
+            line = f"{name:22s} B={B:5d} N={N}: {t*1e6:9.2f} us  {gbps:8.1f} GB/s ({gbps*1e9/PEAK_HBM*100:5.2f}% HBM)"
             if name.startswith("fwd"):
                 tf = B * PAIRS * scale * scale * 8 / t
-                line += f"  {tf/1e12:7.2f} TFLOP/s ({tf/PEAK_F32*100:5.1f}% fp32 peak)  {B*PAIRS*scale*scale/t/1e12:6.3f} Tpair/s"
+                line += f"  {tf/1e12:7.2f} TFLOP/s ({tf/PEAK_F32*100:5.1f}% fp32 peak, 2NM pair evaluations x 8 flop)"
             print(line, flush=True)
 
 
