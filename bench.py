@@ -16,7 +16,14 @@ Workloads (BASELINE.json ``configs``; synthetic data, random-init weights, fp32)
 
 Rank 0 prints ONE JSON line with ``roofline`` (the K1 Chamfer forward launches of the timed
 region, bracketed with HIP events on the launch stream) and ``cpu_baseline`` (the same
-episode step on the host cores through the CPU oracle; N=1 only).
+episode step on the host cores through the CPU oracle; N=1 only).  At N=1 the line also carries
+  ``configs``   short legs of the other BASELINE workloads (c2, c3, c4: episodes/s each),
+  ``kernels``   event-timed rooflines of the other hand-written distance / graph kernels at the
+                BASELINE shapes (K1 backward in-step; K2, K2b, K3, K4b as micro-legs), each with its
+                bound (valu / mfma / hbm), algorithmic work and fraction of peak,
+  ``mfu_direct_equivalent``  the step's FLOPs counted as the REFERENCE formulation would spend them
+                (SURVEY.md 3.1 MAC counts, forward x 3) over the fp32 peak;
+``--no-extra`` skips these legs.  At N>1 ``allreduce`` times each gradient bucket's collective.
 """
 from __future__ import annotations
 
@@ -54,6 +61,24 @@ WORKLOADS = {
 # bytes (2*2048*12 B read + 2*2048*(4+4) B written) and 2*N*M pair evaluations x 8 flop
 HBM_PEAK = 8.0e12                                # B/s  (MI355X_MICROARCH.md)
 F32_PEAK = 157.3e12                              # FLOP/s, fp32 vector == fp32-input MFMA
+
+# forward multiply-accumulates of the REFERENCE formulation (direct 3x3
+# convolutions, repeat + concat decoder), per item
+VGG_MAC_PER_IMAGE = 15.5e9
+DECODER_MAC_PER_CLOUD = 2048 * 3.85e6
+POINTNET_MAC_PER_CLOUD = 2048 * 0.28e6
+DGCNN_MAC_PER_CLOUD = 0.27e12 / 64
+
+
+def direct_equivalent_flops(S, Q, intra, encoder):
+    """FLOPs of one episode step (forward + backward = 3 x forward MACs x 2) as the reference's
+    own formulation would spend them."""
+    images = S + Q
+    clouds_dec = Q + (S if intra else 0)
+    clouds_enc = 2 * S
+    enc = DGCNN_MAC_PER_CLOUD if encoder == "dgcnn" else POINTNET_MAC_PER_CLOUD
+    mac = images * VGG_MAC_PER_IMAGE + clouds_dec * DECODER_MAC_PER_CLOUD + clouds_enc * enc
+    return 3.0 * 2.0 * mac
 
 
 class EventProbe:
@@ -97,17 +122,15 @@ class EventProbe:
         return n, sec, pairs, nbytes, flops
 
 
-def pmc_traffic(kind_prefix, probe, kind):
-    """HBM bytes per launch from the committed rocprofv3 PMC summary (profiles/k1_traffic.json,
-    made by tools/pmc_summary.py on this workload's launches); None when a launch shape of this
-    run has no PMC record."""
+def pmc_traffic(probe, kind):
+    """HBM bytes per op from the committed rocprofv3 PMC summary (profiles/k1_traffic.json, made by
+    tools/pmc_k1.sh + tools/pmc_summary.py on this workload's launches); None when a launch shape of
+    this run has no PMC record."""
     path = os.path.join(ROOT, "profiles", "k1_traffic.json")
     if not os.path.exists(path):
         return None
-    table = {}
-    for rec in json.load(open(path)).get("launches", []):
-        if rec["kernel"].startswith(kind_prefix) and "hbm_bytes_per_launch" in rec:
-            table[rec["cloud_pairs"]] = rec["hbm_bytes_per_launch"]
+    table = {rec["cloud_pairs"]: rec["hbm_bytes_per_op"] for rec in json.load(open(path)).get("ops", [])
+             if rec.get("op") == kind and "hbm_bytes_per_op" in rec}
     total, n = 0.0, 0
     for (k, B, N, M), _, _ in probe.records:
         if k != kind:
@@ -158,18 +181,212 @@ def cpu_baseline(S, Q, intra, encoder, budget_s):
     optimizer, _ = build_optimizer(model, opt)
     step = TrainStep(model, optimizer)
     ep = synthetic_episode(S, Q, seed=99, device="cpu")
+    t0 = time.perf_counter()
+    step([ep])                                   # first call: thread pools, oneDNN primitive caches -- not timed
+    warm = time.perf_counter() - t0
+    print(f"[cpu_baseline] warm-up episode {warm:.1f} s on {cores} threads (not counted)", file=sys.stderr, flush=True)
     n, t0 = 0, time.perf_counter()
     while True:
         step([ep])
         n += 1
         el = time.perf_counter() - t0
         print(f"[cpu_baseline] {n} episode(s) in {el:.1f} s on {cores} threads", file=sys.stderr, flush=True)
-        if el > budget_s or el + el / n > 1.5 * budget_s:
+        if el > budget_s or el + el / n > 1.3 * budget_s:
             break
     return {"value": n / el, "unit": "episodes/s", "cores": cores, "kind": "port",
             "sample": f"{n} episode step(s) of the same workload ({S}-shot {Q}-query"
                       f"{' intra_recon' if intra else ''}), PyTorch-CPU model + C-oracle Chamfer, "
-                      f"{el:.1f} s, includes first-call warm-up"}
+                      f"{el:.1f} s after one untimed warm-up episode ({warm:.1f} s)"}
+
+
+def _event_time(fn, reps, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e-3 / reps
+
+
+def kernel_rooflines(device):
+    """Event-timed micro-legs of the hand-written distance / graph kernels that the default (PointNet,
+    Chamfer) step does not launch, at the BASELINE shapes; algorithmic work as in DESIGN.md section 3."""
+    from fpsg_amd import _hip
+    from fpsg_amd.dgcnn import _reverse_graph, knn_int32
+    from fpsg_amd.metrics import emd_approx, sinkhorn_divergence, sinkhorn_epsilons
+    out = {}
+    N = 2048
+    g = torch.Generator(device="cpu").manual_seed(7)
+    x = (torch.rand(5, N, 3, generator=g) * 2 - 1).to(device)
+    y = torch.tanh(torch.randn(5, N, 3, generator=g)).to(device)
+
+    def entry(bound, achieved, peak, unit, t, shape, work, **more):
+        return {"bound": bound, "achieved": achieved, "peak": peak, "unit": unit, "frac": achieved / peak,
+                "us": t * 1e6, "shape": shape, "work": work, **more}
+
+    # K2: approximate-assignment EMD, forward (evaluation): 10 levels x 3 sweeps of N*M pairs; a pair of the
+    # assignment sweep = distance (8 flop) + exp + sqrt + 4 mul/add, of the two normaliser sweeps = 8 + exp + 3
+    t = _event_time(lambda: emd_approx(x, y), 20)
+    flop = 5 * N * N * 10.0 * (2 * 12 + 14)
+    out["K2_emd_approx_fwd"] = entry("valu", flop / t / 1e12, F32_PEAK / 1e12, "TFLOP/s", t, "B=5 N=M=2048",
+                                     "30 sweeps x N*M pairs x 12-14 flop (v_exp_f32 / v_sqrt_f32 counted as 1)",
+                                     pair_sweeps_per_s=5 * 30.0 * N * N / t)
+    # K2b: Sinkhorn divergence (what emd_wrapper calls): (n_eps + 2) steps x 4 soft-mins x N*M pairs; a pair =
+    # distance (8 flop) + fma + max + sub + exp + add = 13
+    n_eps = len(sinkhorn_epsilons(3.5))
+    t = _event_time(lambda: sinkhorn_divergence(x, y, diameter=3.5), 20)
+    flop = 5 * 4.0 * (n_eps + 2) * N * N * 13.0
+    out["K2b_sinkhorn_divergence"] = entry("valu", flop / t / 1e12, F32_PEAK / 1e12, "TFLOP/s", t,
+                                           f"B=5 N=M=2048, {n_eps} epsilons",
+                                           f"{4 * (n_eps + 2)} soft-mins x N*M pairs x 13 flop (v_exp_f32 counted as 1)",
+                                           launches=n_eps + 3)
+    # K3 / K4b at DGCNN's layer shapes: B = 64 clouds (2 x 32-shot), N = 2048, k = 20
+    B, k = 64, 20
+    for C, Co in ((3, 64), (64, 64), (64, 128), (128, 256)):
+        xc = torch.randn(B, C, N, generator=g).to(device)
+        t = _event_time(lambda: knn_int32(xc, k), 10)
+        flop = B * 2.0 * C * N * N
+        if f"K3_knn_C{C}" in out:
+            pass             # layers 2 and 3 share the 64-channel graph shape
+        elif C >= 64:        # the x^T x term is a real GEMM on fp32-input MFMA
+            out[f"K3_knn_C{C}"] = entry(
+                "mfma", flop / t / 1e12, F32_PEAK / 1e12, "TFLOP/s", t, f"B=64 C={C} N=2048 k=20",
+                "2*C*N*N flop per cloud (x^T x) + top-20 selection", pair_scores_per_s=B * float(N) * N / t)
+        else:            # 3 channels: the top-k selection rounds bind (VALU / DPP)
+            out["K3_knn_C3"] = entry("valu", B * float(N) * N * 8 / t / 1e12, F32_PEAK / 1e12, "TFLOP/s", t,
+                                     "B=64 C=3 N=2048 k=20", "N*N pair scores x 8 flop + top-20 selection",
+                                     pair_scores_per_s=B * float(N) * N / t)
+        # K4b: the fused EdgeConv kernels themselves (C ABI), on this layer's PQ = x^T [W1 ; W2-W1]^T
+        lib = _hip.load()
+        idx = knn_int32(xc, k)
+        PQ = torch.randn(B, N, 2 * Co, generator=g).to(device)
+        sgn = torch.where(torch.randn(Co, generator=g) < 0, -1.0, 1.0).to(device)
+        ysel = torch.empty(B, N, Co, device=device)
+        jsel = torch.empty(B, N, Co, dtype=torch.uint8, device=device)
+        s1 = torch.empty(B, N, Co, device=device)
+        part = torch.empty(lib.fpsg_edgeconv_blocks(B, N, Co), 2, Co, device=device)
+        st = torch.cuda.current_stream().cuda_stream
+        tf = _event_time(lambda: lib.fpsg_edgeconv_fwd(PQ.data_ptr(), idx.data_ptr(), sgn.data_ptr(), B, N, k, Co,
+                                                       ysel.data_ptr(), jsel.data_ptr(), s1.data_ptr(), part.data_ptr(), st), 20)
+        rev, off = _reverse_graph(idx)
+        dzs = torch.randn(B, N, Co, generator=g).to(device)
+        coef = torch.randn(3, Co, generator=g).to(device)
+        dPQ = torch.empty_like(PQ)
+        tb = _event_time(lambda: lib.fpsg_edgeconv_bwd(dzs.data_ptr(), jsel.data_ptr(), PQ.data_ptr(), s1.data_ptr(),
+                                                       rev.data_ptr(), off.data_ptr(), coef.data_ptr(), B, N, k, Co,
+                                                       dPQ.data_ptr(), st), 20)
+        # compulsory HBM bytes: forward reads PQ [B,N,2Co] and idx, writes ysel (4 B) + jsel (1 B) + s1 (4 B) per
+        # [B,N,Co]; backward reads dzs, jsel, s1, PQ, the reverse graph (rev + idx-sized offsets) and writes dPQ
+        fb = B * N * (2 * Co * 4 + k * 4 + Co * 9)
+        bb = B * N * (Co * 4 + Co + Co * 4 + 2 * Co * 4 + k * 4 + 4 + 2 * Co * 4)
+        key = f"K4b_edgeconv_{C}to{Co}"
+        out[key + "_fwd"] = entry("hbm", fb / tf / 1e9, HBM_PEAK / 1e9, "GB/s", tf, f"B=64 N=2048 k=20 Co={Co}",
+                                  "compulsory bytes: PQ + idx read, ysel / jsel / s1 written; the k-fold neighbour gather "
+                                  "is served by L2", gathered_GBps=B * N * k * Co * 4 / tf / 1e9)
+        out[key + "_bwd"] = entry("hbm", bb / tb / 1e9, HBM_PEAK / 1e9, "GB/s", tb, f"B=64 N=2048 k=20 Co={Co}",
+                                  "compulsory bytes: dzs, jsel, s1, PQ, reverse graph read, dPQ written; in-edge gathers "
+                                  "are served by L2")
+    return out
+
+
+def allreduce_probe(step, world):
+    """Per-bucket all-reduce of the flat gradient buffer, one collective at a time (event-timed on the
+    current stream after a barrier): bucket bytes, time, algorithmic and bus bandwidth."""
+    if not torch.distributed.is_initialized():
+        return None
+    res = []
+    for (s, e) in step.buckets.buckets:
+        buf = step.buckets.flat[s:e]
+        for _ in range(2):
+            torch.distributed.all_reduce(buf)
+        torch.cuda.synchronize()
+        torch.distributed.barrier()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            torch.distributed.all_reduce(buf)
+        e1.record()
+        torch.cuda.synchronize()
+        t = e0.elapsed_time(e1) * 1e-3 / 5
+        nbytes = (e - s) * 4
+        res.append({"mb": nbytes / 1e6, "ms": t * 1e3, "algbw_GBps": nbytes / t / 1e9,
+                    "busbw_GBps": nbytes / t / 1e9 * 2 * (world - 1) / max(world, 1)})
+    step.buckets.flat.zero_()
+    return res
+
+
+def run_workload(wl, args, rank, world, device, steps, warmup, probe=None, graph=None, epr=None):
+    """Builds the model of workload ``wl`` and times ``steps`` optimizer steps after ``warmup`` (the contract's
+    timed region: barrier + synchronize on both sides, MAX over ranks).  Returns a dict of results."""
+    S, Q, intra, encoder, epr_default, desc = WORKLOADS[wl]
+    epr = epr or epr_default
+    if graph is None:
+        graph = wl == "c2" and not torch.distributed.is_initialized()
+    if graph:
+        warmup = max(warmup, 1 if epr >= 4 else 4)   # 2 eager uses + the capture before timing
+    opt = default_options(device="cuda", intra_recon=intra, pc_encoder=encoder, n_shot=S, n_query=Q)
+    torch.manual_seed(0)                      # identical initial weights on every rank
+    model = build_model(opt).to(device)
+    if args.channels_last:
+        model.img_encoder.to(memory_format=torch.channels_last)
+    model.train()
+    model.overlap_encoders = bool(args.overlap)
+    optimizer, _ = build_optimizer(model, opt)
+    step = TrainStep(model, optimizer, world=world, bucket_mb=args.bucket_mb, graph=graph)
+    episodes = make_episodes(S, Q, epr, seed=1234 + rank, device=device)   # resident in HBM
+    if args.channels_last:
+        for ep in episodes:
+            for key in ("xs", "xq", "xad"):
+                ep[key] = ep[key].squeeze(0).contiguous(memory_format=torch.channels_last).unsqueeze(0)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+
+    for _ in range(warmup):
+        step(episodes, n_episodes_global=epr * world)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    if probe is not None:
+        probe.enabled = not graph
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = step(episodes, n_episodes_global=epr * world)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if probe is not None and graph:
+        # HIP events cannot be timed inside a captured graph: the K1 launches are bracketed in
+        # an eager replica of the same episodes (same tensors, same neighbouring kernels) run
+        # right after the timed region; profiles/ holds the rocprofv3 durations of the replays.
+        probe.enabled = True
+        for k, ep in enumerate(episodes):
+            step._episode(ep, first=(k == 0))
+        torch.cuda.synchronize()
+    if probe is not None:
+        probe.enabled = False
+    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    if world > 1:
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+    elapsed = float(t.item())
+    eps_per_s = steps * epr * world / elapsed
+    flops = direct_equivalent_flops(S, Q, intra, encoder)
+    return {"value": eps_per_s, "elapsed": elapsed, "steps": steps, "warmup": warmup, "epr": epr, "graph": bool(graph),
+            "loss": float(out[-1]["ttl_loss"].sum().item()), "desc": desc, "S": S, "Q": Q, "intra": intra,
+            "encoder": encoder, "params": sum(p.numel() for p in model.parameters()), "step": step,
+            "mfu": {"direct_equivalent_tflop_per_episode": flops / 1e12,
+                    "direct_equivalent_tflops": eps_per_s / world * flops / 1e12,
+                    "fraction_of_fp32_peak": eps_per_s / world * flops / F32_PEAK,
+                    "note": "FLOPs the REFERENCE formulation spends per episode step (SURVEY.md 3.1: direct 3x3 "
+                            "convolutions, repeat+concat decoder; forward MACs x 3 x 2) times the measured episodes/s "
+                            "per GPU, over the 157.3 TFLOP/s fp32 peak; above 1 is possible because Winograd F(4x4,3x3) "
+                            "and the decoder's split first layer do the same arithmetic with 4x / ~100x fewer multiplies"}}
 
 
 def main():
@@ -179,8 +396,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c5")
     ap.add_argument("--episodes-per-rank", type=int, default=None)
-    ap.add_argument("--cpu-baseline-seconds", type=float, default=20.0)
+    ap.add_argument("--cpu-baseline-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true",
+                    help="skip the N=1 extra legs (other workloads' episodes/s, per-kernel rooflines)")
     ap.add_argument("--bucket-mb", type=float, default=80.0)
     ap.add_argument("--graph", dest="graph", action="store_true", default=None,
                     help="replay each episode's fwd+bwd as a captured hipGraph [default: only for the "
@@ -203,81 +422,32 @@ def main():
     steps = args.steps if args.steps is not None else (5 if epr > 1 else 20)
     warmup = args.warmup if args.warmup is not None else (2 if epr > 1 else 5)
 
-
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU (the hot path has no CPU fallback)")
     rank, world, device = fdist.init_distributed("cuda")
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
-    if args.graph is None:
-        args.graph = args.workload == "c2" and not torch.distributed.is_initialized()
-
-    if args.graph:
-        warmup = max(warmup, 1 if epr >= 4 else 4)   # 2 eager uses + the capture before timing
     torch.backends.cudnn.benchmark = bool(args.miopen_benchmark)
     if args.gemm_tuning is not None:
         os.environ["FPSG_GEMM_TUNING"] = {"off": "0"}.get(args.gemm_tuning, args.gemm_tuning)
     gemm_info = gemm_tuning.enable(path=args.gemm_records)
-    opt = default_options(device="cuda", intra_recon=intra, pc_encoder=encoder, n_shot=S, n_query=Q)
-    torch.manual_seed(0)                      # identical initial weights on every rank
-    model = build_model(opt).to(device)
-    if args.channels_last:
-        model.img_encoder.to(memory_format=torch.channels_last)
-    model.train()
-    model.overlap_encoders = bool(args.overlap)
-    optimizer, _ = build_optimizer(model, opt)
-    step = TrainStep(model, optimizer, world=world, bucket_mb=args.bucket_mb, graph=args.graph)
-    episodes = make_episodes(S, Q, epr, seed=1234 + rank, device=device)   # resident in HBM
-    if args.channels_last:
-        for ep in episodes:
-            for key in ("xs", "xq", "xad"):
-                ep[key] = ep[key].squeeze(0).contiguous(memory_format=torch.channels_last).unsqueeze(0)
 
     probe = EventProbe()
     metrics.set_launch_probe(probe)
-
-    def barrier():
-        if world > 1:
-            torch.distributed.barrier()
-
-    for _ in range(warmup):
-        step(episodes, n_episodes_global=epr * world)
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    probe.enabled = not args.graph
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        out = step(episodes, n_episodes_global=epr * world)
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if args.graph:
-        # HIP events cannot be timed inside a captured graph: the K1 launches are bracketed in
-        # an eager replica of the same episodes (same tensors, same neighbouring kernels) run
-        # right after the timed region; profiles/ holds the rocprofv3 durations of the replays.
-        probe.enabled = True
-        for k, ep in enumerate(episodes):
-            step._episode(ep, first=(k == 0))
-        torch.cuda.synchronize()
-    probe.enabled = False
-
-    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-    if world > 1:
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-    elapsed = float(t.item())
-    loss = float(out[-1]["ttl_loss"].sum().item())
+    main_run = run_workload(args.workload, args, rank, world, device, steps, warmup, probe=probe, graph=args.graph,
+                            epr=epr)
+    steps, warmup = main_run["steps"], main_run["warmup"]
+    elapsed = main_run["elapsed"]
+    allreduce = allreduce_probe(main_run["step"], world) if world > 1 or os.environ.get("FPSG_FORCE_DIST") else None
 
     n_l, sec, pairs, nbytes, flops = probe.summary("chamfer_fwd")
-    nb_l, bsec, _, _, _ = probe.summary("chamfer_bwd")
+    nb_l, bsec, bpairs, _, _ = probe.summary("chamfer_bwd")
 
     if rank == 0:
-        total_eps = steps * epr * world
         res = {
             "metric": "episodes/sec (+ Chamfer-kernel HBM GB/s in roofline.hbm), 2048-pt clouds, "
                       "224x224 images; episode = fwd + Chamfer + bwd, step = E episodes + all-reduce + Adam",
-            "value": total_eps / elapsed,
+            "value": main_run["value"],
             "unit": "episodes/s",
             "n_gpus": world, "steps": steps, "warmup": warmup,
             "ms_per_step": elapsed / steps * 1e3,
@@ -286,20 +456,25 @@ def main():
             "config": {"workload": desc, "id": args.workload, "n_shot": S, "n_query": Q,
                        "intra_recon": intra, "pc_encoder": encoder, "episodes_per_rank_per_step": epr,
                        "episodes_per_step_global": epr * world, "parallelism": f"dp{world}",
-                       "params": sum(p.numel() for p in model.parameters()),
-                       "hip_graph": bool(args.graph), **gemm_info},
-            "final_loss": loss,
+                       "params": main_run["params"],
+                       "hip_graph": main_run["graph"], **gemm_info},
+            "final_loss": main_run["loss"],
             "hbm_peak_allocated_gb": round(torch.cuda.max_memory_allocated(device) / 1e9, 2),
+            "mfu_direct_equivalent": main_run["mfu"],
         }
         if n_l:
             achieved_flops = flops / sec
             res["roofline"] = {
-                "kernel": "chamfer_fwd_kernel (K1, two-sided nearest neighbour + argmin)",
-                "bound": "mfma",   # fp32 compute bound: fp32 vector peak == fp32-input MFMA peak
+                "kernel": "K1 Chamfer forward (chamfer_tile_kernel + chamfer_finalize_kernel: two-sided nearest "
+                          "neighbour + argmin, every pair distance evaluated once), the launches of the timed steps",
+                "bound": "valu",   # fp32 vector-ALU bound (no MFMA instruction in it); same 157.3 TFLOP/s peak
                 "achieved": achieved_flops / 1e12, "peak": F32_PEAK / 1e12, "unit": "TFLOP/s",
                 "frac": achieved_flops / F32_PEAK,
-                "traffic": pmc_traffic("chamfer_fwd_kernel", probe, "chamfer_fwd"),
-                "traffic_unit": "HBM bytes per launch, rocprofv3 PMC (2*FETCH_SIZE+WRITE_SIZE)*1024, "
+                "flop_convention": "SURVEY.md 8(d): 2*N*M directed pair evaluations x 8 flop per cloud pair "
+                                   "(the one-pass kernel evaluates N*M distances; by that count the rate is half)",
+                "achieved_one_pass_convention": achieved_flops / 2e12,
+                "traffic": pmc_traffic(probe, "chamfer_fwd"),
+                "traffic_unit": "HBM bytes per op (tiles + finalize), rocprofv3 PMC (2*FETCH_SIZE+WRITE_SIZE)*1024, "
                                 "profiles/k1_traffic.json",
                 "algorithmic_bytes_per_launch": nbytes / n_l,
                 "launches": n_l, "avg_launch_us": sec / n_l * 1e6,
@@ -311,6 +486,43 @@ def main():
             }
             if nb_l:
                 res["roofline"]["bwd_avg_launch_us"] = bsec / nb_l * 1e6
+        kernels = {}
+        if nb_l:
+            # K1 backward in the step: 131,072 algorithmic bytes per 2048x2048 cloud pair; the
+            # kernel is a latency chain (sort + runs), not a stream
+            bb = bpairs * 131072.0
+            kernels["K1_chamfer_bwd_in_step"] = {
+                "bound": "hbm", "achieved": bb / bsec / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                "frac": bb / bsec / HBM_PEAK, "us": bsec / nb_l * 1e6, "shape": f"B={bpairs / nb_l:.0f} N=M=2048",
+                "work": "131,072 algorithmic bytes per cloud pair; one workgroup per (pair, side): LDS sort of the "
+                        "argmin list + blocked ascending sums, time independent of the in-degree distribution"}
+        if world == 1 and not args.no_extra:
+            del main_run["step"]
+            torch.cuda.empty_cache()
+            configs = {}
+            for wl in ("c2", "c3", "c4"):
+                if wl == args.workload:
+                    continue
+                try:
+                    _, _, _, _, e1, _ = WORKLOADS[wl]
+                    r = run_workload(wl, args, rank, world, device, steps=10 if wl != "c2" else 30, warmup=3)
+                    configs[wl] = {"episodes_per_s": r["value"], "ms_per_episode": 1e3 / r["value"],
+                                   "workload": r["desc"], "hip_graph": r["graph"], "steps": r["steps"],
+                                   "mfu_direct_equivalent": {k: v for k, v in r["mfu"].items() if k != "note"}}
+                    del r
+                    torch.cuda.empty_cache()
+                except Exception as e:      # the headline numbers stay valid without a leg
+                    configs[wl] = {"error": repr(e)}
+            res["configs"] = configs
+            try:
+                kernels.update(kernel_rooflines(device))
+            except Exception as e:
+                kernels["error"] = repr(e)
+        if kernels:
+            res["kernels"] = kernels
+        if allreduce is not None:
+            res["allreduce"] = {"buckets": allreduce, "note": "one blocking all_reduce per gradient bucket after the "
+                                "timed region (in the step they are launched from autograd hooks and overlap backward)"}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 res["cpu_baseline"] = cpu_baseline(S, Q, intra, encoder, args.cpu_baseline_seconds)

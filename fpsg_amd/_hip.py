@@ -42,7 +42,7 @@ SIGNATURES = {
     "fpsg_knn": [_c_f32p, _c_int, _c_int, _c_int, _c_int, _c_i32p, _c_f32p, _c_stream],
     "fpsg_edge_feature_fwd": [_c_f32p, _c_i32p, _c_int, _c_int, _c_int, _c_int, _c_f32p, _c_stream],
     "fpsg_edge_feature_bwd": [_c_f32p, _c_i32p, _c_int, _c_int, _c_int, _c_int, _c_f32p, _c_stream],
-    "fpsg_edgeconv_blocks": [_c_int, _c_int],
+    "fpsg_edgeconv_blocks": [_c_int, _c_int, _c_int],
     "fpsg_edgeconv_fwd": [_c_f32p, _c_i32p, _c_f32p, _c_int, _c_int, _c_int, _c_int, _c_f32p, _c_f32p,
                           _c_f32p, _c_f32p, _c_stream],
     "fpsg_edgeconv_bwd": [_c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_i32p, _c_i32p, _c_f32p, _c_int, _c_int,

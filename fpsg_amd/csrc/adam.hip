@@ -87,7 +87,9 @@ __global__ __launch_bounds__(kAdamThreads) void adam_ptr_kernel(float* __restric
       const float* g = gtab[sg];
       if (g) {
         const long long base = i - seg_off[sg];
-        if (cnt == 4 && ((base & 3) == 0)) {                   // the tensor starts 256-B aligned
+        // a gradient tensor usually starts 256-B aligned, but one that autograd took over from a view
+        // (e.g. a slice of a stacked tensor's gradient) may start anywhere: test the address itself
+        if (cnt == 4 && ((reinterpret_cast<uintptr_t>(g + base) & 15) == 0)) {
           const v4f q = *reinterpret_cast<const v4f*>(g + base);
           gg[0] = q[0]; gg[1] = q[1]; gg[2] = q[2]; gg[3] = q[3];
         } else {

@@ -22,7 +22,6 @@ namespace fpsg {
 namespace {
 
 constexpr int kEcThreads = 256;  // 4 waves
-constexpr int kEcPtsPerWave = 8;
 
 template <int VEC>
 struct VecT;
@@ -75,7 +74,7 @@ __device__ __forceinline__ CloudBlock cloud_block(int bpc) {
 template <int VEC>
 __global__ __launch_bounds__(kEcThreads) void edgeconv_fwd_kernel(
     const float* __restrict__ PQ, const int32_t* __restrict__ idx, const float* __restrict__ sgn,
-    int B, int N, int k, int bpc, float* __restrict__ ysel, uint8_t* __restrict__ jsel, float* __restrict__ s1,
+    int B, int N, int k, int bpc, int ppw, float* __restrict__ ysel, uint8_t* __restrict__ jsel, float* __restrict__ s1,
     float* __restrict__ part) {
   constexpr int Co = 64 * VEC;
   __shared__ float red[4][2][Co];
@@ -91,8 +90,8 @@ __global__ __launch_bounds__(kEcThreads) void edgeconv_fwd_kernel(
 #pragma unroll
   for (int v = 0; v < VEC; ++v) { sum[v] = 0.0f; sumsq[v] = 0.0f; }
 
-  const int n_first = (cb.bx * 4 + wave) * kEcPtsPerWave;
-  for (int pp = 0; pp < kEcPtsPerWave; ++pp) {
+  const int n_first = (cb.bx * 4 + wave) * ppw;
+  for (int pp = 0; pp < ppw; ++pp) {
     const int n = n_first + pp;
     if (n >= N) break;  // wave-uniform
     const size_t row = (size_t)b * N + n;
@@ -146,18 +145,30 @@ __global__ __launch_bounds__(kEcThreads) void edgeconv_fwd_kernel(
 // dzs [B,N,Co] = dz*scale; jsel; PQ; s1 (or null when coef A=Bc=0); rev [B,N*k] edge ids
 // (n*k+j) grouped by destination, ascending inside a group; off [B,N+1] group offsets;
 // coef [3][Co] = A, Bc, mu.  Output dPQ [B,N,2*Co].
+//
+// A workgroup serves one CHANNEL SLICE of 64*VEC channels of a block of points (Co = nsl * 64 * VEC).
+// The in-edge gathers of a cloud touch its whole dzs / jsel / Q arrays about k times; at Co = 256 those
+// are 2 + 0.5 + 2 MB per cloud -- more than the 4 MB L2 of an XCD, and the PMC counters showed 5-6 GB
+// of HBM reads per episode for 0.6 GB of operands.  A 128-channel slice is 2.25 MB per cloud: an XCD
+// works through (cloud, slice) pairs one after the other and the gathers stay in its L2.
+// A wave loads its point's in-edge list with one coalesced read (64 edges per pass, readlane per edge)
+// and keeps the rows of two edges in flight; the sums run in edge order (deterministic, bit-identical
+// to the one-edge-at-a-time form).
 template <int VEC>
 __global__ __launch_bounds__(kEcThreads) void edgeconv_bwd_kernel(
     const float* __restrict__ dzs, const uint8_t* __restrict__ jsel, const float* __restrict__ PQ,
     const float* __restrict__ s1, const int32_t* __restrict__ rev, const int32_t* __restrict__ off,
-    const float* __restrict__ coef, int B, int N, int k, int bpc, int stats, float* __restrict__ dPQ) {
-  constexpr int Co = 64 * VEC;
-  const CloudBlock cb = cloud_block(bpc);
-  if (cb.b >= B) return;
-  const int b = cb.b;
+    const float* __restrict__ coef, int B, int N, int k, int bpc, int ppw, int nsl, int stats, float* __restrict__ dPQ) {
+  const int Co = 64 * VEC * nsl;
+  // (cloud, slice) pairs are dealt to the XCDs like clouds in the forward kernel
+  const int id = blockIdx.x, xcd = id & 7, slot = id >> 3;
+  const int pair = xcd + 8 * (slot / bpc);            // = slice-major inside a cloud: pair = b * nsl + sl
+  const int bx = slot % bpc;
+  const int b = pair / nsl, sl = pair - b * nsl;
+  if (b >= B) return;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int c0 = lane * VEC;
+  const int c0 = sl * 64 * VEC + lane * VEC;
   float A[VEC], Bc[VEC], mu[VEC];
   load_vec<VEC>(coef + c0, A);
   load_vec<VEC>(coef + Co + c0, Bc);
@@ -165,8 +176,15 @@ __global__ __launch_bounds__(kEcThreads) void edgeconv_bwd_kernel(
   const float* __restrict__ pq = PQ + (size_t)b * N * 2 * Co;
   const int32_t* __restrict__ revb = rev + (size_t)b * N * k;
   const int32_t* __restrict__ offb = off + (size_t)b * (N + 1);
-  const int m_first = (cb.bx * 4 + wave) * kEcPtsPerWave;
-  for (int pp = 0; pp < kEcPtsPerWave; ++pp) {
+  const int m_first = (bx * 4 + wave) * ppw;
+
+  auto load_js = [&](size_t rown) -> unsigned {
+    if constexpr (VEC == 1) return jsel[rown * Co + c0];
+    else if constexpr (VEC == 2) return *reinterpret_cast<const uint16_t*>(jsel + rown * Co + c0);
+    else return *reinterpret_cast<const uint32_t*>(jsel + rown * Co + c0);
+  };
+
+  for (int pp = 0; pp < ppw; ++pp) {
     const int m = m_first + pp;
     if (m >= N) break;
     const size_t rowm = (size_t)b * N + m;
@@ -176,25 +194,40 @@ __global__ __launch_bounds__(kEcThreads) void edgeconv_bwd_kernel(
     float acc[VEC], accq[VEC];
 #pragma unroll
     for (int v = 0; v < VEC; ++v) { acc[v] = 0.0f; accq[v] = 0.0f; }
-    for (int t = e0; t < e1; ++t) {
-      const int e = __builtin_amdgcn_readfirstlane(revb[t]);
-      int n = e / k;
-      n = n < 0 ? 0 : (n >= N ? N - 1 : n);
-      const int j = e - n * k;
-      const size_t rown = (size_t)b * N + n;
-      float g[VEC];
-      load_vec<VEC>(dzs + rown * Co + c0, g);
-      unsigned js;
-      if constexpr (VEC == 1) js = jsel[rown * Co + c0];
-      else if constexpr (VEC == 2) js = *reinterpret_cast<const uint16_t*>(jsel + rown * Co + c0);
-      else js = *reinterpret_cast<const uint32_t*>(jsel + rown * Co + c0);
+    for (int tb = e0; tb < e1; tb += 64) {
+      const int here = (e1 - tb) < 64 ? (e1 - tb) : 64;
+      const int mine = lane < here ? revb[tb + lane] : 0;        // one coalesced read of up to 64 edge ids
+      for (int t = 0; t < here; t += 2) {
+        const bool two = t + 1 < here;
+        int n[2], j[2];
+        size_t rown[2];
 #pragma unroll
-      for (int v = 0; v < VEC; ++v) acc[v] += ((int)((js >> (8 * v)) & 0xffu) == j) ? g[v] : 0.0f;
-      if (stats) {
-        float qn[VEC];
-        load_vec<VEC>(pq + (size_t)n * 2 * Co + Co + c0, qn);
+        for (int u = 0; u < 2; ++u) {
+          const int e = __builtin_amdgcn_readlane(mine, (t + u) < here ? (t + u) : t);
+          int nn = e / k;
+          nn = nn < 0 ? 0 : (nn >= N ? N - 1 : nn);
+          n[u] = nn;
+          j[u] = e - nn * k;
+          rown[u] = (size_t)b * N + nn;
+        }
+        float g[2][VEC], qn[2][VEC];
+        unsigned js[2];
 #pragma unroll
-        for (int v = 0; v < VEC; ++v) accq[v] += qn[v];
+        for (int u = 0; u < 2; ++u) {                              // both edges' rows in flight
+          load_vec<VEC>(dzs + rown[u] * Co + c0, g[u]);
+          js[u] = load_js(rown[u]);
+          if (stats) load_vec<VEC>(pq + (size_t)n[u] * 2 * Co + Co + c0, qn[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          if (u == 1 && !two) break;
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) acc[v] += ((int)((js[u] >> (8 * v)) & 0xffu) == j[u]) ? g[u][v] : 0.0f;
+          if (stats) {
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) accq[v] += qn[u][v];
+          }
+        }
       }
     }
     float dp[VEC], dq[VEC];
@@ -218,16 +251,20 @@ __global__ __launch_bounds__(kEcThreads) void edgeconv_bwd_kernel(
   }
 }
 
-inline int ec_blocks_per_cloud(int N) { return (N + 4 * kEcPtsPerWave - 1) / (4 * kEcPtsPerWave); }
-inline dim3 ec_grid(int B, int N) {          // 8 * ceil(B/8) clouds' worth of workgroups, see cloud_block
-  return dim3((unsigned)(8 * ((B + 7) / 8) * ec_blocks_per_cloud(N)));
+// Points per wave.  An XCD keeps ~256 of these 4-wave workgroups resident; they should belong to as few
+// clouds as fit its 4 MB L2 together (the k-fold gathers of a cloud touch 2 MB of P rows at Co = 256,
+// 0.5 MB at Co = 64): one cloud = 256 workgroups at Co = 256, 128 at Co = 128, 64 at Co = 64 (N = 2048).
+inline int ec_points_per_wave(int Co) { return Co == 256 ? 2 : Co == 128 ? 4 : 8; }
+inline int ec_blocks_per_cloud(int N, int Co) { return (N + 4 * ec_points_per_wave(Co) - 1) / (4 * ec_points_per_wave(Co)); }
+inline dim3 ec_grid(int B, int N, int Co) {          // 8 * ceil(B/8) clouds' worth of workgroups, see cloud_block
+  return dim3((unsigned)(8 * ((B + 7) / 8) * ec_blocks_per_cloud(N, Co)));
 }
 
 }  // namespace
 }  // namespace fpsg
 
-extern "C" int fpsg_edgeconv_blocks(int B, int N) {
-  return (int)(((N + 4 * fpsg::kEcPtsPerWave - 1) / (4 * fpsg::kEcPtsPerWave)) * B);
+extern "C" int fpsg_edgeconv_blocks(int B, int N, int Co) {
+  return fpsg::ec_blocks_per_cloud(N, Co) * B;
 }
 
 extern "C" int fpsg_edgeconv_fwd(const float* PQ, const int32_t* idx, const float* sgn, int B, int N,
@@ -245,11 +282,11 @@ extern "C" int fpsg_edgeconv_fwd(const float* PQ, const int32_t* idx, const floa
                    (reinterpret_cast<uintptr_t>(jsel) & 3) == 0 && (reinterpret_cast<uintptr_t>(s1) & 15) == 0,
                FPSG_E_ALIGN, "fpsg_edgeconv_fwd: PQ/ysel/s1 must be 16-byte and jsel 4-byte aligned");
   hipStream_t s = static_cast<hipStream_t>(stream);
-  const dim3 grid = ec_grid(B, N);
-  const int bpc = ec_blocks_per_cloud(N);
-  if (Co == 64) hipLaunchKernelGGL(edgeconv_fwd_kernel<1>, grid, dim3(kEcThreads), 0, s, PQ, idx, sgn, B, N, k, bpc, ysel, jsel, s1, part);
-  else if (Co == 128) hipLaunchKernelGGL(edgeconv_fwd_kernel<2>, grid, dim3(kEcThreads), 0, s, PQ, idx, sgn, B, N, k, bpc, ysel, jsel, s1, part);
-  else hipLaunchKernelGGL(edgeconv_fwd_kernel<4>, grid, dim3(kEcThreads), 0, s, PQ, idx, sgn, B, N, k, bpc, ysel, jsel, s1, part);
+  const dim3 grid = ec_grid(B, N, Co);
+  const int bpc = ec_blocks_per_cloud(N, Co), ppw = ec_points_per_wave(Co);
+  if (Co == 64) hipLaunchKernelGGL(edgeconv_fwd_kernel<1>, grid, dim3(kEcThreads), 0, s, PQ, idx, sgn, B, N, k, bpc, ppw, ysel, jsel, s1, part);
+  else if (Co == 128) hipLaunchKernelGGL(edgeconv_fwd_kernel<2>, grid, dim3(kEcThreads), 0, s, PQ, idx, sgn, B, N, k, bpc, ppw, ysel, jsel, s1, part);
+  else hipLaunchKernelGGL(edgeconv_fwd_kernel<4>, grid, dim3(kEcThreads), 0, s, PQ, idx, sgn, B, N, k, bpc, ppw, ysel, jsel, s1, part);
   return launch_status("fpsg_edgeconv_fwd");
 }
 
@@ -270,11 +307,16 @@ extern "C" int fpsg_edgeconv_bwd(const float* dzs, const uint8_t* jsel, const fl
                    (reinterpret_cast<uintptr_t>(coef) & 15) == 0,
                FPSG_E_ALIGN, "fpsg_edgeconv_bwd: float buffers must be 16-byte aligned");
   hipStream_t s = static_cast<hipStream_t>(stream);
-  const dim3 grid = ec_grid(B, N);
-  const int bpc = ec_blocks_per_cloud(N);
   const int stats = s1 != nullptr;
-  if (Co == 64) hipLaunchKernelGGL(edgeconv_bwd_kernel<1>, grid, dim3(kEcThreads), 0, s, dzs, jsel, PQ, s1, rev, off, coef, B, N, k, bpc, stats, dPQ);
-  else if (Co == 128) hipLaunchKernelGGL(edgeconv_bwd_kernel<2>, grid, dim3(kEcThreads), 0, s, dzs, jsel, PQ, s1, rev, off, coef, B, N, k, bpc, stats, dPQ);
-  else hipLaunchKernelGGL(edgeconv_bwd_kernel<4>, grid, dim3(kEcThreads), 0, s, dzs, jsel, PQ, s1, rev, off, coef, B, N, k, bpc, stats, dPQ);
+  // channel slices: 128 channels at Co = 256 (two slices), whole rows otherwise
+  const int nsl = Co == 256 ? 2 : 1;
+  // An XCD keeps ~256 of these workgroups resident.  They should all belong to ONE (cloud, slice) pair, or
+  // the pairs' working sets (2.25 MB each at 128 channels) evict each other from the 4 MB L2: a pair is cut
+  // into ~256 workgroups (2 points per wave at N = 2048; 4 at 64 channels, where two pairs fit).
+  const int ppw = Co == 64 ? 4 : 2;
+  const int bpc = (N + 4 * ppw - 1) / (4 * ppw);
+  const dim3 grid((unsigned)(8 * ((B * nsl + 7) / 8) * bpc));
+  if (Co == 64) hipLaunchKernelGGL(edgeconv_bwd_kernel<1>, grid, dim3(kEcThreads), 0, s, dzs, jsel, PQ, s1, rev, off, coef, B, N, k, bpc, ppw, nsl, stats, dPQ);
+  else hipLaunchKernelGGL(edgeconv_bwd_kernel<2>, grid, dim3(kEcThreads), 0, s, dzs, jsel, PQ, s1, rev, off, coef, B, N, k, bpc, ppw, nsl, stats, dPQ);
   return launch_status("fpsg_edgeconv_bwd");
 }

@@ -8,26 +8,23 @@
 //   * the N x M soft-assignment matrix is never stored: cost and gradients are accumulated
 //     level by level, so memory is O(N+M) instead of 16 MB per 2048-point pair;
 //   * every level is three dependent sweeps over the N x M pairs (row normalisers,
-//     column consumption, assignment); each sweep is ONE launch spread over
-//     B x ceil(owners/64) workgroups of 16 waves -- the 64 owner points of a workgroup sit
-//     one per lane, the other cloud (+ its per-point weight) is staged in LDS as SoA and
-//     split 16 ways across the waves; partial sums are merged in LDS in fixed wave order,
-//     so results are deterministic (no float atomics);
-//   * the per-pair work is FP32 VALU + one v_exp_f32 (and v_sqrt/v_rcp in the assignment
+//     column consumption, assignment); each sweep is ONE launch of small workgroups: a wave owns
+//     two points and its lanes stride over the other cloud (see emd_sweep_kernel);
+//   * the per-pair work is packed FP32 VALU + one v_exp_f32 (and v_sqrt/v_rcp in the assignment
 //     sweep); distances use the same fma form as K1.
 #include "fpsg_common.h"
 
 namespace fpsg {
 namespace {
 
-constexpr int kEmdWaves = 16;
+constexpr int kEmdWaves = 4;     // waves per workgroup
+constexpr int kEmdOwners = 2;    // owner points per wave
 constexpr int kEmdThreads = 64 * kEmdWaves;
-constexpr int kEmdTile = 2048;  // other-cloud points staged per LDS pass (4 floats each = 32 KiB)
 
 enum EmdMode { kRatioL = 0, kRatioR = 1, kMatch = 2, kGradOther = 3 };
 
 struct EmdArgs {
-  const float* own;      // [B, No, 3] owner cloud (one point per lane)
+  const float* own;      // [B, No, 3] owner cloud
   const float* oth;      // [B, Nt, 3] cloud that is swept
   const float* oth_w;    // [B, Nt] weight of every swept point (remainR | ratioL | ratioR)
   float* own_remain;     // [B, No]  remainL (kRatioL: read, kMatch: updated) | remainR (kRatioR: updated)
@@ -38,86 +35,96 @@ struct EmdArgs {
   float level;
 };
 
-__device__ __forceinline__ float fast_exp(float x) { return __expf(x); }
-
+// One wave = kEmdOwners owner points against the whole swept cloud: lane l takes the candidates
+// l, l+64, l+128, ... straight from global memory (a wave reads contiguous 768-byte runs of the AoS
+// cloud; the cloud stays in L2 -- no LDS staging, no barrier), two candidates per packed FP32
+// instruction, and the per-owner sums are folded over the 64 lanes by a fixed DPP tree
+// (deterministic, no float atomics).  A sweep of one 2048-point pair is 256 workgroups of 4 waves,
+// so even a single pair fills the chip; per pair: distance (3 packed-half instructions) + v_exp_f32 +
+// weights (+ v_sqrt / v_rcp and 4 FMAs in the assignment sweeps): VALU + transcendental bound.
 template <int MODE, bool GRAD>
 __global__ __launch_bounds__(kEmdThreads) void emd_sweep_kernel(EmdArgs a) {
-  __shared__ __attribute__((aligned(16))) float sx[kEmdTile], sy[kEmdTile], sz[kEmdTile], sw[kEmdTile];
-  __shared__ float part[kEmdWaves][5][64];
   const int b = blockIdx.y;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int o = blockIdx.x * 64 + lane;
-  const bool live = o < a.No;
-  const int oc = live ? o : a.No - 1;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int o0 = (blockIdx.x * kEmdWaves + wave) * kEmdOwners;
+  if (o0 >= a.No) return;                               // whole wave; no barrier in this kernel
   const float* __restrict__ own = a.own + (size_t)b * a.No * 3;
   const float* __restrict__ oth = a.oth + (size_t)b * a.Nt * 3;
   const float* __restrict__ ow = a.oth_w + (size_t)b * a.Nt;
-  const float px = own[3 * oc], py = own[3 * oc + 1], pz = own[3 * oc + 2];
-  // factor applied to every pair weight of this owner (assignment sweeps only)
-  float own_fac = 1.0f;
-  if (MODE == kMatch || MODE == kGradOther) own_fac = a.own_ratio[(size_t)b * a.No + oc];
+  v2f px[kEmdOwners], py[kEmdOwners], pz[kEmdOwners];
+  float fac[kEmdOwners];
+#pragma unroll
+  for (int r = 0; r < kEmdOwners; ++r) {
+    const int oc = (o0 + r) < a.No ? (o0 + r) : a.No - 1;
+    const float x = own[3 * oc], y = own[3 * oc + 1], z = own[3 * oc + 2];
+    px[r] = v2f{x, x}; py[r] = v2f{y, y}; pz[r] = v2f{z, z};
+    // factor applied to every pair weight of this owner (assignment sweeps only)
+    fac[r] = (MODE == kMatch || MODE == kGradOther) ? a.own_ratio[(size_t)b * a.No + oc] : 1.0f;
+  }
+  v2f s[kEmdOwners], c[kEmdOwners], gx[kEmdOwners], gy[kEmdOwners], gz[kEmdOwners];
+#pragma unroll
+  for (int r = 0; r < kEmdOwners; ++r) { s[r] = v2f{0, 0}; c[r] = v2f{0, 0}; gx[r] = v2f{0, 0}; gy[r] = v2f{0, 0}; gz[r] = v2f{0, 0}; }
+  const v2f lvl = {a.level, a.level};
 
-  float s = 0.0f, c = 0.0f, gx = 0.0f, gy = 0.0f, gz = 0.0f;
-  for (int t0 = 0; t0 < a.Nt; t0 += kEmdTile) {
-    if (t0) __syncthreads();
-    const int cnt = (a.Nt - t0) < kEmdTile ? (a.Nt - t0) : kEmdTile;
-    for (int e = tid; e < cnt; e += kEmdThreads) {
-      sx[e] = oth[3 * (t0 + e)];
-      sy[e] = oth[3 * (t0 + e) + 1];
-      sz[e] = oth[3 * (t0 + e) + 2];
-      sw[e] = ow[t0 + e];
-    }
-    __syncthreads();
-    const int per = (cnt + kEmdWaves - 1) / kEmdWaves;
-    const int lo = wave * per;
-    const int hi = (lo + per) < cnt ? (lo + per) : cnt;
-    for (int l = lo; l < hi; ++l) {
-      const float dx = sx[l] - px, dy = sy[l] - py, dz = sz[l] - pz;   // LDS broadcast reads
-      const float d2 = fma_rn(dz, dz, fma_rn(dy, dy, dx * dx));
-      const float w = fast_exp(a.level * d2) * sw[l] * own_fac;
-      s += w;
+#pragma unroll 4
+  for (int l0 = lane; l0 < a.Nt; l0 += 128) {           // candidates l0 and l0 + 64 as one packed pair; 4 pairs of loads in flight
+    const int l1 = l0 + 64;
+    const bool in1 = l1 < a.Nt;
+    const int l1c = in1 ? l1 : l0;
+    const v2f cx = {oth[3 * l0], oth[3 * l1c]}, cy = {oth[3 * l0 + 1], oth[3 * l1c + 1]},
+              cz = {oth[3 * l0 + 2], oth[3 * l1c + 2]};
+    const v2f cw = {ow[l0], in1 ? ow[l1] : 0.0f};       // a missing candidate weighs nothing
+#pragma unroll
+    for (int r = 0; r < kEmdOwners; ++r) {
+      const v2f dx = cx - px[r], dy = cy - py[r], dz = cz - pz[r];
+      const v2f d2 = fma_rn(dz, dz, fma_rn(dy, dy, dx * dx));
+      const v2f e = lvl * d2;
+      const v2f f2 = {fac[r], fac[r]};
+      const v2f w = v2f{__expf(e.x), __expf(e.y)} * cw * f2;
+      s[r] += w;
       if (MODE == kMatch || MODE == kGradOther) {
-        const float dist = __builtin_sqrtf(d2);
-        if (MODE == kMatch) c = fma_rn(w, dist, c);
+        const v2f dist = {__builtin_sqrtf(d2.x), __builtin_sqrtf(d2.y)};
+        if (MODE == kMatch) c[r] = fma_rn(w, dist, c[r]);
         if (GRAD) {
-          const float f = w / __builtin_fmaxf(dist, 1e-20f);
-          gx = fma_rn(f, -dx, gx);   // owner - other
-          gy = fma_rn(f, -dy, gy);
-          gz = fma_rn(f, -dz, gz);
+          const v2f f = {w.x / __builtin_fmaxf(dist.x, 1e-20f), w.y / __builtin_fmaxf(dist.y, 1e-20f)};
+          gx[r] = fma_rn(f, -dx, gx[r]);   // owner - other
+          gy[r] = fma_rn(f, -dy, gy[r]);
+          gz[r] = fma_rn(f, -dz, gz[r]);
         }
       }
     }
   }
-  part[wave][0][lane] = s;
-  if (MODE == kMatch) part[wave][1][lane] = c;
-  if (GRAD) { part[wave][2][lane] = gx; part[wave][3][lane] = gy; part[wave][4][lane] = gz; }
-  __syncthreads();
-  if (wave != 0 || !live) return;
-  s = 0.0f; c = 0.0f; gx = 0.0f; gy = 0.0f; gz = 0.0f;
 #pragma unroll
-  for (int w = 0; w < kEmdWaves; ++w) {   // fixed order: deterministic
-    s += part[w][0][lane];
-    if (MODE == kMatch) c += part[w][1][lane];
-    if (GRAD) { gx += part[w][2][lane]; gy += part[w][3][lane]; gz += part[w][4][lane]; }
-  }
-  const size_t oi = (size_t)b * a.No + o;
-  if (MODE == kRatioL) {
-    a.own_ratio[oi] = a.own_remain[oi] / (s + 1e-9f);
-  } else if (MODE == kRatioR) {
-    const float rem = a.own_remain[oi];
-    const float sumr = s * rem;
-    const float consumption = __builtin_fminf(rem / (sumr + 1e-9f), 1.0f);
-    a.own_ratio[oi] = consumption * rem;
-    a.own_remain[oi] = __builtin_fmaxf(0.0f, rem - sumr);
-  } else if (MODE == kMatch) {
-    a.own_cost[oi] += c;
-    a.own_remain[oi] = __builtin_fmaxf(0.0f, a.own_remain[oi] - s);
-  }
-  if (GRAD && (MODE == kMatch || MODE == kGradOther)) {
-    a.own_grad[3 * oi] += gx;
-    a.own_grad[3 * oi + 1] += gy;
-    a.own_grad[3 * oi + 2] += gz;
+  for (int r = 0; r < kEmdOwners; ++r) {
+    const float st = wave_sum(s[r].x + s[r].y);
+    float ct = 0.0f, gxt = 0.0f, gyt = 0.0f, gzt = 0.0f;
+    if (MODE == kMatch) ct = wave_sum(c[r].x + c[r].y);
+    if (GRAD) {
+      gxt = wave_sum(gx[r].x + gx[r].y);
+      gyt = wave_sum(gy[r].x + gy[r].y);
+      gzt = wave_sum(gz[r].x + gz[r].y);
+    }
+    const int o = o0 + r;
+    if (lane != 0 || o >= a.No) continue;
+    const size_t oi = (size_t)b * a.No + o;
+    if (MODE == kRatioL) {
+      a.own_ratio[oi] = a.own_remain[oi] / (st + 1e-9f);
+    } else if (MODE == kRatioR) {
+      const float rem = a.own_remain[oi];
+      const float sumr = st * rem;
+      const float consumption = __builtin_fminf(rem / (sumr + 1e-9f), 1.0f);
+      a.own_ratio[oi] = consumption * rem;
+      a.own_remain[oi] = __builtin_fmaxf(0.0f, rem - sumr);
+    } else if (MODE == kMatch) {
+      a.own_cost[oi] += ct;
+      a.own_remain[oi] = __builtin_fmaxf(0.0f, a.own_remain[oi] - st);
+    }
+    if (GRAD && (MODE == kMatch || MODE == kGradOther)) {
+      a.own_grad[3 * oi] += gxt;
+      a.own_grad[3 * oi + 1] += gyt;
+      a.own_grad[3 * oi + 2] += gzt;
+    }
   }
 }
 
@@ -148,7 +155,7 @@ __global__ __launch_bounds__(256) void emd_cost_kernel(const float* __restrict__
 
 template <int MODE, bool GRAD>
 int sweep(const EmdArgs& a, int B, hipStream_t s, const char* what) {
-  dim3 grid((a.No + 63) / 64, B);
+  dim3 grid((a.No + kEmdWaves * kEmdOwners - 1) / (kEmdWaves * kEmdOwners), B);
   hipLaunchKernelGGL((emd_sweep_kernel<MODE, GRAD>), grid, dim3(kEmdThreads), 0, s, a);
   return launch_status(what);
 }

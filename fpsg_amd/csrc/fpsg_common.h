@@ -52,4 +52,35 @@ constexpr int kWave = 64;
 __device__ __forceinline__ float fma_rn(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 __device__ __forceinline__ v2f fma_rn(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
 
+// Lane exchange v[lane ^ M] without touching memory: DPP inside a row of 16 lanes (M = 4, 8 as two
+// mirrors: (l^7)^3 = l^4, (l^15)^7 = l^8), the swizzle crossbar for 16, a half-wave swap for 32.
+template <int M>
+__device__ __forceinline__ unsigned lane_xor(unsigned v) {
+  const int x = (int)v;
+  if (M == 1) return (unsigned)__builtin_amdgcn_update_dpp(x, x, 0xB1, 0xF, 0xF, false);   // quad_perm [1,0,3,2]
+  if (M == 2) return (unsigned)__builtin_amdgcn_update_dpp(x, x, 0x4E, 0xF, 0xF, false);   // quad_perm [2,3,0,1]
+  if (M == 4) {
+    const int h = __builtin_amdgcn_update_dpp(x, x, 0x141, 0xF, 0xF, false);               // row_half_mirror: l^7
+    return (unsigned)__builtin_amdgcn_update_dpp(h, h, 0x1B, 0xF, 0xF, false);             // quad_perm [3,2,1,0]: ^3
+  }
+  if (M == 8) {
+    const int h = __builtin_amdgcn_update_dpp(x, x, 0x140, 0xF, 0xF, false);               // row_mirror: l^15
+    return (unsigned)__builtin_amdgcn_update_dpp(h, h, 0x141, 0xF, 0xF, false);            // row_half_mirror: ^7
+  }
+  if (M == 16) return (unsigned)__builtin_amdgcn_ds_swizzle(x, (16 << 10) | 0x1F);         // bit mode: xor 16
+  return (unsigned)__shfl_xor(x, 32, 64);
+}
+
+
+// Sum over the 64 lanes of a wave, every lane receives the total; a fixed balanced tree (deterministic).
+__device__ __forceinline__ float wave_sum(float v) {
+  v += __uint_as_float(lane_xor<1>(__float_as_uint(v)));
+  v += __uint_as_float(lane_xor<2>(__float_as_uint(v)));
+  v += __uint_as_float(lane_xor<4>(__float_as_uint(v)));
+  v += __uint_as_float(lane_xor<8>(__float_as_uint(v)));
+  v += __uint_as_float(lane_xor<16>(__float_as_uint(v)));
+  v += __uint_as_float(lane_xor<32>(__float_as_uint(v)));
+  return v;
+}
+
 }  // namespace fpsg

@@ -128,7 +128,7 @@ class _EdgeConvBNMax(torch.autograd.Function):
         ysel = torch.empty((B, N, Co), dtype=torch.float32, device=dev)
         jsel = torch.empty((B, N, Co), dtype=torch.uint8, device=dev)
         s1 = torch.empty((B, N, Co), dtype=torch.float32, device=dev) if training else None
-        part = (torch.empty((lib.fpsg_edgeconv_blocks(B, N), 2, Co), dtype=torch.float32, device=dev)
+        part = (torch.empty((lib.fpsg_edgeconv_blocks(B, N, Co), 2, Co), dtype=torch.float32, device=dev)
                 if training else None)
         with torch.cuda.device(dev):
             rc = lib.fpsg_edgeconv_fwd(_hip.ptr(PQ), _hip.ptr(idx32), _hip.ptr(sgn), B, N, k, Co,

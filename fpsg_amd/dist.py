@@ -100,6 +100,7 @@ class FlatGradBuckets:
             self.buckets.append((start, off))
             self._bucket_size.append(count)
         self._pending = [0] * len(self.buckets)
+        self._next_launch = 0        # buckets [0, _next_launch) have had their all-reduce launched this step
         self._bucket_params: list[list] = [[] for _ in self.buckets]
         for p in params:
             self._bucket_params[self._bucket_of[id(p)]].append(p)
@@ -161,6 +162,7 @@ class FlatGradBuckets:
         self._armed = dist.is_initialized()
         self._armed_first = bool(first)
         self._pending = list(self._bucket_size)
+        self._next_launch = 0
         self._handles = []
         self._streams = {}
 
@@ -190,7 +192,19 @@ class FlatGradBuckets:
             cur = torch.cuda.current_stream(p.device)
             self._streams[cur.cuda_stream] = cur
         if self._pending[b] == 0:
-            if p.is_cuda:
+            self._launch_ready(cur if p.is_cuda else None)
+
+    def _launch_ready(self, cur=None, flush: bool = False) -> None:
+        """Launches the all-reduce of every complete bucket IN BUCKET-INDEX ORDER: bucket b goes out
+        only once buckets 0..b-1 have gone.  Every rank therefore issues the same sequence of
+        collectives whatever order its backward completed them in (a rank without local episodes
+        flushes all of them from ``finish``; the stacked decoder weights deliver the gradients of
+        several buckets at once) -- mismatched sequences would hang or mis-sum in RCCL.  ``flush``
+        also launches the incomplete ones (parameters that received no gradient this step)."""
+        while self._next_launch < len(self.buckets) and (flush or self._pending[self._next_launch] == 0):
+            b = self._next_launch
+            self._next_launch += 1
+            if cur is not None:
                 # a bucket may hold gradients produced on different streams (the encoders can
                 # run on two): the collective is ordered after all of them
                 for key, st in self._streams.items():
@@ -206,12 +220,8 @@ class FlatGradBuckets:
         """Waits for the in-flight buckets, reduces any bucket whose parameters received no
         gradient in the armed backward, and turns the sum into the mean over episodes."""
         if self._armed:
-            for b, left in enumerate(self._pending):
-                if left > 0:  # e.g. parameters unused by this step's graph
-                    self._absorb_bucket(b)
-                    s, e = self.buckets[b]
-                    self._handles.append(dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM,
-                                                         group=self.group, async_op=True))
+            cur = torch.cuda.current_stream(self.flat.device) if self.flat.is_cuda else None
+            self._launch_ready(cur, flush=True)      # the rest, in index order (e.g. parameters unused by this step's graph)
             for h in self._handles:
                 h.wait()
             self._handles = []

@@ -185,7 +185,9 @@ class EpisodePrefetcher:
     The reference assembles an episode on the host and uploads it inside the step
     (``trainNetwork.py:37-43,141``: ``to_cuda``) -- with 32-shot episodes that is 69 images of CPU
     indexing plus 42 MB over PCIe per episode, serial with the GPU work.  Here a background thread
-    draws the next episodes (same order, same RNG stream: it is the only consumer of the loader),
+    draws the next episodes (same order, same RNG stream: it is the only consumer of the loader while
+    it is open -- pass it exactly the episodes that will be used and ``close()`` it before anything
+    else touches the global RNG),
     stages them in pinned memory and uploads them on a side stream; ``next()`` makes the compute
     stream wait on the upload's event, not the host.  On a CPU device it is a plain pass-through."""
 
@@ -245,10 +247,20 @@ class EpisodePrefetcher:
         return sample
 
     def close(self):
-        """Stops the background thread (episodes already staged are dropped)."""
+        """Stops the background thread and WAITS for it (episodes already staged are dropped): after
+        ``close()`` nothing draws from the loader -- or from the global RNG behind it -- any more.  Give
+        the prefetcher exactly the episodes it will be asked for (``itertools.islice``), so that the
+        worker never draws one the consumer does not use."""
+        import queue
         self._stop = True
+        while self._thread.is_alive():
+            try:                               # a worker blocked in put() needs room to see the flag
+                self._q.get(timeout=0.05)
+            except queue.Empty:
+                pass
+        self._thread.join()
         try:
             while True:
                 self._q.get_nowait()
-        except Exception:
+        except queue.Empty:
             pass

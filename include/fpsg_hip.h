@@ -145,7 +145,7 @@ int fpsg_emd_approx(const float* xyz1, const float* xyz2, int B, int N, int M, f
  * forms PQ [B,N,2*Co] = x^T [W1 ; W2-W1]^T (one GEMM): y(n,j) = P[idx[n,j]] + Q[n].
  *   fwd : sgn [Co] = +1 (take max_j) or -1 (take min_j) per channel (= sign of BN gamma);
  *         ysel [B,N,Co] selected extreme of y over j; jsel [B,N,Co] uint8 its slot j (first on
- *         ties); s1 [B,N,Co] = sum_j y (NULL to skip); part [fpsg_edgeconv_blocks(B,N)][2][Co]
+ *         ties); s1 [B,N,Co] = sum_j y (NULL to skip); part [fpsg_edgeconv_blocks(B,N,Co)][2][Co]
  *         per-workgroup sums of y and y^2 for the BatchNorm statistics (NULL to skip).
  *   bwd : dzs [B,N,Co] = dL/dz * scale at the selected edge; rev [B,N*k] edge ids n*k+j sorted
  *         by destination idx (ascending id inside a destination), off [B,N+1] offsets into rev;
@@ -153,7 +153,7 @@ int fpsg_emd_approx(const float* xyz1, const float* xyz2, int B, int N, int M, f
  *         ignored).  dPQ [B,N,2*Co] is fully overwritten.  Deterministic (no float atomics).
  * Co must be 64, 128 or 256; float buffers 16-byte aligned.
  */
-int fpsg_edgeconv_blocks(int B, int N);
+int fpsg_edgeconv_blocks(int B, int N, int Co);
 int fpsg_edgeconv_fwd(const float* PQ, const int32_t* idx, const float* sgn, int B, int N, int k,
                       int Co, float* ysel, uint8_t* jsel, float* s1, float* part,
                       fpsg_stream_t stream);

@@ -30,6 +30,7 @@ class TinyEpisodeNet(nn.Module):
         torch.manual_seed(5)
         self.a = nn.Linear(6, 32)
         self.bn = nn.BatchNorm1d(32)
+        self.mid_unused = nn.Linear(3, 5)      # no gradient either, registered in the MIDDLE of the bucket order
         self.b = nn.Linear(32, 32)
         self.c = nn.Linear(32, 3)
         self.unused = nn.Linear(4, 4)          # never receives a gradient
@@ -76,7 +77,9 @@ def _single(n_eps):
     return [p.detach().clone() for p in model.parameters()], step.buckets.flat.clone()
 
 
-@pytest.mark.parametrize("n_eps,bucket_mb", [(2, 80.0), (4, 1e-4), (3, 1e-4)])
+# n_eps = 1 on two ranks: rank 1 has no local episode and launches every bucket from finish(), rank 0 from
+# its autograd hooks -- both must issue the all-reduces in the same (bucket-index) order
+@pytest.mark.parametrize("n_eps,bucket_mb", [(2, 80.0), (4, 1e-4), (3, 1e-4), (1, 1e-4), (1, 80.0)])
 def test_two_ranks_equal_one_rank(tmp_path, n_eps, bucket_mb):
     world = 2
     port = _free_port()
@@ -89,6 +92,33 @@ def test_two_ranks_equal_one_rank(tmp_path, n_eps, bucket_mb):
             assert torch.allclose(a, b, rtol=1e-5, atol=1e-7)
     for a, b in zip(outs[0]["params"], outs[1]["params"]):
         assert torch.equal(a, b)               # replicas stay bit-identical
+
+
+def test_all_reduces_are_launched_in_bucket_order(monkeypatch):
+    """Whatever order the buckets complete in, the collectives go out in index order (ranks whose
+    backward completes buckets in different orders would otherwise issue mismatched RCCL sequences)."""
+    model = TinyEpisodeNet()
+    fb = fdist.FlatGradBuckets(model, bucket_mb=1e-4)
+    launched = []
+
+    class _Done:
+        def wait(self):
+            return None
+
+    def fake_all_reduce(t, op=None, group=None, async_op=False):
+        launched.append(t.data_ptr())
+        return _Done()
+
+    monkeypatch.setattr(fdist.dist, "is_initialized", lambda: True)
+    monkeypatch.setattr(fdist.dist, "all_reduce", fake_all_reduce)
+    fb.detach()
+    fb.arm(first=True)
+    model.loss(_episode(0))["ttl_loss"].backward()
+    mid = len(launched)
+    fb.finish(1)
+    starts = [fb.flat[s:e].data_ptr() for s, e in fb.buckets]
+    assert launched == starts                          # every bucket once, ascending
+    assert mid < len(starts)                           # the buckets behind an unused parameter waited for finish()
 
 
 def test_bucket_layout_follows_backward_order():

@@ -1,11 +1,17 @@
 """Summarises rocprofv3 --pmc runs (counter_collection.csv) of the K1 kernels into the JSON
-that bench.py reads for `roofline.traffic`.
+that bench.py reads for `roofline.traffic` (profiles/k1_traffic.json).
 
     python tools/pmc_summary.py <fetch_dir> <write_dir> <out.json>
 
-HBM bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: on gfx950 FETCH_SIZE tallies the
-128-B read requests of a coalesced stream at 64 B (MI355X_MICROARCH.md, HBM section); WRITE_SIZE
-is exact.  FETCH_SIZE and WRITE_SIZE need separate passes (TCC counter slots)."""
+HBM bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: on gfx950 FETCH_SIZE tallies the 128-B read
+requests of a coalesced stream at 64 B (MI355X_MICROARCH.md, HBM section); WRITE_SIZE is exact.
+FETCH_SIZE and WRITE_SIZE need separate passes (TCC counter slots).
+
+One K1 forward op is the tile kernel followed by the finalize kernel (fpsg_chamfer_fwd_tiled), or
+one two-pass kernel (fpsg_chamfer_fwd) for few pairs; the backward op is one kernel.  Dispatches
+are grouped into ops in dispatch order; the number of cloud pairs of an op comes from the grid of
+its LAST kernel at N = M = 2048 (finalize: 4096 threads per pair; sorted backward: 2048 per pair;
+two-pass forward <R,W>: 4096*W/R per pair)."""
 import collections
 import csv
 import glob
@@ -14,39 +20,55 @@ import re
 import sys
 
 
-def load(d, counter):
-    agg = collections.defaultdict(list)
+def dispatches(d, counter):
+    rows = []
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] != counter:
                 continue
             m = re.search(r"(chamfer_\w+?_kernel)(<[^>]*>)?", r["Kernel_Name"])
-            if not m:
-                continue
-            agg[(m.group(1) + (m.group(2) or ""), int(r["Grid_Size"]), int(r["Workgroup_Size"]))].append(
-                float(r["Counter_Value"]))
-    return {k: sum(v) / len(v) for k, v in agg.items()}
+            if m:
+                rows.append((int(r["Dispatch_Id"]), m.group(1), m.group(2) or "", int(r["Grid_Size"]),
+                             float(r["Counter_Value"])))
+    rows.sort()
+    return rows
+
+
+def ops(rows):
+    """-> {(op, cloud_pairs): [KiB per op, ...]}"""
+    out = collections.defaultdict(list)
+    pending = None
+    for _, name, tmpl, grid, val in rows:
+        if name == "chamfer_tile_kernel":
+            pending = val
+        elif name == "chamfer_finalize_kernel":
+            out[("chamfer_fwd", grid // 4096)].append(val + (pending or 0.0))
+            pending = None
+        elif name == "chamfer_fwd_kernel":
+            R, W = (int(v) for v in re.findall(r"\d+", tmpl))
+            out[("chamfer_fwd", grid * R // (4096 * W))].append(val)
+        elif name == "chamfer_bwd_sorted_kernel":
+            out[("chamfer_bwd", grid // 2048)].append(val)
+        elif name == "chamfer_bwd_kernel":
+            out[("chamfer_bwd", grid // 4096)].append(val)
+    return {k: sum(v) / len(v) for k, v in out.items()}
 
 
 def main():
-    fetch, write = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
+    fetch, write = ops(dispatches(sys.argv[1], "FETCH_SIZE")), ops(dispatches(sys.argv[2], "WRITE_SIZE"))
     out = {"how": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (separate passes) --kernel-include-regex chamfer "
-                  "-- python bench.py --workload c3 --no-graph --steps 2 --warmup 1 --no-cpu-baseline",
-           "formula": "hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024", "launches": []}
+                  "-- python3 bench.py --no-extra --no-cpu-baseline --steps 2 --warmup 1 (tools/pmc_k1.sh)",
+           "formula": "hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024, summed over the kernels of one op",
+           "ops": []}
     for key in sorted(set(fetch) | set(write)):
-        name, grid, wg = key
+        op, pairs = key
         f, w = fetch.get(key), write.get(key)
-        rec = {"kernel": name, "grid_threads": grid, "workgroup": wg, "FETCH_SIZE_KiB": f, "WRITE_SIZE_KiB": w}
-        m = re.search(r"<(\d+), (\d+)>", name)
-        if m:      # forward: grid = 4096 * B * W / R threads at N = M = 2048
-            rec["cloud_pairs"] = grid * int(m.group(1)) // (4096 * int(m.group(2)))
-            rec["algorithmic_bytes"] = rec["cloud_pairs"] * 81920
-        else:      # backward: 2 sides * B * 2048 threads
-            rec["cloud_pairs"] = grid // 4096
-            rec["algorithmic_bytes"] = rec["cloud_pairs"] * 131072
+        rec = {"op": op, "cloud_pairs": pairs, "FETCH_SIZE_KiB": f, "WRITE_SIZE_KiB": w,
+               "algorithmic_bytes": pairs * (81920 if op == "chamfer_fwd" else 131072)}
         if f is not None and w is not None:
-            rec["hbm_bytes_per_launch"] = (2 * f + w) * 1024
-        out["launches"].append(rec)
+            rec["hbm_bytes_per_op"] = (2 * f + w) * 1024
+            rec["ratio_to_algorithmic"] = rec["hbm_bytes_per_op"] / rec["algorithmic_bytes"]
+        out["ops"].append(rec)
     json.dump(out, open(sys.argv[3], "w"), indent=1)
     print(json.dumps(out, indent=1))
 

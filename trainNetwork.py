@@ -13,6 +13,7 @@ gradients are averaged with an RCCL all-reduce; rank 0 logs, evaluates and saves
 """
 from __future__ import annotations
 
+import itertools
 import os
 import statistics
 import time
@@ -88,7 +89,11 @@ def main(opt):
             state = torch.load(state_path, map_location=device, weights_only=True)
             optimizer.load_state_dict(state["optimizer"])
             scheduler.load_state_dict(state["scheduler"])
-            print(f"Restored optimizer / scheduler state from {state_path}")
+            # the sidecar holds the state AFTER epoch N's scheduler.step(): training continues with epoch
+            # N+1 (the weights-only resume of the reference re-runs epoch N from fresh moments; doing that
+            # here would step the LR schedule twice for epoch N and reuse post-epoch-N moments)
+            start_epoch = int(state.get("epoch", start_epoch)) + 1
+            print(f"Restored optimizer / scheduler state from {state_path}; continuing with epoch {start_epoch}")
     step = TrainStep(model, optimizer, world=world)
     eps_per_step = opt.episodes_per_step or world
     local_n = len(range(rank, eps_per_step, world))
@@ -104,15 +109,27 @@ def main(opt):
         # every rank draws its own episodes; different seeds per (epoch, rank)
         torch.manual_seed(1000003 * epoch + rank)
         sums = torch.zeros(2, dtype=torch.float64, device=device)
-        it = EpisodePrefetcher(iter(dl), device)      # next episodes drawn and uploaded behind the step
         n_steps = max(1, opt.n_episode // eps_per_step)
+        # exactly the episodes this rank uses (the worker must not draw one more from the global RNG: the
+        # evaluation below and the next epoch's seed share it), drawn and uploaded behind the step
+        it = EpisodePrefetcher(itertools.islice(iter(dl), n_steps * local_n), device)
         t0 = time.perf_counter()
-        for _ in range(n_steps):
-            local = [to_device(next(it), device) for _ in range(local_n)]
-            for out in step(local, n_episodes_global=eps_per_step):
-                sums[0] += out["query_rec_loss"].sum() / n_query
-                sums[1] += out["support_rec_loss"].sum() / opt.n_shot
-        it.close()
+        try:
+            for _ in range(n_steps):
+                local = []
+                for _ in range(local_n):
+                    try:
+                        local.append(to_device(next(it), device))
+                    except StopIteration:
+                        raise RuntimeError(
+                            f"the loader ran out of episodes: --n_episode {opt.n_episode} gives this rank "
+                            f"fewer than {n_steps} x {local_n} episodes (episodes_per_step {eps_per_step}, "
+                            f"{world} rank(s))") from None
+                for out in step(local, n_episodes_global=eps_per_step):
+                    sums[0] += out["query_rec_loss"].sum() / n_query
+                    sums[1] += out["support_rec_loss"].sum() / opt.n_shot
+        finally:
+            it.close()
         q_sum, s_sum = fdist.all_reduce_scalars(sums.tolist(), device)   # one host sync per epoch
         done = n_steps * eps_per_step
         dt = time.perf_counter() - t0
