@@ -51,6 +51,11 @@ SIGNATURES = {
     "fpsg_sinkhorn_workspace_floats": [_c_int, _c_int, _c_int],
     "fpsg_sinkhorn_divergence": [_c_f32p, _c_f32p, _c_int, _c_int, _c_int, ctypes.c_void_p, _c_int, _c_f32p, _c_f32p,
                                  _c_stream],
+    "fpsg_dec1_tiles": [_c_int],
+    "fpsg_dec1_fwd": [_c_f32p, _c_f32p, _c_int, _c_int, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_int, _c_int,
+                      _c_int, _c_int, _c_int, ctypes.c_float, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_stream],
+    "fpsg_dec1_bwd": [_c_f32p, _c_f32p, _c_f32p, _c_int, _c_int, _c_f32p, _c_f32p, _c_int, _c_int, _c_int, _c_int,
+                      _c_int, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_stream],
     "fpsg_bn_workspace_floats": [_c_int, _c_int, _c_int],
     "fpsg_bn_act_fwd": [_c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, ctypes.c_float, _c_int, _c_int, _c_int, _c_int,
                         ctypes.c_float, _c_int, ctypes.c_float, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p,

@@ -191,6 +191,109 @@ class _SplitLast(torch.autograd.Function):
         return gw, None
 
 
+def _update_running(bns, r, mean, var):
+    """``r`` sequential momentum updates per module of ``bns`` from the per-call statistics ``mean`` /
+    ``var`` ``[len(bns)*r*C]`` (var unbiased, as torch), in closed form and as multi-tensor ops:
+        run <- (1-m)^r run + m * sum_j (1-m)^(r-1-j) stat_j"""
+    C = bns[0].num_features
+    m = 0.1 if bns[0].momentum is None else bns[0].momentum
+    mean3, var3 = mean.view(len(bns), r, C), var.view(len(bns), r, C)
+    new_mean = mean3[:, 0] * (m * (1 - m) ** (r - 1))      # python scalars only: no
+    new_var = var3[:, 0] * (m * (1 - m) ** (r - 1))        # host->device copies, so the
+    for j in range(1, r):                                    # step can be graph-captured
+        new_mean = new_mean + mean3[:, j] * (m * (1 - m) ** (r - 1 - j))
+        new_var = new_var + var3[:, j] * (m * (1 - m) ** (r - 1 - j))
+    rms = [b.running_mean for b in bns]
+    rvs = [b.running_var for b in bns]
+    torch._foreach_mul_(rms, (1 - m) ** r)
+    torch._foreach_add_(rms, list(new_mean.unbind(0)))
+    torch._foreach_mul_(rvs, (1 - m) ** r)
+    torch._foreach_add_(rvs, list(new_var.unbind(0)))
+    torch._foreach_add_([b.num_batches_tracked for b in bns], r)
+
+
+def _layer1_fused_ok(x, pts, B, P, act) -> bool:
+    """K9 applies: ROCm tensors, ReLU, patch sizes the kernel tiles (P = 4 x a power of two <= 256,
+    B*P <= 8192).  ``FPSG_DEC1=0`` selects the library chain (A/B measurements)."""
+    import os
+    return (x.is_cuda and pts.is_cuda and x.dtype == torch.float32 and act is F.relu
+            and os.environ.get("FPSG_DEC1", "1") != "0" and P % 4 == 0 and P <= 256
+            and ((P // 4) & (P // 4 - 1)) == 0 and B * P <= 8192)
+
+
+class _DecoderLayer1(torch.autograd.Function):
+    """``relu(BN(conv1(cat(x_rep, pts))))`` of all G patch MLPs at once, first layer split into the latent
+    GEMM (library, MFMA) and K9 (``fpsg_dec1_fwd/bwd``): the [G,D,B*P] pre-BatchNorm tensor is never
+    stored, forward or backward.  ``w1 [G,D,L+3]`` stacked conv1 weights, ``b1 [G,D,1]`` biases, ``x [B,L]``
+    latents, ``pts [G,3,B*P]`` deformed patch points.  Returns ``(out [G,D,B*P], batch_mean, batch_var)``."""
+
+    @staticmethod
+    def forward(ctx, w1, b1, x, pts, gamma, beta, running_mean, running_var, training, eps, P):
+        from . import _hip
+        lib = _hip.load()
+        G, D, K = w1.shape
+        B, L = x.shape
+        BP = B * P
+        w1 = w1.contiguous()
+        pts = pts.contiguous()
+        hlat = torch.baddbmm(b1, w1[..., :L], x.t().unsqueeze(0).expand(G, L, B))          # [G,D,B]
+        out = torch.empty((G, D, BP), dtype=torch.float32, device=x.device)
+        chan = torch.empty((4, G * D), dtype=torch.float32, device=x.device)
+        bmean = torch.empty((G * D,), dtype=torch.float32, device=x.device) if training else None
+        bvar = torch.empty((G * D,), dtype=torch.float32, device=x.device) if training else None
+        opt = lambda t: _hip.ptr(t) if t is not None else None
+        with torch.cuda.device(x.device):
+            rc = lib.fpsg_dec1_fwd(_hip.ptr(hlat), _hip.ptr(w1), K, L, _hip.ptr(pts), _hip.ptr(gamma), _hip.ptr(beta),
+                                   opt(running_mean), opt(running_var), G, D, B, P, 1 if training else 0, float(eps),
+                                   _hip.ptr(out), _hip.ptr(chan), opt(bmean), opt(bvar), _hip.stream_of(x))
+        _hip.check(rc, "fpsg_dec1_fwd")
+        ctx.save_for_backward(w1, x, pts, hlat, chan)
+        ctx.cfg = (G, D, B, P, L, K, bool(training))
+        if training:
+            ctx.mark_non_differentiable(bmean, bvar)
+            return out, bmean, bvar
+        return out, None, None
+
+    @staticmethod
+    def backward(ctx, dout, _gm, _gv):
+        from . import _hip
+        lib = _hip.load()
+        w1, x, pts, hlat, chan = ctx.saved_tensors
+        G, D, B, P, L, K, training = ctx.cfg
+        dev = x.device
+        dout = dout.contiguous()
+        T = lib.fpsg_dec1_tiles(D)
+        dhlat = torch.empty((G, D, B), dtype=torch.float32, device=dev)
+        gw = torch.empty((G, D, K), dtype=torch.float32, device=dev)       # latent columns by the GEMM below, point columns by K9
+        dpts_part = torch.empty((G, T, 3, B * P), dtype=torch.float32, device=dev)
+        dgamma = torch.empty((G * D,), dtype=torch.float32, device=dev)
+        dbeta = torch.empty((G * D,), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            rc = lib.fpsg_dec1_bwd(_hip.ptr(dout), _hip.ptr(hlat), _hip.ptr(w1), K, L, _hip.ptr(pts), _hip.ptr(chan),
+                                   G, D, B, P, 1 if training else 0, _hip.ptr(dhlat), _hip.ptr(gw), _hip.ptr(dpts_part),
+                                   _hip.ptr(dgamma), _hip.ptr(dbeta), _hip.stream_of(x))
+        _hip.check(rc, "fpsg_dec1_bwd")
+        # d/dW[:, :L] = dhlat x  written straight into the stacked gradient (ldc = L + 3): no split / concat copies
+        torch.bmm(dhlat, x.unsqueeze(0).expand(G, B, L), out=gw[..., :L])
+        gb = dhlat.sum(dim=2, keepdim=True)
+        gx = torch.matmul(dhlat.reshape(G * D, B).t(), w1.reshape(G * D, K)[:, :L])          # [B,L]
+        gpts = dpts_part.sum(dim=1)
+        return gw, gb, gx, gpts, dgamma, dbeta, None, None, None, None, None
+
+
+class _LazySplit:
+    """``(w[..., :L], w[..., L:], b)`` computed once, when first asked for."""
+
+    def __init__(self, w, b, L):
+        self._args, self._val = (w, b, L), None
+
+    def __call__(self):
+        if self._val is None:
+            w, b, L = self._args
+            self._val = _SplitLast.apply(w, L) + (b,)
+        return self._val
+
+
 def _stack_affine(bns, calls_per_bn):
     """gamma / beta of ``bns`` stacked to ``[G*C]`` for ``_group_batch_norm``."""
     gamma = torch.stack([b.weight for b in bns]).repeat_interleave(calls_per_bn, dim=0).reshape(-1)
@@ -215,22 +318,7 @@ def _group_batch_norm(h, bns, calls_per_bn, act, affine=None):
     if bns[0].training:
         y, mean, var = batch_norm_act(x, gamma, beta, None, None, True, 1.0, bns[0].eps, fuse, return_stats=True)
         with torch.no_grad():
-            # r sequential momentum updates per module, in closed form and as multi-tensor ops:
-            #   run <- (1-m)^r run + m * sum_j (1-m)^(r-1-j) stat_j     (var: unbiased, as torch)
-            m = 0.1 if bns[0].momentum is None else bns[0].momentum
-            mean3, var3 = mean.view(len(bns), r, C), var.view(len(bns), r, C)
-            new_mean = mean3[:, 0] * (m * (1 - m) ** (r - 1))      # python scalars only: no
-            new_var = var3[:, 0] * (m * (1 - m) ** (r - 1))        # host->device copies, so the
-            for j in range(1, r):                                    # step can be graph-captured
-                new_mean = new_mean + mean3[:, j] * (m * (1 - m) ** (r - 1 - j))
-                new_var = new_var + var3[:, j] * (m * (1 - m) ** (r - 1 - j))
-            rms = [b.running_mean for b in bns]
-            rvs = [b.running_var for b in bns]
-            torch._foreach_mul_(rms, (1 - m) ** r)
-            torch._foreach_add_(rms, list(new_mean.unbind(0)))
-            torch._foreach_mul_(rvs, (1 - m) ** r)
-            torch._foreach_add_(rvs, list(new_var.unbind(0)))
-            torch._foreach_add_([b.num_batches_tracked for b in bns], r)
+            _update_running(bns, r, mean, var)
     else:
         rm = torch.stack([b.running_mean for b in bns]).repeat_interleave(r, dim=0).reshape(G * C)
         rv = torch.stack([b.running_var for b in bns]).repeat_interleave(r, dim=0).reshape(G * C)
@@ -299,7 +387,7 @@ class PCDecoder(nn.Module):
         # first node layer: latent and point columns of the stacked weight, split once per pack
         w1, b1 = pack["n1"]
         L = w1.size(2) - self.conf.raw_dim
-        pack["n1_split"] = _SplitLast.apply(w1, L) + (b1,)
+        pack["n1_split"] = _LazySplit(w1, b1, L)      # latent / point columns, split on first use (library path only)
         pack["dbn1"] = _stack_affine([d.bn1 for d in defs], R)
         pack["dbn2"] = _stack_affine([d.bn2 for d in defs], R)
         for i in (1, 2, 3):
@@ -342,13 +430,28 @@ class PCDecoder(nn.Module):
 
         # ---- the G patch MLPs; first layer split into latent and point parts
         nodes = [n for c in clusters for n in c.node_pool]
-        w_lat, w_pts, b = pack["n1_split"]                                              # [G,D,L], [G,D,raw]
-        if w_lat.size(2) != L:
-            raise ValueError(f"PCDecoder: hidden size {L} does not match the first layer ({w_lat.size(2)} latent columns)")
-        D = w_lat.size(1)
-        h_lat = torch.matmul(w_lat, x.t()) + b                                          # [G,D,B]
-        h = torch.bmm(w_pts, pts).view(G, D, B, P) + h_lat.unsqueeze(-1)
-        h = _group_batch_norm(h.view(G, D, B * P), [n.bn1 for n in nodes], 1, act, pack["nbn1"])
+        w1, b1 = pack["n1"]                                                             # [G,D,L+raw], [G,D,1]
+        D = w1.size(1)
+        if w1.size(2) - self.conf.raw_dim != L:
+            raise ValueError(f"PCDecoder: hidden size {L} does not match the first layer ({w1.size(2) - self.conf.raw_dim} latent columns)")
+        bn1s = [n.bn1 for n in nodes]
+        if self.conf.raw_dim == 3 and _layer1_fused_ok(x, pts, B, P, act):
+            # K9: latent GEMM + one pass; the [G,D,B*P] pre-BatchNorm tensor is never stored
+            gamma, beta = pack["nbn1"]
+            training = bn1s[0].training
+            rm = rv = None
+            if not training:
+                rm = torch.stack([b_.running_mean for b_ in bn1s]).reshape(-1)
+                rv = torch.stack([b_.running_var for b_ in bn1s]).reshape(-1)
+            h, bmean, bvar = _DecoderLayer1.apply(w1, b1, x, pts, gamma, beta, rm, rv, training, bn1s[0].eps, P)
+            if training:
+                with torch.no_grad():
+                    _update_running(bn1s, 1, bmean, bvar)
+        else:
+            w_lat, w_pts, b = pack["n1_split"]() if callable(pack["n1_split"]) else pack["n1_split"]   # [G,D,L], [G,D,raw]
+            h_lat = torch.matmul(w_lat, x.t()) + b                                      # [G,D,B]
+            h = torch.bmm(w_pts, pts).view(G, D, B, P) + h_lat.unsqueeze(-1)
+            h = _group_batch_norm(h.view(G, D, B * P), bn1s, 1, act, pack["nbn1"])
         w, b = pack["n2"]
         h = _group_batch_norm(torch.baddbmm(b, w, h), [n.bn2 for n in nodes], 1, act, pack["nbn2"])
         w, b = pack["n3"]

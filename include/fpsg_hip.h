@@ -185,6 +185,28 @@ int fpsg_sinkhorn_divergence(const float* x, const float* y, int B, int N, int M
                              const float* eps_host, int n_eps, float* out, float* ws,
                              fpsg_stream_t stream);
 
+/* ---- K9: first layer of the decoder's patch MLPs ------------------------------------------
+ * Replaces, per decode, the 16 x [conv1 (1539 -> 1539, 1x1) + BatchNorm1d + ReLU] of
+ * PrimitiveNode.forward (src/models/point_cloud_net.py:76-80) applied to cat(x.repeat, patch points)
+ * (src/models/point_cloud_net.py:105-110), in the split form  h[g,d,b,q] = hlat[g,d,b] + w[g,d,wofs:wofs+3] . pts[g,:,b,q]
+ * with hlat = W[:, :L] x + bias computed by the caller (one GEMM per patch).  G patches, D channels, B clouds,
+ * P points per patch (4 x a power of two, <= 256; B*P <= 8192).  w [G,D,ldw] is the stacked conv1 weight.
+ *   fwd: out [G,D,B*P] = relu(BN(h)); statistics per (g,d) over the B*P values (training) or the given running
+ *        statistics; chan [4][G*D] = (scale, shift, mean, rstd) for the backward; batch_mean /
+ *        batch_var_unbiased [G*D] optional (training).  The pre-BatchNorm tensor is never stored.
+ *   bwd: from dout [G,D,B*P]: dhlat [G,D,B] (gradient of the latent GEMM's output), the three point columns of
+ *        dw (same layout / ldw / wofs as w; other columns untouched), dpts_part [G, fpsg_dec1_tiles(D), 3, B*P]
+ *        (partial sums over channel tiles; the caller adds them up), dgamma, dbeta [G*D].
+ * pts, out, dout 16-byte aligned.  Deterministic. */
+int fpsg_dec1_tiles(int D);
+int fpsg_dec1_fwd(const float* hlat, const float* w, int ldw, int wofs, const float* pts,
+                  const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                  int G, int D, int B, int P, int training, float eps, float* out, float* chan,
+                  float* batch_mean, float* batch_var_unbiased, fpsg_stream_t stream);
+int fpsg_dec1_bwd(const float* dout, const float* hlat, const float* w, int ldw, int wofs, const float* pts,
+                  const float* chan, int G, int D, int B, int P, int training, float* dhlat, float* dw,
+                  float* dpts_part, float* dgamma, float* dbeta, fpsg_stream_t stream);
+
 /* ---- K5: BatchNorm fused with its activation (training and eval mode) -------------------
  * Replaces the BatchNorm{1,2}d + ReLU / LeakyReLU module pairs of the reference networks
  * (src/models/image_net.py:14 VGG16-BN trunk; src/pointnet/model.py:30-44,220-233;

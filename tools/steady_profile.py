@@ -33,7 +33,7 @@ def main():
         for r in csv.DictReader(open(f)):
             rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
     rows.sort()
-    marks = [i for i, r in enumerate(rows) if "chamfer_fwd_kernel" in r[2]]
+    marks = [i for i, r in enumerate(rows) if "chamfer_tile_kernel" in r[2] or "chamfer_fwd_kernel" in r[2]]
     per_episode = int(sys.argv[3]) if len(sys.argv) > 3 else 1      # K1-forward launches per episode
     want = int(sys.argv[2]) if len(sys.argv) > 2 else 16
     E = min(want, (len(marks) - 1) // per_episode)
