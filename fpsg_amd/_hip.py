@@ -80,6 +80,11 @@ SIGNATURES = {
     "fpsg_wino_filter_transform": [_c_int, _c_f32p, _c_int, _c_int, _c_int, _c_f32p, _c_stream],
     "fpsg_wino_filter_grad_transform": [_c_int, _c_f32p, _c_int, _c_int, _c_f32p, _c_stream],
     "fpsg_wino_conv_fused": [_c_f32p, _c_f32p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_f32p, _c_stream],
+    "fpsg_wino_input_transform_act": [_c_int, _c_f32p, _c_f32p, _c_f32p, _c_int, _c_int, _c_int, _c_int, _c_f32p, _c_stream],
+    "fpsg_wino_conv_fused_act": [_c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_f32p,
+                                 _c_stream],
+    "fpsg_bn_stats": [_c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, ctypes.c_float, _c_int, _c_int, _c_int, _c_int,
+                      ctypes.c_float, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_stream],
     "fpsg_conv_first_dw_workspace_floats": [_c_int, _c_int, _c_int],
     "fpsg_conv_first_dw": [_c_f32p, _c_f32p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_f32p, _c_f32p, _c_stream],
     "fpsg_adam_step": [_c_f32p, _c_f32p, _c_f32p, _c_f32p, ctypes.c_size_t, ctypes.c_float, ctypes.c_float,

@@ -898,6 +898,32 @@ extern "C" int fpsg_bn_act_fwd(const float* x, const float* pre_bias, const floa
   return launch_status("fpsg_bn_act_fwd(apply)");
 }
 
+extern "C" int fpsg_bn_stats(const float* x, const float* pre_bias, const float* gamma, const float* beta,
+                             float* running_mean, float* running_var, float momentum, int N, int C, int L,
+                             int training, float eps, float* chan, float* batch_mean, float* batch_var_unbiased,
+                             float* ws, fpsg_stream_t stream) {
+  using namespace fpsg;
+  int rc = check_dims("fpsg_bn_stats", N, C, L, kActNone);
+  if (rc) return rc;
+  FPSG_REQUIRE_PTR(x); FPSG_REQUIRE_PTR(chan);
+  FPSG_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0, FPSG_E_ALIGN, "fpsg_bn_stats: x must be 16-byte aligned");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (training) {
+    FPSG_REQUIRE_PTR(ws);
+    const int S = slices_for(N, L);
+    launch_reduce<0>(kActNone, x, nullptr, nullptr, pre_bias, N, C, L, S, 0.0f, ws, s);
+    if ((rc = launch_status("fpsg_bn_stats(stats)"))) return rc;
+    hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3(C), dim3(64), 0, s, ws, gamma, beta, C, S,
+                       (double)N * (double)L, eps, chan, batch_mean, batch_var_unbiased, running_mean, running_var,
+                       momentum);
+    return launch_status("fpsg_bn_stats(finalize)");
+  }
+  FPSG_REQUIRE_PTR(running_mean); FPSG_REQUIRE_PTR(running_var);
+  hipLaunchKernelGGL(bn_eval_chan_kernel, dim3((C + 255) / 256), dim3(256), 0, s, running_mean, running_var,
+                     gamma, beta, C, eps, chan);
+  return launch_status("fpsg_bn_stats(eval)");
+}
+
 extern "C" int fpsg_bn_act_bwd(const float* x, const float* pre_bias, const float* dy, const float* chan, int N,
                                int C, int L, int training, int act, float slope, float* dx, float* dgamma,
                                float* dbeta, float* dpre_bias, float* coef, float* ws, fpsg_stream_t stream) {

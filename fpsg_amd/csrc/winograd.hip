@@ -111,9 +111,15 @@ __device__ __forceinline__ TileIndex tile_of(long p, int Th, int Tw) {
 // Each thread loads the M interior columns of its tile's rows as ONE aligned vector (a wave reads a
 // contiguous row segment) and takes the two halo columns from the neighbouring lanes' vectors;
 // only lanes at a wave edge inside an image row fetch their halo from memory.
+// chan != null: the tensor is the PRE-BatchNorm output of the previous convolution and the transform
+// reads a = relu(fma(x + pre_bias[c], scale[c], shift[c])) instead (exactly the value K5's apply pass
+// would have stored; padding stays zero) -- the BatchNorm + ReLU apply pass between two convolutions of a
+// VGG stage (one read + one write of the activation tensor) is folded into this load.
 template <int M>
 __global__ __launch_bounds__(kWinoThreads) void wino_input_kernel(const float* __restrict__ x, int C, int H, int W,
-                                                                   int Th, int Tw, long P, float* __restrict__ V) {
+                                                                   int Th, int Tw, long P, float* __restrict__ V,
+                                                                   const float* __restrict__ chan,
+                                                                   const float* __restrict__ pre_bias) {
   constexpr int A = Wino<M>::A;
   typedef float vin __attribute__((ext_vector_type(M)));
   const long p_raw = (long)blockIdx.x * kWinoThreads + threadIdx.x;
@@ -127,6 +133,9 @@ __global__ __launch_bounds__(kWinoThreads) void wino_input_kernel(const float* _
   const bool has_left = ti.tw > 0, has_right = ti.tw < Tw - 1;
   const bool left_lane = has_left && lane > 0;              // lane-1 holds tile (th, tw-1)
   const bool right_lane = has_right && lane < kWave - 1;    // lane+1 holds tile (th, tw+1)
+  const bool actv = chan != nullptr;
+  const float sc = actv ? chan[c] : 1.0f, sh = actv ? chan[C + c] : 0.0f, pb = (actv && pre_bias) ? pre_bias[c] : 0.0f;
+  auto act = [&](float v) { return actv ? __builtin_fmaxf(fma_rn(v + pb, sc, sh), 0.0f) : v; };
   float d[A][A];
 #pragma unroll
   for (int i = 0; i < A; ++i) {
@@ -134,14 +143,18 @@ __global__ __launch_bounds__(kWinoThreads) void wino_input_kernel(const float* _
     const bool rin = r >= 0 && r < H;
     const float* rp = xp + (size_t)(rin ? r : 0) * W + c0;
     vin mid;
-    if (rin) mid = *reinterpret_cast<const vin*>(rp);
-    else
+    if (rin) {
+      mid = *reinterpret_cast<const vin*>(rp);
+#pragma unroll
+      for (int j = 0; j < M; ++j) mid[j] = act(mid[j]);
+    } else {
 #pragma unroll
       for (int j = 0; j < M; ++j) mid[j] = 0.0f;
+    }
     float lft = __shfl_up(mid[M - 1], 1, kWave);
     float rgt = __shfl_down(mid[0], 1, kWave);
-    if (!left_lane) lft = (has_left && rin) ? rp[-1] : 0.0f;
-    if (!right_lane) rgt = (has_right && rin) ? rp[M] : 0.0f;
+    if (!left_lane) lft = (has_left && rin) ? act(rp[-1]) : 0.0f;
+    if (!right_lane) rgt = (has_right && rin) ? act(rp[M]) : 0.0f;
     d[i][0] = lft;
 #pragma unroll
     for (int j = 0; j < M; ++j) d[i][1 + j] = mid[j];
@@ -327,8 +340,20 @@ extern "C" int fpsg_wino_input_transform(int m, const float* x, int N, int C, in
   if (rc) return rc;
   FPSG_REQUIRE_PTR(x); FPSG_REQUIRE_PTR(V);
   FPSG_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0, FPSG_E_ALIGN, "fpsg_wino_input_transform: x must be 16-byte aligned");
-  FPSG_WINO_IMAGE_LAUNCH(wino_input_kernel, C, x, C, H, W, H / m, W / m, P, V);
+  FPSG_WINO_IMAGE_LAUNCH(wino_input_kernel, C, x, C, H, W, H / m, W / m, P, V, nullptr, nullptr);
   return launch_status("fpsg_wino_input_transform");
+}
+
+extern "C" int fpsg_wino_input_transform_act(int m, const float* x, const float* chan, const float* pre_bias, int N,
+                                             int C, int H, int W, float* V, fpsg_stream_t stream) {
+  using namespace fpsg;
+  int rc = check_image("fpsg_wino_input_transform_act", m, N, C, H, W);
+  if (rc) return rc;
+  FPSG_REQUIRE_PTR(x); FPSG_REQUIRE_PTR(V); FPSG_REQUIRE_PTR(chan);
+  FPSG_REQUIRE(!misaligned4(pre_bias), FPSG_E_ALIGN, "fpsg_wino_input_transform_act: pre_bias not 4-byte aligned");
+  FPSG_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0, FPSG_E_ALIGN, "fpsg_wino_input_transform_act: x must be 16-byte aligned");
+  FPSG_WINO_IMAGE_LAUNCH(wino_input_kernel, C, x, C, H, W, H / m, W / m, P, V, chan, pre_bias);
+  return launch_status("fpsg_wino_input_transform_act");
 }
 
 extern "C" int fpsg_wino_output_transform(int m, const float* M, int N, int K, int H, int W, float* y,

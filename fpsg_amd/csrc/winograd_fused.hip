@@ -53,12 +53,18 @@ __device__ __forceinline__ void out4(const float (&m)[6], float (&s)[4]) {
   s[3] = fma_rn(8.0f, m34, m12) + m[5];
 }
 
+// ACT: x is the PRE-BatchNorm output of the previous convolution; the patch values are
+// relu(fma(x + pre_bias[c], scale[c], shift[c])) (K5's apply arithmetic), padding stays zero.
+template <bool ACT>
 __global__ __launch_bounds__(kFusedThreads) void wino4_fused_c64_kernel(const float* __restrict__ x,
                                                                         const float* __restrict__ U /*[36][K][64]*/,
                                                                         int K, int H, int W, int Th, int Tw, long P,
-                                                                        int S, float* __restrict__ y) {
-  extern __shared__ __attribute__((aligned(16))) float ulds[];      // [36][kSteps][64] A fragments
+                                                                        int S, float* __restrict__ y,
+                                                                        const float* __restrict__ chan,
+                                                                        const float* __restrict__ pre_bias) {
+  extern __shared__ __attribute__((aligned(16))) float ulds[];      // [36][kSteps][64] A fragments | [3][64] scale, shift, pre-bias
   constexpr int C = 64;
+  float* actp = ulds + kUldsFloats;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int kk = lane >> 4, col = lane & 15;
   const int i = blockIdx.x;
@@ -73,6 +79,11 @@ __global__ __launch_bounds__(kFusedThreads) void wino4_fused_c64_kernel(const fl
     const int kl = rem >> 6, c = rem & 63;
     const int c4 = c >> 2, kq = c & 3;
     ulds[((size_t)c4 * 64 + kq * 16 + kl) * 36 + xi] = U[((size_t)xi * K + k0 + kl) * C + c];
+  }
+  if (ACT && tid < C) {
+    actp[tid] = chan[tid];
+    actp[C + tid] = chan[C + tid];
+    actp[2 * C + tid] = pre_bias ? pre_bias[tid] : 0.0f;
   }
   __syncthreads();
   const long G = (P + 15) >> 4;
@@ -129,18 +140,27 @@ __global__ __launch_bounds__(kFusedThreads) void wino4_fused_c64_kernel(const fl
 #pragma unroll
         for (int q4 = 0; q4 < 9; ++q4) a[q4] = up[q4];
       }
+      float asc = 1.0f, ash = 0.0f, apb = 0.0f;
+      if (ACT) { asc = actp[4 * c4 + kk]; ash = actp[C + 4 * c4 + kk]; apb = actp[2 * C + 4 * c4 + kk]; }
       // d[r][c] as column pairs for the packed transforms: dp[r][j] = (d[r][2j], d[r][2j+1])
       v2f dp[6][3];
 #pragma unroll
       for (int r = 0; r < 6; ++r) {
         const bool rin = r == 0 ? top_in : (r == 5 ? bot_in : true);
-        const float sl = from_left(w.mid[r][3]);
-        const float sr = from_right(w.mid[r][0]);
-        const float lft = left_lane ? sl : (edge_l ? w.e[r] : 0.0f);
-        const float rgt = right_lane ? sr : (edge_r ? w.e[r] : 0.0f);
-        dp[r][0] = (v2f){rin ? lft : 0.0f, rin ? w.mid[r][0] : 0.0f};
-        dp[r][1] = (v2f){rin ? w.mid[r][1] : 0.0f, rin ? w.mid[r][2] : 0.0f};
-        dp[r][2] = (v2f){rin ? w.mid[r][3] : 0.0f, rin ? rgt : 0.0f};
+        v4f mid = w.mid[r];
+        float e = w.e[r];
+        if (ACT) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) mid[u] = __builtin_fmaxf(fma_rn(mid[u] + apb, asc, ash), 0.0f);
+          e = __builtin_fmaxf(fma_rn(e + apb, asc, ash), 0.0f);
+        }
+        const float sl = from_left(mid[3]);
+        const float sr = from_right(mid[0]);
+        const float lft = left_lane ? sl : (edge_l ? e : 0.0f);
+        const float rgt = right_lane ? sr : (edge_r ? e : 0.0f);
+        dp[r][0] = (v2f){rin ? lft : 0.0f, rin ? mid[0] : 0.0f};
+        dp[r][1] = (v2f){rin ? mid[1] : 0.0f, rin ? mid[2] : 0.0f};
+        dp[r][2] = (v2f){rin ? mid[3] : 0.0f, rin ? rgt : 0.0f};
       }
       // transform along rows (down the columns), two columns per instruction: tp[i][j] = (t[i][2j], t[i][2j+1])
       v2f tp[6][3];
@@ -221,23 +241,24 @@ __global__ __launch_bounds__(kFusedThreads) void wino4_fused_c64_kernel(const fl
 }  // namespace
 }  // namespace fpsg
 
-extern "C" int fpsg_wino_conv_fused(const float* x, const float* U, int N, int C, int K, int H, int W, float* y,
-                                    fpsg_stream_t stream) {
+static int wino_conv_fused_launch(const char* fn, const float* x, const float* chan, const float* pre_bias,
+                                  const float* U, int N, int C, int K, int H, int W, float* y, fpsg_stream_t stream) {
   using namespace fpsg;
-  FPSG_REQUIRE(C == 64, FPSG_E_SHAPE, "fpsg_wino_conv_fused: C must be 64 (got %d)", C);
+  FPSG_REQUIRE(C == 64, FPSG_E_SHAPE, "%s: C must be 64 (got %d)", fn, C);
   FPSG_REQUIRE(N > 0 && K > 0 && K % 16 == 0 && K <= 1024 && H > 0 && W > 0 && H % 4 == 0 && W % 4 == 0, FPSG_E_SHAPE,
-               "fpsg_wino_conv_fused: K a positive multiple of 16 (<= 1024), H and W positive multiples of 4 "
-               "(got K=%d H=%d W=%d)", K, H, W);
+               "%s: K a positive multiple of 16 (<= 1024), H and W positive multiples of 4 "
+               "(got K=%d H=%d W=%d)", fn, K, H, W);
   FPSG_REQUIRE_PTR(x); FPSG_REQUIRE_PTR(U); FPSG_REQUIRE_PTR(y);
   FPSG_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0, FPSG_E_ALIGN,
-               "fpsg_wino_conv_fused: x and y must be 16-byte aligned");
+               "%s: x and y must be 16-byte aligned", fn);
   const long P = (long)N * (H / 4) * (W / 4);
   const int S = K / 16;
-  static const hipError_t lds_optin =
-      hipFuncSetAttribute(reinterpret_cast<const void*>(wino4_fused_c64_kernel),
-                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  const size_t lds_bytes = (size_t)(kUldsFloats + 3 * 64) * sizeof(float);
+  const void* kern = chan ? reinterpret_cast<const void*>(wino4_fused_c64_kernel<true>)
+                          : reinterpret_cast<const void*>(wino4_fused_c64_kernel<false>);
+  const hipError_t lds_optin = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (lds_optin != hipSuccess) {
-    set_error("fpsg_wino_conv_fused: cannot reserve %d B of LDS: %s", kUldsFloats * 4, hipGetErrorString(lds_optin));
+    set_error("%s: cannot reserve %zu B of LDS: %s", fn, lds_bytes, hipGetErrorString(lds_optin));
     return static_cast<int>(lds_optin);
   }
   // one workgroup per CU (LDS), a multiple of 8*S workgroups; never more than the tile groups need
@@ -247,7 +268,24 @@ extern "C" int fpsg_wino_conv_fused(const float* x, const float* U, int N, int C
   if (per_slice > need) per_slice = need;
   per_slice = ((per_slice + 7) / 8) * 8;
   dim3 grid((unsigned)(per_slice * S));
-  hipLaunchKernelGGL(wino4_fused_c64_kernel, grid, dim3(kFusedThreads), kUldsFloats * sizeof(float),
-                     static_cast<hipStream_t>(stream), x, U, K, H, W, H / 4, W / 4, P, S, y);
-  return launch_status("fpsg_wino_conv_fused");
+  if (chan)
+    hipLaunchKernelGGL(wino4_fused_c64_kernel<true>, grid, dim3(kFusedThreads), lds_bytes,
+                       static_cast<hipStream_t>(stream), x, U, K, H, W, H / 4, W / 4, P, S, y, chan, pre_bias);
+  else
+    hipLaunchKernelGGL(wino4_fused_c64_kernel<false>, grid, dim3(kFusedThreads), lds_bytes,
+                       static_cast<hipStream_t>(stream), x, U, K, H, W, H / 4, W / 4, P, S, y, nullptr, nullptr);
+  return launch_status(fn);
+}
+
+extern "C" int fpsg_wino_conv_fused(const float* x, const float* U, int N, int C, int K, int H, int W, float* y,
+                                    fpsg_stream_t stream) {
+  return wino_conv_fused_launch("fpsg_wino_conv_fused", x, nullptr, nullptr, U, N, C, K, H, W, y, stream);
+}
+
+extern "C" int fpsg_wino_conv_fused_act(const float* x, const float* chan, const float* pre_bias, const float* U,
+                                        int N, int C, int K, int H, int W, float* y, fpsg_stream_t stream) {
+  using namespace fpsg;
+  FPSG_REQUIRE_PTR(chan);
+  FPSG_REQUIRE(!misaligned4(pre_bias), FPSG_E_ALIGN, "fpsg_wino_conv_fused_act: pre_bias not 4-byte aligned");
+  return wino_conv_fused_launch("fpsg_wino_conv_fused_act", x, chan, pre_bias, U, N, C, K, H, W, y, stream);
 }

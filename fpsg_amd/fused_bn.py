@@ -268,6 +268,41 @@ def _conv_without_bias(conv, x):
     return conv._conv_forward(x, conv.weight, None)
 
 
+def fusable_conv(conv, bn, x) -> bool:
+    """The Conv + BatchNorm pair runs bias-free + K5 pre-bias on this input."""
+    return (conv.bias is not None and x.is_cuda and x.dtype == torch.float32 and fused_enabled()
+            and bn.track_running_stats and conv.padding_mode == "zeros")
+
+
+def foldable_into(y: torch.Tensor, bn, next_conv) -> bool:
+    """BatchNorm(+ReLU) of the bias-free convolution output ``y`` can be applied by ``next_conv``'s Winograd input
+    transform instead of a K5 apply pass: large planes (the one-launch small-tensor K5 has no statistics-only
+    form), a Winograd-eligible consumer."""
+    return (winograd.fold_enabled() and isinstance(next_conv, nn.Conv2d) and _eligible(y) and y.dim() == 4
+            and y.shape[0] * y.shape[2] * y.shape[3] > 16384 and bn.track_running_stats
+            and next_conv.bias is not None and winograd.eligible(y, next_conv))
+
+
+def bn_act_of(y: torch.Tensor, conv, bn, act=None) -> torch.Tensor:
+    """``act(bn(y + conv.bias))`` for the bias-free output ``y`` of ``conv``."""
+    if not _eligible(y):
+        return bn_act(bn, y + conv.bias.view(1, -1, *([1] * (y.dim() - 2))), act)
+    return bn_act(bn, y, act, pre_bias=conv.bias)
+
+
+def bn_act_pool_of(y: torch.Tensor, conv, bn, pool, act=None) -> torch.Tensor:
+    """``pool(act(bn(y + conv.bias)))`` for the bias-free output ``y`` of ``conv`` (K5 pooled variant)."""
+    if not _pool_eligible(y, pool):
+        return pool(bn_act_of(y, conv, bn, act))
+    training = bn.training
+    if training and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked += 1
+    act_code, slope = _parse_act(act)
+    m = (0.1 if bn.momentum is None else float(bn.momentum)) if training else -1.0
+    return _BNActPool.apply(y.contiguous(), bn.weight, bn.bias, bn.running_mean, bn.running_var, bool(training),
+                            bn.eps, act_code, slope, conv.bias, m)
+
+
 def conv_bn_act(conv: nn.modules.conv._ConvNd, bn: nn.modules.batchnorm._BatchNorm, x: torch.Tensor,
                 act=None) -> torch.Tensor:
     """``act(bn(conv(x)))`` for ``nn.Conv1d/2d`` + BatchNorm (+ ReLU / LeakyReLU) triples."""

@@ -16,7 +16,9 @@ import os
 import torch
 import torch.nn as nn
 
-from .fused_bn import bn_act, conv_bn_act, conv_bn_act_pool
+from . import winograd
+from .fused_bn import (_conv_without_bias, bn_act, bn_act_of, bn_act_pool_of, conv_bn_act, conv_bn_act_pool,
+                       foldable_into, fusable_conv)
 
 # VGG-16 ("configuration D"): channel widths, 'P' = 2x2 max-pool
 _VGG16_PLAN = (64, 64, "P", 128, 128, "P", 256, 256, 256, "P", 512, 512, 512, "P", 512, 512,
@@ -74,12 +76,36 @@ class ImageEncoderWarpper(nn.Module):
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         layers = list(self.img_feature_extractor)
         i = 0
+        pending = None      # (y, conv, bn): bias-free output of `conv` whose BatchNorm + ReLU the next conv applies
         while i < len(layers):
             layer = layers[i]
-            if (isinstance(layer, nn.Conv2d) and i + 2 < len(layers) and isinstance(layers[i + 1], nn.BatchNorm2d)
-                    and isinstance(layers[i + 2], nn.ReLU)):
+            triple = (isinstance(layer, nn.Conv2d) and i + 2 < len(layers) and isinstance(layers[i + 1], nn.BatchNorm2d)
+                      and isinstance(layers[i + 2], nn.ReLU))
+            if triple and (pending is not None or fusable_conv(layer, layers[i + 1], x)):
+                bn = layers[i + 1]
                 # conv (bias-free) -> K5: bias + BatchNorm + ReLU in one pass, bias gradient from its dx
-                # pass; a stage's closing 2x2 max-pool joins the same pass
+                # pass; a stage's closing 2x2 max-pool joins the same pass; between two Winograd
+                # convolutions of a stage the BatchNorm + ReLU apply is folded into the second one's load
+                if pending is not None:
+                    py, pconv, pbn = pending
+                    y = winograd.bn_relu_conv3x3(py, pconv.bias, pbn, layer.weight)
+                    pending = None
+                else:
+                    y = _conv_without_bias(layer, x)
+                nxt = layers[i + 3] if i + 3 < len(layers) else None
+                next_is_triple = (isinstance(nxt, nn.Conv2d) and i + 5 < len(layers)
+                                  and isinstance(layers[i + 4], nn.BatchNorm2d) and isinstance(layers[i + 5], nn.ReLU))
+                if isinstance(nxt, nn.MaxPool2d):
+                    x = bn_act_pool_of(y, layer, bn, nxt, "relu")
+                    i += 4
+                elif next_is_triple and fusable_conv(nxt, layers[i + 4], y) and foldable_into(y, bn, nxt):
+                    pending = (y, layer, bn)
+                    x = y                     # placeholder: the next iteration consumes `pending`
+                    i += 3
+                else:
+                    x = bn_act_of(y, layer, bn, "relu")
+                    i += 3
+            elif triple:
                 if i + 3 < len(layers) and isinstance(layers[i + 3], nn.MaxPool2d):
                     x = conv_bn_act_pool(layer, layers[i + 1], layers[i + 3], x, "relu")
                     i += 4

@@ -184,6 +184,106 @@ class _Conv3x3(torch.autograd.Function):
         return gx, gw, None
 
 
+def _input_act(m, x, chan, pre_bias):
+    N, C, H, W = x.shape
+    V = torch.empty(((m + 2) ** 2, C, N * (H // m) * (W // m)), dtype=torch.float32, device=x.device)
+    _call("fpsg_wino_input_transform_act", m, _hip.ptr(x), _hip.ptr(chan), _hip.ptr(pre_bias) if pre_bias is not None else None,
+          N, C, H, W, _hip.ptr(V), _hip.stream_of(x))
+    return V
+
+
+def _fused_act(x, chan, pre_bias, U):
+    N, C, H, W = x.shape
+    K = U.shape[1]
+    y = torch.empty((N, K, H, W), dtype=torch.float32, device=x.device)
+    _call("fpsg_wino_conv_fused_act", _hip.ptr(x), _hip.ptr(chan), _hip.ptr(pre_bias) if pre_bias is not None else None,
+          _hip.ptr(U), N, C, K, H, W, _hip.ptr(y), _hip.stream_of(x))
+    return y
+
+
+def fold_enabled() -> bool:
+    """``FPSG_BN_FOLD=0``: BatchNorm + ReLU between two Winograd convolutions as its own K5 pass (A/B)."""
+    return os.environ.get("FPSG_BN_FOLD", "1") != "0"
+
+
+class _BNReluConv3x3(torch.autograd.Function):
+    """``conv3x3(relu(BN(y + pre_bias)), w)`` for the PRE-BatchNorm output ``y`` of the previous convolution,
+    without the activation tensor: K5's statistics pass (``fpsg_bn_stats``), then the Winograd input
+    transform (or K6f) applies scale / shift / ReLU while loading.  The backward is the convolution's
+    (data + weight gradient, ``V`` kept or rebuilt through the same activating transform) followed by K5's
+    BatchNorm + ReLU backward on ``y``.  Forward and backward values are those of ``bn_act`` + ``conv3x3``
+    bit for bit (same kernels' arithmetic, one pass less over the tensor)."""
+
+    @staticmethod
+    def forward(ctx, y, pre_bias, gamma, beta, running_mean, running_var, training, momentum, eps, w, m):
+        y, w = y.contiguous(), w.contiguous()
+        N, C, H, W = y.shape
+        K = w.shape[0]
+        lib = _hip.load()
+        dev = y.device
+        chan = torch.empty((4, C), dtype=torch.float32, device=dev)
+        ws = torch.empty((lib.fpsg_bn_workspace_floats(N, C, H * W),), dtype=torch.float32, device=dev)
+        opt = lambda t: _hip.ptr(t) if t is not None else None
+        with torch.cuda.device(dev):
+            _call("fpsg_bn_stats", _hip.ptr(y), opt(pre_bias), opt(gamma), opt(beta), opt(running_mean), opt(running_var),
+                  float(momentum), N, C, H * W, 1 if training else 0, float(eps), _hip.ptr(chan), None, None,
+                  _hip.ptr(ws), _hip.stream_of(y))
+            if _can_fuse(m, C, K):
+                out = _fused_act(y, chan, pre_bias, _filter(m, w, False))
+                V = None                                     # rebuilt for the weight gradient
+            else:
+                V = _input_act(m, y, chan, pre_bias)
+                out = _output(m, torch.bmm(_filter(m, w, False), V), N, H, W)
+        ctx.save_for_backward(y, chan, pre_bias, w, V if ctx.needs_input_grad[9] else None)
+        ctx.cfg = (N, C, H, W, m, bool(training), gamma is not None, beta is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        y, chan, pre_bias, w, V = ctx.saved_tensors
+        N, C, H, W, m, training, has_g, has_b = ctx.cfg
+        K = w.shape[0]
+        lib = _hip.load()
+        dev = y.device
+        gout = gout.contiguous()
+        gw = None
+        with torch.cuda.device(dev):
+            # convolution backward: gradient of the (never stored) activation, and of the filter
+            if _can_fuse(m, K, C):
+                ga = _fused(gout, _filter(m, w, True))
+            else:
+                ga = _output(m, torch.bmm(_filter(m, w, True), _input(m, gout)), N, H, W)
+            if ctx.needs_input_grad[9]:
+                if V is None:
+                    V = _input_act(m, y, chan, pre_bias)
+                gw = _filter_grad(m, torch.bmm(_grad_output(m, gout), V.transpose(1, 2)), w)
+            # BatchNorm + ReLU backward on y (K5)
+            want_dpb = pre_bias is not None and ctx.needs_input_grad[1]
+            dy = torch.empty_like(y)
+            dgamma = torch.empty((C,), dtype=torch.float32, device=dev)
+            dbeta = torch.empty((C,), dtype=torch.float32, device=dev)
+            dpb = torch.empty((C,), dtype=torch.float32, device=dev) if want_dpb else None
+            coef = torch.empty((3, C), dtype=torch.float32, device=dev)
+            ws = torch.empty((lib.fpsg_bn_workspace_floats(N, C, H * W),), dtype=torch.float32, device=dev)
+            _call("fpsg_bn_act_bwd", _hip.ptr(y), _hip.ptr(pre_bias) if pre_bias is not None else None, _hip.ptr(ga),
+                  _hip.ptr(chan), N, C, H * W, 1 if training else 0, 1, 0.0, _hip.ptr(dy), _hip.ptr(dgamma),
+                  _hip.ptr(dbeta), _hip.ptr(dpb) if want_dpb else None, _hip.ptr(coef), _hip.ptr(ws), _hip.stream_of(y))
+        return (dy, dpb, dgamma if has_g else None, dbeta if has_b else None, None, None, None, None, None, gw, None)
+
+
+def bn_relu_conv3x3(y, pre_bias, bn, weight, m=None):
+    """``conv3x3(relu(bn(y + pre_bias)), weight)`` with ``bn`` an ``nn.BatchNorm2d`` in its current mode; updates
+    its running statistics / ``num_batches_tracked`` as the module would."""
+    if m is None:
+        m = tile_size(y.shape[2], y.shape[3])
+    training = bn.training
+    if training and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked += 1
+    mom = (0.1 if bn.momentum is None else float(bn.momentum)) if training else -1.0
+    return _BNReluConv3x3.apply(y, pre_bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, bool(training), mom,
+                                bn.eps, weight, m)
+
+
 def conv3x3(x: torch.Tensor, weight: torch.Tensor, m: int | None = None) -> torch.Tensor:
     """``F.conv2d(x, weight, None, 1, 1)`` for ``x [N,C,H,W]`` (H, W even), ``weight [K,C,3,3]``;
     ``m``: output tile size 2 or 4 (default: ``tile_size(H, W)``)."""

@@ -231,6 +231,12 @@ int fpsg_bn_act_fwd(const float* x, const float* pre_bias, const float* gamma, c
                     float* running_mean, float* running_var, float momentum, int N, int C, int L, int training,
                     float eps, int act, float slope, float* y, float* chan, float* batch_mean,
                     float* batch_var_unbiased, float* ws, fpsg_stream_t stream);
+/* Statistics half of fpsg_bn_act_fwd alone: chan [4][C] (scale, shift, mean, rstd) from the batch (training; running
+ * statistics updated as there) or from the running statistics (eval); nothing is applied or written besides. */
+int fpsg_bn_stats(const float* x, const float* pre_bias, const float* gamma, const float* beta,
+                  float* running_mean, float* running_var, float momentum, int N, int C, int L, int training,
+                  float eps, float* chan, float* batch_mean, float* batch_var_unbiased, float* ws,
+                  fpsg_stream_t stream);
 int fpsg_bn_act_bwd(const float* x, const float* pre_bias, const float* dy, const float* chan, int N, int C,
                     int L, int training, int act, float slope, float* dx, float* dgamma, float* dbeta,
                     float* dpre_bias, float* coef, float* ws, fpsg_stream_t stream);
@@ -302,6 +308,16 @@ int fpsg_wino_filter_grad_transform(int m, const float* dU, int K, int C, float*
  */
 int fpsg_wino_conv_fused(const float* x, const float* U, int N, int C, int K, int H, int W, float* y,
                          fpsg_stream_t stream);
+
+/* The same two entry points reading a PRE-BatchNorm tensor: the values fed to the transform are
+ * relu(fma(x + pre_bias[c], chan[c], chan[C + c])) -- K5's apply arithmetic with chan = (scale, shift, ..) from
+ * fpsg_bn_stats / fpsg_bn_act_fwd -- so that the BatchNorm + ReLU apply pass between two convolutions of a VGG
+ * stage (conv -> BN -> ReLU -> conv, src/models/image_net.py:14) is folded into the second convolution's
+ * load (one read + one write of the activation tensor less per layer).  pre_bias may be NULL. */
+int fpsg_wino_input_transform_act(int m, const float* x, const float* chan, const float* pre_bias, int N, int C,
+                                  int H, int W, float* V, fpsg_stream_t stream);
+int fpsg_wino_conv_fused_act(const float* x, const float* chan, const float* pre_bias, const float* U, int N, int C,
+                             int K, int H, int W, float* y, fpsg_stream_t stream);
 
 /* ---- K8: weight gradient of the first VGG convolution (3 -> 64 channels, 3x3, padding 1) ------
  * vgg16_bn.features[0] of src/models/image_net.py:14 in the backward of the train step:

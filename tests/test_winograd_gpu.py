@@ -185,3 +185,74 @@ def test_full_size_layers_against_the_library_and_linearity(gpu, layer):
         lhs = wg.conv3x3(1.5 * x1 + x2, w)
         rhs = 1.5 * wg.conv3x3(x1, w) + wg.conv3x3(x2, w)
     assert float((lhs - rhs).abs().max()) <= 6e-5 * float(rhs.abs().max())
+
+
+@pytest.mark.parametrize("C,K,H,N", [(64, 64, 112, 6), (64, 128, 56, 6), (128, 128, 56, 6), (256, 256, 28, 24)])
+@pytest.mark.parametrize("mode", ["train", "eval"])
+def test_bn_relu_folded_into_next_conv_equals_two_ops(gpu, C, K, H, N, mode):
+    """``bn_relu_conv3x3(y, pre_bias, bn, w)`` -- BatchNorm + ReLU applied by the convolution's own input
+    transform (fpsg_wino_input_transform_act; fpsg_wino_conv_fused_act for 64 input channels) -- against the
+    two ops it replaces, ``conv3x3(bn_act(bn, y, relu, pre_bias), w)``: the activation values are formed with
+    the same arithmetic, so output, running statistics and all gradients agree bit for bit."""
+    import copy
+    from fpsg_amd.fused_bn import bn_act
+    from fpsg_amd.winograd import bn_relu_conv3x3, conv3x3
+    torch.manual_seed(C + K + H)
+    bn = torch.nn.BatchNorm2d(C).to(gpu).train(mode == "train")
+    with torch.no_grad():
+        bn.weight.copy_(torch.randn(C) * 0.3 + 1)
+        bn.bias.copy_(torch.randn(C) * 0.1)
+        bn.running_mean.copy_(torch.randn(C) * 0.1)
+        bn.running_var.copy_(torch.rand(C) + 0.5)
+    bn2 = copy.deepcopy(bn)
+    y = torch.randn(N, C, H, H, device=gpu)
+    pb = (torch.randn(C, device=gpu) * 0.05)
+    w = torch.randn(K, C, 3, 3, device=gpu) * 0.05
+    g = torch.randn(N, K, H, H, device=gpu)
+    res = []
+    for fold, mod in ((True, bn), (False, bn2)):
+        yi, pbi, wi = y.clone().requires_grad_(), pb.clone().requires_grad_(), w.clone().requires_grad_()
+        out = bn_relu_conv3x3(yi, pbi, mod, wi) if fold else conv3x3(bn_act(mod, yi, "relu", pre_bias=pbi), wi)
+        out.backward(g)
+        res.append((out.detach(), yi.grad, pbi.grad, wi.grad, mod.weight.grad, mod.bias.grad, mod.running_mean.clone(),
+                    mod.running_var.clone(), int(mod.num_batches_tracked)))
+    for a, b in zip(res[0][:-1], res[1][:-1]):
+        assert torch.equal(a, b)
+    assert res[0][-1] == res[1][-1]
+
+
+def test_trunk_with_and_without_the_fold(gpu, monkeypatch):
+    """The whole VGG16-BN trunk with the fold on and off (112x112: conv1_2 and conv2_2 take it): the library
+    kernels in between are not bit-reproducible run to run, so the yardstick is a second run without it."""
+    import copy
+    from fpsg_amd import winograd
+    from fpsg_amd.image_net import ImageEncoderWarpper
+    torch.manual_seed(4)
+    base = ImageEncoderWarpper("vgg_16").to(gpu).train()
+    x = torch.rand(6, 3, 112, 112, device=gpu) * 2 - 1
+    w = torch.randn(6, 512, device=gpu)
+    calls = {"n": 0}
+    orig = winograd._BNReluConv3x3.forward
+
+    def counted(*a, **k):
+        calls["n"] += 1
+        return orig(*a, **k)
+
+    monkeypatch.setattr(winograd._BNReluConv3x3, "forward", staticmethod(counted))
+
+    def run(fold):
+        monkeypatch.setenv("FPSG_BN_FOLD", fold)
+        calls["n"] = 0
+        net = copy.deepcopy(base)
+        out = net(x)
+        (out * w).sum().backward()
+        assert calls["n"] == (2 if fold == "1" else 0), (fold, calls)
+        return out.detach(), torch.cat([p.grad.reshape(-1) for p in net.parameters()])
+
+    o1, g1 = run("1")
+    o0, g0 = run("0")
+    o0b, g0b = run("0")
+    noise_o = float((o0 - o0b).abs().max()) + 1e-6 * float(o0.abs().max())
+    noise_g = float((g0 - g0b).norm()) + 1e-5 * float(g0.norm())
+    assert float((o1 - o0).abs().max()) <= 3 * noise_o
+    assert float((g1 - g0).norm()) <= 3 * noise_g
