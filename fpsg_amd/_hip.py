@@ -39,6 +39,7 @@ SIGNATURES = {
                                 _c_int, _c_int, _c_int, _c_f32p, _c_f32p, _c_stream],
     "fpsg_chamfer_bwd_scan": [_c_f32p, _c_f32p, _c_i32p, _c_i32p, _c_f32p, _c_f32p,
                               _c_int, _c_int, _c_int, _c_f32p, _c_f32p, _c_stream],
+    "fpsg_knn_workspace_floats": [_c_int, _c_int, _c_int],
     "fpsg_knn": [_c_f32p, _c_int, _c_int, _c_int, _c_int, _c_i32p, _c_f32p, _c_stream],
     "fpsg_edge_feature_fwd": [_c_f32p, _c_i32p, _c_int, _c_int, _c_int, _c_int, _c_f32p, _c_stream],
     "fpsg_edge_feature_bwd": [_c_f32p, _c_i32p, _c_int, _c_int, _c_int, _c_int, _c_f32p, _c_stream],
@@ -98,6 +99,7 @@ SIGNATURES = {
 }
 _RESTYPES = {"fpsg_last_error": ctypes.c_char_p, "fpsg_chamfer_workspace_bytes": ctypes.c_size_t,
              "fpsg_sinkhorn_workspace_floats": ctypes.c_size_t,
+             "fpsg_knn_workspace_floats": ctypes.c_size_t,
              "fpsg_bn_workspace_floats": ctypes.c_size_t, "fpsg_bn_pool_workspace_floats": ctypes.c_size_t, "fpsg_bn_max_workspace_floats": ctypes.c_size_t, "fpsg_conv_first_dw_workspace_floats": ctypes.c_size_t, "fpsg_emd_workspace_floats": ctypes.c_size_t}
 
 _lib = None

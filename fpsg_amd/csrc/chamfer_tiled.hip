@@ -333,10 +333,23 @@ __global__ __launch_bounds__(kFinThreads) void chamfer_finalize_kernel(
     const int j0 = (int)(unsigned)(key & 0xffffffffull) * kChunk;
     const float x = P1[3 * i + 0], y = P1[3 * i + 1], z = P1[3 * i + 2];
     float cx[kChunk], cy[kChunk], cz[kChunk];
+    if (((reinterpret_cast<uintptr_t>(P2) & 15) == 0) && j0 + kChunk <= M) {
+      // a chunk is 192 contiguous, 16-byte aligned bytes: twelve 16-byte loads instead of 48 scalar ones
+      float f[3 * kChunk];
+      const v4f* c4 = reinterpret_cast<const v4f*>(P2 + 3 * j0);
 #pragma unroll
-    for (int u = 0; u < kChunk; ++u) {                 // all loads first; candidates past M read the last one
-      const int j = (j0 + u) < M ? (j0 + u) : (M - 1);
-      cx[u] = P2[3 * j + 0]; cy[u] = P2[3 * j + 1]; cz[u] = P2[3 * j + 2];
+      for (int u = 0; u < (3 * kChunk) / 4; ++u) {
+        const v4f v = c4[u];
+        f[4 * u] = v.x; f[4 * u + 1] = v.y; f[4 * u + 2] = v.z; f[4 * u + 3] = v.w;
+      }
+#pragma unroll
+      for (int u = 0; u < kChunk; ++u) { cx[u] = f[3 * u]; cy[u] = f[3 * u + 1]; cz[u] = f[3 * u + 2]; }
+    } else {
+#pragma unroll
+      for (int u = 0; u < kChunk; ++u) {               // all loads first; candidates past M read the last one
+        const int j = (j0 + u) < M ? (j0 + u) : (M - 1);
+        cx[u] = P2[3 * j + 0]; cy[u] = P2[3 * j + 1]; cz[u] = P2[3 * j + 2];
+      }
     }
     float bd = __builtin_inff();
     int bi = 0;

@@ -43,6 +43,43 @@ __global__ __launch_bounds__(256) void sqnorm_kernel(const float* __restrict__ x
   xx[(size_t)b * N + j] = acc;
 }
 
+// Squared norms AND a point-major, k-interleaved copy of the features for the MFMA B operands:
+//   xk[b][n][kk * (C/4) + c4] = x[b][4*c4 + kk][n]      (C a multiple of 16)
+// so that lane group kk of the 16x16x4 MFMA fetches its operands of FOUR consecutive channel steps
+// (channels 4*c4 + kk, c4 = 4m .. 4m+3) with one 16-byte load.  The channel-major rows give a lane 4 bytes
+// per load (16 loads per 16-candidate tile at C = 64): phase A was load-issue bound at 3x its MFMA time.
+// One workgroup = 64 points: coalesced reads of the [C][64] slab, transposed through LDS, 16-byte stores.
+constexpr int kPrepPts = 64;
+__global__ __launch_bounds__(256) void knn_prep_kernel(const float* __restrict__ x, int C, int N,
+                                                       float* __restrict__ xx, float* __restrict__ xk) {
+  extern __shared__ __attribute__((aligned(16))) float tile[];      // [64][C + 4]
+  const int b = blockIdx.y;
+  const int n0 = blockIdx.x * kPrepPts;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int ld = C + 4;
+  const int C4 = C >> 2;
+  const float* xb = x + (size_t)b * C * N;
+  const int n = n0 + lane;
+  for (int c = wave; c < C; c += 4) {
+    const float v = n < N ? xb[(size_t)c * N + n] : 0.0f;
+    tile[lane * ld + (c & 3) * C4 + (c >> 2)] = v;
+  }
+  __syncthreads();
+  if (wave == 0 && n < N) {                 // squared norm in channel order (the oracle's fma chain)
+    float acc = 0.0f;
+    for (int c = 0; c < C; ++c) {
+      const float v = tile[lane * ld + (c & 3) * C4 + (c >> 2)];
+      acc = fma_rn(v, v, acc);
+    }
+    xx[(size_t)b * N + n] = acc;
+  }
+  float* dst = xk + ((size_t)b * N + n0) * C;
+  for (int e = threadIdx.x; e < kPrepPts * C4; e += 256) {
+    const int p = e / C4, q = e - p * C4;
+    if (n0 + p < N) *reinterpret_cast<v4f*>(dst + (size_t)p * C + 4 * q) = *reinterpret_cast<const v4f*>(tile + p * ld + 4 * q);
+  }
+}
+
 __device__ __forceinline__ unsigned orderable(float f) {
   const unsigned u = __float_as_uint(f);
   return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
@@ -89,6 +126,21 @@ __device__ __forceinline__ void load_b(const float* __restrict__ xb, int C, int 
   }
 }
 
+// the same operands from the k-interleaved point-major copy: C4T/4 16-byte loads
+template <int C4T>
+__device__ __forceinline__ void load_b_pm(const float* __restrict__ xkb, int C, int N, int tile, int kk,
+                                          int col, float (&b)[C4T]) {
+  const int j = tile * 16 + col;
+  const bool jin = j < N;   // also false for tiles past the end: no loads are issued
+  const v4f* src = reinterpret_cast<const v4f*>(xkb + (size_t)(jin ? j : 0) * C + kk * (C >> 2));
+#pragma unroll
+  for (int m = 0; m < C4T / 4; ++m) {
+    v4f v = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (jin && 16 * m < C) v = src[m];
+    b[4 * m] = v.x; b[4 * m + 1] = v.y; b[4 * m + 2] = v.z; b[4 * m + 3] = v.w;
+  }
+}
+
 template <int C4T>
 __device__ __forceinline__ void score_tile(const float (&a)[C4T], const float (&b)[C4T], int tile,
                                            int N, int kk, int col, const float* __restrict__ xxb,
@@ -111,9 +163,10 @@ __device__ __forceinline__ void score_tile(const float (&a)[C4T], const float (&
 // LDS: pd[kQ][ldp] floats (+ qa[C4*4][16] floats for the generic-C path).
 // C4T > 0: compile-time channel steps (C <= 4*C4T), register-resident operands.
 // C4T == 0: any C, operands re-read per step (slow path for unusual channel counts).
-template <int VPL, int C4T, int NW>
+template <int VPL, int C4T, int NW, bool PM>
 __global__ __launch_bounds__(64 * NW) void knn_kernel(const float* __restrict__ x,
-                                                          const float* __restrict__ xx, int C,
+                                                          const float* __restrict__ xx,
+                                                          const float* __restrict__ xk, int C,
                                                           int N, int k, int ldp,
                                                           int32_t* __restrict__ idx) {
   constexpr int kKnnWaves = NW;
@@ -128,6 +181,11 @@ __global__ __launch_bounds__(64 * NW) void knn_kernel(const float* __restrict__ 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const float* __restrict__ xb = x + (size_t)b * C * N;
   const float* __restrict__ xxb = xx + (size_t)b * N;
+  const float* __restrict__ xkb = PM ? xk + (size_t)b * N * C : nullptr;
+  auto ldb = [&](int tile, auto& dst) {
+    if constexpr (PM) load_b_pm<(C4T > 0 ? C4T : 4)>(xkb, C, N, tile, lane >> 4, lane & 15, dst);
+    else load_b<(C4T > 0 ? C4T : 1)>(xb, C, N, tile, lane >> 4, lane & 15, dst);
+  };
   const int kk = lane >> 4;       // k index inside an MFMA step (0..3)
   const int col = lane & 15;      // candidate column of this lane / query row for A
   const int n_tiles = (N + 15) >> 4;
@@ -176,28 +234,28 @@ __global__ __launch_bounds__(64 * NW) void knn_kernel(const float* __restrict__ 
       const int tw = t_first + wave;
       if constexpr (NW >= 16) {
         // 4 waves per SIMD (128 VGPRs each): prefetch one tile ahead, two register sets
-        load_b<C4T>(xb, C, N, tw < t_last ? tw : n_tiles, kk, col, b0);
+        ldb(tw < t_last ? tw : n_tiles, b0);
         for (int t = tw; t < t_last; t += 2 * NW) {
-          load_b<C4T>(xb, C, N, t + NW < t_last ? t + NW : n_tiles, kk, col, b1);
+          ldb(t + NW < t_last ? t + NW : n_tiles, b1);
           score_tile<C4T>(a, b0, t, N, kk, col, xxb, xxq, pd, ldp, c0);
           if (t + NW < t_last) {
-            load_b<C4T>(xb, C, N, t + 2 * NW < t_last ? t + 2 * NW : n_tiles, kk, col, b0);
+            ldb(t + 2 * NW < t_last ? t + 2 * NW : n_tiles, b0);
             score_tile<C4T>(a, b1, t + NW, N, kk, col, xxb, xxq, pd, ldp, c0);
           }
         }
       } else {
         float b2[C4T];
-        load_b<C4T>(xb, C, N, tw < t_last ? tw : n_tiles, kk, col, b0);
-        load_b<C4T>(xb, C, N, tw + NW < t_last ? tw + NW : n_tiles, kk, col, b1);
+        ldb(tw < t_last ? tw : n_tiles, b0);
+        ldb(tw + NW < t_last ? tw + NW : n_tiles, b1);
         for (int t = tw; t < t_last; t += 3 * NW) {
-          load_b<C4T>(xb, C, N, t + 2 * NW < t_last ? t + 2 * NW : n_tiles, kk, col, b2);
+          ldb(t + 2 * NW < t_last ? t + 2 * NW : n_tiles, b2);
           score_tile<C4T>(a, b0, t, N, kk, col, xxb, xxq, pd, ldp, c0);
           if (t + NW < t_last) {
-            load_b<C4T>(xb, C, N, t + 3 * NW < t_last ? t + 3 * NW : n_tiles, kk, col, b0);
+            ldb(t + 3 * NW < t_last ? t + 3 * NW : n_tiles, b0);
             score_tile<C4T>(a, b1, t + NW, N, kk, col, xxb, xxq, pd, ldp, c0);
           }
           if (t + 2 * NW < t_last) {
-            load_b<C4T>(xb, C, N, t + 4 * NW < t_last ? t + 4 * NW : n_tiles, kk, col, b1);
+            ldb(t + 4 * NW < t_last ? t + 4 * NW : n_tiles, b1);
             score_tile<C4T>(a, b2, t + 2 * NW, N, kk, col, xxb, xxq, pd, ldp, c0);
           }
         }
@@ -340,8 +398,8 @@ __global__ __launch_bounds__(64 * NW) void knn_kernel(const float* __restrict__ 
   }
 }
 
-template <int VPL, int C4T, int NW>
-int launch_knn(const float* x, const float* xx, int B, int C, int N, int k, int32_t* idx,
+template <int VPL, int C4T, int NW, bool PM = false>
+int launch_knn(const float* x, const float* xx, const float* xk, int B, int C, int N, int k, int32_t* idx,
                hipStream_t s) {
   const int n_cols = ((N + 15) / 16) * 16;
   const int cw = n_cols < 64 * VPL ? n_cols : 64 * VPL;
@@ -350,7 +408,7 @@ int launch_knn(const float* x, const float* xx, int B, int C, int N, int k, int3
   const size_t lds_bytes = ((size_t)kQ * ldp + (C4T == 0 ? (size_t)C4 * 4 * kQ : 0)) * sizeof(float) +
                            NW * 64 * sizeof(unsigned long long);
   dim3 grid((N + kQ - 1) / kQ, B);
-  auto kern = knn_kernel<VPL, C4T, NW>;
+  auto kern = knn_kernel<VPL, C4T, NW, PM>;
   // one-time opt-in to the full 160 KiB of LDS for this instantiation (per process)
   static const hipError_t lds_optin = hipFuncSetAttribute(
       reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -358,24 +416,33 @@ int launch_knn(const float* x, const float* xx, int B, int C, int N, int k, int3
     set_error("fpsg_knn: cannot reserve %zu B of LDS: %s", lds_bytes, hipGetErrorString(lds_optin));
     return (int)lds_optin;
   }
-  hipLaunchKernelGGL(kern, grid, dim3(64 * NW), lds_bytes, s, x, xx, C, N, k, ldp, idx);
+  hipLaunchKernelGGL(kern, grid, dim3(64 * NW), lds_bytes, s, x, xx, xk, C, N, k, ldp, idx);
   return launch_status("fpsg_knn");
 }
 
 template <int VPL>
-int launch_knn_c(const float* x, const float* xx, int B, int C, int N, int k, int32_t* idx,
+int launch_knn_c(const float* x, const float* xx, const float* xk, int B, int C, int N, int k, int32_t* idx,
                  hipStream_t s) {
-  if (C <= 4) return launch_knn<VPL, 1, 16>(x, xx, B, C, N, k, idx, s);
-  if (C > 32 && C <= 64) return launch_knn<VPL, 16, 16>(x, xx, B, C, N, k, idx, s);
-  if (C > 64 && C <= 128) return launch_knn<VPL, 32, 8>(x, xx, B, C, N, k, idx, s);
-  return launch_knn<VPL, 0, 8>(x, xx, B, C, N, k, idx, s);
+  if (C <= 4) return launch_knn<VPL, 1, 16>(x, xx, nullptr, B, C, N, k, idx, s);
+  if (xk && C > 32 && C <= 64) return launch_knn<VPL, 16, 16, true>(x, xx, xk, B, C, N, k, idx, s);
+  if (xk && C > 64 && C <= 128) return launch_knn<VPL, 32, 8, true>(x, xx, xk, B, C, N, k, idx, s);
+  if (C > 32 && C <= 64) return launch_knn<VPL, 16, 16>(x, xx, nullptr, B, C, N, k, idx, s);
+  if (C > 64 && C <= 128) return launch_knn<VPL, 32, 8>(x, xx, nullptr, B, C, N, k, idx, s);
+  return launch_knn<VPL, 0, 8>(x, xx, nullptr, B, C, N, k, idx, s);
 }
+
+inline bool knn_uses_pm(int C) { return C % 16 == 0 && C > 32 && C <= 128; }
 
 }  // namespace
 }  // namespace fpsg
 
+extern "C" size_t fpsg_knn_workspace_floats(int B, int C, int N) {
+  if (B <= 0 || C <= 0 || N <= 0) return 0;
+  return (size_t)B * N + (fpsg::knn_uses_pm(C) ? (size_t)B * N * C : 0);
+}
+
 extern "C" int fpsg_knn(const float* x, int B, int C, int N, int k, int32_t* idx,
-                        float* sqnorm_ws, fpsg_stream_t stream) {
+                        float* ws, fpsg_stream_t stream) {
   using namespace fpsg;
   FPSG_REQUIRE(B > 0 && C > 0 && N > 0 && k > 0, FPSG_E_SHAPE,
                "fpsg_knn: B,C,N,k must be positive (got %d,%d,%d,%d)", B, C, N, k);
@@ -383,13 +450,22 @@ extern "C" int fpsg_knn(const float* x, int B, int C, int N, int k, int32_t* idx
   FPSG_REQUIRE(C <= 440 && (long)N <= (1L << 24), FPSG_E_LIMIT,
                "fpsg_knn: C=%d exceeds 440 (16 x C query tile beside the 128 KiB score tile) or N=%d > 2^24", C, N);
   FPSG_REQUIRE(B <= 65535, FPSG_E_LIMIT, "fpsg_knn: B=%d exceeds 65535", B);
-  FPSG_REQUIRE_PTR(x); FPSG_REQUIRE_PTR(idx); FPSG_REQUIRE_PTR(sqnorm_ws);
+  FPSG_REQUIRE_PTR(x); FPSG_REQUIRE_PTR(idx); FPSG_REQUIRE_PTR(ws);
   hipStream_t s = static_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL(sqnorm_kernel, dim3((N + 255) / 256, B), dim3(256), 0, s, x, C, N, sqnorm_ws);
-  int rc = launch_status("fpsg_knn(sqnorm)");
+  float* xx = ws;
+  float* xk = nullptr;
+  // the point-major copy needs 16-byte aligned rows; otherwise the channel-major operands are read as before
+  if (knn_uses_pm(C) && (reinterpret_cast<uintptr_t>(ws) & 15) == 0 && (((size_t)B * N) & 3) == 0) {
+    xk = ws + (size_t)B * N;
+    hipLaunchKernelGGL(knn_prep_kernel, dim3((N + kPrepPts - 1) / kPrepPts, B), dim3(256),
+                       (size_t)kPrepPts * (C + 4) * sizeof(float), s, x, C, N, xx, xk);
+  } else {
+    hipLaunchKernelGGL(sqnorm_kernel, dim3((N + 255) / 256, B), dim3(256), 0, s, x, C, N, xx);
+  }
+  int rc = launch_status("fpsg_knn(prepare)");
   if (rc) return rc;
   const int vpl = (((N + 15) / 16) * 16 + 63) / 64;
-  if (vpl <= 8) return launch_knn_c<8>(x, sqnorm_ws, B, C, N, k, idx, s);
-  if (vpl <= 16) return launch_knn_c<16>(x, sqnorm_ws, B, C, N, k, idx, s);
-  return launch_knn_c<32>(x, sqnorm_ws, B, C, N, k, idx, s);   // N > 2048: chunks of 2048 columns
+  if (vpl <= 8) return launch_knn_c<8>(x, xx, xk, B, C, N, k, idx, s);
+  if (vpl <= 16) return launch_knn_c<16>(x, xx, xk, B, C, N, k, idx, s);
+  return launch_knn_c<32>(x, xx, xk, B, C, N, k, idx, s);   // N > 2048: chunks of 2048 columns
 }

@@ -37,9 +37,10 @@ def knn_int32(x: torch.Tensor, k: int) -> torch.Tensor:
     if not 0 < k <= min(N, 64):
         raise ValueError(f"k={k} must be in [1, min(N, 64)] (N={N})")
     idx = torch.empty((B, N, k), dtype=torch.int32, device=x.device)
-    ws = torch.empty((B, N), dtype=torch.float32, device=x.device)
+    lib = _hip.load()
+    ws = torch.empty((lib.fpsg_knn_workspace_floats(B, C, N),), dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
-        rc = _hip.load().fpsg_knn(_hip.ptr(x), B, C, N, k, _hip.ptr(idx), _hip.ptr(ws),
+        rc = lib.fpsg_knn(_hip.ptr(x), B, C, N, k, _hip.ptr(idx), _hip.ptr(ws),
                                   _hip.stream_of(x))
     _hip.check(rc, "fpsg_knn")
     return idx

@@ -106,11 +106,14 @@ int fpsg_chamfer_bwd_scan(const float* xyz1, const float* xyz2,
  * Replaces `knn(x, k)` of src/dgcnn/model.py:13-20 (torch.matmul into a [B,N,N] matrix +
  * torch.topk).  x [B,C,N] fp32 channel-major; idx [B,N,k] int32: for every point the k
  * points with the largest  pd_ij = (-|x_j|^2 + 2 x_i.x_j) - |x_i|^2, nearest first (self
- * included), equal values -> lower index first.  sqnorm_ws: caller scratch of B*N floats.
+ * included), equal values -> lower index first.  ws: caller scratch of fpsg_knn_workspace_floats(B,C,N) floats,
+ * 16-byte aligned (squared norms; for C = 48..128, a multiple of 16, also a point-major k-interleaved copy of x
+ * that lets a lane fetch its MFMA operands of four channel steps with one 16-byte load).
  * Limits: k <= min(64, N), C <= 440.  Any N: the score tile in LDS covers 2048 candidates at a
  * time, longer clouds are processed in chunks whose sorted top-k lists are merged.
  */
-int fpsg_knn(const float* x, int B, int C, int N, int k, int32_t* idx, float* sqnorm_ws,
+size_t fpsg_knn_workspace_floats(int B, int C, int N);
+int fpsg_knn(const float* x, int B, int C, int N, int k, int32_t* idx, float* ws,
              fpsg_stream_t stream);
 
 /* ---- K4a: EdgeConv edge features (materialising form) ------------------------------
