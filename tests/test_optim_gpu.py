@@ -167,3 +167,28 @@ def test_single_episode_step_reads_gradients_in_place(gpu):
     assert bool((step.buckets.flat == 7.0).all())                 # no gather happened
     assert optimizer._gather is None and optimizer._gtab_host is not None
     assert not torch.equal(before, optimizer.flat_param) and bool(torch.isfinite(optimizer.flat_param).all())
+
+
+def test_pointer_table_step_with_unaligned_gradient_views(gpu):
+    """A gradient that autograd took over from a VIEW (e.g. a slice of a stacked tensor's gradient) may start at
+    any 4-byte offset: the pointer-table kernel must not assume 16-byte alignment of the tensor start."""
+    from fpsg_amd.optim import FlatAdam
+    torch.manual_seed(3)
+    params = [nn.Parameter(torch.randn(n, device=gpu)) for n in (1539, 8, 769, 5)]
+    ref = [nn.Parameter(p.detach().clone()) for p in params]
+    opt = FlatAdam(params, lr=1e-2)
+    opt_ref = torch.optim.Adam(ref, lr=1e-2)
+    big = torch.randn(4000, device=gpu)
+    off = 1                                           # odd float offset: 4-byte aligned only
+    misaligned = 0
+    for p, r in zip(params, ref):
+        g = big[off:off + p.numel()]
+        misaligned += g.data_ptr() % 16 != 0
+        p.grad = g                                    # a view with a storage offset, read in place
+        r.grad = g.clone()
+        off += p.numel() + 1
+    assert misaligned >= 3 and opt._pointer_table() is not None
+    opt.step()
+    opt_ref.step()
+    for p, r in zip(params, ref):
+        assert torch.allclose(p, r, rtol=1e-6, atol=1e-7)
