@@ -43,19 +43,22 @@ def init_distributed(device_type: str | None = None) -> tuple[int, int, torch.de
     if device_type is None:
         device_type = "cuda" if torch.cuda.is_available() else "cpu"
     if device_type == "cuda":
-        torch.cuda.set_device(local_rank)
-        device = torch.device("cuda", local_rank)
+        # FPSG_LOCAL_DEVICE: rehearsals of the multi-rank path on a box with fewer GPUs than ranks (every rank
+        # on the given device, with FPSG_DIST_BACKEND=gloo -- RCCL refuses two ranks on one device)
+        index = int(os.environ.get("FPSG_LOCAL_DEVICE", local_rank))
+        torch.cuda.set_device(index)
+        device = torch.device("cuda", index)
     else:
         device = torch.device("cpu")
     force = bool(os.environ.get("FPSG_FORCE_DIST"))   # single-rank group: exercises RCCL on one GPU
     if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
+        backend = os.environ.get("FPSG_DIST_BACKEND") or ("nccl" if device_type == "cuda" else "gloo")
         kwargs = {}
-        if device_type == "cuda":
+        if device_type == "cuda" and backend == "nccl":
             kwargs["device_id"] = device
-        dist.init_process_group(backend="nccl" if device_type == "cuda" else "gloo",
-                                rank=rank, world_size=world, **kwargs)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kwargs)
     return rank, world, device
 
 
