@@ -115,7 +115,7 @@ __device__ __forceinline__ TileIndex tile_of(long p, int Th, int Tw) {
 // reads a = relu(fma(x + pre_bias[c], scale[c], shift[c])) instead (exactly the value K5's apply pass
 // would have stored; padding stays zero) -- the BatchNorm + ReLU apply pass between two convolutions of a
 // VGG stage (one read + one write of the activation tensor) is folded into this load.
-template <int M>
+template <int M, bool ACT>
 __global__ __launch_bounds__(kWinoThreads) void wino_input_kernel(const float* __restrict__ x, int C, int H, int W,
                                                                    int Th, int Tw, long P, float* __restrict__ V,
                                                                    const float* __restrict__ chan,
@@ -133,31 +133,44 @@ __global__ __launch_bounds__(kWinoThreads) void wino_input_kernel(const float* _
   const bool has_left = ti.tw > 0, has_right = ti.tw < Tw - 1;
   const bool left_lane = has_left && lane > 0;              // lane-1 holds tile (th, tw-1)
   const bool right_lane = has_right && lane < kWave - 1;    // lane+1 holds tile (th, tw+1)
-  const bool actv = chan != nullptr;
-  const float sc = actv ? chan[c] : 1.0f, sh = actv ? chan[C + c] : 0.0f, pb = (actv && pre_bias) ? pre_bias[c] : 0.0f;
-  auto act = [&](float v) { return actv ? __builtin_fmaxf(fma_rn(v + pb, sc, sh), 0.0f) : v; };
-  float d[A][A];
+  float sc = 1.0f, sh = 0.0f, pb = 0.0f;
+  if (ACT) { sc = chan[c]; sh = chan[C + c]; pb = pre_bias ? pre_bias[c] : 0.0f; }
+  auto act = [&](float v) { return ACT ? __builtin_fmaxf(fma_rn(v + pb, sc, sh), 0.0f) : v; };
+  // All loads of the tile are issued before the first use: rows outside the image read a clamped (valid)
+  // row and are zeroed afterwards, so no load sits behind a branch that would serialise the waits.
+  vin mid[A];
+  bool rin[A];
+  const float* rp[A];
 #pragma unroll
   for (int i = 0; i < A; ++i) {
     const int r = r0 + i;
-    const bool rin = r >= 0 && r < H;
-    const float* rp = xp + (size_t)(rin ? r : 0) * W + c0;
-    vin mid;
-    if (rin) {
-      mid = *reinterpret_cast<const vin*>(rp);
+    rin[i] = r >= 0 && r < H;
+    rp[i] = xp + (size_t)(rin[i] ? r : (r < 0 ? 0 : H - 1)) * W + c0;
+    mid[i] = *reinterpret_cast<const vin*>(rp[i]);
+  }
+  float el[A], er[A];                                       // halo columns of the lanes at a wave edge
 #pragma unroll
-      for (int j = 0; j < M; ++j) mid[j] = act(mid[j]);
-    } else {
+  for (int i = 0; i < A; ++i) el[i] = er[i] = 0.0f;
+  if (has_left && !left_lane) {
 #pragma unroll
-      for (int j = 0; j < M; ++j) mid[j] = 0.0f;
-    }
-    float lft = __shfl_up(mid[M - 1], 1, kWave);
-    float rgt = __shfl_down(mid[0], 1, kWave);
-    if (!left_lane) lft = (has_left && rin) ? act(rp[-1]) : 0.0f;
-    if (!right_lane) rgt = (has_right && rin) ? act(rp[M]) : 0.0f;
+    for (int i = 0; i < A; ++i) el[i] = rp[i][-1];
+  }
+  if (has_right && !right_lane) {
+#pragma unroll
+    for (int i = 0; i < A; ++i) er[i] = rp[i][M];
+  }
+  float d[A][A];
+#pragma unroll
+  for (int i = 0; i < A; ++i) {
+#pragma unroll
+    for (int j = 0; j < M; ++j) mid[i][j] = rin[i] ? act(mid[i][j]) : 0.0f;
+    float lft = __shfl_up(mid[i][M - 1], 1, kWave);
+    float rgt = __shfl_down(mid[i][0], 1, kWave);
+    if (!left_lane) lft = (has_left && rin[i]) ? act(el[i]) : 0.0f;
+    if (!right_lane) rgt = (has_right && rin[i]) ? act(er[i]) : 0.0f;
     d[i][0] = lft;
 #pragma unroll
-    for (int j = 0; j < M; ++j) d[i][1 + j] = mid[j];
+    for (int j = 0; j < M; ++j) d[i][1 + j] = mid[i][j];
     d[i][A - 1] = rgt;
   }
   float t[A][A];        // t[j][i]: column j of the tile after the transform along rows
@@ -340,7 +353,10 @@ extern "C" int fpsg_wino_input_transform(int m, const float* x, int N, int C, in
   if (rc) return rc;
   FPSG_REQUIRE_PTR(x); FPSG_REQUIRE_PTR(V);
   FPSG_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0, FPSG_E_ALIGN, "fpsg_wino_input_transform: x must be 16-byte aligned");
-  FPSG_WINO_IMAGE_LAUNCH(wino_input_kernel, C, x, C, H, W, H / m, W / m, P, V, nullptr, nullptr);
+  const long P = (long)N * (H / m) * (W / m);
+  dim3 grid((unsigned)((P + kWinoThreads - 1) / kWinoThreads), C);
+  if (m == 2) hipLaunchKernelGGL((wino_input_kernel<2, false>), grid, dim3(kWinoThreads), 0, static_cast<hipStream_t>(stream), x, C, H, W, H / m, W / m, P, V, nullptr, nullptr);
+  else hipLaunchKernelGGL((wino_input_kernel<4, false>), grid, dim3(kWinoThreads), 0, static_cast<hipStream_t>(stream), x, C, H, W, H / m, W / m, P, V, nullptr, nullptr);
   return launch_status("fpsg_wino_input_transform");
 }
 
@@ -352,7 +368,10 @@ extern "C" int fpsg_wino_input_transform_act(int m, const float* x, const float*
   FPSG_REQUIRE_PTR(x); FPSG_REQUIRE_PTR(V); FPSG_REQUIRE_PTR(chan);
   FPSG_REQUIRE(!misaligned4(pre_bias), FPSG_E_ALIGN, "fpsg_wino_input_transform_act: pre_bias not 4-byte aligned");
   FPSG_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0, FPSG_E_ALIGN, "fpsg_wino_input_transform_act: x must be 16-byte aligned");
-  FPSG_WINO_IMAGE_LAUNCH(wino_input_kernel, C, x, C, H, W, H / m, W / m, P, V, chan, pre_bias);
+  const long P = (long)N * (H / m) * (W / m);
+  dim3 grid((unsigned)((P + kWinoThreads - 1) / kWinoThreads), C);
+  if (m == 2) hipLaunchKernelGGL((wino_input_kernel<2, true>), grid, dim3(kWinoThreads), 0, static_cast<hipStream_t>(stream), x, C, H, W, H / m, W / m, P, V, chan, pre_bias);
+  else hipLaunchKernelGGL((wino_input_kernel<4, true>), grid, dim3(kWinoThreads), 0, static_cast<hipStream_t>(stream), x, C, H, W, H / m, W / m, P, V, chan, pre_bias);
   return launch_status("fpsg_wino_input_transform_act");
 }
 
