@@ -28,22 +28,22 @@ constexpr int kFusedThreads = 256;
 constexpr int kSteps = 16;          // 64 input channels / 4 per MFMA step
 constexpr int kUldsFloats = 36 * kSteps * 64;
 
-// the same transform on two independent columns per instruction (v_pk_fma_f32 / v_pk_add_f32)
-__device__ __forceinline__ void in4x2(const v2f (&d)[6], v2f (&t)[6]) {
-  const v2f c4 = {4.0f, 4.0f}, cm5 = {-5.0f, -5.0f}, cm4 = {-4.0f, -4.0f}, c2 = {2.0f, 2.0f};
-  t[0] = fma_rn(c4, d[0], fma_rn(cm5, d[2], d[4]));
-  t[1] = fma_rn(cm4, d[1] + d[2], d[3] + d[4]);
-  t[2] = fma_rn(c4, d[1] - d[2], d[4] - d[3]);
-  t[3] = fma_rn(c2, d[3] - d[1], d[4] - d[2]);
-  t[4] = fma_rn(c2, d[1] - d[3], d[4] - d[2]);
-  t[5] = fma_rn(c4, d[1], fma_rn(cm5, d[3], d[5]));
+// lane i <- lane i-1 / i+1 inside its row of 16 lanes (DPP row_shr:1 / row_shl:1, one VALU op); the lanes
+// without a neighbour in their row (column 0 / 15) keep `keep`
+__device__ __forceinline__ float from_left_or(float keep, float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(keep), __float_as_int(v), 0x111, 0xF, 0xF, false));
 }
-// lane i <- lane i-1 / i+1 inside its row of 16 lanes (DPP row_shr:1 / row_shl:1): one VALU op
-__device__ __forceinline__ float from_left(float v) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x111, 0xF, 0xF, false));
+__device__ __forceinline__ float from_right_or(float keep, float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(keep), __float_as_int(v), 0x101, 0xF, 0xF, false));
 }
-__device__ __forceinline__ float from_right(float v) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x101, 0xF, 0xF, false));
+// B^T d for one column (winograd.hip's Wino<4>::in), d[0] entering through `c0` (4, or 0 for a masked row/column)
+__device__ __forceinline__ void in4(const float (&d)[6], float c0, float (&t)[6]) {
+  t[0] = fma_rn(c0, d[0], fma_rn(-5.0f, d[2], d[4]));
+  t[1] = fma_rn(-4.0f, d[1] + d[2], d[3] + d[4]);
+  t[2] = fma_rn(4.0f, d[1] - d[2], d[4] - d[3]);
+  t[3] = fma_rn(2.0f, d[3] - d[1], d[4] - d[2]);
+  t[4] = fma_rn(2.0f, d[1] - d[3], d[4] - d[2]);
+  t[5] = fma_rn(4.0f, d[1], fma_rn(-5.0f, d[3], d[5]));
 }
 __device__ __forceinline__ void out4(const float (&m)[6], float (&s)[4]) {
   const float p12 = m[1] + m[2], m12 = m[1] - m[2], p34 = m[3] + m[4], m34 = m[3] - m[4];
@@ -86,6 +86,9 @@ __global__ __launch_bounds__(kFusedThreads) void wino4_fused_c64_kernel(const fl
     actp[2 * C + tid] = pre_bias ? pre_bias[tid] : 0.0f;
   }
   __syncthreads();
+  // x as a buffer resource: loads are `descriptor + 32-bit lane offset + scalar step offset` (no address VALU)
+  const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(x), 0, (int)(P * 16 * C * sizeof(float)), 0x00020000);
   const long G = (P + 15) >> 4;
   for (long g = (long)j * 4 + wave; g < G; g += 4L * per_slice) {
     const long p_raw = g * 16 + col;
@@ -96,100 +99,103 @@ __global__ __launch_bounds__(kFusedThreads) void wino4_fused_c64_kernel(const fl
     const int th = (int)(q % Th);
     const long n = q / Th;
     const bool has_left = tw > 0, has_right = tw < Tw - 1;
-    const bool left_lane = has_left && col > 0, right_lane = has_right && col < 15;
+    const bool edge_l = has_left && col == 0, edge_r = has_right && col == 15;
     const int r0 = 4 * th - 1;
     v4f acc[36];
 #pragma unroll
     for (int xi = 0; xi < 36; ++xi) acc[xi] = (v4f){0.0f, 0.0f, 0.0f, 0.0f};
-    const float* xn = x + (((size_t)n * C + kk) * H) * W + 4 * tw;      // channel kk of step 0
-    const size_t step_stride = (size_t)4 * H * W;                        // 4 channels per step
-    const bool edge_l = has_left && !left_lane, edge_r = has_right && !right_lane;
     // rows r0+1 .. r0+4 are the tile's own output rows: always inside the image; only the halo rows
-    // r0 (top) and r0+5 (bottom) can fall outside and are then read from a valid row and zeroed
+    // r0 (top) and r0+5 (bottom) can fall outside.  They are then read from a valid row and enter the
+    // transform with weight 0: B^T uses row 0 only as 4*d[0] (the 4 becomes 0) and row 5 only as +d[5]
+    // (multiplied by 0); the halo columns likewise (x 0 when the tile touches the image's left / right edge).
     const bool top_in = r0 >= 0, bot_in = r0 + 5 < H;
-    int roff[6];
-#pragma unroll
-    for (int r = 0; r < 6; ++r) {
-      const int row = r0 + r;
-      roff[r] = (row < 0 ? 0 : (row >= H ? H - 1 : row)) * W;
-    }
-
-    // the patch of one channel step as loaded: interior vectors + the two edge-lane halo columns.
-    // One wave per SIMD (the U slice fills the LDS), so the ~2 us of load latency is covered by
-    // issuing the loads two steps ahead of their use.
-    struct Raw { v4f mid[6]; float e[6]; };     // e: the halo column of a lane at the edge of its row of 16
-    // no branches around the loads: the compiler then counts outstanding loads exactly
-    // (s_waitcnt vmcnt(n) per buffer instead of vmcnt(0)); lanes without an edge halo re-read
-    // their own first / last interior element
-    // (a lane is at most at one edge: column 0 needs the element left of its vector, column 15 the
-    // one right of it)
-    const int eoff = edge_l ? -1 : (edge_r ? 4 : 0);
-    auto load_raw = [&](int c4, Raw& w) {
-      const float* xp = xn + (size_t)c4 * step_stride;
+    const float c4t = top_in ? 4.0f : 0.0f, mb = bot_in ? 1.0f : 0.0f;
+    const float ml = has_left ? 1.0f : 0.0f, mr = has_right ? 1.0f : 0.0f;
+    const float ml5 = ml * mb, mr5 = mr * mb;
+    // byte offsets of the lane's six patch rows inside channel kk of step 0 (the tensor is below 4 GiB: checked
+    // by the host); a step's loads are `uniform base + 32-bit lane offset`, no per-step address arithmetic
+    uint32_t boff[6], eoffb[6];
+    {
+      const uint32_t lane_elem = (uint32_t)((((size_t)n * C + kk) * H) * W + 4 * tw);
+      // a lane is at most at one edge of its row of 16: column 0 needs the element left of its vector, column
+      // 15 the one right of it; the others re-read their own first element (never used)
+      const uint32_t eadd = edge_l ? (uint32_t)-4 : (edge_r ? 16u : 0u);
 #pragma unroll
       for (int r = 0; r < 6; ++r) {
-        w.mid[r] = *reinterpret_cast<const v4f*>(xp + roff[r]);
-        w.e[r] = xp[roff[r] + eoff];
+        const int row = r0 + r;
+        boff[r] = (lane_elem + (uint32_t)((row < 0 ? 0 : (row >= H ? H - 1 : row)) * W)) * 4u;
+        eoffb[r] = boff[r] + eadd;
+      }
+    }
+    const uint32_t step_bytes = (uint32_t)(4 * H * W) * 4u;            // 4 channels per step
+
+    // the patch of one channel step as loaded: interior vectors + the halo element of an edge lane.
+    // One wave per SIMD (the U slice fills the LDS), so the load latency is covered by issuing the loads
+    // two steps ahead of their use; no branches around the loads (the compiler then counts outstanding
+    // loads exactly: s_waitcnt vmcnt(n) per buffer instead of vmcnt(0)).
+    struct Raw { v4f mid[6]; float e[6]; };
+    auto load_raw = [&](int c4, Raw& w) {
+      const uint32_t sbase = (uint32_t)c4 * step_bytes;                  // wave-uniform: the buffer load's soffset
+#pragma unroll
+      for (int r = 0; r < 6; ++r) {
+        w.mid[r] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, boff[r], sbase, 0));
+        w.e[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xrsrc, eoffb[r], sbase, 0));
       }
     };
     auto compute = [&](int c4, const Raw& w) {
-      // this step's 36 A fragments: issued first, in flight under the input transform
-      v4f a[9];
-      {
-        const v4f* up = reinterpret_cast<const v4f*>(ulds + ((size_t)c4 * 64 + lane) * 36);
-#pragma unroll
-        for (int q4 = 0; q4 < 9; ++q4) a[q4] = up[q4];
-      }
+      // this step's 36 A fragments, read in three groups of 12 (two rows of transform points each): the first
+      // is in flight under the input transform, the next under the previous rows' products
+      const v4f* up = reinterpret_cast<const v4f*>(ulds + ((size_t)c4 * 64 + lane) * 36);
+      v4f a[3] = {up[0], up[1], up[2]};
       float asc = 1.0f, ash = 0.0f, apb = 0.0f;
       if (ACT) { asc = actp[4 * c4 + kk]; ash = actp[C + 4 * c4 + kk]; apb = actp[2 * C + 4 * c4 + kk]; }
-      // d[r][c] as column pairs for the packed transforms: dp[r][j] = (d[r][2j], d[r][2j+1])
-      v2f dp[6][3];
+      // Scalar fp32 only (the file is compiled with -fno-slp-vectorize): fp32 MFMAs and fp32 VALU operations do
+      // not overlap on this hardware (tools/micro/mfma_f32_*.hip), so the step costs MFMA time + VALU issue
+      // time, and a packed v_pk_*_f32 beside MFMAs costs more than the two scalar operations it replaces.
+      float d[6][6];
 #pragma unroll
       for (int r = 0; r < 6; ++r) {
-        const bool rin = r == 0 ? top_in : (r == 5 ? bot_in : true);
-        v4f mid = w.mid[r];
-        float e = w.e[r];
+        float m0 = w.mid[r][0], m1 = w.mid[r][1], m2 = w.mid[r][2], m3 = w.mid[r][3], e = w.e[r];
         if (ACT) {
-#pragma unroll
-          for (int u = 0; u < 4; ++u) mid[u] = __builtin_fmaxf(fma_rn(mid[u] + apb, asc, ash), 0.0f);
+          m0 = __builtin_fmaxf(fma_rn(m0 + apb, asc, ash), 0.0f);
+          m1 = __builtin_fmaxf(fma_rn(m1 + apb, asc, ash), 0.0f);
+          m2 = __builtin_fmaxf(fma_rn(m2 + apb, asc, ash), 0.0f);
+          m3 = __builtin_fmaxf(fma_rn(m3 + apb, asc, ash), 0.0f);
           e = __builtin_fmaxf(fma_rn(e + apb, asc, ash), 0.0f);
         }
-        const float sl = from_left(mid[3]);
-        const float sr = from_right(mid[0]);
-        const float lft = left_lane ? sl : (edge_l ? e : 0.0f);
-        const float rgt = right_lane ? sr : (edge_r ? e : 0.0f);
-        dp[r][0] = (v2f){rin ? lft : 0.0f, rin ? mid[0] : 0.0f};
-        dp[r][1] = (v2f){rin ? mid[1] : 0.0f, rin ? mid[2] : 0.0f};
-        dp[r][2] = (v2f){rin ? mid[3] : 0.0f, rin ? rgt : 0.0f};
+        d[r][0] = from_left_or(e, m3) * (r == 5 ? ml5 : ml);       // column 0 of its row of 16 keeps e
+        d[r][5] = from_right_or(e, m0) * (r == 5 ? mr5 : mr);      // column 15 keeps e
+        d[r][1] = r == 5 ? m0 * mb : m0;
+        d[r][2] = r == 5 ? m1 * mb : m1;
+        d[r][3] = r == 5 ? m2 * mb : m2;
+        d[r][4] = r == 5 ? m3 * mb : m3;
       }
-      // transform along rows (down the columns), two columns per instruction: tp[i][j] = (t[i][2j], t[i][2j+1])
-      v2f tp[6][3];
+      // transform along rows (down the columns)
+      float t[6][6];        // t[j][i]: column j after the transform along rows
 #pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        v2f colv[6], o[6];
-#pragma unroll
-        for (int r = 0; r < 6; ++r) colv[r] = dp[r][j];
-        in4x2(colv, o);
-#pragma unroll
-        for (int i = 0; i < 6; ++i) tp[i][j] = o[i];
+      for (int j = 0; j < 6; ++j) {
+        const float colv[6] = {d[0][j], d[1][j], d[2][j], d[3][j], d[4][j], d[5][j]};
+        in4(colv, c4t, t[j]);
       }
-      // transform along columns, two rows per instruction, and the 12 products of those rows
+      // transform along columns, one row of 6 transform points at a time, and that row's 6 products
 #pragma unroll
-      for (int ip = 0; ip < 3; ++ip) {
-        v2f rowv[6], o[6];
+      for (int i = 0; i < 6; ++i) {
+        const float rowv[6] = {t[0][i], t[1][i], t[2][i], t[3][i], t[4][i], t[5][i]};
+        float o[6];
+        in4(rowv, 4.0f, o);
+        v4f an[3];
+        if (i == 1 || i == 3) {
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
-          rowv[2 * j] = (v2f){tp[2 * ip][j][0], tp[2 * ip + 1][j][0]};
-          rowv[2 * j + 1] = (v2f){tp[2 * ip][j][1], tp[2 * ip + 1][j][1]};
+          for (int q4 = 0; q4 < 3; ++q4) an[q4] = up[3 * ((i + 1) / 2) + q4];
         }
-        in4x2(rowv, o);
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+        for (int c = 0; c < 6; ++c) {
+          const int xi = 6 * i + c, xl = xi % 12;
+          acc[xi] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[xl >> 2][xl & 3], o[c], acc[xi], 0, 0, 0);
+        }
+        if (i == 1 || i == 3) {
 #pragma unroll
-          for (int c = 0; c < 6; ++c) {
-            const int xi = 6 * (2 * ip + h) + c;
-            acc[xi] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[xi >> 2][xi & 3], o[c][h], acc[xi], 0, 0, 0);
-          }
+          for (int q4 = 0; q4 < 3; ++q4) a[q4] = an[q4];
         }
       }
     };
@@ -251,6 +257,8 @@ static int wino_conv_fused_launch(const char* fn, const float* x, const float* c
   FPSG_REQUIRE_PTR(x); FPSG_REQUIRE_PTR(U); FPSG_REQUIRE_PTR(y);
   FPSG_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0, FPSG_E_ALIGN,
                "%s: x and y must be 16-byte aligned", fn);
+  FPSG_REQUIRE((size_t)N * C * H * W * sizeof(float) < ((size_t)1 << 32), FPSG_E_LIMIT,
+               "%s: x must be below 4 GiB (32-bit lane offsets; got N=%d H=%d W=%d)", fn, N, H, W);
   const long P = (long)N * (H / 4) * (W / 4);
   const int S = K / 16;
   const size_t lds_bytes = (size_t)(kUldsFloats + 3 * 64) * sizeof(float);
