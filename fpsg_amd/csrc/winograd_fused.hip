@@ -143,10 +143,14 @@ __global__ __launch_bounds__(kFusedThreads) void wino4_fused_c64_kernel(const fl
       }
     };
     auto compute = [&](int c4, const Raw& w) {
-      // this step's 36 A fragments, read in three groups of 12 (two rows of transform points each): the first
-      // is in flight under the input transform, the next under the previous rows' products
-      const v4f* up = reinterpret_cast<const v4f*>(ulds + ((size_t)c4 * 64 + lane) * 36);
-      v4f a[3] = {up[0], up[1], up[2]};
+      // this step's 36 A fragments: issued first (pinned by the sched_barrier), in flight under the input transform
+      v4f a[9];
+      {
+        const v4f* up = reinterpret_cast<const v4f*>(ulds + ((size_t)c4 * 64 + lane) * 36);
+#pragma unroll
+        for (int q4 = 0; q4 < 9; ++q4) a[q4] = up[q4];
+      }
+      __builtin_amdgcn_sched_barrier(0);
       float asc = 1.0f, ash = 0.0f, apb = 0.0f;
       if (ACT) { asc = actp[4 * c4 + kk]; ash = actp[C + 4 * c4 + kk]; apb = actp[2 * C + 4 * c4 + kk]; }
       // Scalar fp32 only (the file is compiled with -fno-slp-vectorize): fp32 MFMAs and fp32 VALU operations do
@@ -183,19 +187,25 @@ __global__ __launch_bounds__(kFusedThreads) void wino4_fused_c64_kernel(const fl
         const float rowv[6] = {t[0][i], t[1][i], t[2][i], t[3][i], t[4][i], t[5][i]};
         float o[6];
         in4(rowv, 4.0f, o);
-        v4f an[3];
-        if (i == 1 || i == 3) {
-#pragma unroll
-          for (int q4 = 0; q4 < 3; ++q4) an[q4] = up[3 * ((i + 1) / 2) + q4];
-        }
-#pragma unroll
-        for (int c = 0; c < 6; ++c) {
-          const int xi = 6 * i + c, xl = xi % 12;
-          acc[xi] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[xl >> 2][xl & 3], o[c], acc[xi], 0, 0, 0);
-        }
-        if (i == 1 || i == 3) {
-#pragma unroll
-          for (int q4 = 0; q4 < 3; ++q4) a[q4] = an[q4];
+        // The row's six products as one block, in place on AGPR tuples.  (Through the builtin the register
+        // allocator moves the 36 accumulators between AGPR tuples every step, ~60 v_accvgpr_* beside 36 MFMAs.)
+        // The compiler does not see MFMAs inside asm: s_nop 1 covers the two wait states gfx950 needs between
+        // a VALU write of o[] and the MFMA reading it; the accumulator reads after the last step are covered below.
+        {
+          const int x0 = 6 * i, l0 = x0;
+#define FPSG_A(c) a[(l0 + (c)) >> 2][(l0 + (c)) & 3]
+          asm volatile(
+              "s_nop 1\n\t"
+              "v_mfma_f32_16x16x4_f32 %0, %6, %12, %0\n\t"
+              "v_mfma_f32_16x16x4_f32 %1, %7, %13, %1\n\t"
+              "v_mfma_f32_16x16x4_f32 %2, %8, %14, %2\n\t"
+              "v_mfma_f32_16x16x4_f32 %3, %9, %15, %3\n\t"
+              "v_mfma_f32_16x16x4_f32 %4, %10, %16, %4\n\t"
+              "v_mfma_f32_16x16x4_f32 %5, %11, %17, %5"
+              : "+a"(acc[x0]), "+a"(acc[x0 + 1]), "+a"(acc[x0 + 2]), "+a"(acc[x0 + 3]), "+a"(acc[x0 + 4]), "+a"(acc[x0 + 5])
+              : "v"(FPSG_A(0)), "v"(FPSG_A(1)), "v"(FPSG_A(2)), "v"(FPSG_A(3)), "v"(FPSG_A(4)), "v"(FPSG_A(5)),
+                "v"(o[0]), "v"(o[1]), "v"(o[2]), "v"(o[3]), "v"(o[4]), "v"(o[5]));
+#undef FPSG_A
         }
       }
     };
@@ -203,21 +213,21 @@ __global__ __launch_bounds__(kFusedThreads) void wino4_fused_c64_kernel(const fl
     // all of them to the top and spills)
 #define FPSG_LOAD(st, buf) load_raw((st) < kSteps ? (st) : kSteps - 1, buf); __builtin_amdgcn_sched_barrier(0)
 #define FPSG_COMPUTE(st, buf) compute(st, buf); __builtin_amdgcn_sched_barrier(0)
-    Raw ra, rb, rc;
+    Raw ra, rb;
     FPSG_LOAD(0, ra);
     FPSG_LOAD(1, rb);
 #pragma unroll 1
-    for (int c4 = 0; c4 < kSteps - 1; c4 += 3) {          // steps 0 .. 14, loads two steps ahead
-      FPSG_LOAD(c4 + 2, rc);
+    for (int c4 = 0; c4 < kSteps; c4 += 2) {              // a step's loads are issued one to two steps ahead
       FPSG_COMPUTE(c4, ra);
-      FPSG_LOAD(c4 + 3, ra);                              // <= 15
+      FPSG_LOAD(c4 + 2, ra);                              // clamped to the last step
       FPSG_COMPUTE(c4 + 1, rb);
-      FPSG_LOAD(c4 + 4, rb);                              // clamped to the last step
-      FPSG_COMPUTE(c4 + 2, rc);
+      FPSG_LOAD(c4 + 3, rb);
     }
-    FPSG_COMPUTE(kSteps - 1, ra);
 #undef FPSG_COMPUTE
 #undef FPSG_LOAD
+    // the compiler does not see MFMAs in the asm statements: cover the MFMA-write -> VALU-read distance by hand
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
     // output transform: accumulator element r of acc[xi] = M[xi][k0 + 4*kk + r][tile col]
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
