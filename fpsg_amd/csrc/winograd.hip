@@ -55,12 +55,15 @@ template <> struct Wino<2> {
 
 template <> struct Wino<4> {
   static constexpr int A = 6;
+  // 12 operations: rows 1,2 = (d4 - 4 d2) +- (d3 - 4 d1), rows 3,4 = (d4 - d2) +- 2 (d3 - d1)
   static __device__ __forceinline__ void in(const float (&d)[6], float (&t)[6]) {
+    const float p = fma_rn(-4.0f, d[2], d[4]), q = fma_rn(-4.0f, d[1], d[3]);
+    const float r = d[4] - d[2], s = d[3] - d[1];
     t[0] = fma_rn(4.0f, d[0], fma_rn(-5.0f, d[2], d[4]));
-    t[1] = fma_rn(-4.0f, d[1] + d[2], d[3] + d[4]);
-    t[2] = fma_rn(4.0f, d[1] - d[2], d[4] - d[3]);
-    t[3] = fma_rn(2.0f, d[3] - d[1], d[4] - d[2]);
-    t[4] = fma_rn(2.0f, d[1] - d[3], d[4] - d[2]);
+    t[1] = p + q;
+    t[2] = p - q;
+    t[3] = fma_rn(2.0f, s, r);
+    t[4] = fma_rn(-2.0f, s, r);
     t[5] = fma_rn(4.0f, d[1], fma_rn(-5.0f, d[3], d[5]));
   }
   static __device__ __forceinline__ void out(const float (&m)[6], float (&s)[4]) {

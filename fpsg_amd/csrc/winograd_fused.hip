@@ -19,6 +19,8 @@
 // (round-robin dispatch: id % 8), so that the re-reads of x by the other slices hit that L2.
 // Same arithmetic per element as winograd.hip's transforms; the channel sum runs in the MFMA's
 // k order.  Deterministic.
+#include <type_traits>
+
 #include "fpsg_common.h"
 
 namespace fpsg {
@@ -38,11 +40,13 @@ __device__ __forceinline__ float from_right_or(float keep, float v) {
 }
 // B^T d for one column (winograd.hip's Wino<4>::in), d[0] entering through `c0` (4, or 0 for a masked row/column)
 __device__ __forceinline__ void in4(const float (&d)[6], float c0, float (&t)[6]) {
+  const float p = fma_rn(-4.0f, d[2], d[4]), q = fma_rn(-4.0f, d[1], d[3]);
+  const float r = d[4] - d[2], s = d[3] - d[1];
   t[0] = fma_rn(c0, d[0], fma_rn(-5.0f, d[2], d[4]));
-  t[1] = fma_rn(-4.0f, d[1] + d[2], d[3] + d[4]);
-  t[2] = fma_rn(4.0f, d[1] - d[2], d[4] - d[3]);
-  t[3] = fma_rn(2.0f, d[3] - d[1], d[4] - d[2]);
-  t[4] = fma_rn(2.0f, d[1] - d[3], d[4] - d[2]);
+  t[1] = p + q;
+  t[2] = p - q;
+  t[3] = fma_rn(2.0f, s, r);
+  t[4] = fma_rn(-2.0f, s, r);
   t[5] = fma_rn(4.0f, d[1], fma_rn(-5.0f, d[3], d[5]));
 }
 __device__ __forceinline__ void out4(const float (&m)[6], float (&s)[4]) {
@@ -94,16 +98,15 @@ __global__ __launch_bounds__(kFusedThreads) void wino4_fused_c64_kernel(const fl
     const long p_raw = g * 16 + col;
     const bool live = p_raw < P;
     const long p = live ? p_raw : P - 1;
-    const int tw = (int)(p % Tw);
-    const long q = p / Tw;
-    const int th = (int)(q % Th);
-    const long n = q / Th;
+    const unsigned pu = (unsigned)p;                                    // P < 2^20 (the 4 GiB check of the host)
+    const int tw = (int)(pu % (unsigned)Tw);
+    const unsigned q = pu / (unsigned)Tw;
+    const int th = (int)(q % (unsigned)Th);
+    const unsigned n = q / (unsigned)Th;
     const bool has_left = tw > 0, has_right = tw < Tw - 1;
     const bool edge_l = has_left && col == 0, edge_r = has_right && col == 15;
     const int r0 = 4 * th - 1;
-    v4f acc[36];
-#pragma unroll
-    for (int xi = 0; xi < 36; ++xi) acc[xi] = (v4f){0.0f, 0.0f, 0.0f, 0.0f};
+    v4f acc[36];                                   // written by step 0 (C = 0), accumulated in place afterwards
     // rows r0+1 .. r0+4 are the tile's own output rows: always inside the image; only the halo rows
     // r0 (top) and r0+5 (bottom) can fall outside.  They are then read from a valid row and enter the
     // transform with weight 0: B^T uses row 0 only as 4*d[0] (the 4 becomes 0) and row 5 only as +d[5]
@@ -111,7 +114,7 @@ __global__ __launch_bounds__(kFusedThreads) void wino4_fused_c64_kernel(const fl
     const bool top_in = r0 >= 0, bot_in = r0 + 5 < H;
     const float c4t = top_in ? 4.0f : 0.0f, mb = bot_in ? 1.0f : 0.0f;
     const float ml = has_left ? 1.0f : 0.0f, mr = has_right ? 1.0f : 0.0f;
-    const float ml5 = ml * mb, mr5 = mr * mb;
+    const float c4l = 4.0f * ml, mr5 = mr * mb;
     // byte offsets of the lane's six patch rows inside channel kk of step 0 (the tensor is below 4 GiB: checked
     // by the host); a step's loads are `uniform base + 32-bit lane offset`, no per-step address arithmetic
     uint32_t boff[6], eoffb[6];
@@ -142,7 +145,8 @@ __global__ __launch_bounds__(kFusedThreads) void wino4_fused_c64_kernel(const fl
         w.e[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xrsrc, eoffb[r], sbase, 0));
       }
     };
-    auto compute = [&](int c4, const Raw& w) {
+    // (accr: the accumulators as a parameter -- asm operands in a generic lambda cannot name captured arrays)
+    auto compute = [&](int c4, const Raw& w, v4f (&accr)[36], auto first) {
       // this step's 36 A fragments: issued first (pinned by the sched_barrier), in flight under the input transform
       v4f a[9];
       {
@@ -167,7 +171,8 @@ __global__ __launch_bounds__(kFusedThreads) void wino4_fused_c64_kernel(const fl
           m3 = __builtin_fmaxf(fma_rn(m3 + apb, asc, ash), 0.0f);
           e = __builtin_fmaxf(fma_rn(e + apb, asc, ash), 0.0f);
         }
-        d[r][0] = from_left_or(e, m3) * (r == 5 ? ml5 : ml);       // column 0 of its row of 16 keeps e
+        const float lft = from_left_or(e, m3);                     // column 0 of its row of 16 keeps e
+        d[r][0] = r == 5 ? lft * mb : lft;                         // (the left edge enters through c4l below)
         d[r][5] = from_right_or(e, m0) * (r == 5 ? mr5 : mr);      // column 15 keeps e
         d[r][1] = r == 5 ? m0 * mb : m0;
         d[r][2] = r == 5 ? m1 * mb : m1;
@@ -186,7 +191,7 @@ __global__ __launch_bounds__(kFusedThreads) void wino4_fused_c64_kernel(const fl
       for (int i = 0; i < 6; ++i) {
         const float rowv[6] = {t[0][i], t[1][i], t[2][i], t[3][i], t[4][i], t[5][i]};
         float o[6];
-        in4(rowv, 4.0f, o);
+        in4(rowv, c4l, o);
         // The row's six products as one block, in place on AGPR tuples.  (Through the builtin the register
         // allocator moves the 36 accumulators between AGPR tuples every step, ~60 v_accvgpr_* beside 36 MFMAs.)
         // The compiler does not see MFMAs inside asm: s_nop 1 covers the two wait states gfx950 needs between
@@ -194,17 +199,33 @@ __global__ __launch_bounds__(kFusedThreads) void wino4_fused_c64_kernel(const fl
         {
           const int x0 = 6 * i, l0 = x0;
 #define FPSG_A(c) a[(l0 + (c)) >> 2][(l0 + (c)) & 3]
-          asm volatile(
-              "s_nop 1\n\t"
-              "v_mfma_f32_16x16x4_f32 %0, %6, %12, %0\n\t"
-              "v_mfma_f32_16x16x4_f32 %1, %7, %13, %1\n\t"
-              "v_mfma_f32_16x16x4_f32 %2, %8, %14, %2\n\t"
-              "v_mfma_f32_16x16x4_f32 %3, %9, %15, %3\n\t"
-              "v_mfma_f32_16x16x4_f32 %4, %10, %16, %4\n\t"
-              "v_mfma_f32_16x16x4_f32 %5, %11, %17, %5"
-              : "+a"(acc[x0]), "+a"(acc[x0 + 1]), "+a"(acc[x0 + 2]), "+a"(acc[x0 + 3]), "+a"(acc[x0 + 4]), "+a"(acc[x0 + 5])
-              : "v"(FPSG_A(0)), "v"(FPSG_A(1)), "v"(FPSG_A(2)), "v"(FPSG_A(3)), "v"(FPSG_A(4)), "v"(FPSG_A(5)),
-                "v"(o[0]), "v"(o[1]), "v"(o[2]), "v"(o[3]), "v"(o[4]), "v"(o[5]));
+          if constexpr (decltype(first)::value) {
+            asm volatile(
+                "s_nop 1\n\t"
+                "v_mfma_f32_16x16x4_f32 %0, %6, %12, 0\n\t"
+                "v_mfma_f32_16x16x4_f32 %1, %7, %13, 0\n\t"
+                "v_mfma_f32_16x16x4_f32 %2, %8, %14, 0\n\t"
+                "v_mfma_f32_16x16x4_f32 %3, %9, %15, 0\n\t"
+                "v_mfma_f32_16x16x4_f32 %4, %10, %16, 0\n\t"
+                "v_mfma_f32_16x16x4_f32 %5, %11, %17, 0"
+                : "=&a"(accr[x0]), "=&a"(accr[x0 + 1]), "=&a"(accr[x0 + 2]), "=&a"(accr[x0 + 3]), "=&a"(accr[x0 + 4]),
+                  "=&a"(accr[x0 + 5])
+                : "v"(FPSG_A(0)), "v"(FPSG_A(1)), "v"(FPSG_A(2)), "v"(FPSG_A(3)), "v"(FPSG_A(4)), "v"(FPSG_A(5)),
+                  "v"(o[0]), "v"(o[1]), "v"(o[2]), "v"(o[3]), "v"(o[4]), "v"(o[5]));
+          } else {
+            asm volatile(
+                "s_nop 1\n\t"
+                "v_mfma_f32_16x16x4_f32 %0, %6, %12, %0\n\t"
+                "v_mfma_f32_16x16x4_f32 %1, %7, %13, %1\n\t"
+                "v_mfma_f32_16x16x4_f32 %2, %8, %14, %2\n\t"
+                "v_mfma_f32_16x16x4_f32 %3, %9, %15, %3\n\t"
+                "v_mfma_f32_16x16x4_f32 %4, %10, %16, %4\n\t"
+                "v_mfma_f32_16x16x4_f32 %5, %11, %17, %5"
+                : "+a"(accr[x0]), "+a"(accr[x0 + 1]), "+a"(accr[x0 + 2]), "+a"(accr[x0 + 3]), "+a"(accr[x0 + 4]),
+                  "+a"(accr[x0 + 5])
+                : "v"(FPSG_A(0)), "v"(FPSG_A(1)), "v"(FPSG_A(2)), "v"(FPSG_A(3)), "v"(FPSG_A(4)), "v"(FPSG_A(5)),
+                  "v"(o[0]), "v"(o[1]), "v"(o[2]), "v"(o[3]), "v"(o[4]), "v"(o[5]));
+          }
 #undef FPSG_A
         }
       }
@@ -212,18 +233,24 @@ __global__ __launch_bounds__(kFusedThreads) void wino4_fused_c64_kernel(const fl
     // sched_barrier: keep each step's loads where they are written (the scheduler otherwise hoists
     // all of them to the top and spills)
 #define FPSG_LOAD(st, buf) load_raw((st) < kSteps ? (st) : kSteps - 1, buf); __builtin_amdgcn_sched_barrier(0)
-#define FPSG_COMPUTE(st, buf) compute(st, buf); __builtin_amdgcn_sched_barrier(0)
+#define FPSG_COMPUTE(st, buf) compute(st, buf, acc, std::false_type{}); __builtin_amdgcn_sched_barrier(0)
+#define FPSG_COMPUTE_FIRST(st, buf) compute(st, buf, acc, std::true_type{}); __builtin_amdgcn_sched_barrier(0)
     Raw ra, rb;
     FPSG_LOAD(0, ra);
     FPSG_LOAD(1, rb);
+    FPSG_COMPUTE_FIRST(0, ra);                            // step 0 writes the accumulators (C = 0)
+    FPSG_LOAD(2, ra);
+    FPSG_COMPUTE(1, rb);
+    FPSG_LOAD(3, rb);
 #pragma unroll 1
-    for (int c4 = 0; c4 < kSteps; c4 += 2) {              // a step's loads are issued one to two steps ahead
+    for (int c4 = 2; c4 < kSteps; c4 += 2) {              // a step's loads are issued one to two steps ahead
       FPSG_COMPUTE(c4, ra);
       FPSG_LOAD(c4 + 2, ra);                              // clamped to the last step
       FPSG_COMPUTE(c4 + 1, rb);
       FPSG_LOAD(c4 + 3, rb);
     }
 #undef FPSG_COMPUTE
+#undef FPSG_COMPUTE_FIRST
 #undef FPSG_LOAD
     // the compiler does not see MFMAs in the asm statements: cover the MFMA-write -> VALU-read distance by hand
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
