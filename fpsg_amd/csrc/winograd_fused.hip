@@ -78,11 +78,22 @@ __global__ __launch_bounds__(kFusedThreads) void wino4_fused_c64_kernel(const fl
   const int k0 = slice * 16;
   // ulds[(c4*64 + lane)*36 + xi] = U[xi][k0 + lane%16][4*c4 + lane/16]: a lane's 36 A fragments of a
   // step are contiguous (nine 16-byte LDS reads; 8 lanes x 16 B cover the 32 banks once)
-  for (int e = tid; e < kUldsFloats; e += kFusedThreads) {               // reads of U coalesced (c fastest)
-    const int xi = e / (16 * C), rem = e - xi * (16 * C);
-    const int kl = rem >> 6, c = rem & 63;
-    const int c4 = c >> 2, kq = c & 3;
-    ulds[((size_t)c4 * 64 + kq * 16 + kl) * 36 + xi] = U[((size_t)xi * K + k0 + kl) * C + c];
+  // A thread owns (output channel kl, channel group c4) for all 36 transform points: 36 vector loads issued
+  // together (a workgroup reads 4 KB contiguous per point; one round trip instead of one per element), then
+  // four points at a time go to LDS as 16-byte writes (the points are the fastest LDS index).
+  {
+    const int kl = tid >> 4, c4 = tid & 15;
+    const float* up = U + ((size_t)k0 + kl) * C + 4 * c4;
+    v4f ub[36];
+#pragma unroll
+    for (int xi = 0; xi < 36; ++xi) ub[xi] = *reinterpret_cast<const v4f*>(up + (size_t)xi * K * C);
+#pragma unroll
+    for (int kq = 0; kq < 4; ++kq) {
+      v4f* dst = reinterpret_cast<v4f*>(ulds + ((size_t)c4 * 64 + kq * 16 + kl) * 36);
+#pragma unroll
+      for (int x4 = 0; x4 < 9; ++x4)
+        dst[x4] = (v4f){ub[4 * x4][kq], ub[4 * x4 + 1][kq], ub[4 * x4 + 2][kq], ub[4 * x4 + 3][kq]};
+    }
   }
   if (ACT && tid < C) {
     actp[tid] = chan[tid];
@@ -292,8 +303,8 @@ static int wino_conv_fused_launch(const char* fn, const float* x, const float* c
                "%s: K a positive multiple of 16 (<= 1024), H and W positive multiples of 4 "
                "(got K=%d H=%d W=%d)", fn, K, H, W);
   FPSG_REQUIRE_PTR(x); FPSG_REQUIRE_PTR(U); FPSG_REQUIRE_PTR(y);
-  FPSG_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0, FPSG_E_ALIGN,
-               "%s: x and y must be 16-byte aligned", fn);
+  FPSG_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(U)) & 15) == 0,
+               FPSG_E_ALIGN, "%s: x, y and U must be 16-byte aligned", fn);
   FPSG_REQUIRE((size_t)N * C * H * W * sizeof(float) < ((size_t)1 << 32), FPSG_E_LIMIT,
                "%s: x must be below 4 GiB (32-bit lane offsets; got N=%d H=%d W=%d)", fn, N, H, W);
   const long P = (long)N * (H / 4) * (W / 4);

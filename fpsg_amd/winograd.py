@@ -61,8 +61,9 @@ def fused_enabled() -> bool:
     return os.environ.get("FPSG_WINOGRAD_FUSED", "1") != "0"
 
 
-def _can_fuse(m: int, c_in: int, c_out: int) -> bool:
-    return fused_enabled() and m == 4 and c_in == 64 and c_out % 16 == 0
+def _can_fuse(m: int, c_in: int, c_out: int, n_pixels: int) -> bool:
+    """``n_pixels`` = N*H*W of the tensor the kernel reads: K6f addresses it with 32-bit byte offsets (< 4 GiB)."""
+    return fused_enabled() and m == 4 and c_in == 64 and c_out % 16 == 0 and n_pixels * 64 * 4 < (1 << 32)
 
 
 def _wide_enough(c_in: int, c_out: int, m: int) -> bool:
@@ -154,7 +155,7 @@ class _Conv3x3(torch.autograd.Function):
         N, C, H, W = x.shape
         K = w.shape[0]
         with torch.cuda.device(x.device):
-            if _can_fuse(m, C, K):
+            if _can_fuse(m, C, K, N * H * W):
                 y = _fused(x, _filter(m, w, False))
                 keep, kept_is_v = x, False                 # V is rebuilt for the weight gradient
             else:
@@ -174,7 +175,7 @@ class _Conv3x3(torch.autograd.Function):
         gx = gw = None
         with torch.cuda.device(gy.device):
             if ctx.needs_input_grad[0]:
-                if _can_fuse(m, K, C):                     # the data gradient is a convolution K -> C
+                if _can_fuse(m, K, C, N * H * W):                     # the data gradient is a convolution K -> C
                     gx = _fused(gy, _filter(m, w, True))
                 else:
                     gx = _output(m, torch.bmm(_filter(m, w, True), _input(m, gy)), N, H, W)
@@ -228,7 +229,7 @@ class _BNReluConv3x3(torch.autograd.Function):
             _call("fpsg_bn_stats", _hip.ptr(y), opt(pre_bias), opt(gamma), opt(beta), opt(running_mean), opt(running_var),
                   float(momentum), N, C, H * W, 1 if training else 0, float(eps), _hip.ptr(chan), None, None,
                   _hip.ptr(ws), _hip.stream_of(y))
-            if _can_fuse(m, C, K):
+            if _can_fuse(m, C, K, N * H * W):
                 out = _fused_act(y, chan, pre_bias, _filter(m, w, False))
                 V = None                                     # rebuilt for the weight gradient
             else:
@@ -249,7 +250,7 @@ class _BNReluConv3x3(torch.autograd.Function):
         gw = None
         with torch.cuda.device(dev):
             # convolution backward: gradient of the (never stored) activation, and of the filter
-            if _can_fuse(m, K, C):
+            if _can_fuse(m, K, C, N * H * W):
                 ga = _fused(gout, _filter(m, w, True))
             else:
                 ga = _output(m, torch.bmm(_filter(m, w, True), _input(m, gout)), N, H, W)

@@ -307,7 +307,8 @@ int fpsg_wino_filter_grad_transform(int m, const float* dU, int K, int C, float*
  * gradients): y [N,K,H,W] = conv(x [N,64,H,W], w) from U = fpsg_wino_filter_transform(4, w, ...)
  * [36,K,64]; input transform, the 36 MFMA products and the output transform stay on chip -- with 64
  * channels the separate GEMM is bound by the traffic of V and M (2 x 2.25 x the image tensor each
- * way).  C must be 64, K a multiple of 16, H and W multiples of 4; x, y 16-byte aligned.
+ * way).  C must be 64, K a multiple of 16, H and W multiples of 4; x, y, U 16-byte aligned; x below 4 GiB
+ * (32-bit lane offsets; FPSG_E_LIMIT otherwise -- the caller then takes the three-kernel form).
  */
 int fpsg_wino_conv_fused(const float* x, const float* U, int N, int C, int K, int H, int W, float* y,
                          fpsg_stream_t stream);

@@ -35,9 +35,12 @@ def test_winograd_eligibility_needs_gpu_fp32_3x3(monkeypatch):
     with pytest.raises(ValueError):
         wg.conv3x3(torch.randn(1, 4, 6, 8), torch.randn(4, 4, 3, 3), 4)
     monkeypatch.setenv("FPSG_WINOGRAD_FUSED", "0")
-    assert not wg._can_fuse(4, 64, 64)
+    px = 37 * 224 * 224
+    assert not wg._can_fuse(4, 64, 64, px)
     monkeypatch.delenv("FPSG_WINOGRAD_FUSED")
-    assert wg._can_fuse(4, 64, 128) and not wg._can_fuse(4, 128, 64) and not wg._can_fuse(2, 64, 64)
+    assert wg._can_fuse(4, 64, 128, px) and not wg._can_fuse(4, 128, 64, px) and not wg._can_fuse(2, 64, 64, px)
+    # K6f addresses its input with 32-bit byte offsets: 4 GiB and above takes the three-kernel form
+    assert wg._can_fuse(4, 64, 64, (1 << 24) - 1) and not wg._can_fuse(4, 64, 64, 1 << 24)
 
 
 def test_filter_cache_lives_only_inside_weights_frozen():
