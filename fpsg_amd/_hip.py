@@ -66,7 +66,7 @@ SIGNATURES = {
     "fpsg_bn_pool_workspace_floats": [_c_int, _c_int, _c_int, _c_int],
     "fpsg_bn_act_pool_fwd": [_c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, ctypes.c_float, _c_int, _c_int, _c_int, _c_int,
                              _c_int, ctypes.c_float, _c_int, ctypes.c_float, _c_f32p, _c_f32p, _c_f32p, _c_f32p,
-                             _c_f32p, _c_stream],
+                             _c_f32p, _c_f32p, _c_int, _c_stream],
     "fpsg_bn_act_pool_bwd": [_c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
                              ctypes.c_float, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_stream],
     "fpsg_bn_max_workspace_floats": [_c_int, _c_int, _c_int],
@@ -77,6 +77,9 @@ SIGNATURES = {
                             ctypes.c_float, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_stream],
     "fpsg_wino_input_transform": [_c_int, _c_f32p, _c_int, _c_int, _c_int, _c_int, _c_f32p, _c_stream],
     "fpsg_wino_output_transform": [_c_int, _c_f32p, _c_int, _c_int, _c_int, _c_int, _c_f32p, _c_stream],
+    "fpsg_wino_stats_parts": [_c_int, _c_int, _c_int, _c_int],
+    "fpsg_wino_output_transform_stats": [_c_int, _c_f32p, _c_int, _c_int, _c_int, _c_int, _c_f32p, _c_f32p, _c_f32p,
+                                         _c_stream],
     "fpsg_wino_grad_output_transform": [_c_int, _c_f32p, _c_int, _c_int, _c_int, _c_int, _c_f32p, _c_stream],
     "fpsg_wino_filter_transform": [_c_int, _c_f32p, _c_int, _c_int, _c_int, _c_f32p, _c_stream],
     "fpsg_wino_filter_grad_transform": [_c_int, _c_f32p, _c_int, _c_int, _c_f32p, _c_stream],
@@ -84,8 +87,11 @@ SIGNATURES = {
     "fpsg_wino_input_transform_act": [_c_int, _c_f32p, _c_f32p, _c_f32p, _c_int, _c_int, _c_int, _c_int, _c_f32p, _c_stream],
     "fpsg_wino_conv_fused_act": [_c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_f32p,
                                  _c_stream],
+    "fpsg_wino_conv_fused_parts": [_c_int, _c_int, _c_int, _c_int],
+    "fpsg_wino_conv_fused_stats": [_c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_f32p,
+                                   _c_f32p, _c_f32p, _c_stream],
     "fpsg_bn_stats": [_c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, ctypes.c_float, _c_int, _c_int, _c_int, _c_int,
-                      ctypes.c_float, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_stream],
+                      ctypes.c_float, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_int, _c_stream],
     "fpsg_conv_first_dw_workspace_floats": [_c_int, _c_int, _c_int],
     "fpsg_conv_first_dw": [_c_f32p, _c_f32p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_f32p, _c_f32p, _c_stream],
     "fpsg_adam_step": [_c_f32p, _c_f32p, _c_f32p, _c_f32p, ctypes.c_size_t, ctypes.c_float, ctypes.c_float,

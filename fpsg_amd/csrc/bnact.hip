@@ -123,8 +123,8 @@ __global__ __launch_bounds__(kBnThreads) void bn_reduce_kernel(
 
 // forward finalize: mean / biased var -> chan = (scale, shift, mean, rstd); optional outputs of
 // the batch mean and UNBIASED variance (what running statistics are updated with).
-// One wave per channel: lane s holds slice s of the channel's partial sums (S <= 64), fixed
-// shuffle tree in fp64.
+// One wave per channel: lane s sums slices s, s + 64, ... of the channel's partial sums in fp64 (K5's own passes
+// use S <= 64; a convolution's epilogue delivers one slice per workgroup), then a fixed shuffle tree.
 __device__ __forceinline__ void wave_sum2(double& a, double& b) {
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) { a += __shfl_down(a, off, 64); b += __shfl_down(b, off, 64); }
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(64) void bn_fwd_finalize_kernel(const float* __rest
                                        float* __restrict__ run_var, float momentum) {
   const int c = blockIdx.x, lane = threadIdx.x;
   double s0 = 0.0, s1 = 0.0;
-  if (lane < S) { s0 = part[((size_t)c * S + lane) * 2]; s1 = part[((size_t)c * S + lane) * 2 + 1]; }
+  for (int sl = lane; sl < S; sl += 64) { s0 += part[((size_t)c * S + sl) * 2]; s1 += part[((size_t)c * S + sl) * 2 + 1]; }
   wave_sum2(s0, s1);
   if (lane != 0) return;
   const double mean = s0 / count;
@@ -901,7 +901,7 @@ extern "C" int fpsg_bn_act_fwd(const float* x, const float* pre_bias, const floa
 extern "C" int fpsg_bn_stats(const float* x, const float* pre_bias, const float* gamma, const float* beta,
                              float* running_mean, float* running_var, float momentum, int N, int C, int L,
                              int training, float eps, float* chan, float* batch_mean, float* batch_var_unbiased,
-                             float* ws, fpsg_stream_t stream) {
+                             float* ws, const float* parts, int n_parts, fpsg_stream_t stream) {
   using namespace fpsg;
   int rc = check_dims("fpsg_bn_stats", N, C, L, kActNone);
   if (rc) return rc;
@@ -909,11 +909,16 @@ extern "C" int fpsg_bn_stats(const float* x, const float* pre_bias, const float*
   FPSG_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0, FPSG_E_ALIGN, "fpsg_bn_stats: x must be 16-byte aligned");
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (training) {
-    FPSG_REQUIRE_PTR(ws);
-    const int S = slices_for(N, L);
-    launch_reduce<0>(kActNone, x, nullptr, nullptr, pre_bias, N, C, L, S, 0.0f, ws, s);
-    if ((rc = launch_status("fpsg_bn_stats(stats)"))) return rc;
-    hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3(C), dim3(64), 0, s, ws, gamma, beta, C, S,
+    int S = n_parts;
+    if (parts) {
+      FPSG_REQUIRE(n_parts > 0, FPSG_E_SHAPE, "fpsg_bn_stats: n_parts must be positive with parts (got %d)", n_parts);
+    } else {
+      FPSG_REQUIRE_PTR(ws);
+      S = slices_for(N, L);
+      launch_reduce<0>(kActNone, x, nullptr, nullptr, pre_bias, N, C, L, S, 0.0f, ws, s);
+      if ((rc = launch_status("fpsg_bn_stats(stats)"))) return rc;
+    }
+    hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3(C), dim3(64), 0, s, parts ? parts : ws, gamma, beta, C, S,
                        (double)N * (double)L, eps, chan, batch_mean, batch_var_unbiased, running_mean, running_var,
                        momentum);
     return launch_status("fpsg_bn_stats(finalize)");
@@ -966,7 +971,8 @@ extern "C" size_t fpsg_bn_pool_workspace_floats(int N, int C, int H, int W) {
 extern "C" int fpsg_bn_act_pool_fwd(const float* x, const float* pre_bias, const float* gamma, const float* beta,
                                     float* running_mean, float* running_var, float momentum, int N, int C, int H, int W,
                                     int training, float eps, int act, float slope, float* y_pooled, float* chan,
-                                    float* batch_mean, float* batch_var_unbiased, float* ws, fpsg_stream_t stream) {
+                                    float* batch_mean, float* batch_var_unbiased, float* ws, const float* parts,
+                                    int n_parts, fpsg_stream_t stream) {
   using namespace fpsg;
   int rc = check_pool_dims("fpsg_bn_act_pool_fwd", N, C, H, W, act);
   if (rc) return rc;
@@ -976,11 +982,16 @@ extern "C" int fpsg_bn_act_pool_fwd(const float* x, const float* pre_bias, const
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int L = H * W;
   if (training) {
-    FPSG_REQUIRE_PTR(ws);
-    const int S = slices_for(N, L);
-    launch_reduce<0>(kActNone, x, nullptr, nullptr, pre_bias, N, C, L, S, 0.0f, ws, s);
-    if ((rc = launch_status("fpsg_bn_act_pool_fwd(stats)"))) return rc;
-    hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3(C), dim3(64), 0, s, ws, gamma, beta, C, S,
+    int S = n_parts;
+    if (parts) {
+      FPSG_REQUIRE(n_parts > 0, FPSG_E_SHAPE, "fpsg_bn_act_pool_fwd: n_parts must be positive with parts (got %d)", n_parts);
+    } else {
+      FPSG_REQUIRE_PTR(ws);
+      S = slices_for(N, L);
+      launch_reduce<0>(kActNone, x, nullptr, nullptr, pre_bias, N, C, L, S, 0.0f, ws, s);
+      if ((rc = launch_status("fpsg_bn_act_pool_fwd(stats)"))) return rc;
+    }
+    hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3(C), dim3(64), 0, s, parts ? parts : ws, gamma, beta, C, S,
                        (double)N * (double)L, eps, chan, batch_mean, batch_var_unbiased, running_mean, running_var,
                        momentum);
     if ((rc = launch_status("fpsg_bn_act_pool_fwd(finalize)"))) return rc;

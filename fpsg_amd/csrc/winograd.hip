@@ -198,13 +198,22 @@ __global__ __launch_bounds__(kWinoThreads) void wino_input_kernel(const float* _
   }
 }
 
-template <int M>
+// STATS: the kernel also accumulates, per output channel, the partial sums a following BatchNorm needs --
+// sum(y + bias[k]) and sum((y + bias[k])^2) over the workgroup's 256 tiles -> parts[k][blockIdx.x][2] (per thread 16
+// pixels in row order, then the wave's fixed tree, then the four waves in order: deterministic).  K5's
+// statistics pass over y (one read of the tensor) is then not needed (fpsg_bn_stats with parts).
+template <int M, bool STATS>
 __global__ __launch_bounds__(kWinoThreads) void wino_output_kernel(const float* __restrict__ Mt, int K, int H, int W,
-                                                                    int Th, int Tw, long P, float* __restrict__ y) {
+                                                                    int Th, int Tw, long P, float* __restrict__ y,
+                                                                    const float* __restrict__ bias,
+                                                                    float* __restrict__ parts) {
   constexpr int A = Wino<M>::A;
   typedef float vout __attribute__((ext_vector_type(M)));
-  const long p = (long)blockIdx.x * kWinoThreads + threadIdx.x;
-  if (p >= P) return;
+  __shared__ float red[2 * (kWinoThreads / kWave)];
+  const long p_raw = (long)blockIdx.x * kWinoThreads + threadIdx.x;
+  const bool live = p_raw < P;
+  if (!STATS && !live) return;
+  const long p = live ? p_raw : P - 1;          // (STATS) dead lanes stay for the reduction and add nothing
   const int k = blockIdx.y;
   const TileIndex ti = tile_of(p, Th, Tw);
   const size_t plane = (size_t)K * P;
@@ -218,6 +227,8 @@ __global__ __launch_bounds__(kWinoThreads) void wino_output_kernel(const float* 
     Wino<M>::out(m, s[j]);
   }
   float* yp = y + (((size_t)ti.n * K + k) * H + M * ti.th) * W + M * ti.tw;
+  const float b = (STATS && bias) ? bias[k] : 0.0f;
+  float a0 = 0.0f, a1 = 0.0f;
 #pragma unroll
   for (int i = 0; i < M; ++i) {
     float row[A], o[M];
@@ -227,7 +238,30 @@ __global__ __launch_bounds__(kWinoThreads) void wino_output_kernel(const float* 
     vout ov;
 #pragma unroll
     for (int j = 0; j < M; ++j) ov[j] = o[j];
-    *reinterpret_cast<vout*>(yp + (size_t)i * W) = ov;
+    if (live) *reinterpret_cast<vout*>(yp + (size_t)i * W) = ov;
+    if (STATS) {
+#pragma unroll
+      for (int j = 0; j < M; ++j) {
+        const float v = live ? o[j] + b : 0.0f;
+        a0 += v;
+        a1 = fma_rn(v, v, a1);
+      }
+    }
+  }
+  if (STATS) {
+    a0 = wave_sum(a0);
+    a1 = wave_sum(a1);
+    const int wave = threadIdx.x / kWave;
+    if ((threadIdx.x & (kWave - 1)) == 0) { red[2 * wave] = a0; red[2 * wave + 1] = a1; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float t0 = red[0], t1 = red[1];
+#pragma unroll
+      for (int w = 1; w < kWinoThreads / kWave; ++w) { t0 += red[2 * w]; t1 += red[2 * w + 1]; }
+      float* out = parts + ((size_t)k * gridDim.x + blockIdx.x) * 2;
+      out[0] = t0;
+      out[1] = t1;
+    }
   }
 }
 
@@ -385,8 +419,34 @@ extern "C" int fpsg_wino_output_transform(int m, const float* M, int N, int K, i
   if (rc) return rc;
   FPSG_REQUIRE_PTR(M); FPSG_REQUIRE_PTR(y);
   FPSG_REQUIRE((reinterpret_cast<uintptr_t>(y) & 15) == 0, FPSG_E_ALIGN, "fpsg_wino_output_transform: y must be 16-byte aligned");
-  FPSG_WINO_IMAGE_LAUNCH(wino_output_kernel, K, M, K, H, W, H / m, W / m, P, y);
+  const long P = (long)N * (H / m) * (W / m);
+  dim3 grid((unsigned)((P + kWinoThreads - 1) / kWinoThreads), K);
+  hipStream_t hs = static_cast<hipStream_t>(stream);
+  if (m == 2) hipLaunchKernelGGL((wino_output_kernel<2, false>), grid, dim3(kWinoThreads), 0, hs, M, K, H, W, H / m, W / m, P, y, nullptr, nullptr);
+  else hipLaunchKernelGGL((wino_output_kernel<4, false>), grid, dim3(kWinoThreads), 0, hs, M, K, H, W, H / m, W / m, P, y, nullptr, nullptr);
   return launch_status("fpsg_wino_output_transform");
+}
+
+extern "C" int fpsg_wino_stats_parts(int m, int N, int H, int W) {
+  if ((m != 2 && m != 4) || N <= 0 || H <= 0 || W <= 0 || H % m || W % m) return 0;
+  const long P = (long)N * (H / m) * (W / m);
+  return (int)((P + fpsg::kWinoThreads - 1) / fpsg::kWinoThreads);
+}
+
+extern "C" int fpsg_wino_output_transform_stats(int m, const float* M, int N, int K, int H, int W, float* y,
+                                                const float* bias, float* parts, fpsg_stream_t stream) {
+  using namespace fpsg;
+  int rc = check_image("fpsg_wino_output_transform_stats", m, N, K, H, W);
+  if (rc) return rc;
+  FPSG_REQUIRE_PTR(M); FPSG_REQUIRE_PTR(y); FPSG_REQUIRE_PTR(parts);
+  FPSG_REQUIRE((reinterpret_cast<uintptr_t>(y) & 15) == 0, FPSG_E_ALIGN, "fpsg_wino_output_transform_stats: y must be 16-byte aligned");
+  FPSG_REQUIRE(!misaligned4(bias) && !misaligned4(parts), FPSG_E_ALIGN, "fpsg_wino_output_transform_stats: bias / parts not 4-byte aligned");
+  const long P = (long)N * (H / m) * (W / m);
+  dim3 grid((unsigned)((P + kWinoThreads - 1) / kWinoThreads), K);
+  hipStream_t hs = static_cast<hipStream_t>(stream);
+  if (m == 2) hipLaunchKernelGGL((wino_output_kernel<2, true>), grid, dim3(kWinoThreads), 0, hs, M, K, H, W, H / m, W / m, P, y, bias, parts);
+  else hipLaunchKernelGGL((wino_output_kernel<4, true>), grid, dim3(kWinoThreads), 0, hs, M, K, H, W, H / m, W / m, P, y, bias, parts);
+  return launch_status("fpsg_wino_output_transform_stats");
 }
 
 extern "C" int fpsg_wino_grad_output_transform(int m, const float* dy, int N, int K, int H, int W, float* dM,

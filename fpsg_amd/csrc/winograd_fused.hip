@@ -59,13 +59,19 @@ __device__ __forceinline__ void out4(const float (&m)[6], float (&s)[4]) {
 
 // ACT: x is the PRE-BatchNorm output of the previous convolution; the patch values are
 // relu(fma(x + pre_bias[c], scale[c], shift[c])) (K5's apply arithmetic), padding stays zero.
-template <bool ACT>
+// STATS: per output channel the partial sums sum(y + out_bias[k]), sum((y + out_bias[k])^2) over the workgroup's
+// tiles -> parts[k][index of the workgroup in its slice][2] for the BatchNorm that follows (fpsg_bn_stats with
+// parts): a lane keeps the sums of its 4 channels over its tile groups, then its row of 16 lanes (fixed DPP tree),
+// then the four waves in order.  Deterministic.
+template <bool ACT, bool STATS>
 __global__ __launch_bounds__(kFusedThreads) void wino4_fused_c64_kernel(const float* __restrict__ x,
                                                                         const float* __restrict__ U /*[36][K][64]*/,
                                                                         int K, int H, int W, int Th, int Tw, long P,
                                                                         int S, float* __restrict__ y,
                                                                         const float* __restrict__ chan,
-                                                                        const float* __restrict__ pre_bias) {
+                                                                        const float* __restrict__ pre_bias,
+                                                                        const float* __restrict__ out_bias,
+                                                                        float* __restrict__ parts) {
   extern __shared__ __attribute__((aligned(16))) float ulds[];      // [36][kSteps][64] A fragments | [3][64] scale, shift, pre-bias
   constexpr int C = 64;
   float* actp = ulds + kUldsFloats;
@@ -104,6 +110,11 @@ __global__ __launch_bounds__(kFusedThreads) void wino4_fused_c64_kernel(const fl
   // x as a buffer resource: loads are `descriptor + 32-bit lane offset + scalar step offset` (no address VALU)
   const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(x), 0, (int)(P * 16 * C * sizeof(float)), 0x00020000);
+  float st0[4] = {0.0f, 0.0f, 0.0f, 0.0f}, st1[4] = {0.0f, 0.0f, 0.0f, 0.0f}, ob[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+  if (STATS && out_bias) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) ob[r] = out_bias[k0 + 4 * kk + r];
+  }
   const long G = (P + 15) >> 4;
   for (long g = (long)j * 4 + wave; g < G; g += 4L * per_slice) {
     const long p_raw = g * 16 + col;
@@ -286,8 +297,40 @@ __global__ __launch_bounds__(kFusedThreads) void wino4_fused_c64_kernel(const fl
           for (int c = 0; c < 6; ++c) rowv[c] = s[c][a];
           out4(rowv, o);
           *reinterpret_cast<v4f*>(yp + (size_t)a * W) = (v4f){o[0], o[1], o[2], o[3]};
+          if (STATS) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const float v = o[u] + ob[r];
+              st0[r] += v;
+              st1[r] = fma_rn(v, v, st1[r]);
+            }
+          }
         }
       }
+    }
+  }
+  if (STATS) {
+    __syncthreads();                                      // every wave is done with the U slice: reuse its LDS
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float a0 = st0[r], a1 = st1[r];
+      a0 += __uint_as_float(lane_xor<1>(__float_as_uint(a0))); a1 += __uint_as_float(lane_xor<1>(__float_as_uint(a1)));
+      a0 += __uint_as_float(lane_xor<2>(__float_as_uint(a0))); a1 += __uint_as_float(lane_xor<2>(__float_as_uint(a1)));
+      a0 += __uint_as_float(lane_xor<4>(__float_as_uint(a0))); a1 += __uint_as_float(lane_xor<4>(__float_as_uint(a1)));
+      a0 += __uint_as_float(lane_xor<8>(__float_as_uint(a0))); a1 += __uint_as_float(lane_xor<8>(__float_as_uint(a1)));
+      if (col == 0) {
+        ulds[((wave * 4 + kk) * 4 + r) * 2] = a0;
+        ulds[((wave * 4 + kk) * 4 + r) * 2 + 1] = a1;
+      }
+    }
+    __syncthreads();
+    if (tid < 16) {                                       // tid = 4 * kk + r: channel k0 + tid
+      float t0 = 0.0f, t1 = 0.0f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) { t0 += ulds[(w * 16 + tid) * 2]; t1 += ulds[(w * 16 + tid) * 2 + 1]; }
+      float* out = parts + ((size_t)(k0 + tid) * per_slice + j) * 2;
+      out[0] = t0;
+      out[1] = t1;
     }
   }
 }
@@ -295,8 +338,18 @@ __global__ __launch_bounds__(kFusedThreads) void wino4_fused_c64_kernel(const fl
 }  // namespace
 }  // namespace fpsg
 
+static long wino_fused_per_slice(long P, int S) {
+  // one workgroup per CU (LDS), a multiple of 8*S workgroups; never more than the tile groups need
+  const long G = (P + 15) / 16;
+  long per_slice = (256 + S - 1) / S;
+  const long need = (G + 3) / 4;
+  if (per_slice > need) per_slice = need;
+  return ((per_slice + 7) / 8) * 8;
+}
+
 static int wino_conv_fused_launch(const char* fn, const float* x, const float* chan, const float* pre_bias,
-                                  const float* U, int N, int C, int K, int H, int W, float* y, fpsg_stream_t stream) {
+                                  const float* U, int N, int C, int K, int H, int W, float* y, const float* out_bias,
+                                  float* parts, fpsg_stream_t stream) {
   using namespace fpsg;
   FPSG_REQUIRE(C == 64, FPSG_E_SHAPE, "%s: C must be 64 (got %d)", fn, C);
   FPSG_REQUIRE(N > 0 && K > 0 && K % 16 == 0 && K <= 1024 && H > 0 && W > 0 && H % 4 == 0 && W % 4 == 0, FPSG_E_SHAPE,
@@ -305,37 +358,31 @@ static int wino_conv_fused_launch(const char* fn, const float* x, const float* c
   FPSG_REQUIRE_PTR(x); FPSG_REQUIRE_PTR(U); FPSG_REQUIRE_PTR(y);
   FPSG_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(U)) & 15) == 0,
                FPSG_E_ALIGN, "%s: x, y and U must be 16-byte aligned", fn);
+  FPSG_REQUIRE(!misaligned4(out_bias) && !misaligned4(parts), FPSG_E_ALIGN, "%s: out_bias / parts not 4-byte aligned", fn);
   FPSG_REQUIRE((size_t)N * C * H * W * sizeof(float) < ((size_t)1 << 32), FPSG_E_LIMIT,
                "%s: x must be below 4 GiB (32-bit lane offsets; got N=%d H=%d W=%d)", fn, N, H, W);
   const long P = (long)N * (H / 4) * (W / 4);
   const int S = K / 16;
   const size_t lds_bytes = (size_t)(kUldsFloats + 3 * 64) * sizeof(float);
-  const void* kern = chan ? reinterpret_cast<const void*>(wino4_fused_c64_kernel<true>)
-                          : reinterpret_cast<const void*>(wino4_fused_c64_kernel<false>);
-  const hipError_t lds_optin = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  typedef void (*kern_t)(const float*, const float*, int, int, int, int, int, long, int, float*, const float*,
+                         const float*, const float*, float*);
+  const kern_t kern = chan ? (parts ? wino4_fused_c64_kernel<true, true> : wino4_fused_c64_kernel<true, false>)
+                           : (parts ? wino4_fused_c64_kernel<false, true> : wino4_fused_c64_kernel<false, false>);
+  const hipError_t lds_optin = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (lds_optin != hipSuccess) {
     set_error("%s: cannot reserve %zu B of LDS: %s", fn, lds_bytes, hipGetErrorString(lds_optin));
     return static_cast<int>(lds_optin);
   }
-  // one workgroup per CU (LDS), a multiple of 8*S workgroups; never more than the tile groups need
-  const long G = (P + 15) / 16;
-  long per_slice = (256 + S - 1) / S;
-  const long need = (G + 3) / 4;
-  if (per_slice > need) per_slice = need;
-  per_slice = ((per_slice + 7) / 8) * 8;
-  dim3 grid((unsigned)(per_slice * S));
-  if (chan)
-    hipLaunchKernelGGL(wino4_fused_c64_kernel<true>, grid, dim3(kFusedThreads), lds_bytes,
-                       static_cast<hipStream_t>(stream), x, U, K, H, W, H / 4, W / 4, P, S, y, chan, pre_bias);
-  else
-    hipLaunchKernelGGL(wino4_fused_c64_kernel<false>, grid, dim3(kFusedThreads), lds_bytes,
-                       static_cast<hipStream_t>(stream), x, U, K, H, W, H / 4, W / 4, P, S, y, nullptr, nullptr);
+  dim3 grid((unsigned)(wino_fused_per_slice(P, S) * S));
+  hipLaunchKernelGGL(kern, grid, dim3(kFusedThreads), lds_bytes, static_cast<hipStream_t>(stream), x, U, K, H, W, H / 4,
+                     W / 4, P, S, y, chan, pre_bias, out_bias, parts);
   return launch_status(fn);
 }
 
 extern "C" int fpsg_wino_conv_fused(const float* x, const float* U, int N, int C, int K, int H, int W, float* y,
                                     fpsg_stream_t stream) {
-  return wino_conv_fused_launch("fpsg_wino_conv_fused", x, nullptr, nullptr, U, N, C, K, H, W, y, stream);
+  return wino_conv_fused_launch("fpsg_wino_conv_fused", x, nullptr, nullptr, U, N, C, K, H, W, y, nullptr, nullptr, stream);
 }
 
 extern "C" int fpsg_wino_conv_fused_act(const float* x, const float* chan, const float* pre_bias, const float* U,
@@ -343,5 +390,19 @@ extern "C" int fpsg_wino_conv_fused_act(const float* x, const float* chan, const
   using namespace fpsg;
   FPSG_REQUIRE_PTR(chan);
   FPSG_REQUIRE(!misaligned4(pre_bias), FPSG_E_ALIGN, "fpsg_wino_conv_fused_act: pre_bias not 4-byte aligned");
-  return wino_conv_fused_launch("fpsg_wino_conv_fused_act", x, chan, pre_bias, U, N, C, K, H, W, y, stream);
+  return wino_conv_fused_launch("fpsg_wino_conv_fused_act", x, chan, pre_bias, U, N, C, K, H, W, y, nullptr, nullptr, stream);
+}
+
+extern "C" int fpsg_wino_conv_fused_parts(int N, int K, int H, int W) {
+  if (N <= 0 || K <= 0 || K % 16 || H <= 0 || W <= 0 || H % 4 || W % 4) return 0;
+  return (int)wino_fused_per_slice((long)N * (H / 4) * (W / 4), K / 16);
+}
+
+extern "C" int fpsg_wino_conv_fused_stats(const float* x, const float* chan, const float* pre_bias, const float* U,
+                                          int N, int C, int K, int H, int W, float* y, const float* out_bias,
+                                          float* parts, fpsg_stream_t stream) {
+  using namespace fpsg;
+  FPSG_REQUIRE_PTR(parts);
+  FPSG_REQUIRE(!misaligned4(pre_bias), FPSG_E_ALIGN, "fpsg_wino_conv_fused_stats: pre_bias not 4-byte aligned");
+  return wino_conv_fused_launch("fpsg_wino_conv_fused_stats", x, chan, pre_bias, U, N, C, K, H, W, y, out_bias, parts, stream);
 }

@@ -101,19 +101,23 @@ class _BNActPool(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, running_mean, running_var, training, eps, act_code, slope, pre_bias,
-                momentum=-1.0):
+                momentum=-1.0, parts=None):
+        """``parts``: statistics partial sums of ``x + pre_bias`` delivered by the producing convolution."""
         N, C, H, W = x.shape
         lib = _hip.load()
         dev = x.device
         yp = torch.empty((N, C, H // 2, W // 2), dtype=torch.float32, device=dev)
         chan = torch.empty((4, C), dtype=torch.float32, device=dev)
-        ws = torch.empty((lib.fpsg_bn_pool_workspace_floats(N, C, H, W),), dtype=torch.float32, device=dev)
+        use_parts = parts is not None and training
+        ws = None if use_parts else torch.empty((lib.fpsg_bn_pool_workspace_floats(N, C, H, W),), dtype=torch.float32,
+                                                device=dev)
         opt = lambda t: _hip.ptr(t) if t is not None else None
         with torch.cuda.device(dev):
             rc = lib.fpsg_bn_act_pool_fwd(_hip.ptr(x), opt(pre_bias), opt(weight), opt(bias), opt(running_mean),
                                           opt(running_var), float(momentum), N, C, H, W, 1 if training else 0,
                                           float(eps), act_code, float(slope), _hip.ptr(yp), _hip.ptr(chan), None, None,
-                                          _hip.ptr(ws), _hip.stream_of(x))
+                                          opt(ws), _hip.ptr(parts) if use_parts else None,
+                                          parts.shape[1] if use_parts else 0, _hip.stream_of(x))
         _hip.check(rc, "fpsg_bn_act_pool_fwd")
         ctx.save_for_backward(x, chan, pre_bias)
         ctx.cfg = (N, C, H, W, training, act_code, slope, weight is not None, bias is not None)
@@ -140,7 +144,8 @@ class _BNActPool(torch.autograd.Function):
                                           _hip.ptr(dpb) if want_dpb else None, _hip.ptr(coef), _hip.ptr(ws),
                                           _hip.stream_of(x))
         _hip.check(rc, "fpsg_bn_act_pool_bwd")
-        return dx, (dgamma if has_w else None), (dbeta if has_b else None), None, None, None, None, None, None, dpb, None
+        return (dx, (dgamma if has_w else None), (dbeta if has_b else None), None, None, None, None, None, None, dpb, None,
+                None)
 
 
 class _BNActMax(torch.autograd.Function):
@@ -252,12 +257,24 @@ def _is_pointwise(conv) -> bool:
             and conv.padding == (0,) and conv.dilation == (1,) and conv.groups == 1)
 
 
-def _conv_without_bias(conv, x):
+def wants_conv_stats(conv, bn, x) -> bool:
+    """The convolution's epilogue should deliver the statistics of ``bn`` (training mode, a Winograd layer, planes
+    large enough for the consumers that take them: the pooled K5 pass and the fold into the next convolution)."""
+    return (bn.training and winograd.stats_enabled() and isinstance(conv, nn.Conv2d) and x.dim() == 4
+            and x.shape[0] * x.shape[2] * x.shape[3] > 16384 and winograd.eligible(x, conv))
+
+
+def _conv_without_bias(conv, x, want_parts: bool = False):
     """The convolution of ``conv`` without its bias: K6 (Winograd transforms + MFMA batched GEMM)
     for the 3x3 layers; a batched GEMM for the 1x1 ``Conv1d`` of the shared MLPs (the library
     convolution wraps the same product in NHWC transposes of ``[B,1024,N]`` tensors for its
     weight gradient, and its GEMM kernel is not covered by the recorded kernel choices); the
-    library convolution otherwise."""
+    library convolution otherwise.  ``want_parts``: -> ``(y, parts)``, the statistics partial sums of ``y + conv.bias``
+    from the convolution's epilogue (None where the kernel does not deliver them)."""
+    if want_parts:
+        if isinstance(conv, nn.Conv2d) and winograd.eligible(x, conv):
+            return winograd.conv3x3(x, conv.weight, stats_bias=conv.bias, want_parts=True)
+        return _conv_without_bias(conv, x), None
     if isinstance(conv, nn.Conv2d) and winograd.eligible(x, conv):
         return winograd.conv3x3(x, conv.weight)
     if isinstance(conv, nn.Conv2d) and conv_first.eligible(x, conv):
@@ -290,8 +307,9 @@ def bn_act_of(y: torch.Tensor, conv, bn, act=None) -> torch.Tensor:
     return bn_act(bn, y, act, pre_bias=conv.bias)
 
 
-def bn_act_pool_of(y: torch.Tensor, conv, bn, pool, act=None) -> torch.Tensor:
-    """``pool(act(bn(y + conv.bias)))`` for the bias-free output ``y`` of ``conv`` (K5 pooled variant)."""
+def bn_act_pool_of(y: torch.Tensor, conv, bn, pool, act=None, parts=None) -> torch.Tensor:
+    """``pool(act(bn(y + conv.bias)))`` for the bias-free output ``y`` of ``conv`` (K5 pooled variant); ``parts``:
+    the statistics partial sums the convolution delivered with ``y``."""
     if not _pool_eligible(y, pool):
         return pool(bn_act_of(y, conv, bn, act))
     training = bn.training
@@ -300,7 +318,7 @@ def bn_act_pool_of(y: torch.Tensor, conv, bn, pool, act=None) -> torch.Tensor:
     act_code, slope = _parse_act(act)
     m = (0.1 if bn.momentum is None else float(bn.momentum)) if training else -1.0
     return _BNActPool.apply(y.contiguous(), bn.weight, bn.bias, bn.running_mean, bn.running_var, bool(training),
-                            bn.eps, act_code, slope, conv.bias, m)
+                            bn.eps, act_code, slope, conv.bias, m, parts)
 
 
 def conv_bn_act(conv: nn.modules.conv._ConvNd, bn: nn.modules.batchnorm._BatchNorm, x: torch.Tensor,

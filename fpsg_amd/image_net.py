@@ -18,7 +18,7 @@ import torch.nn as nn
 
 from . import winograd
 from .fused_bn import (_conv_without_bias, bn_act, bn_act_of, bn_act_pool_of, conv_bn_act, conv_bn_act_pool,
-                       foldable_into, fusable_conv)
+                       foldable_into, fusable_conv, wants_conv_stats)
 
 # VGG-16 ("configuration D"): channel widths, 'P' = 2x2 max-pool
 _VGG16_PLAN = (64, 64, "P", 128, 128, "P", 256, 256, 256, "P", 512, 512, 512, "P", 512, 512,
@@ -76,7 +76,7 @@ class ImageEncoderWarpper(nn.Module):
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         layers = list(self.img_feature_extractor)
         i = 0
-        pending = None      # (y, conv, bn): bias-free output of `conv` whose BatchNorm + ReLU the next conv applies
+        pending = None      # (y, conv, bn, parts): bias-free output of `conv` whose BatchNorm + ReLU the next conv applies
         while i < len(layers):
             layer = layers[i]
             triple = (isinstance(layer, nn.Conv2d) and i + 2 < len(layers) and isinstance(layers[i + 1], nn.BatchNorm2d)
@@ -86,20 +86,27 @@ class ImageEncoderWarpper(nn.Module):
                 # conv (bias-free) -> K5: bias + BatchNorm + ReLU in one pass, bias gradient from its dx
                 # pass; a stage's closing 2x2 max-pool joins the same pass; between two Winograd
                 # convolutions of a stage the BatchNorm + ReLU apply is folded into the second one's load
+                # the convolution's epilogue also sums y + bias and its square per channel: the BatchNorm that
+                # follows takes its statistics from those partial sums instead of reading y again
+                want = wants_conv_stats(layer, bn, x)
+                parts = None
                 if pending is not None:
-                    py, pconv, pbn = pending
-                    y = winograd.bn_relu_conv3x3(py, pconv.bias, pbn, layer.weight)
+                    py, pconv, pbn, pparts = pending
+                    y = winograd.bn_relu_conv3x3(py, pconv.bias, pbn, layer.weight, parts=pparts,
+                                                 stats_bias=layer.bias, want_parts=want)
                     pending = None
                 else:
-                    y = _conv_without_bias(layer, x)
+                    y = _conv_without_bias(layer, x, want)
+                if want:
+                    y, parts = y
                 nxt = layers[i + 3] if i + 3 < len(layers) else None
                 next_is_triple = (isinstance(nxt, nn.Conv2d) and i + 5 < len(layers)
                                   and isinstance(layers[i + 4], nn.BatchNorm2d) and isinstance(layers[i + 5], nn.ReLU))
                 if isinstance(nxt, nn.MaxPool2d):
-                    x = bn_act_pool_of(y, layer, bn, nxt, "relu")
+                    x = bn_act_pool_of(y, layer, bn, nxt, "relu", parts)
                     i += 4
                 elif next_is_triple and fusable_conv(nxt, layers[i + 4], y) and foldable_into(y, bn, nxt):
-                    pending = (y, layer, bn)
+                    pending = (y, layer, bn, parts)
                     x = y                     # placeholder: the next iteration consumes `pending`
                     i += 3
                 else:

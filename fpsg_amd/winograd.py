@@ -118,11 +118,37 @@ def _input(m, x):
     return V
 
 
-def _output(m, M, N, H, W):
+def stats_enabled() -> bool:
+    """The output transform also accumulates the statistics of the BatchNorm that follows the convolution
+    (K5's statistics pass then does not read the tensor again).  ``FPSG_CONV_STATS=0`` switches it off (A/B)."""
+    return os.environ.get("FPSG_CONV_STATS", "1") != "0"
+
+
+def _output(m, M, N, H, W, stats_bias=None, want_parts=False):
+    """``want_parts``: -> (y, parts [K, S, 2]) with the per-workgroup partial sums of ``y + stats_bias`` and its square."""
     K = M.shape[1]
     y = torch.empty((N, K, H, W), dtype=torch.float32, device=M.device)
-    _call("fpsg_wino_output_transform", m, _hip.ptr(M), N, K, H, W, _hip.ptr(y), _hip.stream_of(M))
-    return y
+    if not want_parts:
+        _call("fpsg_wino_output_transform", m, _hip.ptr(M), N, K, H, W, _hip.ptr(y), _hip.stream_of(M))
+        return y
+    S = _hip.load().fpsg_wino_stats_parts(m, N, H, W)
+    parts = torch.empty((K, S, 2), dtype=torch.float32, device=M.device)
+    _call("fpsg_wino_output_transform_stats", m, _hip.ptr(M), N, K, H, W, _hip.ptr(y),
+          _hip.ptr(stats_bias) if stats_bias is not None else None, _hip.ptr(parts), _hip.stream_of(M))
+    return y, parts
+
+
+def _fused_stats(x, chan, pre_bias, U, stats_bias):
+    """K6f (plain: ``chan`` None; or applying BatchNorm + ReLU while loading) -> (y, parts [K, S, 2])."""
+    N, C, H, W = x.shape
+    K = U.shape[1]
+    y = torch.empty((N, K, H, W), dtype=torch.float32, device=x.device)
+    S = _hip.load().fpsg_wino_conv_fused_parts(N, K, H, W)
+    parts = torch.empty((K, S, 2), dtype=torch.float32, device=x.device)
+    opt = lambda t: _hip.ptr(t) if t is not None else None
+    _call("fpsg_wino_conv_fused_stats", _hip.ptr(x), opt(chan), opt(pre_bias), _hip.ptr(U), N, C, K, H, W, _hip.ptr(y),
+          opt(stats_bias), _hip.ptr(parts), _hip.stream_of(x))
+    return y, parts
 
 
 def _fused(x, U):
@@ -149,25 +175,40 @@ def _filter_grad(m, dU, like):
 
 
 class _Conv3x3(torch.autograd.Function):
+    """``want_parts``: the op returns ``(y, parts)``; ``parts`` (not differentiable) are the
+    statistics partial sums of ``y + stats_bias`` for the BatchNorm that follows (``_output``)."""
+
     @staticmethod
-    def forward(ctx, x, w, m):
+    def forward(ctx, x, w, m, stats_bias=None, want_parts=False):
         x, w = x.contiguous(), w.contiguous()
         N, C, H, W = x.shape
         K = w.shape[0]
+        parts = None
         with torch.cuda.device(x.device):
             if _can_fuse(m, C, K, N * H * W):
-                y = _fused(x, _filter(m, w, False))
+                if want_parts:
+                    y, parts = _fused_stats(x, None, None, _filter(m, w, False), stats_bias)
+                else:
+                    y = _fused(x, _filter(m, w, False))
                 keep, kept_is_v = x, False                 # V is rebuilt for the weight gradient
             else:
                 V = _input(m, x)
-                y = _output(m, torch.bmm(_filter(m, w, False), V), N, H, W)
+                Mt = torch.bmm(_filter(m, w, False), V)
+                if want_parts:
+                    y, parts = _output(m, Mt, N, H, W, stats_bias, True)
+                else:
+                    y = _output(m, Mt, N, H, W)
                 keep, kept_is_v = V, True
         ctx.save_for_backward(keep if ctx.needs_input_grad[1] else None, w)
         ctx.dims = (N, C, H, W, m, kept_is_v)
-        return y
+        if not want_parts:
+            return y
+        if parts is not None:
+            ctx.mark_non_differentiable(parts)
+        return y, parts
 
     @staticmethod
-    def backward(ctx, gy):
+    def backward(ctx, gy, _gparts=None):
         kept, w = ctx.saved_tensors
         N, C, H, W, m, kept_is_v = ctx.dims
         K = w.shape[0]
@@ -182,7 +223,7 @@ class _Conv3x3(torch.autograd.Function):
             if ctx.needs_input_grad[1]:
                 V = kept if kept_is_v else _input(m, kept)
                 gw = _filter_grad(m, torch.bmm(_grad_output(m, gy), V.transpose(1, 2)), w)
-        return gx, gw, None
+        return gx, gw, None, None, None
 
 
 def _input_act(m, x, chan, pre_bias):
@@ -216,31 +257,49 @@ class _BNReluConv3x3(torch.autograd.Function):
     bit for bit (same kernels' arithmetic, one pass less over the tensor)."""
 
     @staticmethod
-    def forward(ctx, y, pre_bias, gamma, beta, running_mean, running_var, training, momentum, eps, w, m):
+    def forward(ctx, y, pre_bias, gamma, beta, running_mean, running_var, training, momentum, eps, w, m, parts=None,
+                stats_bias=None, want_parts=False):
+        """``parts``: statistics partial sums of ``y + pre_bias`` from the convolution that produced ``y`` (the
+        pass over ``y`` is skipped); ``stats_bias`` / ``want_parts``: the same for this convolution's output
+        (-> ``(out, out_parts)``)."""
         y, w = y.contiguous(), w.contiguous()
         N, C, H, W = y.shape
         K = w.shape[0]
         lib = _hip.load()
         dev = y.device
         chan = torch.empty((4, C), dtype=torch.float32, device=dev)
-        ws = torch.empty((lib.fpsg_bn_workspace_floats(N, C, H * W),), dtype=torch.float32, device=dev)
+        use_parts = parts is not None and training
+        ws = None if use_parts else torch.empty((lib.fpsg_bn_workspace_floats(N, C, H * W),), dtype=torch.float32, device=dev)
         opt = lambda t: _hip.ptr(t) if t is not None else None
+        out_parts = None
         with torch.cuda.device(dev):
             _call("fpsg_bn_stats", _hip.ptr(y), opt(pre_bias), opt(gamma), opt(beta), opt(running_mean), opt(running_var),
                   float(momentum), N, C, H * W, 1 if training else 0, float(eps), _hip.ptr(chan), None, None,
-                  _hip.ptr(ws), _hip.stream_of(y))
+                  opt(ws), _hip.ptr(parts) if use_parts else None, parts.shape[1] if use_parts else 0,
+                  _hip.stream_of(y))
             if _can_fuse(m, C, K, N * H * W):
-                out = _fused_act(y, chan, pre_bias, _filter(m, w, False))
+                if want_parts:
+                    out, out_parts = _fused_stats(y, chan, pre_bias, _filter(m, w, False), stats_bias)
+                else:
+                    out = _fused_act(y, chan, pre_bias, _filter(m, w, False))
                 V = None                                     # rebuilt for the weight gradient
             else:
                 V = _input_act(m, y, chan, pre_bias)
-                out = _output(m, torch.bmm(_filter(m, w, False), V), N, H, W)
+                Mt = torch.bmm(_filter(m, w, False), V)
+                if want_parts:
+                    out, out_parts = _output(m, Mt, N, H, W, stats_bias, True)
+                else:
+                    out = _output(m, Mt, N, H, W)
         ctx.save_for_backward(y, chan, pre_bias, w, V if ctx.needs_input_grad[9] else None)
         ctx.cfg = (N, C, H, W, m, bool(training), gamma is not None, beta is not None)
-        return out
+        if not want_parts:
+            return out
+        if out_parts is not None:
+            ctx.mark_non_differentiable(out_parts)
+        return out, out_parts
 
     @staticmethod
-    def backward(ctx, gout):
+    def backward(ctx, gout, _gparts=None):
         y, chan, pre_bias, w, V = ctx.saved_tensors
         N, C, H, W, m, training, has_g, has_b = ctx.cfg
         K = w.shape[0]
@@ -269,12 +328,14 @@ class _BNReluConv3x3(torch.autograd.Function):
             _call("fpsg_bn_act_bwd", _hip.ptr(y), _hip.ptr(pre_bias) if pre_bias is not None else None, _hip.ptr(ga),
                   _hip.ptr(chan), N, C, H * W, 1 if training else 0, 1, 0.0, _hip.ptr(dy), _hip.ptr(dgamma),
                   _hip.ptr(dbeta), _hip.ptr(dpb) if want_dpb else None, _hip.ptr(coef), _hip.ptr(ws), _hip.stream_of(y))
-        return (dy, dpb, dgamma if has_g else None, dbeta if has_b else None, None, None, None, None, None, gw, None)
+        return (dy, dpb, dgamma if has_g else None, dbeta if has_b else None, None, None, None, None, None, gw, None,
+                None, None, None)
 
 
-def bn_relu_conv3x3(y, pre_bias, bn, weight, m=None):
+def bn_relu_conv3x3(y, pre_bias, bn, weight, m=None, parts=None, stats_bias=None, want_parts=False):
     """``conv3x3(relu(bn(y + pre_bias)), weight)`` with ``bn`` an ``nn.BatchNorm2d`` in its current mode; updates
-    its running statistics / ``num_batches_tracked`` as the module would."""
+    its running statistics / ``num_batches_tracked`` as the module would.  ``parts`` / ``stats_bias`` /
+    ``want_parts``: see ``_BNReluConv3x3.forward``."""
     if m is None:
         m = tile_size(y.shape[2], y.shape[3])
     training = bn.training
@@ -282,16 +343,19 @@ def bn_relu_conv3x3(y, pre_bias, bn, weight, m=None):
         bn.num_batches_tracked += 1
     mom = (0.1 if bn.momentum is None else float(bn.momentum)) if training else -1.0
     return _BNReluConv3x3.apply(y, pre_bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, bool(training), mom,
-                                bn.eps, weight, m)
+                                bn.eps, weight, m, parts, stats_bias, bool(want_parts))
 
 
-def conv3x3(x: torch.Tensor, weight: torch.Tensor, m: int | None = None) -> torch.Tensor:
+def conv3x3(x: torch.Tensor, weight: torch.Tensor, m: int | None = None, stats_bias=None, want_parts: bool = False):
     """``F.conv2d(x, weight, None, 1, 1)`` for ``x [N,C,H,W]`` (H, W even), ``weight [K,C,3,3]``;
-    ``m``: output tile size 2 or 4 (default: ``tile_size(H, W)``)."""
+    ``m``: output tile size 2 or 4 (default: ``tile_size(H, W)``).  ``want_parts``: -> ``(y, parts)``, the statistics
+    partial sums of ``y + stats_bias`` for a following BatchNorm (None where the kernel does not deliver them)."""
     if x.dim() != 4 or weight.dim() != 4 or tuple(weight.shape[2:]) != (3, 3) or weight.shape[1] != x.shape[1]:
         raise ValueError(f"conv3x3: x {tuple(x.shape)} / weight {tuple(weight.shape)}")
     if m is None:
         m = tile_size(x.shape[2], x.shape[3])
     if m not in (2, 4) or x.shape[2] % m or x.shape[3] % m:
         raise ValueError(f"conv3x3: H and W must be multiples of the tile size m={m} (2 or 4)")
+    if want_parts:
+        return _Conv3x3.apply(x, weight, m, stats_bias, True)
     return _Conv3x3.apply(x, weight, m)

@@ -235,11 +235,14 @@ int fpsg_bn_act_fwd(const float* x, const float* pre_bias, const float* gamma, c
                     float eps, int act, float slope, float* y, float* chan, float* batch_mean,
                     float* batch_var_unbiased, float* ws, fpsg_stream_t stream);
 /* Statistics half of fpsg_bn_act_fwd alone: chan [4][C] (scale, shift, mean, rstd) from the batch (training; running
- * statistics updated as there) or from the running statistics (eval); nothing is applied or written besides. */
+ * statistics updated as there) or from the running statistics (eval); nothing is applied or written besides.
+ * parts (optional, training): partial sums [C][n_parts][2] = (sum(x + pre_bias), sum((x + pre_bias)^2)) that the
+ * producing convolution's epilogue accumulated (fpsg_wino_output_transform_stats, fpsg_wino_conv_fused_stats):
+ * the pass over x is skipped and only the fp64 finalize runs (ws may then be NULL). */
 int fpsg_bn_stats(const float* x, const float* pre_bias, const float* gamma, const float* beta,
                   float* running_mean, float* running_var, float momentum, int N, int C, int L, int training,
                   float eps, float* chan, float* batch_mean, float* batch_var_unbiased, float* ws,
-                  fpsg_stream_t stream);
+                  const float* parts, int n_parts, fpsg_stream_t stream);
 int fpsg_bn_act_bwd(const float* x, const float* pre_bias, const float* dy, const float* chan, int N, int C,
                     int L, int training, int act, float slope, float* dx, float* dgamma, float* dbeta,
                     float* dpre_bias, float* coef, float* ws, fpsg_stream_t stream);
@@ -250,13 +253,15 @@ int fpsg_bn_act_bwd(const float* x, const float* pre_bias, const float* dy, cons
  * tensor; the backward re-derives each window's activations and arg-max from x (scan order
  * (h,w), first strictly greater or NaN wins, as torch's max_pool2d), so neither the
  * full-resolution activation, nor pooling indices, nor the scattered gradient exist in HBM.
- * Other arguments as fpsg_bn_act_fwd / _bwd; ws: fpsg_bn_pool_workspace_floats(N,C,H,W).
+ * Other arguments as fpsg_bn_act_fwd / _bwd; ws: fpsg_bn_pool_workspace_floats(N,C,H,W); parts / n_parts as
+ * fpsg_bn_stats (statistics delivered by the producing convolution).
  */
 size_t fpsg_bn_pool_workspace_floats(int N, int C, int H, int W);
 int fpsg_bn_act_pool_fwd(const float* x, const float* pre_bias, const float* gamma, const float* beta,
                          float* running_mean, float* running_var, float momentum, int N, int C, int H, int W,
                          int training, float eps, int act, float slope, float* y_pooled, float* chan,
-                         float* batch_mean, float* batch_var_unbiased, float* ws, fpsg_stream_t stream);
+                         float* batch_mean, float* batch_var_unbiased, float* ws, const float* parts, int n_parts,
+                         fpsg_stream_t stream);
 int fpsg_bn_act_pool_bwd(const float* x, const float* pre_bias, const float* dy_pooled, const float* chan,
                          int N, int C, int H, int W, int training, int act, float slope, float* dx,
                          float* dgamma, float* dbeta, float* dpre_bias, float* coef, float* ws,
@@ -297,6 +302,13 @@ int fpsg_bn_act_max_bwd(const float* x, const float* pre_bias, const float* gout
  */
 int fpsg_wino_input_transform(int m, const float* x, int N, int C, int H, int W, float* V, fpsg_stream_t stream);
 int fpsg_wino_output_transform(int m, const float* M, int N, int K, int H, int W, float* y, fpsg_stream_t stream);
+/* The same, also accumulating the statistics of the BatchNorm that follows the convolution
+ * (nn.Conv2d -> nn.BatchNorm2d of image_net.py:14): parts [K][fpsg_wino_stats_parts(m,N,H,W)][2] =
+ * (sum(y + bias[k]), sum((y + bias[k])^2)) per workgroup of 256 tiles (bias optional: the convolution's bias, which K5
+ * adds inside the BatchNorm); fpsg_bn_stats / fpsg_bn_act_pool_fwd take them instead of reading y again.  Deterministic. */
+int fpsg_wino_stats_parts(int m, int N, int H, int W);
+int fpsg_wino_output_transform_stats(int m, const float* M, int N, int K, int H, int W, float* y, const float* bias,
+                                     float* parts, fpsg_stream_t stream);
 int fpsg_wino_grad_output_transform(int m, const float* dy, int N, int K, int H, int W, float* dM,
                                     fpsg_stream_t stream);
 int fpsg_wino_filter_transform(int m, const float* w, int K, int C, int flip_transpose, float* U,
@@ -312,6 +324,14 @@ int fpsg_wino_filter_grad_transform(int m, const float* dU, int K, int C, float*
  */
 int fpsg_wino_conv_fused(const float* x, const float* U, int N, int C, int K, int H, int W, float* y,
                          fpsg_stream_t stream);
+
+/* fpsg_wino_conv_fused / _act (chan = NULL: the plain form) also accumulating the statistics of the BatchNorm that
+ * follows this convolution: parts [K][fpsg_wino_conv_fused_parts(N,K,H,W)][2] = (sum(y + out_bias[k]),
+ * sum((y + out_bias[k])^2)) per workgroup (out_bias optional), taken by fpsg_bn_stats / fpsg_bn_act_pool_fwd instead of
+ * reading y again.  Deterministic. */
+int fpsg_wino_conv_fused_parts(int N, int K, int H, int W);
+int fpsg_wino_conv_fused_stats(const float* x, const float* chan, const float* pre_bias, const float* U, int N, int C,
+                               int K, int H, int W, float* y, const float* out_bias, float* parts, fpsg_stream_t stream);
 
 /* The same two entry points reading a PRE-BatchNorm tensor: the values fed to the transform are
  * relu(fma(x + pre_bias[c], chan[c], chan[C + c])) -- K5's apply arithmetic with chan = (scale, shift, ..) from

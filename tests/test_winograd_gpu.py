@@ -240,6 +240,8 @@ def test_trunk_with_and_without_the_fold(gpu, monkeypatch):
 
     monkeypatch.setattr(winograd._BNReluConv3x3, "forward", staticmethod(counted))
 
+    monkeypatch.setenv("FPSG_CONV_STATS", "0")       # same statistics kernels in both arms (see the next test)
+
     def run(fold):
         monkeypatch.setenv("FPSG_BN_FOLD", fold)
         calls["n"] = 0
@@ -256,3 +258,141 @@ def test_trunk_with_and_without_the_fold(gpu, monkeypatch):
     noise_g = float((g0 - g0b).norm()) + 1e-5 * float(g0.norm())
     assert float((o1 - o0).abs().max()) <= 3 * noise_o
     assert float((g1 - g0).norm()) <= 3 * noise_g
+
+
+def test_trunk_with_batchnorm_statistics_from_the_convolutions(gpu, monkeypatch):
+    """The VGG16-BN trunk (training mode) with the BatchNorm statistics accumulated by the producing convolutions'
+    epilogues (K6f, K6's output transform) against K5's own statistics passes: the sums are grouped differently, so
+    the two agree to accumulated fp32 round-off (13 BatchNorm layers) on the features and the running statistics.  The
+    gradients of a randomly initialised trunk at batch 6 amplify any fp32-level perturbation to the percent level
+    (tests/_gradcheck.py: the reference's own fp32 arithmetic is that far from float64), so they are bounded loosely
+    here; the single-layer test above holds them to 2e-5.  The epilogue form must really be taken."""
+    import copy
+    from fpsg_amd import winograd
+    from fpsg_amd.image_net import ImageEncoderWarpper
+    torch.manual_seed(5)
+    base = ImageEncoderWarpper("vgg_16").to(gpu).train()
+    x = torch.rand(6, 3, 112, 112, device=gpu) * 2 - 1
+    w = torch.randn(6, 512, device=gpu)
+    used = {"n": 0}
+    orig_out, orig_fused = winograd._output, winograd._fused_stats
+
+    def out_counted(m, M, N, H, W, stats_bias=None, want_parts=False):
+        used["n"] += 1 if want_parts else 0
+        return orig_out(m, M, N, H, W, stats_bias, want_parts)
+
+    def fused_counted(*a):
+        used["n"] += 1
+        return orig_fused(*a)
+
+    monkeypatch.setattr(winograd, "_output", out_counted)
+    monkeypatch.setattr(winograd, "_fused_stats", fused_counted)
+
+    def run(flag):
+        monkeypatch.setenv("FPSG_CONV_STATS", flag)
+        used["n"] = 0
+        net = copy.deepcopy(base)
+        out = net(x)
+        (out * w).sum().backward()
+        rm = torch.cat([b.reshape(-1) for n_, b in net.named_buffers() if "running" in n_])
+        return out.detach(), torch.cat([p.grad.reshape(-1) for p in net.parameters()]), rm, used["n"]
+
+    o1, g1, r1, n1 = run("1")
+    o0, g0, r0, n0 = run("0")
+    assert n0 == 0 and n1 == 3, (n0, n1)        # 6 x 112x112: conv1_2, conv2_1 (K6f) and conv2_2 (K6) are large enough
+    assert float((o1 - o0).abs().max()) <= 2e-4 * float(o0.abs().max())
+    assert float((g1 - g0).norm()) <= 5e-2 * float(g0.norm())
+    assert float(torch.dot(g1, g0) / (g1.norm() * g0.norm())) > 0.999
+    assert float((r1 - r0).abs().max()) <= 1e-5 * float(r0.abs().max())
+
+
+@pytest.mark.parametrize("m,shape", [(4, (3, 8, 12, 20)), (2, (5, 16, 6, 10)), (4, (37, 32, 28, 28)), (2, (37, 24, 14, 14)),
+                                     (4, (2, 5, 112, 112))])
+def test_output_transform_delivers_batchnorm_partial_sums(gpu, m, shape):
+    """fpsg_wino_output_transform_stats: the same pixels as the plain output transform, and per channel the
+    partial sums of (y + bias) and (y + bias)^2 over each workgroup's tiles (ragged last workgroup included)."""
+    from fpsg_amd import winograd as wg
+    N, K, H, W = shape
+    torch.manual_seed(H + K)
+    P = N * (H // m) * (W // m)
+    Mt = torch.randn((m + 2) ** 2, K, P, device=gpu)
+    b = torch.randn(K, device=gpu)
+    y_ref = wg._output(m, Mt, N, H, W)
+    for bias in (b, None):
+        y, parts = wg._output(m, Mt, N, H, W, bias, True)
+        assert torch.equal(y, y_ref)
+        assert parts.shape == (K, (P + 255) // 256, 2)
+        v = y.double() + (bias.double().view(1, -1, 1, 1) if bias is not None else 0.0)
+        s0, s1 = v.sum((0, 2, 3)), (v * v).sum((0, 2, 3))
+        got = parts.double().sum(1)
+        n = N * H * W
+        scale = float(v.abs().max())
+        assert float((got[:, 0] - s0).abs().max()) <= 2e-6 * n * scale
+        assert float((got[:, 1] - s1).abs().max()) <= 2e-6 * n * scale * scale
+        y2, parts2 = wg._output(m, Mt, N, H, W, bias, True)
+        assert torch.equal(parts, parts2)                      # deterministic
+
+
+@pytest.mark.parametrize("C,K,H,N", [(128, 128, 56, 6), (32, 48, 28, 24), (64, 64, 56, 5), (64, 128, 36, 3)])
+def test_batchnorm_statistics_from_the_convolution_epilogue(gpu, C, K, H, N):
+    """conv -> BatchNorm -> ReLU -> conv / pool with the first convolution's epilogue delivering the BatchNorm
+    statistics (``parts``) against the same ops with K5's own statistics pass: the partial sums are grouped
+    differently (fp32 per workgroup, fp64 across), so values agree to fp32 round-off, not bit for bit."""
+    import copy
+    from fpsg_amd.fused_bn import _BNActPool
+    from fpsg_amd.winograd import bn_relu_conv3x3, conv3x3
+    torch.manual_seed(C + H)
+    x = torch.randn(N, C, H, H, device=gpu)
+    w0 = torch.randn(C, C, 3, 3, device=gpu) * (2.0 / (9 * C)) ** 0.5
+    w1 = torch.randn(K, C, 3, 3, device=gpu) * (2.0 / (9 * C)) ** 0.5
+    pb = torch.randn(C, device=gpu) * 0.05
+    bn = torch.nn.BatchNorm2d(C).to(gpu).train()
+    with torch.no_grad():
+        bn.weight.copy_(torch.randn(C) * 0.3 + 1)
+        bn.bias.copy_(torch.randn(C) * 0.1)
+    res = []
+    for use in (True, False):
+        mod = copy.deepcopy(bn)
+        xi = x.clone().requires_grad_()
+        if use:
+            y, parts = conv3x3(xi, w0, stats_bias=pb, want_parts=True)
+            assert parts is not None and not parts.requires_grad
+        else:
+            y, parts = conv3x3(xi, w0), None
+        out = bn_relu_conv3x3(y, pb, mod, w1, parts=parts)
+        mom = 0.1
+        pooled = _BNActPool.apply(y, mod.weight, mod.bias, None, None, True, mod.eps, 1, 0.0, pb, -1.0, parts)
+        (out.sum() * 0.01 + (pooled * pooled).sum()).backward()
+        res.append((out.detach(), pooled.detach(), xi.grad, mod.weight.grad, mod.running_mean.clone(), mod.running_var.clone()))
+    for a, b_ in zip(res[0], res[1]):
+        scale = float(b_.abs().max()) + 1e-30
+        assert float((a - b_).abs().max()) <= 2e-5 * scale, float((a - b_).abs().max()) / scale
+
+
+@pytest.mark.parametrize("shape", [(3, 64, 64, 32, 32), (2, 64, 128, 28, 36), (37, 64, 32, 56, 56), (1, 64, 16, 4, 4)])
+@pytest.mark.parametrize("act", [False, True])
+def test_fused_kernel_delivers_batchnorm_partial_sums(gpu, shape, act):
+    """fpsg_wino_conv_fused_stats: the pixels of the plain / activating K6f bit for bit, and per output channel the
+    partial sums of (y + out_bias) and its square per workgroup."""
+    from fpsg_amd import winograd as wg
+    N, C, K, H, W = shape
+    torch.manual_seed(K + H)
+    x = torch.randn(N, C, H, W, device=gpu)
+    w = torch.randn(K, C, 3, 3, device=gpu) * 0.05
+    U = wg._filter(4, w, False)
+    ob = torch.randn(K, device=gpu)
+    chan = pb = None
+    if act:
+        chan = torch.randn(4, C, device=gpu) * 0.5 + 1.0
+        pb = torch.randn(C, device=gpu) * 0.1
+    y_ref = wg._fused_act(x, chan, pb, U) if act else wg._fused(x, U)
+    for bias in (ob, None):
+        y, parts = wg._fused_stats(x, chan, pb, U, bias)
+        assert torch.equal(y, y_ref)
+        v = y.double() + (bias.double().view(1, -1, 1, 1) if bias is not None else 0.0)
+        s0, s1 = v.sum((0, 2, 3)), (v * v).sum((0, 2, 3))
+        got = parts.double().sum(1)
+        n, scale = N * H * W, float(v.abs().max())
+        assert float((got[:, 0] - s0).abs().max()) <= 2e-6 * n * scale
+        assert float((got[:, 1] - s1).abs().max()) <= 2e-6 * n * scale * scale
+        assert torch.equal(parts, wg._fused_stats(x, chan, pb, U, bias)[1])
