@@ -70,6 +70,66 @@ __device__ __forceinline__ int segment_of(const long long* __restrict__ seg_off,
   return lo;
 }
 
+// the (up to) four gradient elements of flat positions i .. i+cnt-1 from the segment table (0 where a segment has none)
+__device__ __forceinline__ bool gather_grad4(const float* const* __restrict__ gtab, const long long* __restrict__ seg_off,
+                                             int nseg, long long i, int cnt, float (&gg)[4]) {
+  int sg = segment_of(seg_off, nseg, i);
+  bool any = false;
+  gg[0] = gg[1] = gg[2] = gg[3] = 0.0f;
+  if (i + cnt <= seg_off[sg + 1]) {
+    const float* g = gtab[sg];
+    if (g) {
+      any = true;
+      const long long base = i - seg_off[sg];
+      // a gradient tensor usually starts 256-B aligned, but one that autograd took over from a view
+      // (e.g. a slice of a stacked tensor's gradient) may start anywhere: test the address itself
+      if (cnt == 4 && ((reinterpret_cast<uintptr_t>(g + base) & 15) == 0)) {
+        const v4f q = *reinterpret_cast<const v4f*>(g + base);
+        gg[0] = q[0]; gg[1] = q[1]; gg[2] = q[2]; gg[3] = q[3];
+      } else {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) if (u < cnt) gg[u] = g[base + u];
+      }
+    }
+  } else {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (u >= cnt) break;
+      while (i + u >= seg_off[sg + 1]) ++sg;
+      const float* g = gtab[sg];
+      any = any || g != nullptr;
+      gg[u] = g ? g[i + u - seg_off[sg]] : 0.0f;
+    }
+  }
+  return any;
+}
+
+// flat[i] (+)= the segment table's gradient: the episode's fresh gradient tensors added into (or, first episode of a
+// step, copied over) the step's flat gradient buffer in ONE stream at HBM rate -- the multi-tensor add it replaces
+// runs ~25 chunked launches at half of it.  accumulate = 0 writes zeros where a parameter has no gradient.
+__global__ __launch_bounds__(kAdamThreads) void flat_accumulate_kernel(float* __restrict__ flat,
+                                                                       const float* const* __restrict__ gtab,
+                                                                       const long long* __restrict__ seg_off, int nseg,
+                                                                       size_t n4, size_t n, int accumulate) {
+  const size_t stride = (size_t)gridDim.x * kAdamThreads;
+  for (size_t j = (size_t)blockIdx.x * kAdamThreads + threadIdx.x; j < n4 + 1; j += stride) {
+    const long long i = (long long)(4 * j);
+    const int cnt = j < n4 ? 4 : (int)(n - 4 * n4);
+    if (cnt == 0) break;
+    float gg[4];
+    const bool any = gather_grad4(gtab, seg_off, nseg, i, cnt, gg);
+    if (accumulate && !any) continue;
+    if (cnt == 4) {
+      v4f f = accumulate ? reinterpret_cast<const v4f*>(flat)[j] : (v4f){0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+      for (int u = 0; u < 4; ++u) f[u] += gg[u];
+      reinterpret_cast<v4f*>(flat)[j] = f;
+    } else {
+      for (int u = 0; u < cnt; ++u) flat[(size_t)i + u] = (accumulate ? flat[(size_t)i + u] : 0.0f) + gg[u];
+    }
+  }
+}
+
 __global__ __launch_bounds__(kAdamThreads) void adam_ptr_kernel(float* __restrict__ p, const float* const* __restrict__ gtab,
                                                                 const long long* __restrict__ seg_off, int nseg,
                                                                 float* __restrict__ m, float* __restrict__ v, size_t n4,
@@ -81,31 +141,8 @@ __global__ __launch_bounds__(kAdamThreads) void adam_ptr_kernel(float* __restric
     const long long i = (long long)(4 * j);
     const int cnt = j < n4 ? 4 : (int)(n - 4 * n4);          // the last "vector" is the tail
     if (cnt == 0) break;
-    int sg = segment_of(seg_off, nseg, i);
-    float gg[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-    if (i + cnt <= seg_off[sg + 1]) {
-      const float* g = gtab[sg];
-      if (g) {
-        const long long base = i - seg_off[sg];
-        // a gradient tensor usually starts 256-B aligned, but one that autograd took over from a view
-        // (e.g. a slice of a stacked tensor's gradient) may start anywhere: test the address itself
-        if (cnt == 4 && ((reinterpret_cast<uintptr_t>(g + base) & 15) == 0)) {
-          const v4f q = *reinterpret_cast<const v4f*>(g + base);
-          gg[0] = q[0]; gg[1] = q[1]; gg[2] = q[2]; gg[3] = q[3];
-        } else {
-#pragma unroll
-          for (int u = 0; u < 4; ++u) if (u < cnt) gg[u] = g[base + u];
-        }
-      }
-    } else {
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        if (u >= cnt) break;
-        while (i + u >= seg_off[sg + 1]) ++sg;
-        const float* g = gtab[sg];
-        gg[u] = g ? g[i + u - seg_off[sg]] : 0.0f;
-      }
-    }
+    float gg[4];
+    gather_grad4(gtab, seg_off, nseg, i, cnt, gg);
     if (cnt == 4) {                                            // flat buffers: aligned vectors
       v4f pv = reinterpret_cast<const v4f*>(p)[j];
       v4f mv = reinterpret_cast<const v4f*>(m)[j];
@@ -184,4 +221,19 @@ extern "C" int fpsg_adam_step(float* param, const float* grad, float* exp_avg, f
   hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(kAdamThreads), 0, static_cast<hipStream_t>(stream), param,
                      grad, exp_avg, exp_avg_sq, n4, n, step_size, beta1, beta2, eps, inv_sqrt_bc2, grad_scale);
   return launch_status("fpsg_adam_step");
+}
+
+extern "C" int fpsg_flat_accumulate_segments(float* flat, const float* const* grad_ptrs, const long long* seg_off, int nseg,
+                                             size_t n, int accumulate, fpsg_stream_t stream) {
+  using namespace fpsg;
+  FPSG_REQUIRE(n > 0 && nseg > 0, FPSG_E_SHAPE, "fpsg_flat_accumulate_segments: n, nseg must be positive (got %zu, %d)", n, nseg);
+  FPSG_REQUIRE_PTR(flat);
+  FPSG_REQUIRE(grad_ptrs != nullptr && seg_off != nullptr, FPSG_E_NULL, "fpsg_flat_accumulate_segments: null table");
+  FPSG_REQUIRE((reinterpret_cast<uintptr_t>(flat) & 15) == 0, FPSG_E_ALIGN, "fpsg_flat_accumulate_segments: flat must be 16-byte aligned");
+  const size_t n4 = n / 4;
+  size_t blocks = (n4 + 1 + kAdamThreads - 1) / kAdamThreads;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  hipLaunchKernelGGL(flat_accumulate_kernel, dim3((unsigned)blocks), dim3(kAdamThreads), 0, static_cast<hipStream_t>(stream),
+                     flat, grad_ptrs, seg_off, nseg, n4, n, accumulate);
+  return launch_status("fpsg_flat_accumulate_segments");
 }

@@ -25,6 +25,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import _hip
+from .bn_counters import count_batch
 from .fused_bn import bn_act
 
 
@@ -196,8 +197,8 @@ def edgeconv_fused(x_pm: torch.Tensor, idx32: torch.Tensor, block: nn.Sequential
     wc = torch.cat((w[:, :C], w[:, C:] - w[:, :C]), dim=0)          # [2Co, C]: rows of P then Q
     PQ = torch.matmul(x_pm, wc.t())                                  # [B,N,2Co], one GEMM
     training = bn.training or (bn.running_mean is None)
-    if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
-        bn.num_batches_tracked += 1
+    if bn.training and bn.track_running_stats:
+        count_batch(bn)
     momentum = 0.1 if bn.momentum is None else bn.momentum
     return _EdgeConvBNMax.apply(PQ.contiguous(), idx32, bn.weight, bn.bias, bn.running_mean,
                                 bn.running_var, training, momentum, bn.eps, act.negative_slope)

@@ -112,6 +112,16 @@ class FlatGradBuckets:
         self._armed_first = False
         self._streams: dict = {}     # every stream a gradient was produced on in this backward
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in params]
+        # segment table of the flat layout (K7's format): absorb() adds an episode's gradient tensors in one launch
+        self._layout_params = list(reversed(params))
+        self._seg_off = self._gtab = None
+        if dev.type == "cuda" and dt == torch.float32:
+            offs, o = [], 0
+            for p in self._layout_params:
+                offs.append(o)
+                o += p.numel()
+            self._seg_off = torch.tensor(offs + [o], dtype=torch.int64, device=dev)
+            self._gtab = torch.zeros(len(self._layout_params), dtype=torch.int64, device=dev)
         self.attach()
 
     # -- bookkeeping ---------------------------------------------------------------
@@ -142,6 +152,8 @@ class FlatGradBuckets:
         """Adds the gradients a backward left in ``p.grad`` into the flat buffer with
         multi-tensor launches; ``first`` overwrites instead (no ``zero()`` needed).  The sums
         are the same fp32 adds, in the same order over episodes, as in-place accumulation."""
+        if self._absorb_segments(first):
+            return
         dst, src, missing = [], [], []
         for p in self.params:
             if p.grad is None:
@@ -157,6 +169,33 @@ class FlatGradBuckets:
                     torch._foreach_zero_(missing)
             elif dst:
                 torch._foreach_add_(dst, src)
+
+    def _absorb_segments(self, first: bool) -> bool:
+        """``absorb`` as ONE launch (``fpsg_flat_accumulate_segments``: the gradient tensors read through a pointer
+        table, the flat buffer updated at HBM rate) when every gradient is a dense fp32 tensor laid out like its
+        parameter; False -> the multi-tensor path.  Not under stream capture (the table upload is a host copy)."""
+        if self._gtab is None or os.environ.get("FPSG_ABSORB_SEGMENTS", "1") == "0" or torch.cuda.is_current_stream_capturing():
+            return False
+        dev = self.flat.device
+        ptrs = []
+        for p in self._layout_params:
+            g = p.grad
+            if g is None:
+                ptrs.append(0)
+            elif (g.dtype == torch.float32 and g.device == dev and g.numel() == p.numel() and g.stride() == p.stride()
+                  and g.data_ptr() != self.views[id(p)].data_ptr()):
+                ptrs.append(g.data_ptr())
+            else:
+                return False
+        from . import _hip
+        # a fresh pinned tensor per call: the caching host allocator keeps it until the copy ran
+        self._gtab.copy_(torch.tensor(ptrs, dtype=torch.int64).pin_memory(), non_blocking=True)
+        with torch.cuda.device(dev):
+            rc = _hip.load().fpsg_flat_accumulate_segments(_hip.ptr(self.flat), _hip.ptr(self._gtab), _hip.ptr(self._seg_off),
+                                                           len(ptrs), self.flat.numel(), 0 if first else 1,
+                                                           _hip.stream_of(self.flat))
+        _hip.check(rc, "fpsg_flat_accumulate_segments")
+        return True
 
     def arm(self, first: bool = False) -> None:
         """Call (after ``detach()``) before the backward of the LAST local episode of a step:

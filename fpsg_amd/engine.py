@@ -15,7 +15,7 @@ import torch
 import torch.optim as optim
 
 from . import dist as fdist
-from . import winograd
+from . import bn_counters, winograd
 from .few_shot import ImgPCProtoNet
 from .image_net import ImageEncoderWarpper
 from .optim import FlatAdam
@@ -107,7 +107,8 @@ class TrainStep:
         multi-tensor copy (``first``) / add into the flat buffer (``absorb=False``: the step is
         this one episode and the optimizer reads the gradients where they are)."""
         self.buckets.detach()
-        out = self.model.loss(sample)
+        with bn_counters.deferred():        # the ~20 num_batches_tracked increments as multi-tensor adds
+            out = self.model.loss(sample)
         out["ttl_loss"].sum().backward()
         if absorb:
             self.buckets.absorb(first)
@@ -119,7 +120,8 @@ class TrainStep:
         as its gradients are complete."""
         self.buckets.detach()
         self.buckets.arm(first)
-        out = self.model.loss(sample)
+        with bn_counters.deferred():
+            out = self.model.loss(sample)
         out["ttl_loss"].sum().backward()
         return {n: v.detach() for n, v in out.items()}
 

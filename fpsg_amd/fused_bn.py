@@ -23,6 +23,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .bn_counters import count_batch
 from . import _hip, conv_first, winograd
 
 _ACT_CODES = {None: 0, "none": 0, "relu": 1, "leaky": 2}
@@ -246,8 +247,8 @@ def bn_act(bn: nn.modules.batchnorm._BatchNorm, x: torch.Tensor, act=None, pre_b
             x = x + pre_bias.view(1, -1, *([1] * (x.dim() - 2)))
         return _plain_act(bn(x), *_parse_act(act))
     training = bn.training
-    if training and bn.num_batches_tracked is not None:
-        bn.num_batches_tracked += 1
+    if training:
+        count_batch(bn)
     return batch_norm_act(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, bn.momentum,
                           bn.eps, act, pre_bias=pre_bias)
 
@@ -313,8 +314,8 @@ def bn_act_pool_of(y: torch.Tensor, conv, bn, pool, act=None, parts=None) -> tor
     if not _pool_eligible(y, pool):
         return pool(bn_act_of(y, conv, bn, act))
     training = bn.training
-    if training and bn.num_batches_tracked is not None:
-        bn.num_batches_tracked += 1
+    if training:
+        count_batch(bn)
     act_code, slope = _parse_act(act)
     m = (0.1 if bn.momentum is None else float(bn.momentum)) if training else -1.0
     return _BNActPool.apply(y.contiguous(), bn.weight, bn.bias, bn.running_mean, bn.running_var, bool(training),
@@ -354,8 +355,8 @@ def conv_bn_act_pool(conv: nn.Conv2d, bn: nn.BatchNorm2d, pool: nn.MaxPool2d, x:
             return pool(bn_act(bn, y + conv.bias.view(1, -1, 1, 1), act))
         return pool(bn_act(bn, y, act, pre_bias=conv.bias))
     training = bn.training
-    if training and bn.num_batches_tracked is not None:
-        bn.num_batches_tracked += 1
+    if training:
+        count_batch(bn)
     act_code, slope = _parse_act(act)
     m = (0.1 if bn.momentum is None else float(bn.momentum)) if training else -1.0
     return _BNActPool.apply(y.contiguous(), bn.weight, bn.bias, bn.running_mean, bn.running_var, bool(training),
@@ -373,8 +374,8 @@ def conv_bn_act_max(conv: nn.Conv1d, bn: nn.BatchNorm1d, x: torch.Tensor, act=No
     if not fused:
         return conv_bn_act(conv, bn, x, act).max(dim=2)[0]
     training = bn.training
-    if training and bn.num_batches_tracked is not None:
-        bn.num_batches_tracked += 1
+    if training:
+        count_batch(bn)
     act_code, slope = _parse_act(act)
     m = (0.1 if bn.momentum is None else float(bn.momentum)) if training else -1.0
     return _BNActMax.apply(y.contiguous(), bn.weight, bn.bias, bn.running_mean, bn.running_var, bool(training),

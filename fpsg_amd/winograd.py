@@ -22,6 +22,7 @@ import os
 import torch
 
 from . import _hip
+from .bn_counters import count_batch
 
 # Below these widths the transforms' HBM traffic (4x / 2.25x the image tensors) outweighs the saved
 # multiplications (profiles/: wino_bench): 4x4 tiles pay off from 64 channels (conv1_2 ... conv4_3 of
@@ -339,8 +340,8 @@ def bn_relu_conv3x3(y, pre_bias, bn, weight, m=None, parts=None, stats_bias=None
     if m is None:
         m = tile_size(y.shape[2], y.shape[3])
     training = bn.training
-    if training and bn.num_batches_tracked is not None:
-        bn.num_batches_tracked += 1
+    if training:
+        count_batch(bn)
     mom = (0.1 if bn.momentum is None else float(bn.momentum)) if training else -1.0
     return _BNReluConv3x3.apply(y, pre_bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, bool(training), mom,
                                 bn.eps, weight, m, parts, stats_bias, bool(want_parts))

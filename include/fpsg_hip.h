@@ -373,6 +373,13 @@ int fpsg_adam_step(float* param, const float* grad, float* exp_avg, float* exp_a
 int fpsg_adam_step_segments(float* param, const float* const* grad_ptrs, const long long* seg_off, int nseg,
                             float* exp_avg, float* exp_avg_sq, size_t n, float lr, float beta1, float beta2,
                             float eps, int step, float grad_scale, fpsg_stream_t stream);
+/* The gradient accumulation of a step of several episodes (optimizer.zero_grad() once, loss.backward() per
+ * episode, trainNetwork.py:140-148) on the flat gradient buffer: flat[i] += the segment table's gradient
+ * (accumulate = 1; segments without gradient untouched) or flat[i] = it (accumulate = 0: first episode, zeros where a
+ * segment has none).  Same table format as fpsg_adam_step_segments; one stream at HBM rate.  flat 16-byte aligned.
+ */
+int fpsg_flat_accumulate_segments(float* flat, const float* const* grad_ptrs, const long long* seg_off, int nseg,
+                                  size_t n, int accumulate, fpsg_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -87,3 +87,25 @@ def test_fused_bn_helpers_run_the_plain_modules_on_cpu():
     assert torch.equal(conv_bn_act_pool(conv2, bn2, pool, img, "relu"), pool(torch.relu(b3(c3(img)))))
     c4, b4 = copy.deepcopy(c3), copy.deepcopy(b3)
     assert torch.equal(conv_bn_act(c3, b3, img, ("leaky", 0.2)), torch.nn.functional.leaky_relu(b4(c4(img)), 0.2))
+
+
+def test_deferred_batch_counters_match_immediate_increments():
+    """fpsg_amd.bn_counters: inside deferred() the num_batches_tracked increments of the fused BatchNorm paths are
+    collected and applied as multi-tensor adds at the end of the block -- same values as incrementing on the spot,
+    also for a module that runs twice and for nested blocks."""
+    import torch
+    from fpsg_amd import bn_counters
+    a, b, c = (torch.nn.BatchNorm1d(4) for _ in range(3))
+    c.num_batches_tracked = None                       # track_running_stats=False style module
+    b.num_batches_tracked += 5
+    bn_counters.count_batch(a)
+    assert int(a.num_batches_tracked) == 1
+    with bn_counters.deferred():
+        bn_counters.count_batch(a)
+        bn_counters.count_batch(b)
+        with bn_counters.deferred():
+            bn_counters.count_batch(a)
+        bn_counters.count_batch(c)
+        assert int(a.num_batches_tracked) == 1 and int(b.num_batches_tracked) == 5     # not yet
+    assert int(a.num_batches_tracked) == 3 and int(b.num_batches_tracked) == 6
+    assert bn_counters._pending is None

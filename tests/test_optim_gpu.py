@@ -192,3 +192,60 @@ def test_pointer_table_step_with_unaligned_gradient_views(gpu):
     opt_ref.step()
     for p, r in zip(params, ref):
         assert torch.allclose(p, r, rtol=1e-6, atol=1e-7)
+
+
+def test_gradient_accumulation_over_episodes_in_one_launch(gpu, monkeypatch):
+    """FlatGradBuckets.absorb through fpsg_flat_accumulate_segments (pointer table, one launch) against the
+    multi-tensor path it replaces: first episode copies (zeros for a parameter without gradient), later episodes
+    add -- bit for bit (the same fp32 adds); odd sizes, a tail that is not a multiple of 4, an unaligned gradient
+    view and a channels_last parameter (falls back) included."""
+    from fpsg_amd.dist import FlatGradBuckets
+    torch.manual_seed(3)
+
+    class Net(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a = nn.Parameter(torch.randn(37, 5))
+            self.b = nn.Parameter(torch.randn(3))
+            self.c = nn.Parameter(torch.randn(130, 7, 3))
+            self.unused = nn.Parameter(torch.randn(11))
+            self.d = nn.Parameter(torch.randn(2, 2))
+
+    def run(flag, channels_last=False):
+        monkeypatch.setenv("FPSG_ABSORB_SEGMENTS", flag)
+        torch.manual_seed(7)
+        net = Net().to(gpu)
+        if channels_last:
+            net.e = nn.Parameter(torch.randn(4, 6, 3, 3, device=gpu).contiguous(memory_format=torch.channels_last))
+        fb = FlatGradBuckets(net, bucket_mb=0.001)
+        snaps = []
+        for ep in range(3):
+            fb.detach()
+            big = torch.randn(5000, device=gpu)
+            for n_, p in net.named_parameters():
+                if n_ == "unused" or (n_ == "d" and ep == 1):
+                    continue
+                if n_ == "b":
+                    p.grad = big[1:4]                          # a view that starts 4 bytes past an aligned address
+                else:
+                    p.grad = torch.randn_like(p)
+            fb.absorb(first=(ep == 0))
+            snaps.append(fb.flat.clone())
+        return snaps
+
+    for cl in (False, True):
+        seg, ref = run("1", cl), run("0", cl)
+        for s_, r_ in zip(seg, ref):
+            assert torch.equal(s_, r_)
+    # the one-launch form is really taken for the plain model
+    calls = {"n": 0}
+    orig = FlatGradBuckets._absorb_segments
+
+    def counted(self, first):
+        ok = orig(self, first)
+        calls["n"] += 1 if ok else 0
+        return ok
+
+    monkeypatch.setattr(FlatGradBuckets, "_absorb_segments", counted)
+    run("1")
+    assert calls["n"] == 3
