@@ -93,6 +93,8 @@ SIGNATURES = {
     "fpsg_bn_stats": [_c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, ctypes.c_float, _c_int, _c_int, _c_int, _c_int,
                       ctypes.c_float, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_int, _c_stream],
     "fpsg_conv_first_dw_workspace_floats": [_c_int, _c_int, _c_int],
+    "fpsg_conv_first_parts": [_c_int, _c_int, _c_int],
+    "fpsg_conv_first_fwd": [_c_f32p, _c_f32p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_f32p, _c_f32p, _c_f32p, _c_stream],
     "fpsg_conv_first_dw": [_c_f32p, _c_f32p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_f32p, _c_f32p, _c_stream],
     "fpsg_adam_step": [_c_f32p, _c_f32p, _c_f32p, _c_f32p, ctypes.c_size_t, ctypes.c_float, ctypes.c_float,
                        ctypes.c_float, ctypes.c_float, _c_int, ctypes.c_float, _c_stream],

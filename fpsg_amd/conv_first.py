@@ -1,10 +1,11 @@
 """The first convolution of the VGG16-BN trunk (3 -> 64 channels, 3x3, padding 1;
 ``vgg16_bn.features[0]``, reference ``src/models/image_net.py:14``).
 
-Forward (and the data gradient, which the train step never asks for: images carry no gradient) are
-the library's; the WEIGHT gradient is K8 (``fpsg_conv_first_dw``): ``dy`` -- 475 MB at 37 images --
-is read once, where the library spends two layout transposes and an NHWC implicit GEMM on a
-1,728-element result."""
+The forward is K8f (``fpsg_conv_first_fwd``: bound by the write of the output; optionally also the partial sums of
+the BatchNorm statistics that follow), the WEIGHT gradient K8 (``fpsg_conv_first_dw``): ``dy`` -- 475 MB at 37
+images -- is read once, where the library spends two layout transposes and an NHWC implicit GEMM on a
+1,728-element result.  The data gradient, which the train step never asks for (images carry no gradient), is
+the library's.  ``FPSG_CONV_FIRST_FWD=0``: the library's forward (A/B)."""
 from __future__ import annotations
 
 import os
@@ -24,14 +25,40 @@ def eligible(x: torch.Tensor, conv: torch.nn.Conv2d) -> bool:
             and x.shape[3] % 4 == 0)
 
 
+def _forward(x, w, stats_bias=None, want_parts=False):
+    xc, wc = x.contiguous(), w.contiguous()
+    N, _, H, W = xc.shape
+    lib = _hip.load()
+    y = torch.empty((N, 64, H, W), dtype=torch.float32, device=x.device)
+    parts = None
+    if want_parts:
+        parts = torch.empty((64, lib.fpsg_conv_first_parts(N, H, W), 2), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = lib.fpsg_conv_first_fwd(_hip.ptr(xc), _hip.ptr(wc), N, 3, 64, H, W, _hip.ptr(y),
+                                     _hip.ptr(stats_bias) if (want_parts and stats_bias is not None) else None,
+                                     _hip.ptr(parts) if want_parts else None, _hip.stream_of(xc))
+    _hip.check(rc, "fpsg_conv_first_fwd")
+    return y, parts
+
+
 class _ConvFirst(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, x, w):
-        ctx.save_for_backward(x, w)
-        return F.conv2d(x, w, None, 1, 1)
+    """``want_parts``: -> ``(y, parts)`` with the statistics partial sums of ``y + stats_bias`` (not differentiable)."""
 
     @staticmethod
-    def backward(ctx, gy):
+    def forward(ctx, x, w, stats_bias=None, want_parts=False):
+        ctx.save_for_backward(x, w)
+        if os.environ.get("FPSG_CONV_FIRST_FWD", "1") == "0":
+            y, parts = F.conv2d(x, w, None, 1, 1), None
+        else:
+            y, parts = _forward(x, w, stats_bias, want_parts)
+        if not want_parts:
+            return y
+        if parts is not None:
+            ctx.mark_non_differentiable(parts)
+        return y, parts
+
+    @staticmethod
+    def backward(ctx, gy, _gparts=None):
         x, w = ctx.saved_tensors
         gx = gw = None
         if ctx.needs_input_grad[0]:
@@ -47,9 +74,12 @@ class _ConvFirst(torch.autograd.Function):
                 rc = lib.fpsg_conv_first_dw(_hip.ptr(xc), _hip.ptr(gy), N, 3, 64, H, W, _hip.ptr(gw), _hip.ptr(ws),
                                             _hip.stream_of(gy))
             _hip.check(rc, "fpsg_conv_first_dw")
-        return gx, gw
+        return gx, gw, None, None
 
 
-def conv3x3_first(x: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
-    """``F.conv2d(x, weight, None, 1, 1)`` for ``x [N,3,H,W]``, ``weight [64,3,3,3]``."""
+def conv3x3_first(x: torch.Tensor, weight: torch.Tensor, stats_bias=None, want_parts: bool = False):
+    """``F.conv2d(x, weight, None, 1, 1)`` for ``x [N,3,H,W]``, ``weight [64,3,3,3]``; ``want_parts``: ->
+    ``(y, parts)``, the statistics partial sums of ``y + stats_bias`` for a following BatchNorm."""
+    if want_parts:
+        return _ConvFirst.apply(x, weight, stats_bias, True)
     return _ConvFirst.apply(x, weight)

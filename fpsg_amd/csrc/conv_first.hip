@@ -107,6 +107,121 @@ __global__ __launch_bounds__(1024) void conv_first_dw_reduce_kernel(const float*
   }
 }
 
+
+// ---- K8f: the FORWARD of the same layer ----------------------------------------------------------------------
+// y[n,k,h,w] = sum over (c, a, b) of w[k][c][a][b] * x[n,c,h+a-1,w+b-1], zero padding: 27 multiply-adds per output and
+// 64 outputs per input pixel -- bound by the write of y (475 MB at 37 images).  A thread owns 4 adjacent pixels: its
+// 3 x 3 x 6 input patch sits in registers (rows as aligned 16-byte loads, the two halo columns from the neighbouring
+// lanes; every load is issued before the first use), the 64 x 27 weights are wave-uniform (scalar loads), and each
+// output channel is one 16-byte store per thread, a wave writing 1 KB contiguous.  Per output the taps are added in
+// (c, a, b) order by an fma chain starting from 0 (the oracle of tests/test_winograd_gpu.py restates exactly this).
+// STATS: per channel the partial sums of y + bias[k] and its square over the workgroup's 1024 pixels ->
+// parts[k][blockIdx.x][2] for the BatchNorm that follows (fpsg_bn_stats with parts).  Deterministic.
+template <bool STATS>
+__global__ __launch_bounds__(kFirstThreads) void conv_first_fwd_kernel(const float* __restrict__ x,
+                                                                       const float* __restrict__ wt /*[64][27]*/, int H,
+                                                                       int W, long Q, float* __restrict__ y,
+                                                                       const float* __restrict__ bias,
+                                                                       float* __restrict__ parts) {
+  __shared__ float red[kFirstThreads / 64][64][2];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const long q_raw = (long)blockIdx.x * kFirstThreads + tid;
+  const bool live = q_raw < Q;
+  const long q = live ? q_raw : Q - 1;          // dead lanes shadow the last quad: every lane takes part in the shuffles
+  const int W4 = W >> 2;
+  const int w4 = (int)(q % W4);
+  const long t = q / W4;
+  const int h = (int)(t % H);
+  const long n = t / H;
+  const bool has_left = w4 > 0, has_right = w4 < W4 - 1;
+  const bool left_lane = has_left && lane > 0, right_lane = has_right && lane < 63;
+  v4f mid[3][3];
+  float el[3][3], er[3][3];
+  const float* rp[3][3];
+  bool rin[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const int r = h + a - 1;
+    rin[a] = r >= 0 && r < H;
+    const int rc = rin[a] ? r : h;               // rows outside the image: a valid row, zeroed below
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      rp[c][a] = x + (((size_t)n * 3 + c) * H + rc) * W + 4 * w4;
+      mid[c][a] = *reinterpret_cast<const v4f*>(rp[c][a]);
+      el[c][a] = er[c][a] = 0.0f;
+    }
+  }
+  if (has_left && !left_lane) {                  // the wave's edge lanes fetch their halo column (one branch each:
+#pragma unroll                                   // loads behind per-element branches would serialise their waits)
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) el[c][a] = rp[c][a][-1];
+  }
+  if (has_right && !right_lane) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) er[c][a] = rp[c][a][4];
+  }
+  float d[3][3][6];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      v4f m = mid[c][a];
+      if (!rin[a]) m = (v4f){0.0f, 0.0f, 0.0f, 0.0f};
+      float lft = __shfl_up(m[3], 1, 64), rgt = __shfl_down(m[0], 1, 64);
+      if (!left_lane) lft = (has_left && rin[a]) ? el[c][a] : 0.0f;
+      if (!right_lane) rgt = (has_right && rin[a]) ? er[c][a] : 0.0f;
+      d[c][a][0] = lft; d[c][a][1] = m[0]; d[c][a][2] = m[1]; d[c][a][3] = m[2]; d[c][a][4] = m[3]; d[c][a][5] = rgt;
+    }
+  }
+  const size_t plane = (size_t)H * W;
+  float* yp = y + ((size_t)n * 64 * H + h) * W + 4 * w4;
+#pragma unroll 2
+  for (int k = 0; k < 64; ++k) {
+    const float* wk = wt + k * 27;
+    float o[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+          const float wv = wk[(c * 3 + a) * 3 + b];
+#pragma unroll
+          for (int p = 0; p < 4; ++p) o[p] = fma_rn(wv, d[c][a][b + p], o[p]);
+        }
+      }
+    }
+    if (live) *reinterpret_cast<v4f*>(yp + (size_t)k * plane) = (v4f){o[0], o[1], o[2], o[3]};
+    if (STATS) {
+      const float bk = bias ? bias[k] : 0.0f;
+      float s0 = 0.0f, s1 = 0.0f;
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        const float v = live ? o[p] + bk : 0.0f;
+        s0 += v;
+        s1 = fma_rn(v, v, s1);
+      }
+      s0 = wave_sum(s0);
+      s1 = wave_sum(s1);
+      if (lane == 0) { red[wave][k][0] = s0; red[wave][k][1] = s1; }
+    }
+  }
+  if (STATS) {
+    __syncthreads();
+    if (tid < 64) {
+      float t0 = red[0][tid][0], t1 = red[0][tid][1];
+#pragma unroll
+      for (int w2 = 1; w2 < kFirstThreads / 64; ++w2) { t0 += red[w2][tid][0]; t1 += red[w2][tid][1]; }
+      float* out = parts + ((size_t)tid * gridDim.x + blockIdx.x) * 2;
+      out[0] = t0;
+      out[1] = t1;
+    }
+  }
+}
+
 }  // namespace
 }  // namespace fpsg
 
@@ -132,4 +247,32 @@ extern "C" int fpsg_conv_first_dw(const float* x, const float* dy, int N, int C,
   if (rc) return rc;
   hipLaunchKernelGGL(conv_first_dw_reduce_kernel, dim3(64), dim3(1024), 0, s, ws, blocks, dw);
   return launch_status("fpsg_conv_first_dw(reduce)");
+}
+
+extern "C" int fpsg_conv_first_parts(int N, int H, int W) {
+  if (N <= 0 || H <= 0 || W <= 0 || W % 4) return 0;
+  const long Q = (long)N * H * (W / 4);
+  return (int)((Q + fpsg::kFirstThreads - 1) / fpsg::kFirstThreads);
+}
+
+extern "C" int fpsg_conv_first_fwd(const float* x, const float* w, int N, int C, int K, int H, int W, float* y,
+                                   const float* bias, float* parts, fpsg_stream_t stream) {
+  using namespace fpsg;
+  FPSG_REQUIRE(C == 3 && K == 64, FPSG_E_SHAPE, "fpsg_conv_first_fwd: the 3 -> 64 channel layer only (got %d -> %d)", C, K);
+  FPSG_REQUIRE(N > 0 && H > 0 && W > 0 && W % 4 == 0, FPSG_E_SHAPE,
+               "fpsg_conv_first_fwd: N, H positive and W a positive multiple of 4 (got %d,%d,%d)", N, H, W);
+  FPSG_REQUIRE_PTR(x); FPSG_REQUIRE_PTR(w); FPSG_REQUIRE_PTR(y);
+  FPSG_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0, FPSG_E_ALIGN,
+               "fpsg_conv_first_fwd: x and y must be 16-byte aligned");
+  FPSG_REQUIRE(!misaligned4(bias) && !misaligned4(parts) && !misaligned4(w), FPSG_E_ALIGN,
+               "fpsg_conv_first_fwd: w / bias / parts not 4-byte aligned");
+  const long Q = (long)N * H * (W / 4);
+  const long blocks = (Q + kFirstThreads - 1) / kFirstThreads;
+  FPSG_REQUIRE(blocks < (1L << 31), FPSG_E_LIMIT, "fpsg_conv_first_fwd: %ld workgroups beyond the grid limit", blocks);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (parts)
+    hipLaunchKernelGGL(conv_first_fwd_kernel<true>, dim3((unsigned)blocks), dim3(kFirstThreads), 0, s, x, w, H, W, Q, y, bias, parts);
+  else
+    hipLaunchKernelGGL(conv_first_fwd_kernel<false>, dim3((unsigned)blocks), dim3(kFirstThreads), 0, s, x, w, H, W, Q, y, nullptr, nullptr);
+  return launch_status("fpsg_conv_first_fwd");
 }

@@ -262,7 +262,8 @@ def wants_conv_stats(conv, bn, x) -> bool:
     """The convolution's epilogue should deliver the statistics of ``bn`` (training mode, a Winograd layer, planes
     large enough for the consumers that take them: the pooled K5 pass and the fold into the next convolution)."""
     return (bn.training and winograd.stats_enabled() and isinstance(conv, nn.Conv2d) and x.dim() == 4
-            and x.shape[0] * x.shape[2] * x.shape[3] > 16384 and winograd.eligible(x, conv))
+            and x.shape[0] * x.shape[2] * x.shape[3] > 16384
+            and (winograd.eligible(x, conv) or conv_first.eligible(x, conv)))
 
 
 def _conv_without_bias(conv, x, want_parts: bool = False):
@@ -275,6 +276,8 @@ def _conv_without_bias(conv, x, want_parts: bool = False):
     if want_parts:
         if isinstance(conv, nn.Conv2d) and winograd.eligible(x, conv):
             return winograd.conv3x3(x, conv.weight, stats_bias=conv.bias, want_parts=True)
+        if isinstance(conv, nn.Conv2d) and conv_first.eligible(x, conv):
+            return conv_first.conv3x3_first(x, conv.weight, stats_bias=conv.bias, want_parts=True)
         return _conv_without_bias(conv, x), None
     if isinstance(conv, nn.Conv2d) and winograd.eligible(x, conv):
         return winograd.conv3x3(x, conv.weight)

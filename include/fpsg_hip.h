@@ -353,6 +353,15 @@ int fpsg_wino_conv_fused_act(const float* x, const float* chan, const float* pre
 size_t fpsg_conv_first_dw_workspace_floats(int N, int H, int W);
 int fpsg_conv_first_dw(const float* x, const float* dy, int N, int C, int K, int H, int W, float* dw, float* ws,
                        fpsg_stream_t stream);
+/* K8f: the forward of the same layer, y [N,64,H,W] = conv(x [N,3,H,W], w [64,3,3,3]), zero padding, no bias
+ * (nn.Conv2d(3, 64, 3, padding=1) of vgg16_bn.features[0]; K5 adds the bias inside the BatchNorm).  Bound by the
+ * write of y; per output the 27 taps are added in (c, a, b) order by an fma chain from 0.  parts (optional):
+ * [64][fpsg_conv_first_parts(N,H,W)][2] partial sums of y + bias[k] (bias optional) and its square for the
+ * BatchNorm that follows (fpsg_bn_stats with parts).  W a multiple of 4; x, y 16-byte aligned.  Deterministic.
+ */
+int fpsg_conv_first_parts(int N, int H, int W);
+int fpsg_conv_first_fwd(const float* x, const float* w, int N, int C, int K, int H, int W, float* y, const float* bias,
+                        float* parts, fpsg_stream_t stream);
 
 /* ---- K7: Adam step over flat buffers ---------------------------------------------------------
  * Replaces torch.optim.Adam(lr, betas=(.9,.999)).step() of the train loop (src/trainNetwork.py:

@@ -148,7 +148,7 @@ def test_first_layer_weight_gradient(gpu, shape):
     wl = w.to(gpu).requires_grad_()
     yl = F.conv2d(x.to(gpu), wl, None, 1, 1)
     yl.backward(g.to(gpu))
-    assert torch.equal(y, yl)
+    assert float((y - yl).abs().max()) <= 2e-6 * float(yl.abs().max())      # K8f forward vs the library's
     scale = float(w64.grad.abs().max())
     e_ours = float((wg.grad.double().cpu() - w64.grad).abs().max()) / scale
     e_lib = float((wl.grad.double().cpu() - w64.grad).abs().max()) / scale
@@ -396,3 +396,38 @@ def test_fused_kernel_delivers_batchnorm_partial_sums(gpu, shape, act):
         assert float((got[:, 0] - s0).abs().max()) <= 2e-6 * n * scale
         assert float((got[:, 1] - s1).abs().max()) <= 2e-6 * n * scale * scale
         assert torch.equal(parts, wg._fused_stats(x, chan, pb, U, bias)[1])
+
+
+@pytest.mark.parametrize("shape", [(2, 8, 8), (3, 30, 36), (1, 5, 4), (5, 64, 64), (2, 224, 224), (37, 56, 100)])
+def test_first_layer_forward_and_its_batchnorm_partial_sums(gpu, shape):
+    """K8f (fpsg_conv_first_fwd) against the reference's operator, F.conv2d(x, w, None, 1, 1) of
+    vgg16_bn.features[0] (src/models/image_net.py:14), in float64; with parts: the same pixels and the partial
+    sums of y + bias and its square.  The autograd op keeps K8 for the weight gradient."""
+    from fpsg_amd.conv_first import _forward, conv3x3_first
+    N, H, W = shape
+    torch.manual_seed(H * 7 + W)
+    x = torch.randn(N, 3, H, W)
+    w = torch.randn(64, 3, 3, 3) * 0.2
+    b = torch.randn(64)
+    y64 = F.conv2d(x.double(), w.double(), None, 1, 1)
+    xg, wg_, bg = x.to(gpu), w.to(gpu), b.to(gpu)
+    y, none = _forward(xg, wg_)
+    assert none is None
+    assert _errs(y, y64) <= 1e-6
+    y2, parts = _forward(xg, wg_, bg, True)
+    assert torch.equal(y, y2)
+    v = y.double() + bg.double().view(1, -1, 1, 1)
+    got = parts.double().sum(1)
+    n, scale = N * H * W, float(v.abs().max())
+    assert float((got[:, 0] - v.sum((0, 2, 3))).abs().max()) <= 2e-6 * n * scale
+    assert float((got[:, 1] - (v * v).sum((0, 2, 3))).abs().max()) <= 2e-6 * n * scale * scale
+    assert torch.equal(parts, _forward(xg, wg_, bg, True)[1])
+    # through autograd: same forward values, K8 weight gradient against float64
+    wr = wg_.clone().requires_grad_()
+    out = conv3x3_first(xg, wr)
+    assert torch.equal(out, y)
+    g = torch.randn(N, 64, H, W)
+    out.backward(g.to(gpu))
+    w64 = w.double().requires_grad_()
+    F.conv2d(x.double(), w64, None, 1, 1).backward(g.double())
+    assert _errs(wr.grad, w64.grad) <= 1e-5
