@@ -409,8 +409,10 @@ int launch_knn(const float* x, const float* xx, const float* xk, int B, int C, i
                            NW * 64 * sizeof(unsigned long long);
   dim3 grid((N + kQ - 1) / kQ, B);
   auto kern = knn_kernel<VPL, C4T, NW, PM>;
-  // one-time opt-in to the full 160 KiB of LDS for this instantiation (per process)
-  static const hipError_t lds_optin = hipFuncSetAttribute(
+  // opt-in to the full 160 KiB of LDS for this instantiation: per call (the attribute belongs to the current
+  // device's copy of the function, so a process driving several devices needs it on each; the call is a host-side
+  // table update, ~1 us)
+  const hipError_t lds_optin = hipFuncSetAttribute(
       reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (lds_optin != hipSuccess && lds_bytes > 64 * 1024) {
     set_error("fpsg_knn: cannot reserve %zu B of LDS: %s", lds_bytes, hipGetErrorString(lds_optin));

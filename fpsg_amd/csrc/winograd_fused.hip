@@ -116,57 +116,81 @@ __global__ __launch_bounds__(kFusedThreads) void wino4_fused_c64_kernel(const fl
     for (int r = 0; r < 4; ++r) ob[r] = out_bias[k0 + 4 * kk + r];
   }
   const long G = (P + 15) >> 4;
-  for (long g = (long)j * 4 + wave; g < G; g += 4L * per_slice) {
+  // What a lane needs to know about its tile in a group of 16: where it is, and how it enters the transform.
+  // Rows r0+1 .. r0+4 are the tile's own output rows: always inside the image; only the halo rows r0 (top) and
+  // r0+5 (bottom) can fall outside.  They are then read from a valid row and enter the transform with weight 0:
+  // B^T uses row 0 only as 4*d[0] (the 4 becomes 0) and row 5 only as +d[5] (multiplied by 0); the halo columns
+  // likewise (x 0 when the tile touches the image's left / right edge).
+  struct Tile {
+    uint32_t boff[6], eoffb[6];     // byte offsets of the six patch rows inside channel kk of step 0 / of the edge element
+    float c4t, mb, c4l, mr, mr5;
+    int tw, th;
+    unsigned n;
+    bool live;
+  };
+  auto locate = [&](long g, Tile& t) {
     const long p_raw = g * 16 + col;
-    const bool live = p_raw < P;
-    const long p = live ? p_raw : P - 1;
+    t.live = p_raw < P;
+    const long p = t.live ? p_raw : P - 1;
     const unsigned pu = (unsigned)p;                                    // P < 2^20 (the 4 GiB check of the host)
-    const int tw = (int)(pu % (unsigned)Tw);
+    t.tw = (int)(pu % (unsigned)Tw);
     const unsigned q = pu / (unsigned)Tw;
-    const int th = (int)(q % (unsigned)Th);
-    const unsigned n = q / (unsigned)Th;
-    const bool has_left = tw > 0, has_right = tw < Tw - 1;
+    t.th = (int)(q % (unsigned)Th);
+    t.n = q / (unsigned)Th;
+    const bool has_left = t.tw > 0, has_right = t.tw < Tw - 1;
     const bool edge_l = has_left && col == 0, edge_r = has_right && col == 15;
-    const int r0 = 4 * th - 1;
-    v4f acc[36];                                   // written by step 0 (C = 0), accumulated in place afterwards
-    // rows r0+1 .. r0+4 are the tile's own output rows: always inside the image; only the halo rows
-    // r0 (top) and r0+5 (bottom) can fall outside.  They are then read from a valid row and enter the
-    // transform with weight 0: B^T uses row 0 only as 4*d[0] (the 4 becomes 0) and row 5 only as +d[5]
-    // (multiplied by 0); the halo columns likewise (x 0 when the tile touches the image's left / right edge).
+    const int r0 = 4 * t.th - 1;
     const bool top_in = r0 >= 0, bot_in = r0 + 5 < H;
-    const float c4t = top_in ? 4.0f : 0.0f, mb = bot_in ? 1.0f : 0.0f;
-    const float ml = has_left ? 1.0f : 0.0f, mr = has_right ? 1.0f : 0.0f;
-    const float c4l = 4.0f * ml, mr5 = mr * mb;
-    // byte offsets of the lane's six patch rows inside channel kk of step 0 (the tensor is below 4 GiB: checked
-    // by the host); a step's loads are `uniform base + 32-bit lane offset`, no per-step address arithmetic
-    uint32_t boff[6], eoffb[6];
-    {
-      const uint32_t lane_elem = (uint32_t)((((size_t)n * C + kk) * H) * W + 4 * tw);
-      // a lane is at most at one edge of its row of 16: column 0 needs the element left of its vector, column
-      // 15 the one right of it; the others re-read their own first element (never used)
-      const uint32_t eadd = edge_l ? (uint32_t)-4 : (edge_r ? 16u : 0u);
+    t.c4t = top_in ? 4.0f : 0.0f;
+    t.mb = bot_in ? 1.0f : 0.0f;
+    t.c4l = has_left ? 4.0f : 0.0f;
+    t.mr = has_right ? 1.0f : 0.0f;
+    t.mr5 = t.mr * t.mb;
+    // the tensor is below 4 GiB (checked by the host): a step's loads are `uniform base + 32-bit lane offset`
+    const uint32_t lane_elem = (uint32_t)((((size_t)t.n * C + kk) * H) * W + 4 * t.tw);
+    // a lane is at most at one edge of its row of 16: column 0 needs the element left of its vector, column
+    // 15 the one right of it; the others re-read their own first element (never used)
+    const uint32_t eadd = edge_l ? (uint32_t)-4 : (edge_r ? 16u : 0u);
 #pragma unroll
-      for (int r = 0; r < 6; ++r) {
-        const int row = r0 + r;
-        boff[r] = (lane_elem + (uint32_t)((row < 0 ? 0 : (row >= H ? H - 1 : row)) * W)) * 4u;
-        eoffb[r] = boff[r] + eadd;
-      }
+    for (int r = 0; r < 6; ++r) {
+      const int row = r0 + r;
+      t.boff[r] = (lane_elem + (uint32_t)((row < 0 ? 0 : (row >= H ? H - 1 : row)) * W)) * 4u;
+      t.eoffb[r] = t.boff[r] + eadd;
     }
-    const uint32_t step_bytes = (uint32_t)(4 * H * W) * 4u;            // 4 channels per step
-
-    // the patch of one channel step as loaded: interior vectors + the halo element of an edge lane.
-    // One wave per SIMD (the U slice fills the LDS), so the load latency is covered by issuing the loads
-    // two steps ahead of their use; no branches around the loads (the compiler then counts outstanding
-    // loads exactly: s_waitcnt vmcnt(n) per buffer instead of vmcnt(0)).
-    struct Raw { v4f mid[6]; float e[6]; };
-    auto load_raw = [&](int c4, Raw& w) {
-      const uint32_t sbase = (uint32_t)c4 * step_bytes;                  // wave-uniform: the buffer load's soffset
+  };
+  const uint32_t step_bytes = (uint32_t)(4 * H * W) * 4u;              // 4 channels per step
+  struct Raw { v4f mid[6]; float e[6]; };
+  auto load_raw = [&](const Tile& t, int c4, Raw& w) {
+    const uint32_t sbase = (uint32_t)c4 * step_bytes;                  // wave-uniform: the buffer load's soffset
 #pragma unroll
-      for (int r = 0; r < 6; ++r) {
-        w.mid[r] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, boff[r], sbase, 0));
-        w.e[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xrsrc, eoffb[r], sbase, 0));
-      }
-    };
+    for (int r = 0; r < 6; ++r) {
+      w.mid[r] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, t.boff[r], sbase, 0));
+      w.e[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xrsrc, t.eoffb[r], sbase, 0));
+    }
+  };
+  const long g_stride = 4L * per_slice;
+  Tile cur, nxt;
+  Raw ra, rb;
+  long g = (long)j * 4 + wave;
+  if (g < G) {
+    locate(g, cur);
+    load_raw(cur, 0, ra);
+    load_raw(cur, 1, rb);
+  }
+  for (; g < G; g += g_stride) {
+    // the next group's first two patches are loaded under this group's last steps and its output transform
+    // (a group otherwise starts with both buffers cold: ~7 % of the kernel parked at s_waitcnt)
+    locate(g + g_stride < G ? g + g_stride : g, nxt);
+    const float c4t = cur.c4t, mb = cur.mb, c4l = cur.c4l, mr = cur.mr, mr5 = cur.mr5;
+    const bool live = cur.live;
+    const int tw = cur.tw, th = cur.th;
+    const unsigned n = cur.n;
+    v4f acc[36];                                   // written by step 0 (C = 0), accumulated in place afterwards
+
+    // The patch of one channel step as loaded: interior vectors + the halo element of an edge lane.  One wave per
+    // SIMD (the U slice fills the LDS), so the load latency is covered by issuing the loads one to two steps ahead of
+    // their use; no branches around the loads (the compiler then counts outstanding loads exactly: s_waitcnt
+    // vmcnt(n) per buffer instead of vmcnt(0)).
     // (accr: the accumulators as a parameter -- asm operands in a generic lambda cannot name captured arrays)
     auto compute = [&](int c4, const Raw& w, v4f (&accr)[36], auto first) {
       // this step's 36 A fragments: issued first (pinned by the sched_barrier), in flight under the input transform
@@ -254,25 +278,29 @@ __global__ __launch_bounds__(kFusedThreads) void wino4_fused_c64_kernel(const fl
     };
     // sched_barrier: keep each step's loads where they are written (the scheduler otherwise hoists
     // all of them to the top and spills)
-#define FPSG_LOAD(st, buf) load_raw((st) < kSteps ? (st) : kSteps - 1, buf); __builtin_amdgcn_sched_barrier(0)
+#define FPSG_LOAD(st, buf) load_raw(cur, st, buf); __builtin_amdgcn_sched_barrier(0)
+#define FPSG_LOAD_NEXT(st, buf) load_raw(nxt, st, buf); __builtin_amdgcn_sched_barrier(0)
 #define FPSG_COMPUTE(st, buf) compute(st, buf, acc, std::false_type{}); __builtin_amdgcn_sched_barrier(0)
 #define FPSG_COMPUTE_FIRST(st, buf) compute(st, buf, acc, std::true_type{}); __builtin_amdgcn_sched_barrier(0)
-    Raw ra, rb;
-    FPSG_LOAD(0, ra);
-    FPSG_LOAD(1, rb);
+    __builtin_amdgcn_sched_barrier(0);
     FPSG_COMPUTE_FIRST(0, ra);                            // step 0 writes the accumulators (C = 0)
     FPSG_LOAD(2, ra);
     FPSG_COMPUTE(1, rb);
     FPSG_LOAD(3, rb);
 #pragma unroll 1
-    for (int c4 = 2; c4 < kSteps; c4 += 2) {              // a step's loads are issued one to two steps ahead
+    for (int c4 = 2; c4 < kSteps - 2; c4 += 2) {          // steps 2 .. 13; a step's loads are issued one to two steps ahead
       FPSG_COMPUTE(c4, ra);
-      FPSG_LOAD(c4 + 2, ra);                              // clamped to the last step
+      FPSG_LOAD(c4 + 2, ra);                              // <= 15
       FPSG_COMPUTE(c4 + 1, rb);
       FPSG_LOAD(c4 + 3, rb);
     }
+    FPSG_COMPUTE(kSteps - 2, ra);
+    FPSG_LOAD_NEXT(0, ra);
+    FPSG_COMPUTE(kSteps - 1, rb);
+    FPSG_LOAD_NEXT(1, rb);
 #undef FPSG_COMPUTE
 #undef FPSG_COMPUTE_FIRST
+#undef FPSG_LOAD_NEXT
 #undef FPSG_LOAD
     // the compiler does not see MFMAs in the asm statements: cover the MFMA-write -> VALU-read distance by hand
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
@@ -308,6 +336,7 @@ __global__ __launch_bounds__(kFusedThreads) void wino4_fused_c64_kernel(const fl
         }
       }
     }
+    cur = nxt;
   }
   if (STATS) {
     __syncthreads();                                      // every wave is done with the U slice: reuse its LDS
