@@ -281,6 +281,37 @@ class _DecoderLayer1(torch.autograd.Function):
         return gw, gb, gx, gpts, dgamma, dbeta, None, None, None, None, None
 
 
+class _StackFrozen(torch.autograd.Function):
+    """``torch.stack(tensors)`` whose VALUES are taken from the step-scoped cache of ``winograd.weights_frozen`` when
+    the same parameters were stacked earlier in the step (the parameters do not change between the episodes of an
+    optimizer step: 247 MB of decoder weights are then copied once per step instead of once per episode); the
+    gradient is unbound to the parameters as ``torch.stack``'s is."""
+
+    @staticmethod
+    def forward(ctx, key, *tensors):
+        from . import winograd
+        cache = winograd.frozen_cache()
+        full_key = ("stack", key) + tuple(t.data_ptr() for t in tensors)
+        if cache is not None and full_key in cache:
+            return cache[full_key].detach()          # a new tensor on the cached storage: this node's output
+        out = torch.stack([t.detach() for t in tensors])
+        if cache is not None:
+            cache[full_key] = out
+            return out.detach()
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return (None,) + tuple(g.unbind(0))
+
+
+def _stack(key, tensors):
+    tensors = list(tensors)
+    if tensors[0].is_cuda and torch.is_grad_enabled() and any(t.requires_grad for t in tensors):
+        return _StackFrozen.apply(key, *tensors)
+    return torch.stack(tensors)
+
+
 class _LazySplit:
     """``(w[..., :L], w[..., L:], b)`` computed once, when first asked for."""
 
@@ -375,8 +406,8 @@ class PCDecoder(nn.Module):
         nodes = [n for c in clusters for n in c.node_pool]
 
         def stack_w(mods, name, repeat=1):
-            w = torch.stack([getattr(m, name).weight.squeeze(-1) for m in mods])       # [n,out,in]
-            b = torch.stack([getattr(m, name).bias for m in mods])                     # [n,out]
+            w = _stack(name + ".w", [getattr(m, name).weight.squeeze(-1) for m in mods])   # [n,out,in]
+            b = torch.stack([getattr(m, name).bias for m in mods])                         # [n,out]
             if repeat > 1:
                 w = w.repeat_interleave(repeat, dim=0)
                 b = b.repeat_interleave(repeat, dim=0)

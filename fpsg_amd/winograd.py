@@ -96,6 +96,14 @@ class weights_frozen:
         return False
 
 
+def frozen_cache():
+    """The step-scoped cache of a ``weights_frozen`` block (None outside one, or while a hipGraph is captured):
+    derived forms of the weights -- transformed filters here, the decoder's stacked weights -- keyed by the caller."""
+    if _frozen_cache is None or (torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()):
+        return None
+    return _frozen_cache
+
+
 def _filter(m, w, flip):
     cache = _frozen_cache
     if cache is not None and torch.cuda.is_current_stream_capturing():

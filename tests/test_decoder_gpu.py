@@ -115,3 +115,55 @@ def test_pack_shared_by_two_decodes_sums_gradients(gpu):
     for n in a:
         s = float(b[n].abs().max()) + 1e-12
         assert float((a[n] - b[n]).abs().max()) <= 1e-4 * s + 1e-7, n
+
+
+def test_stacked_weights_are_copied_once_per_step(gpu, monkeypatch):
+    """Inside ``winograd.weights_frozen()`` (the episodes of one optimizer step) the 16 patch MLPs' weights are
+    stacked once: later packs take the cached values; outputs and every parameter gradient of each episode are
+    those of the uncached form bit for bit, and the cache ends with the block."""
+    from fpsg_amd import point_cloud_net as pcn
+    from fpsg_amd import winograd
+    dec, hidden, grids = _make(3, 11)
+    dec = dec.to(gpu).train()
+    gg = [[g.to(gpu) for g in c] for c in grids]
+    stacks = {"n": 0}
+    orig = torch.stack
+
+    def counted(ts, *a, **k):
+        ts = list(ts)
+        if len(ts) and ts[0].dim() == 2 and ts[0].numel() > 100000:      # a layer's weight matrices
+            stacks["n"] += 1
+        return orig(ts, *a, **k)
+
+    monkeypatch.setattr(torch, "stack", counted)
+
+    def episodes(cached):
+        net = copy.deepcopy(dec)
+        res = []
+        ctx = winograd.weights_frozen() if cached else None
+        if ctx:
+            ctx.__enter__()
+        try:
+            for ep in range(2):
+                net.zero_grad(set_to_none=True)
+                h = (hidden.to(gpu) * (1 + ep)).requires_grad_()
+                out = net(h, grid=gg, pack=net.pack_parameters())
+                (out * out).sum().backward()
+                res.append((out.detach().clone(), h.grad.clone(), [p.grad.clone() for p in net.parameters()]))
+        finally:
+            if ctx:
+                ctx.__exit__(None, None, None)
+        return res
+
+    stacks["n"] = 0
+    plain = episodes(False)
+    n_plain = stacks["n"]
+    stacks["n"] = 0
+    cached = episodes(True)
+    n_cached = stacks["n"]
+    assert n_plain == 2 * n_cached and n_cached >= 3, (n_plain, n_cached)
+    for (o0, h0, g0), (o1, h1, g1) in zip(plain, cached):
+        assert torch.equal(o0, o1) and torch.equal(h0, h1)
+        for a, b in zip(g0, g1):
+            assert torch.equal(a, b)
+    assert winograd.frozen_cache() is None
