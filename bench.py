@@ -290,6 +290,76 @@ def kernel_rooflines(device):
         out[key + "_bwd"] = entry("hbm", bb / tb / 1e9, HBM_PEAK / 1e9, "GB/s", tb, f"B=64 N=2048 k=20 Co={Co}",
                                   "compulsory bytes: dzs, jsel, s1, PQ, reverse graph read, dPQ written; in-edge gathers "
                                   "are served by L2")
+    out.update(trunk_kernel_rooflines(device, entry))
+    return out
+
+
+def trunk_kernel_rooflines(device, entry):
+    """The hand-written kernels of the image branch and the optimizer at the step's shapes (37 images): K5 / K6
+    transforms / K7 / K8 / K8f against the HBM peak with their algorithmic bytes, K6f against
+    the fp32 MFMA peak in the Winograd domain."""
+    import torch.nn as nn
+    from fpsg_amd import winograd as wg
+    from fpsg_amd.conv_first import _forward as first_fwd, conv3x3_first
+    from fpsg_amd.fused_bn import bn_act
+    from fpsg_amd.optim import FlatAdam
+    out = {}
+    n_img = 37
+    hbm = lambda nbytes, t, shape, work, **more: entry("hbm", nbytes / t / 1e9, HBM_PEAK / 1e9, "GB/s", t, shape, work, **more)
+    # K6f: both 64-input-channel layers; flop in the Winograd domain (36 products of [K x 64] . [64 x tiles])
+    for K, H in ((64, 224), (128, 112)):
+        x = torch.randn(n_img, 64, H, H, device=device)
+        U = wg._filter(4, torch.randn(K, 64, 3, 3, device=device) * 0.05, False)
+        t = _event_time(lambda: wg._fused(x, U), 10)
+        flop = 2.0 * 36 * K * 64 * n_img * (H // 4) ** 2
+        out[f"K6f_fused_conv_64to{K}"] = entry(
+            "mfma", flop / t / 1e12, F32_PEAK / 1e12, "TFLOP/s", t, f"({n_img},64,{H},{H})",
+            "36 x [K x 64].[64 x tiles] products (Winograd domain; x4 = direct-equivalent); fp32 MFMA and fp32 VALU "
+            "do not overlap on gfx950, so the transform's vector instructions add to the MFMA time (DESIGN.md K6f)",
+            hbm_GBps=(x.numel() + n_img * K * H * H) * 4 / t / 1e9)
+        del x, U
+    # K6 transforms at the largest three-kernel layer (128 channels @112): (1 + 2.25) x the activation tensor
+    x = torch.randn(n_img, 128, 112, 112, device=device)
+    V = wg._input(4, x)
+    nb = 3.25 * x.numel() * 4
+    for name, fn in (("input", lambda: wg._input(4, x)), ("output", lambda: wg._output(4, V, n_img, 112, 112)),
+                     ("grad_output", lambda: wg._grad_output(4, x))):
+        t = _event_time(fn, 10)
+        out[f"K6_{name}_transform"] = hbm(nb, t, f"({n_img},128,112,112) m=4", "1 read + 2.25 writes (or the reverse) of the tensor")
+    del V
+    # K5: BatchNorm + ReLU on the same tensor: forward 2 reads + 1 write, backward 4 reads + 1 write
+    bn = nn.BatchNorm2d(128).to(device).train()
+    xr = x.requires_grad_()
+    g = torch.randn_like(x)
+    t = _event_time(lambda: bn_act(bn, xr, "relu"), 10)
+    out["K5_bn_relu_fwd"] = hbm(3.0 * x.numel() * 4, t, f"({n_img},128,112,112)", "statistics pass + apply pass: 2R + 1W")
+    y = bn_act(bn, xr, "relu")
+    t = _event_time(lambda: torch.autograd.grad(y, xr, g, retain_graph=True), 10)
+    out["K5_bn_relu_bwd"] = hbm(5.0 * x.numel() * 4, t, f"({n_img},128,112,112)", "sums pass (x, dy) + dx pass (x, dy -> dx): 4R + 1W")
+    del x, xr, g, y
+    # K8f / K8: the first convolution (3 -> 64 @224): forward bound by the write of y, weight gradient by the read of dy
+    x = torch.randn(n_img, 3, 224, 224, device=device)
+    w = (torch.randn(64, 3, 3, 3, device=device) * 0.2).requires_grad_()
+    b = torch.zeros(64, device=device)
+    t = _event_time(lambda: first_fwd(x, w.detach(), b, True), 10)
+    ybytes = n_img * 64 * 224 * 224 * 4
+    out["K8f_first_conv_fwd"] = hbm(ybytes + x.numel() * 4, t, f"({n_img},3,224,224) -> 64 channels",
+                                    "x read, y written once; BatchNorm partial sums in the epilogue")
+    yv = conv3x3_first(x, w)
+    gy = torch.randn_like(yv)
+    t = _event_time(lambda: torch.autograd.grad(yv, w, gy, retain_graph=True), 10)
+    out["K8_first_conv_dw"] = hbm(ybytes + x.numel() * 4, t, f"dy ({n_img},64,224,224)", "dy and x read once")
+    del x, yv, gy
+    # K7: Adam over the model's 77.4 M parameters: 4 reads + 3 writes
+    n = 77445125
+    p = nn.Parameter(torch.randn(n, device=device))
+    opt = FlatAdam([p], lr=1e-3)
+    p.grad = torch.randn(n, device=device)
+    opt.bind_gradients(p.grad)
+    t = _event_time(lambda: opt.step(), 10)
+    out["K7_adam_step"] = hbm(28.0 * n, t, f"{n} parameters", "param, grad, exp_avg, exp_avg_sq read; param and both moments written")
+    del p, opt
+    torch.cuda.empty_cache()
     return out
 
 
