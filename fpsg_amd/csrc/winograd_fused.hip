@@ -12,13 +12,17 @@
 //     (channel c = 4*step + lane/16, tile = lane%16) loads its tile's 6x6 patch -- interior columns
 //     as one aligned vector, halo columns from the neighbouring lanes -- transforms it (the 36
 //     values ARE the B fragments of v_mfma_f32_16x16x4_f32 for that step) and issues 36 MFMAs,
-//     one per transform point, accumulating M[xi][16 k][16 tiles] in 144 accumulator VGPRs;
+//     one per transform point, accumulating M[xi][16 k][16 tiles] in 144 accumulator registers (AGPRs);
 //   * after the 16 channel steps a lane holds M[0..35] for its tile and 4 output channels:
 //     the output transform runs in registers and the 4x4 pixels are stored as aligned vectors.
 // Workgroup -> (slice, tile range) mapping keeps the workgroups of one tile range on one XCD
 // (round-robin dispatch: id % 8), so that the re-reads of x by the other slices hit that L2.
-// Same arithmetic per element as winograd.hip's transforms; the channel sum runs in the MFMA's
-// k order.  Deterministic.
+// fp32 MFMAs and fp32 VALU instructions do not overlap on gfx950 (tools/micro/mfma_f32_*.hip): a step costs its 36
+// MFMAs PLUS every vector instruction, so the code below is written for few instructions -- scalar transform on the
+// columns as loaded, 12-operation B^T d, out-of-image rows / columns through transform weights instead of selects,
+// the products as in-place asm blocks on AGPR tuples, buffer loads without address arithmetic.
+// Same arithmetic per element as winograd.hip's transforms (masked rows / columns enter as x 0 instead of a selected
+// 0: the sign of a zero may differ); the channel sum runs in the MFMA's k order.  Deterministic.
 #include <type_traits>
 
 #include "fpsg_common.h"
