@@ -87,6 +87,9 @@ SIGNATURES = {
     "fpsg_wino_input_transform_act": [_c_int, _c_f32p, _c_f32p, _c_f32p, _c_int, _c_int, _c_int, _c_int, _c_f32p, _c_stream],
     "fpsg_wino_conv_fused_act": [_c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_f32p,
                                  _c_stream],
+    "fpsg_wino_dw_fused_workspace_floats": [_c_int, _c_int, _c_int, _c_int],
+    "fpsg_wino_dw_fused": [_c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_f32p, _c_f32p,
+                           _c_stream],
     "fpsg_wino_conv_fused_parts": [_c_int, _c_int, _c_int, _c_int],
     "fpsg_wino_conv_fused_stats": [_c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_f32p,
                                    _c_f32p, _c_f32p, _c_stream],
@@ -109,7 +112,8 @@ SIGNATURES = {
 _RESTYPES = {"fpsg_last_error": ctypes.c_char_p, "fpsg_chamfer_workspace_bytes": ctypes.c_size_t,
              "fpsg_sinkhorn_workspace_floats": ctypes.c_size_t,
              "fpsg_knn_workspace_floats": ctypes.c_size_t,
-             "fpsg_bn_workspace_floats": ctypes.c_size_t, "fpsg_bn_pool_workspace_floats": ctypes.c_size_t, "fpsg_bn_max_workspace_floats": ctypes.c_size_t, "fpsg_conv_first_dw_workspace_floats": ctypes.c_size_t, "fpsg_emd_workspace_floats": ctypes.c_size_t}
+             "fpsg_bn_workspace_floats": ctypes.c_size_t, "fpsg_bn_pool_workspace_floats": ctypes.c_size_t, "fpsg_bn_max_workspace_floats": ctypes.c_size_t, "fpsg_conv_first_dw_workspace_floats": ctypes.c_size_t, "fpsg_emd_workspace_floats": ctypes.c_size_t,
+             "fpsg_wino_dw_fused_workspace_floats": ctypes.c_size_t}
 
 _lib = None
 _lock = threading.Lock()

@@ -67,6 +67,27 @@ def _can_fuse(m: int, c_in: int, c_out: int, n_pixels: int) -> bool:
     return fused_enabled() and m == 4 and c_in == 64 and c_out % 16 == 0 and n_pixels * 64 * 4 < (1 << 32)
 
 
+def _can_fuse_dw(m: int, c_in: int, c_out: int, N: int, H: int, W: int) -> bool:
+    """K6w (``fpsg_wino_dw_fused``): the weight gradient of a 64-input-channel layer in one pass -- no transformed
+    input, no transformed output gradient, no GEMM with the tile-long reduction.  ``FPSG_WINOGRAD_DW=0``: the
+    three-kernel form (A/B)."""
+    return (fused_enabled() and os.environ.get("FPSG_WINOGRAD_DW", "1") != "0" and m == 4 and c_in == 64
+            and c_out % 16 == 0 and H % 4 == 0 and W % 16 == 0 and N * max(c_in, c_out) * H * W * 4 < (1 << 31))
+
+
+def _fused_dw(x, chan, pre_bias, gy):
+    """dU [36, K, 64] of the convolution whose input was ``x`` (or relu(BN(x)) with ``chan``) and output gradient ``gy``."""
+    N, C, H, W = x.shape
+    K = gy.shape[1]
+    lib = _hip.load()
+    dU = torch.empty((36, K, C), dtype=torch.float32, device=x.device)
+    ws = torch.empty((lib.fpsg_wino_dw_fused_workspace_floats(N, K, H, W),), dtype=torch.float32, device=x.device)
+    opt = lambda t: _hip.ptr(t) if t is not None else None
+    _call("fpsg_wino_dw_fused", _hip.ptr(x), opt(chan), opt(pre_bias), _hip.ptr(gy), N, C, K, H, W, _hip.ptr(dU),
+          _hip.ptr(ws), _hip.stream_of(x))
+    return dU
+
+
 def _wide_enough(c_in: int, c_out: int, m: int) -> bool:
     lo, hi = min(c_in, c_out), max(c_in, c_out)
     return lo >= MIN_CHANNELS_M4 if m == 4 else (lo >= MIN_CHANNELS_M2 and hi >= MIN_WIDE_CHANNELS_M2)
@@ -230,8 +251,11 @@ class _Conv3x3(torch.autograd.Function):
                 else:
                     gx = _output(m, torch.bmm(_filter(m, w, True), _input(m, gy)), N, H, W)
             if ctx.needs_input_grad[1]:
-                V = kept if kept_is_v else _input(m, kept)
-                gw = _filter_grad(m, torch.bmm(_grad_output(m, gy), V.transpose(1, 2)), w)
+                if not kept_is_v and _can_fuse_dw(m, C, K, N, H, W):
+                    gw = _filter_grad(m, _fused_dw(kept, None, None, gy), w)
+                else:
+                    V = kept if kept_is_v else _input(m, kept)
+                    gw = _filter_grad(m, torch.bmm(_grad_output(m, gy), V.transpose(1, 2)), w)
         return gx, gw, None, None, None
 
 
@@ -323,9 +347,12 @@ class _BNReluConv3x3(torch.autograd.Function):
             else:
                 ga = _output(m, torch.bmm(_filter(m, w, True), _input(m, gout)), N, H, W)
             if ctx.needs_input_grad[9]:
-                if V is None:
-                    V = _input_act(m, y, chan, pre_bias)
-                gw = _filter_grad(m, torch.bmm(_grad_output(m, gout), V.transpose(1, 2)), w)
+                if V is None and _can_fuse_dw(m, C, K, N, H, W):
+                    gw = _filter_grad(m, _fused_dw(y, chan, pre_bias, gout), w)
+                else:
+                    if V is None:
+                        V = _input_act(m, y, chan, pre_bias)
+                    gw = _filter_grad(m, torch.bmm(_grad_output(m, gout), V.transpose(1, 2)), w)
             # BatchNorm + ReLU backward on y (K5)
             want_dpb = pre_bias is not None and ctx.needs_input_grad[1]
             dy = torch.empty_like(y)

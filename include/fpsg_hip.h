@@ -333,6 +333,19 @@ int fpsg_wino_conv_fused_parts(int N, int K, int H, int W);
 int fpsg_wino_conv_fused_stats(const float* x, const float* chan, const float* pre_bias, const float* U, int N, int C,
                                int K, int H, int W, float* y, const float* out_bias, float* parts, fpsg_stream_t stream);
 
+/* K6w: the WEIGHT gradient of the same convolutions (64 input channels) in one pass: dU [36,K,64] = sum over tiles of
+ * (A dY A^T)[k] x (B^T d B)[c], both transform-domain operands formed in registers from dy [N,K,H,W] and the layer's
+ * input x [N,64,H,W] (chan != NULL: x is the PRE-BatchNorm tensor and relu(fma(x + pre_bias[c], chan[c], chan[C+c]))
+ * is what the convolution saw, as in fpsg_wino_conv_fused_act); dw = fpsg_wino_filter_grad_transform(4, dU).  Replaces
+ * fpsg_wino_input_transform + fpsg_wino_grad_output_transform + the batched GEMM with the tile-long reduction.
+ * H a multiple of 4, W of 16 (the four tiles of an MFMA step lie in one tile row); x, dy 16-byte aligned and below
+ * 2 GiB each; ws: fpsg_wino_dw_fused_workspace_floats(N,K,H,W) floats (per-range partials, summed in a fixed order in
+ * fp64).  Deterministic.
+ */
+size_t fpsg_wino_dw_fused_workspace_floats(int N, int K, int H, int W);
+int fpsg_wino_dw_fused(const float* x, const float* chan, const float* pre_bias, const float* dy, int N, int C, int K,
+                       int H, int W, float* dU, float* ws, fpsg_stream_t stream);
+
 /* The same two entry points reading a PRE-BatchNorm tensor: the values fed to the transform are
  * relu(fma(x + pre_bias[c], chan[c], chan[C + c])) -- K5's apply arithmetic with chan = (scale, shift, ..) from
  * fpsg_bn_stats / fpsg_bn_act_fwd -- so that the BatchNorm + ReLU apply pass between two convolutions of a VGG

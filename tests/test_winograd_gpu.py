@@ -431,3 +431,36 @@ def test_first_layer_forward_and_its_batchnorm_partial_sums(gpu, shape):
     w64 = w.double().requires_grad_()
     F.conv2d(x.double(), w64, None, 1, 1).backward(g.double())
     assert _errs(wr.grad, w64.grad) <= 1e-5
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 64, 16, 16), (3, 64, 32, 8, 48), (1, 64, 16, 4, 16), (5, 64, 128, 28, 32),
+                                   (37, 64, 64, 56, 48)])
+@pytest.mark.parametrize("act", [False, True])
+def test_fused_weight_gradient_matches_three_kernel_form(gpu, shape, act):
+    """K6w (fpsg_wino_dw_fused): dU of a 64-input-channel layer against the three-kernel form (input transform,
+    grad-output transform, batched GEMM over the tiles) and the resulting dw against conv2d's weight gradient in
+    float64; with ``act`` the input is a pre-BatchNorm tensor.  Ranges without steps, image borders, one tile row
+    per image and several images per range are among the shapes.  Deterministic."""
+    from fpsg_amd import winograd as wg
+    N, C, K, H, W = shape
+    torch.manual_seed(K + H + W)
+    x = torch.randn(N, C, H, W, device=gpu)
+    gy = torch.randn(N, K, H, W, device=gpu)
+    chan = pb = None
+    a = x
+    if act:
+        chan = torch.randn(4, C, device=gpu) * 0.5 + 1.0
+        pb = torch.randn(C, device=gpu) * 0.1
+        a = torch.relu((x + pb.view(1, -1, 1, 1)) * chan[0].view(1, -1, 1, 1) + chan[1].view(1, -1, 1, 1))
+    assert wg._can_fuse_dw(4, C, K, N, H, W)
+    dU = wg._fused_dw(x, chan, pb, gy)
+    V = wg._input_act(4, x, chan, pb) if act else wg._input(4, x)
+    ref = torch.bmm(wg._grad_output(4, gy), V.transpose(1, 2))
+    scale = float(ref.abs().max())
+    assert float((dU - ref).abs().max()) <= 2e-5 * scale, float((dU - ref).abs().max()) / scale
+    assert torch.equal(dU, wg._fused_dw(x, chan, pb, gy))
+    w = torch.randn(K, C, 3, 3, device=gpu)
+    gw = wg._filter_grad(4, dU, w)
+    w64 = w.double().cpu().requires_grad_()
+    F.conv2d(a.double().cpu(), w64, None, 1, 1).backward(gy.double().cpu())
+    assert _errs(gw, w64.grad) <= 2e-5

@@ -37,3 +37,19 @@ for (K, H) in ((64, 224), (128, 112)):
     flops = 2 * 36 * K * 64 * 37 * (H // 4) ** 2
     print(f"K6f 64->{K} (37,64,{H},{H}) {t * 1e6:8.1f} us  {flops / t / 1e12:6.1f} TFLOP/s (Winograd domain)  "
           f"{100 * flops / t / 157.3e12:5.1f} % of fp32 MFMA peak   max |K6f - K6| = {err:.2e}")
+
+# K6w: the weight gradient of the same layers in one pass, against the three-kernel form it replaces
+for (K, H) in ((64, 224), (128, 112)):
+    x = torch.randn(37, 64, H, H, device=dev)
+    gy = torch.randn(37, K, H, H, device=dev)
+    three = lambda: torch.bmm(wg._grad_output(4, gy), wg._input(4, x).transpose(1, 2))
+    ref = three()
+    dU = wg._fused_dw(x, None, None, gy)
+    err = (dU - ref).abs().max().item() / ref.abs().max().item()
+    t3 = gpu_time(three, reps=10)
+    t = gpu_time(lambda: wg._fused_dw(x, None, None, gy), reps=10)
+    flops = 2 * 36 * K * 64 * 37 * (H // 4) ** 2
+    print(f"K6w dU 64->{K} (37,64,{H},{H}) {t * 1e6:8.1f} us  {flops / t / 1e12:6.1f} TFLOP/s (Winograd domain)  "
+          f"{100 * flops / t / 157.3e12:5.1f} % of fp32 MFMA peak   three-kernel form {t3 * 1e6:8.1f} us   "
+          f"max |K6w - form| / scale = {err:.2e}")
+    del x, gy, ref, dU
