@@ -317,7 +317,13 @@ def trunk_kernel_rooflines(device, entry):
             "36 x [K x 64].[64 x tiles] products (Winograd domain; x4 = direct-equivalent); fp32 MFMA and fp32 VALU "
             "do not overlap on gfx950, so the transform's vector instructions add to the MFMA time (DESIGN.md K6f)",
             hbm_GBps=(x.numel() + n_img * K * H * H) * 4 / t / 1e9)
-        del x, U
+        gy = torch.randn(n_img, K, H, H, device=device)
+        t = _event_time(lambda: wg._fused_dw(x, None, None, gy), 10)
+        out[f"K6w_fused_dw_64to{K}"] = entry(
+            "mfma", flop / t / 1e12, F32_PEAK / 1e12, "TFLOP/s", t, f"x ({n_img},64,{H},{H}), dy {K} channels",
+            "the same 36 products reduced over the tiles, both operands transformed in registers (two transforms per "
+            "lane and step add to the MFMA time)")
+        del x, U, gy
     # K6 transforms at the largest three-kernel layer (128 channels @112): (1 + 2.25) x the activation tensor
     x = torch.randn(n_img, 128, 112, 112, device=device)
     V = wg._input(4, x)
