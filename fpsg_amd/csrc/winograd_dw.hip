@@ -52,17 +52,18 @@ __device__ __forceinline__ void gout4(const float (&y)[4], float (&r)[6]) {
 
 // LDS staging of one MFMA step (4 horizontally adjacent tiles), filled by LDS-DMA loads (buffer_load_dwordx4 ... lds:
 // a wave instruction moves 64 x 16 bytes from per-lane global addresses to 1 KB of consecutive LDS):
-//   x : [64 channels][6 patch rows][6 chunks of 4 floats] + 1 pad chunk per channel  -- chunk 0 / 5 hold the halo
-//       columns, chunks 1..4 the four tiles; 37 chunks per channel make the channel stride 148 floats, so that the
-//       16-byte reads of 8 lanes (8 channels) fall into 8 different bank groups
-//   dy: [16 output channels][4 rows][4 chunks] + 1 pad chunk per channel (stride 68 floats)
+//   x : [6 patch rows][64 channels][6 chunks of 4 floats] -- chunk 0 / 5 hold the halo columns, chunks 1..4 the four
+//       tiles; 36 wave instructions.  A lane's 16-byte reads (channel = its column of 16 lanes) are 24 floats apart
+//       between neighbouring lanes: 2-way bank conflicts, no padding -- 40 KB per stage so that TWO stages of TWO
+//       workgroups fill the CU's 160 KB exactly;
+//   dy: [16 output channels][16 chunks], chunk (row a, tile kk) of channel k stored at slot (4a + kk + (k & 7)) & 15 (the
+//       channels are 64 floats = a whole bank cycle apart; the rotation spreads 8 lanes over the 8 bank groups); 4
+//       wave instructions.
 // Reading the operands straight from global memory costs one cache access per LANE (a lane's neighbours hold other
 // channels, 200 KB apart): 64 accesses per instruction bound the first version at 1.2 ms for conv1_2's shape.
-constexpr int kXChunks = 64 * 37;                    // 2368 = 37 wave instructions
-constexpr int kGChunks = 16 * 17;                    // 272  -> 5 wave instructions (the last one partly dummy)
-constexpr int kXInstr = kXChunks / 64, kGInstr = (kGChunks + 63) / 64;
-constexpr int kStageFloats = (kXInstr + kGInstr) * 64 * 4;          // 42 KB per buffer
-constexpr int kMaxDma = 11;                          // DMA instructions per wave and step (10 + 1 or 9 + 2)
+constexpr int kXInstr = 36, kGInstr = 4;
+constexpr int kStageFloats = (kXInstr + kGInstr) * 64 * 4;          // 40 KB per buffer
+constexpr int kDma = 10;                             // DMA instructions per wave and step: 9 of x, 1 of dy
 
 template <bool ACT>
 __global__ __launch_bounds__(kDwThreads) void wino4_dw_c64_kernel(const float* __restrict__ x, const float* __restrict__ dy,
@@ -72,7 +73,7 @@ __global__ __launch_bounds__(kDwThreads) void wino4_dw_c64_kernel(const float* _
                                                                   const float* __restrict__ chan,
                                                                   const float* __restrict__ pre_bias) {
   constexpr int C = 64;
-  extern __shared__ __attribute__((aligned(16))) float stage[];      // kStageFloats: one step's operands
+  extern __shared__ __attribute__((aligned(16))) float stage[];      // two buffers of kStageFloats
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int kk = lane >> 4, col = lane & 15;
@@ -97,29 +98,22 @@ __global__ __launch_bounds__(kDwThreads) void wino4_dw_c64_kernel(const float* _
   float asc = 1.0f, ash = 0.0f, apb = 0.0f;
   if (ACT) { asc = chan[cx]; ash = chan[C + cx]; apb = pre_bias ? pre_bias[cx] : 0.0f; }
 
-  // ---- this wave's share of a step's DMA instructions.  Slots 0..8: x instructions wave, wave + 4, ..., wave + 32;
-  // slot 9: x instruction 36 (wave 0) or dy instruction wave - 1 (waves 1..3); slot 10: dy instruction 3 (wave 0) or 4
-  // (wave 1).  Per instruction a lane fetches one 16-byte chunk, the same chunk of the step's window in every step:
+  // ---- this wave's share of a step's DMA instructions: x instructions wave, wave + 4, ..., wave + 32 and dy instruction
+  // `wave`.  Per instruction a lane fetches one 16-byte chunk, the same chunk of the step's window in every step:
   // byte offset = rowoff[d] (everything but the tile column; recomputed when the tile row changes) + 16 * tw0.
-  int fix[kMaxDma];          // float offset of the lane's chunk for (image 0, tile row 0, tile column 0), without its row
-  int rsel[kMaxDma];         // x: the patch row 0..5 of the chunk (clamped rows change with the tile row); dy: unused
-  const bool slot9_x = wave == 0, slot10_used = wave < 2;
-  auto x_chunk = [&](int I, int& f, int& rs) {
-    const int e = I * 64 + lane, ch = e / 37, rem = e - ch * 37;
-    rs = rem == 36 ? 0 : rem / 6;                                     // (the pad chunk re-reads the channel's chunk 1)
-    f = ch * H * W + 4 * (rem == 36 ? 1 : rem - 6 * (rem / 6)) - 4;
-  };
-  auto g_chunk = [&](int J, int& f) {
-    const int e0 = J * 64 + lane, e = e0 < kGChunks ? e0 : kGChunks - 1;   // (the last instruction is partly dummy)
-    const int k = e / 17, rem = e - k * 17;
-    f = ((kb * 16 + k) * H + (rem == 16 ? 0 : rem >> 2)) * W + 4 * (rem == 16 ? 0 : rem & 3);
-  };
+  int fix[kDma];             // float offset of the lane's chunk for (image 0, tile row 0, tile column 0), without its row
+  int rsel[9];               // x: the patch row 0..5 of the chunk (clamped rows change with the tile row)
 #pragma unroll
-  for (int d = 0; d < 9; ++d) x_chunk(wave + 4 * d, fix[d], rsel[d]);
-  rsel[9] = rsel[10] = 0;
-  if (slot9_x) x_chunk(36, fix[9], rsel[9]); else g_chunk(wave - 1, fix[9]);
-  g_chunk(wave == 0 ? 3 : 4, fix[10]);
-  const int lds9 = slot9_x ? 36 : kXInstr + wave - 1, lds10 = kXInstr + (wave == 0 ? 3 : 4);   // instruction slots in LDS
+  for (int d = 0; d < 9; ++d) {
+    const int p = (wave + 4 * d) * 64 + lane;                          // LDS chunk slot = [row][channel][chunk]
+    const int r = p / 384, rem = p - r * 384, ch = rem / 6, q = rem - 6 * ch;
+    rsel[d] = r;
+    fix[d] = ch * H * W + 4 * q - 4;
+  }
+  {
+    const int p = wave * 64 + lane, k = p >> 4, j = ((p & 15) - (k & 7)) & 15;    // slot -> (row a, tile kk) of channel k
+    fix[9] = ((kb * 16 + k) * H + (j >> 2)) * W + 4 * (j & 3);
+  }
   // the step's position: tile index 4*s = (image n, tile row th, tile column tw0); all wave-uniform
   int tw0, th;
   unsigned n;
@@ -130,37 +124,28 @@ __global__ __launch_bounds__(kDwThreads) void wino4_dw_c64_kernel(const float* _
     th = (int)(q % (unsigned)Th);
     n = q / (unsigned)Th;
   }
-  uint32_t rowoff[kMaxDma];
+  uint32_t rowoff[kDma];
   auto place_row = [&]() {
     const int r0 = 4 * th - 1;
     const int xbase = (int)(n * (unsigned)(C * H * W)), gbase = (int)(n * (unsigned)(K * H * W)) + 4 * th * W;
-    auto xoff = [&](int d) {
-      const int row = r0 + rsel[d];
-      return (uint32_t)(xbase + fix[d] + (row < 0 ? 0 : (row >= H ? H - 1 : row)) * W) * 4u;
-    };
 #pragma unroll
-    for (int d = 0; d < 9; ++d) rowoff[d] = xoff(d);
-    rowoff[9] = slot9_x ? xoff(9) : (uint32_t)(gbase + fix[9]) * 4u;
-    rowoff[10] = (uint32_t)(gbase + fix[10]) * 4u;
+    for (int d = 0; d < 9; ++d) {
+      const int row = r0 + rsel[d];
+      rowoff[d] = (uint32_t)(xbase + fix[d] + (row < 0 ? 0 : (row >= H ? H - 1 : row)) * W) * 4u;
+    }
+    rowoff[9] = (uint32_t)(gbase + fix[9]) * 4u;
   };
   place_row();
-  auto issue = [&]() {                           // the DMA of the step at (n, th, tw0) into the stage
+  auto issue = [&](int buf) {                    // the DMA of the step at (n, th, tw0) into stage buffer `buf`
     const uint32_t cadv = (uint32_t)tw0 * 16u;   // wave-uniform; added per lane: a buffer load's range check looks at the
                                                  // lane offset alone (the window's first chunk starts at -16 B in row 0)
-    float* sb = stage;
+    float* sb = stage + buf * kStageFloats;
 #pragma unroll
     for (int d = 0; d < 9; ++d)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (__attribute__((address_space(3))) void*)(sb + (wave + 4 * d) * 256), 16,
                                                rowoff[d] + cadv, 0, 0, 0);
-    if (slot9_x)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (__attribute__((address_space(3))) void*)(sb + lds9 * 256), 16,
-                                               rowoff[9] + cadv, 0, 0, 0);
-    else
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(grsrc, (__attribute__((address_space(3))) void*)(sb + lds9 * 256), 16,
-                                               rowoff[9] + cadv, 0, 0, 0);
-    if (slot10_used)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(grsrc, (__attribute__((address_space(3))) void*)(sb + lds10 * 256), 16,
-                                               rowoff[10] + cadv, 0, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(grsrc, (__attribute__((address_space(3))) void*)(sb + (kXInstr + wave) * 256), 16,
+                                             rowoff[9] + cadv, 0, 0, 0);
   };
   auto advance = [&]() {
     tw0 += 4;
@@ -185,11 +170,11 @@ __global__ __launch_bounds__(kDwThreads) void wino4_dw_c64_kernel(const float* _
     const float c4t = r0 >= 0 ? 4.0f : 0.0f, mb = r0 + 5 < H ? 1.0f : 0.0f;
     const float c4l = tw > 0 ? 4.0f : 0.0f, mr = tw < Tw - 1 ? 1.0f : 0.0f, mr5 = mr * mb;
     // B operand: V = B^T d B of the 6x6 input patch of (channel cx, tile kk): three 16-byte LDS reads per row
-    const v4f* xs = reinterpret_cast<const v4f*>(sb) + cx * 37 + kk;
+    const v4f* xs = reinterpret_cast<const v4f*>(sb) + cx * 6 + kk;
     float d[6][6];
 #pragma unroll
     for (int r = 0; r < 6; ++r) {
-      const v4f lf = xs[r * 6], md = xs[r * 6 + 1], rt = xs[r * 6 + 2];
+      const v4f lf = xs[r * 384], md = xs[r * 384 + 1], rt = xs[r * 384 + 2];
       const float l = act(lf[3]), m0 = act(md[0]), m1 = act(md[1]), m2 = act(md[2]), m3 = act(md[3]), rr = act(rt[0]);
       d[r][0] = r == 5 ? l * mb : l;                                 // (the left edge enters through c4l below)
       d[r][1] = r == 5 ? m0 * mb : m0;
@@ -205,10 +190,10 @@ __global__ __launch_bounds__(kDwThreads) void wino4_dw_c64_kernel(const float* _
       in4(colv, c4t, t[j]);
     }
     // A operand: dM = A dY A^T of the 4x4 tile of dy of (output channel kb*16 + col, tile kk)
-    const v4f* gs = reinterpret_cast<const v4f*>(sb + kXInstr * 256) + col * 17 + kk;
+    const v4f* gs = reinterpret_cast<const v4f*>(sb + kXInstr * 256) + col * 16;
     v4f g[4];
 #pragma unroll
-    for (int a = 0; a < 4; ++a) g[a] = gs[a * 4];
+    for (int a = 0; a < 4; ++a) g[a] = gs[(4 * a + kk + (col & 7)) & 15];
     float u[4][6];        // u[j][i]: column j after the transform along rows
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -239,20 +224,26 @@ __global__ __launch_bounds__(kDwThreads) void wino4_dw_c64_kernel(const float* _
             "v"(ob[0]), "v"(ob[1]), "v"(ob[2]), "v"(ob[3]), "v"(ob[4]), "v"(ob[5]));
     }
   };
-  // ---- steps.  One stage buffer (43 KB) so that TWO workgroups share a CU (2 waves per SIMD: 107 + 144 registers):
-  // while one workgroup waits for its DMA or sits in a barrier the other one transforms and multiplies.  (The DMA
-  // instructions cost ~60-180 cycles of issue each, 11 per wave and step: with one workgroup per CU and the next
-  // step's DMA issued under the current step that showed up as 46 % issue stalls.)
+  // ---- steps: two stage buffers, the DMA of step s + 1 under the transforms and products of step s, one barrier per
+  // step (the next buffer is complete for every wave, and every wave is done reading the buffer that the DMA after next
+  // overwrites); 80 KB of LDS and 105 + 144 registers let TWO workgroups share a CU, which covers the DMA instructions'
+  // issue cost (~60-180 cycles each, 10 per wave and step: 46 % issue stalls with one workgroup per CU).
+  issue(0);
+  __builtin_amdgcn_s_waitcnt(0);
+  __syncthreads();
+  int buf = 0;
   for (long s = s0; s < s1; ++s) {
-    issue();
     const int tw_now = tw0 + kk, th_now = th;
-    advance();
+    if (s + 1 < s1) {
+      advance();
+      issue(buf ^ 1);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    compute(stage + buf * kStageFloats, tw_now, th_now, acc);
+    __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_waitcnt(0);
-    __syncthreads();                             // the step's operands are in LDS for every wave
-    __builtin_amdgcn_sched_barrier(0);
-    compute(stage, tw_now, th_now, acc);
-    __builtin_amdgcn_sched_barrier(0);
-    __syncthreads();                             // every wave has read them: the next step's DMA may overwrite
+    __syncthreads();
+    buf ^= 1;
   }
   // the compiler does not see MFMAs in the asm statements: cover the MFMA-write -> VALU-read distance by hand
   asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
@@ -308,7 +299,7 @@ extern "C" int fpsg_wino_dw_fused(const float* x, const float* chan, const float
   const int spr = (int)((n_steps + R - 1) / R);
   hipStream_t s = static_cast<hipStream_t>(stream);
   dim3 grid((unsigned)(R * KB));
-  const size_t lds_bytes = (size_t)kStageFloats * sizeof(float);
+  const size_t lds_bytes = 2 * (size_t)kStageFloats * sizeof(float);
   typedef void (*kern_t)(const float*, const float*, int, int, int, int, int, int, long, int, int, float*, const float*,
                          const float*);
   const kern_t kern = chan ? wino4_dw_c64_kernel<true> : wino4_dw_c64_kernel<false>;
