@@ -162,6 +162,9 @@ __global__ __launch_bounds__(kDwThreads) void wino4_dw_c64_kernel(const float* _
 #pragma unroll
   for (int xi = 0; xi < 36; ++xi) acc[xi] = (v4f){0.0f, 0.0f, 0.0f, 0.0f};
   auto act = [&](float v) { return ACT ? __builtin_fmaxf(fma_rn(v + apb, asc, ash), 0.0f) : v; };
+  int gslot[4];                                  // the lane's four dy chunks in its channel's rotated slots
+#pragma unroll
+  for (int a = 0; a < 4; ++a) gslot[a] = (4 * a + kk + (col & 7)) & 15;
   auto compute = [&](const float* sb, int tw, int thc, v4f (&accr)[36]) {
     // Out-of-image rows / columns enter the transform with weight 0 (as in winograd_fused.hip): rows r0+1 .. r0+4 are
     // always inside; the top row through the 4 of B^T's first row, the left column likewise in the second pass, the
@@ -193,7 +196,7 @@ __global__ __launch_bounds__(kDwThreads) void wino4_dw_c64_kernel(const float* _
     const v4f* gs = reinterpret_cast<const v4f*>(sb + kXInstr * 256) + col * 16;
     v4f g[4];
 #pragma unroll
-    for (int a = 0; a < 4; ++a) g[a] = gs[(4 * a + kk + (col & 7)) & 15];
+    for (int a = 0; a < 4; ++a) g[a] = gs[gslot[a]];
     float u[4][6];        // u[j][i]: column j after the transform along rows
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
