@@ -18,8 +18,6 @@
 // Workgroups of the same tile range sit on one XCD (id % 8), so the input tensor is fetched once per range.
 // fp32 MFMAs and fp32 VALU instructions do not overlap on gfx950: scalar transforms, few instructions, products as
 // in-place asm blocks on AGPR tuples (compiled with -fno-slp-vectorize; see winograd_fused.hip).
-#include <type_traits>
-
 #include "fpsg_common.h"
 
 namespace fpsg {
