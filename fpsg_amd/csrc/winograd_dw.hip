@@ -266,9 +266,12 @@ __global__ __launch_bounds__(256) void wino_dw_reduce_kernel(const float* __rest
   dU[e] = (float)a;
 }
 
-long dw_ranges(int KB) {                       // two workgroups per CU, a multiple of 8 ranges per channel block
-  long R = (512 + KB - 1) / KB;
-  return ((R + 7) / 8) * 8;
+// Tile ranges per channel block: two workgroups per CU at most, at least ~32 steps per range (each range costs a
+// [36][16][64] partial written and read back: 75 MB for 128 ranges at K = 64), a multiple of 8 (XCD placement).
+long dw_ranges(int KB, long n_steps) {
+  long cap = ((512 + KB - 1) / KB + 7) / 8 * 8;
+  long want = ((n_steps + 31) / 32 + 7) / 8 * 8;
+  return want < cap ? want : cap;
 }
 
 }  // namespace
@@ -276,7 +279,8 @@ long dw_ranges(int KB) {                       // two workgroups per CU, a multi
 
 extern "C" size_t fpsg_wino_dw_fused_workspace_floats(int N, int K, int H, int W) {
   if (N <= 0 || K <= 0 || K % 16 || H <= 0 || W <= 0) return 0;
-  return (size_t)fpsg::dw_ranges(K / 16) * 36 * K * 64;
+  if (H % 4 || W % 16) return 0;
+  return (size_t)fpsg::dw_ranges(K / 16, (long)N * (H / 4) * (W / 4) / 4) * 36 * K * 64;
 }
 
 extern "C" int fpsg_wino_dw_fused(const float* x, const float* chan, const float* pre_bias, const float* dy, int N, int C,
@@ -296,7 +300,7 @@ extern "C" int fpsg_wino_dw_fused(const float* x, const float* chan, const float
                "%s: x and dy must be below 2 GiB each (32-bit lane offsets; got N=%d K=%d H=%d W=%d)", fn, N, K, H, W);
   const int Th = H / 4, Tw = W / 4, KB = K / 16;
   const long n_steps = (long)N * Th * Tw / 4;
-  const long R = dw_ranges(KB);
+  const long R = dw_ranges(KB, n_steps);
   const int spr = (int)((n_steps + R - 1) / R);
   hipStream_t s = static_cast<hipStream_t>(stream);
   dim3 grid((unsigned)(R * KB));

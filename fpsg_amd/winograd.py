@@ -67,12 +67,17 @@ def _can_fuse(m: int, c_in: int, c_out: int, n_pixels: int) -> bool:
     return fused_enabled() and m == 4 and c_in == 64 and c_out % 16 == 0 and n_pixels * 64 * 4 < (1 << 32)
 
 
+MIN_DW_TILES = 16384      # below (2 images at 224x224: 6272 tiles) the per-range partial sums cost more than K6w saves
+
+
 def _can_fuse_dw(m: int, c_in: int, c_out: int, N: int, H: int, W: int) -> bool:
     """K6w (``fpsg_wino_dw_fused``): the weight gradient of a 64-input-channel layer in one pass -- no transformed
-    input, no transformed output gradient, no GEMM with the tile-long reduction.  ``FPSG_WINOGRAD_DW=0``: the
+    input, no transformed output gradient, no GEMM with the tile-long reduction; taken from ``MIN_DW_TILES`` tiles
+    up (1-shot episodes stay with the three-kernel form: 256 vs 255 episodes/s).  ``FPSG_WINOGRAD_DW=0``: the
     three-kernel form (A/B)."""
     return (fused_enabled() and os.environ.get("FPSG_WINOGRAD_DW", "1") != "0" and m == 4 and c_in == 64
-            and c_out % 16 == 0 and H % 4 == 0 and W % 16 == 0 and N * max(c_in, c_out) * H * W * 4 < (1 << 31))
+            and c_out % 16 == 0 and H % 4 == 0 and W % 16 == 0 and N * max(c_in, c_out) * H * W * 4 < (1 << 31)
+            and N * (H // 4) * (W // 4) >= MIN_DW_TILES)
 
 
 def _fused_dw(x, chan, pre_bias, gy):

@@ -452,7 +452,8 @@ def test_fused_weight_gradient_matches_three_kernel_form(gpu, shape, act):
         chan = torch.randn(4, C, device=gpu) * 0.5 + 1.0
         pb = torch.randn(C, device=gpu) * 0.1
         a = torch.relu((x + pb.view(1, -1, 1, 1)) * chan[0].view(1, -1, 1, 1) + chan[1].view(1, -1, 1, 1))
-    assert wg._can_fuse_dw(4, C, K, N, H, W)
+    assert wg._can_fuse_dw(4, 64, 64, 37, 224, 224) and wg._can_fuse_dw(4, 64, 128, 37, 112, 112)
+    assert not wg._can_fuse_dw(4, 64, 64, 2, 224, 224) and not wg._can_fuse_dw(4, 128, 128, 37, 112, 112)
     dU = wg._fused_dw(x, chan, pb, gy)
     V = wg._input_act(4, x, chan, pb) if act else wg._input(4, x)
     ref = torch.bmm(wg._grad_output(4, gy), V.transpose(1, 2))
