@@ -61,7 +61,7 @@ __global__ __launch_bounds__(kAdamThreads) void adam_kernel(float* __restrict__ 
 // needs no 310 MB gather.  A vector of four elements looks its segment up by bisection (10 steps
 // over ~600 cached offsets, free next to 28 B of traffic per element); a vector that straddles
 // two segments is done element by element.
-__device__ __forceinline__ int segment_of(const long long* __restrict__ seg_off, int nseg, long long i) {
+__device__ __forceinline__ int segment_of(const long long* seg_off, int nseg, long long i) {
   int lo = 0, hi = nseg;
   while (hi - lo > 1) {
     const int mid = (lo + hi) >> 1;
@@ -70,8 +70,10 @@ __device__ __forceinline__ int segment_of(const long long* __restrict__ seg_off,
   return lo;
 }
 
+constexpr int kSegLds = 2048;       // segment offsets kept in LDS by flat_accumulate_kernel (16 KB)
+
 // the (up to) four gradient elements of flat positions i .. i+cnt-1 from the segment table (0 where a segment has none)
-__device__ __forceinline__ bool gather_grad4(const float* const* __restrict__ gtab, const long long* __restrict__ seg_off,
+__device__ __forceinline__ bool gather_grad4(const float* const* __restrict__ gtab, const long long* seg_off,
                                              int nseg, long long i, int cnt, float (&gg)[4]) {
   int sg = segment_of(seg_off, nseg, i);
   bool any = false;
@@ -111,13 +113,22 @@ __global__ __launch_bounds__(kAdamThreads) void flat_accumulate_kernel(float* __
                                                                        const float* const* __restrict__ gtab,
                                                                        const long long* __restrict__ seg_off, int nseg,
                                                                        size_t n4, size_t n, int accumulate) {
+  // the segment table in LDS (when it fits): the bisection is ten dependent reads per vector -- from L2 they bound the
+  // kernel at 3.2 TB/s of its 12 B per element
+  __shared__ long long soff[kSegLds];
+  const long long* so = seg_off;
+  if (nseg + 1 <= kSegLds) {
+    for (int e = threadIdx.x; e <= nseg; e += kAdamThreads) soff[e] = seg_off[e];
+    __syncthreads();
+    so = soff;
+  }
   const size_t stride = (size_t)gridDim.x * kAdamThreads;
   for (size_t j = (size_t)blockIdx.x * kAdamThreads + threadIdx.x; j < n4 + 1; j += stride) {
     const long long i = (long long)(4 * j);
     const int cnt = j < n4 ? 4 : (int)(n - 4 * n4);
     if (cnt == 0) break;
     float gg[4];
-    const bool any = gather_grad4(gtab, seg_off, nseg, i, cnt, gg);
+    const bool any = gather_grad4(gtab, so, nseg, i, cnt, gg);
     if (accumulate && !any) continue;
     if (cnt == 4) {
       v4f f = accumulate ? reinterpret_cast<const v4f*>(flat)[j] : (v4f){0.0f, 0.0f, 0.0f, 0.0f};
