@@ -26,6 +26,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import bn_counters
 from .fused_bn import batch_norm_act, bn_act
 from .pointnet import PointNetfeat
 from .utils import get_template
@@ -203,13 +204,11 @@ def _update_running(bns, r, mean, var):
     for j in range(1, r):                                    # step can be graph-captured
         new_mean = new_mean + mean3[:, j] * (m * (1 - m) ** (r - 1 - j))
         new_var = new_var + var3[:, j] * (m * (1 - m) ** (r - 1 - j))
-    rms = [b.running_mean for b in bns]
-    rvs = [b.running_var for b in bns]
-    torch._foreach_mul_(rms, (1 - m) ** r)
-    torch._foreach_add_(rms, list(new_mean.unbind(0)))
-    torch._foreach_mul_(rvs, (1 - m) ** r)
-    torch._foreach_add_(rvs, list(new_var.unbind(0)))
-    torch._foreach_add_([b.num_batches_tracked for b in bns], r)
+    # (inside the train step's bn_counters.deferred() block these are batched with the other layers' updates)
+    bn_counters.update_running([b.running_mean for b in bns] + [b.running_var for b in bns], (1 - m) ** r,
+                               list(new_mean.unbind(0)) + list(new_var.unbind(0)))
+    for b in bns:
+        bn_counters.count_batch(b, r)
 
 
 def _layer1_fused_ok(x, pts, B, P, act) -> bool:

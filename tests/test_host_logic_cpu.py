@@ -109,3 +109,32 @@ def test_deferred_batch_counters_match_immediate_increments():
         assert int(a.num_batches_tracked) == 1 and int(b.num_batches_tracked) == 5     # not yet
     assert int(a.num_batches_tracked) == 3 and int(b.num_batches_tracked) == 6
     assert bn_counters._pending is None
+
+
+def test_deferred_running_statistics_keep_order_and_values():
+    """bn_counters.update_running inside deferred(): a tensor updated twice in the block gets both updates in order
+    (rounds), tensors of different calls share the multi-tensor ops; values are those of immediate updates bit for bit."""
+    import torch
+    from fpsg_amd import bn_counters
+    torch.manual_seed(0)
+    a0, b0, c0 = torch.randn(5), torch.randn(5), torch.randn(3)
+    adds = [torch.randn(5), torch.randn(5), torch.randn(3), torch.randn(5)]
+
+    def run(deferred):
+        a, b, c = a0.clone(), b0.clone(), c0.clone()
+        ctx = bn_counters.deferred() if deferred else None
+        if ctx:
+            ctx.__enter__()
+        bn_counters.update_running([a, b], 0.9, [adds[0], adds[1]])
+        bn_counters.update_running([c], 0.81, [adds[2]])
+        bn_counters.update_running([a], 0.9, [adds[3]])            # second update of `a`
+        if ctx:
+            assert torch.equal(a, a0)                               # nothing applied yet
+            ctx.__exit__(None, None, None)
+        return a, b, c
+
+    for x, y in zip(run(True), run(False)):
+        assert torch.equal(x, y)
+    a, _, _ = run(True)
+    assert torch.equal(a, (a0 * 0.9 + adds[0]) * 0.9 + adds[3])
+    assert bn_counters._stats is None
