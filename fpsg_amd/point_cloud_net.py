@@ -192,6 +192,18 @@ class _SplitLast(torch.autograd.Function):
         return gw, None
 
 
+_MOMENTUM_WEIGHTS: dict = {}
+
+
+def _momentum_weights(r, m, device):
+    key = (r, float(m), str(device))
+    w = _MOMENTUM_WEIGHTS.get(key)
+    if w is None:
+        w = torch.tensor([m * (1 - m) ** (r - 1 - j) for j in range(r)], dtype=torch.float32, device=device).view(1, r, 1)
+        _MOMENTUM_WEIGHTS[key] = w
+    return w
+
+
 def _update_running(bns, r, mean, var):
     """``r`` sequential momentum updates per module of ``bns`` from the per-call statistics ``mean`` /
     ``var`` ``[len(bns)*r*C]`` (var unbiased, as torch), in closed form and as multi-tensor ops:
@@ -199,11 +211,13 @@ def _update_running(bns, r, mean, var):
     C = bns[0].num_features
     m = 0.1 if bns[0].momentum is None else bns[0].momentum
     mean3, var3 = mean.view(len(bns), r, C), var.view(len(bns), r, C)
-    new_mean = mean3[:, 0] * (m * (1 - m) ** (r - 1))      # python scalars only: no
-    new_var = var3[:, 0] * (m * (1 - m) ** (r - 1))        # host->device copies, so the
-    for j in range(1, r):                                    # step can be graph-captured
-        new_mean = new_mean + mean3[:, j] * (m * (1 - m) ** (r - 1 - j))
-        new_var = new_var + var3[:, j] * (m * (1 - m) ** (r - 1 - j))
+    if r == 1:
+        new_mean, new_var = mean3[:, 0] * m, var3[:, 0] * m
+    else:
+        # one weighted sum over the r calls (the weights live on the device, built once per (r, m): the step stays
+        # capturable) instead of 2r - 1 elementwise launches per statistic
+        coef = _momentum_weights(r, m, mean.device)
+        new_mean, new_var = (mean3 * coef).sum(1), (var3 * coef).sum(1)
     # (inside the train step's bn_counters.deferred() block these are batched with the other layers' updates)
     bn_counters.update_running([b.running_mean for b in bns] + [b.running_var for b in bns], (1 - m) ** r,
                                list(new_mean.unbind(0)) + list(new_var.unbind(0)))
@@ -326,15 +340,18 @@ class _LazySplit:
 
 def _stack_affine(bns, calls_per_bn):
     """gamma / beta of ``bns`` stacked to ``[G*C]`` for ``_group_batch_norm``."""
-    gamma = torch.stack([b.weight for b in bns]).repeat_interleave(calls_per_bn, dim=0).reshape(-1)
-    beta = torch.stack([b.bias for b in bns]).repeat_interleave(calls_per_bn, dim=0).reshape(-1)
-    return gamma, beta
+    gamma, beta = torch.stack([b.weight for b in bns]), torch.stack([b.bias for b in bns])
+    if calls_per_bn > 1:
+        gamma, beta = gamma.repeat_interleave(calls_per_bn, dim=0), beta.repeat_interleave(calls_per_bn, dim=0)
+    return gamma.reshape(-1), beta.reshape(-1)
 
 
-def _group_batch_norm(h, bns, calls_per_bn, act, affine=None):
+def _group_batch_norm(h, bns, calls_per_bn, act, affine=None, pre_bias=None):
     """BatchNorm over the last axis of ``h [G, C, M]`` with an independent set of statistics
     per group ``g`` (one reference ``BatchNorm1d`` call each), then ``act``.
 
+    ``pre_bias`` ``[G*C]``: the bias of the layer that produced ``h``, added inside the BatchNorm pass (K5) instead
+    of by the GEMM (``baddbmm`` with a broadcast bias first copies it over the whole output, then reads it back).
     ``bns``: the ``len(bns) * calls_per_bn == G`` modules owning the affine parameters and
     running statistics; module ``i`` serves groups ``i*calls_per_bn .. (i+1)*calls_per_bn-1``,
     i.e. it is "called" ``calls_per_bn`` times in that order, as in the reference loop, and
@@ -346,13 +363,14 @@ def _group_batch_norm(h, bns, calls_per_bn, act, affine=None):
     fuse = "relu" if act is F.relu else None       # BatchNorm + ReLU as one pass (K5) on the GPU
     post = (lambda t: t) if act is F.relu else act
     if bns[0].training:
-        y, mean, var = batch_norm_act(x, gamma, beta, None, None, True, 1.0, bns[0].eps, fuse, return_stats=True)
+        y, mean, var = batch_norm_act(x, gamma, beta, None, None, True, 1.0, bns[0].eps, fuse, return_stats=True,
+                                      pre_bias=pre_bias)
         with torch.no_grad():
             _update_running(bns, r, mean, var)
     else:
         rm = torch.stack([b.running_mean for b in bns]).repeat_interleave(r, dim=0).reshape(G * C)
         rv = torch.stack([b.running_var for b in bns]).repeat_interleave(r, dim=0).reshape(G * C)
-        y = batch_norm_act(x, gamma, beta, rm, rv, False, 0.0, bns[0].eps, fuse)
+        y = batch_norm_act(x, gamma, beta, rm, rv, False, 0.0, bns[0].eps, fuse, pre_bias=pre_bias)
     return post(y.reshape(G, C, M))
 
 
@@ -452,9 +470,9 @@ class PCDecoder(nn.Module):
         # ---- per-cluster deformers, applied to each of the cluster's R patches
         defs = [c.deformer for c in clusters]
         w, b = pack["d1"]
-        h = _group_batch_norm(torch.baddbmm(b, w, h), [d.bn1 for d in defs], R, act, pack["dbn1"])
+        h = _group_batch_norm(torch.bmm(w, h), [d.bn1 for d in defs], R, act, pack["dbn1"], b.reshape(-1))
         w, b = pack["d2"]
-        h = _group_batch_norm(torch.baddbmm(b, w, h), [d.bn2 for d in defs], R, act, pack["dbn2"])
+        h = _group_batch_norm(torch.bmm(w, h), [d.bn2 for d in defs], R, act, pack["dbn2"], b.reshape(-1))
         w, b = pack["d3"]
         pts = torch.tanh(torch.baddbmm(b, w, h))                                        # [G,raw,B*P]
 
@@ -483,9 +501,9 @@ class PCDecoder(nn.Module):
             h = torch.bmm(w_pts, pts).view(G, D, B, P) + h_lat.unsqueeze(-1)
             h = _group_batch_norm(h.view(G, D, B * P), bn1s, 1, act, pack["nbn1"])
         w, b = pack["n2"]
-        h = _group_batch_norm(torch.baddbmm(b, w, h), [n.bn2 for n in nodes], 1, act, pack["nbn2"])
+        h = _group_batch_norm(torch.bmm(w, h), [n.bn2 for n in nodes], 1, act, pack["nbn2"], b.reshape(-1))
         w, b = pack["n3"]
-        h = _group_batch_norm(torch.baddbmm(b, w, h), [n.bn3 for n in nodes], 1, act, pack["nbn3"])
+        h = _group_batch_norm(torch.bmm(w, h), [n.bn3 for n in nodes], 1, act, pack["nbn3"], b.reshape(-1))
         w, b = pack["n4"]
         out = torch.tanh(torch.baddbmm(b, w, h))                                        # [G,3,B*P]
         return out.view(G, 3, B, P).permute(2, 0, 3, 1).reshape(B, G * P, 3).contiguous()

@@ -1,5 +1,5 @@
-"""Which Python lines launch the small PyTorch kernels of an episode step (the ~1.4 ms of 'glue'): torch.profiler
-with stacks over two c5 episodes, aten kernels grouped by the innermost fpsg_amd / repo frame.
+"""Which PyTorch ops make up the ~1.4 ms of small-kernel 'glue' of an episode step: torch.profiler over two c5
+episodes, aten ops (GEMMs left out) grouped by input shapes (python stacks are not recorded on this build).
     python tools/glue_profile.py > gpurun_out/glue_profile.txt"""
 import collections
 import os
@@ -23,18 +23,17 @@ episodes = bench.make_episodes(S, Q, 2, seed=1, device=dev)
 for _ in range(3):
     step(episodes, n_episodes_global=2)
 torch.cuda.synchronize()
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
     step(episodes, n_episodes_global=2)
     torch.cuda.synchronize()
 agg = collections.defaultdict(lambda: [0, 0.0])
-for ev in prof.key_averages(group_by_stack_n=12):
+for ev in prof.key_averages(group_by_input_shape=True):
     t = getattr(ev, "self_device_time_total", 0)
-    if not t or not ev.key.startswith("aten::"):
+    if not t or not ev.key.startswith("aten::") or ev.key in ("aten::bmm", "aten::baddbmm", "aten::mm", "aten::addmm"):
         continue
-    frame = next((f for f in (ev.stack or []) if "/root/repo" in f or "fpsg_amd" in f), "(no repo frame)")
-    agg[(ev.key, frame.strip()[-100:])][0] += ev.count
-    agg[(ev.key, frame.strip()[-100:])][1] += t
+    agg[(ev.key, str(ev.input_shapes)[:110])][0] += ev.count
+    agg[(ev.key, str(ev.input_shapes)[:110])][1] += t
 rows = sorted(agg.items(), key=lambda kv: -kv[1][1])
-print("# aten ops of one 2-episode step by self device time: calls, us, op, innermost repo frame")
-for (name, frame), (n, t) in rows[:70]:
-    print(f"{n:5d} {t:9.1f}  {name:34s} {frame}")
+print("# small aten ops of one 2-episode step by self device time: calls, us, op, input shapes")
+for (name, shp), (n, t) in rows[:70]:
+    print(f"{n:5d} {t:9.1f}  {name:28s} {shp}")
