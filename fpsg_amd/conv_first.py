@@ -46,6 +46,7 @@ class _ConvFirst(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, stats_bias=None, want_parts=False):
+        ctx.set_materialize_grads(False)        # no zero tensor for the (non-differentiable) parts output
         ctx.save_for_backward(x, w)
         if os.environ.get("FPSG_CONV_FIRST_FWD", "1") == "0":
             y, parts = F.conv2d(x, w, None, 1, 1), None
@@ -59,6 +60,8 @@ class _ConvFirst(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gy, _gparts=None):
+        if gy is None:
+            return None, None, None, None
         x, w = ctx.saved_tensors
         gx = gw = None
         if ctx.needs_input_grad[0]:

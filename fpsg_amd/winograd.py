@@ -215,6 +215,7 @@ class _Conv3x3(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, m, stats_bias=None, want_parts=False):
+        ctx.set_materialize_grads(False)        # no zero tensor for the (non-differentiable) parts output
         x, w = x.contiguous(), w.contiguous()
         N, C, H, W = x.shape
         K = w.shape[0]
@@ -244,6 +245,8 @@ class _Conv3x3(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gy, _gparts=None):
+        if gy is None:
+            return None, None, None, None, None
         kept, w = ctx.saved_tensors
         N, C, H, W, m, kept_is_v = ctx.dims
         K = w.shape[0]
@@ -300,6 +303,7 @@ class _BNReluConv3x3(torch.autograd.Function):
         """``parts``: statistics partial sums of ``y + pre_bias`` from the convolution that produced ``y`` (the
         pass over ``y`` is skipped); ``stats_bias`` / ``want_parts``: the same for this convolution's output
         (-> ``(out, out_parts)``)."""
+        ctx.set_materialize_grads(False)        # no zero tensor for the (non-differentiable) parts output
         y, w = y.contiguous(), w.contiguous()
         N, C, H, W = y.shape
         K = w.shape[0]
@@ -338,6 +342,8 @@ class _BNReluConv3x3(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gout, _gparts=None):
+        if gout is None:
+            return (None,) * 14
         y, chan, pre_bias, w, V = ctx.saved_tensors
         N, C, H, W, m, training, has_g, has_b = ctx.cfg
         K = w.shape[0]
