@@ -340,7 +340,7 @@ class _LazySplit:
 
 def _stack_affine(bns, calls_per_bn):
     """gamma / beta of ``bns`` stacked to ``[G*C]`` for ``_group_batch_norm``."""
-    gamma, beta = torch.stack([b.weight for b in bns]), torch.stack([b.bias for b in bns])
+    gamma, beta = _stack("bn.weight", [b.weight for b in bns]), _stack("bn.bias", [b.bias for b in bns])
     if calls_per_bn > 1:
         gamma, beta = gamma.repeat_interleave(calls_per_bn, dim=0), beta.repeat_interleave(calls_per_bn, dim=0)
     return gamma.reshape(-1), beta.reshape(-1)
@@ -424,7 +424,7 @@ class PCDecoder(nn.Module):
 
         def stack_w(mods, name, repeat=1):
             w = _stack(name + ".w", [getattr(m, name).weight.squeeze(-1) for m in mods])   # [n,out,in]
-            b = torch.stack([getattr(m, name).bias for m in mods])                         # [n,out]
+            b = _stack(name + ".b", [getattr(m, name).bias for m in mods])                 # [n,out]
             if repeat > 1:
                 w = w.repeat_interleave(repeat, dim=0)
                 b = b.repeat_interleave(repeat, dim=0)
