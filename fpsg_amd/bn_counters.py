@@ -15,7 +15,7 @@ import contextlib
 import torch
 
 _pending = None      # id(tensor) -> [tensor, count] while a ``deferred()`` block is open
-_stats = None        # [(tensors, scale, addends)] in call order while a block is open
+_stats = None        # [(tensors, scale, addends, alpha)] in call order while a block is open
 
 
 def count_batch(bn, times: int = 1) -> None:
@@ -33,16 +33,16 @@ def count_batch(bn, times: int = 1) -> None:
         entry[1] += times
 
 
-def update_running(tensors, scale: float, addends) -> None:
-    """``t <- t * scale + a`` for every (t, a) of ``tensors`` / ``addends`` (running statistics), as the two
-    multi-tensor ops ``_foreach_mul_`` / ``_foreach_add_`` -- now, or batched with the other updates of the
+def update_running(tensors, scale: float, addends, alpha: float = 1.0) -> None:
+    """``t <- t * scale + alpha * a`` for every (t, a) of ``tensors`` / ``addends`` (running statistics), as the two
+    multi-tensor ops ``_foreach_mul_`` / ``_foreach_add_(alpha=)`` -- now, or batched with the other updates of the
     enclosing ``deferred()`` block."""
     tensors, addends = list(tensors), list(addends)
     if _stats is None:
         torch._foreach_mul_(tensors, scale)
-        torch._foreach_add_(tensors, addends)
+        torch._foreach_add_(tensors, addends, alpha=alpha)
     else:
-        _stats.append((tensors, float(scale), addends))
+        _stats.append((tensors, float(scale), addends, float(alpha)))
 
 
 @contextlib.contextmanager
@@ -62,11 +62,11 @@ def deferred():
             by_count.setdefault((c, t.device), []).append(t)
         # running statistics: round k holds every tensor's k-th update of the block, so updates of one tensor stay in order
         seen, rounds = {}, {}
-        for tensors, scale, addends in stats:
+        for tensors, scale, addends, alpha in stats:
             for t, a in zip(tensors, addends):
                 k = seen.get(id(t), 0)
                 seen[id(t)] = k + 1
-                ts, scs, adds = rounds.setdefault((k, t.device), ([], [], []))
+                ts, scs, adds = rounds.setdefault((k, t.device, alpha), ([], [], []))
                 ts.append(t)
                 scs.append(scale)
                 adds.append(a)
@@ -79,4 +79,4 @@ def deferred():
                     torch._foreach_mul_(ts, scs[0])
                 else:
                     torch._foreach_mul_(ts, scs)
-                torch._foreach_add_(ts, adds)
+                torch._foreach_add_(ts, adds, alpha=key[2])

@@ -211,8 +211,9 @@ def _update_running(bns, r, mean, var):
     C = bns[0].num_features
     m = 0.1 if bns[0].momentum is None else bns[0].momentum
     mean3, var3 = mean.view(len(bns), r, C), var.view(len(bns), r, C)
+    alpha = 1.0
     if r == 1:
-        new_mean, new_var = mean3[:, 0] * m, var3[:, 0] * m
+        new_mean, new_var, alpha = mean3[:, 0], var3[:, 0], m          # run <- (1-m) run + m stat: m applied by the add
     else:
         # one weighted sum over the r calls (the weights live on the device, built once per (r, m): the step stays
         # capturable) instead of 2r - 1 elementwise launches per statistic
@@ -220,7 +221,7 @@ def _update_running(bns, r, mean, var):
         new_mean, new_var = (mean3 * coef).sum(1), (var3 * coef).sum(1)
     # (inside the train step's bn_counters.deferred() block these are batched with the other layers' updates)
     bn_counters.update_running([b.running_mean for b in bns] + [b.running_var for b in bns], (1 - m) ** r,
-                               list(new_mean.unbind(0)) + list(new_var.unbind(0)))
+                               list(new_mean.unbind(0)) + list(new_var.unbind(0)), alpha)
     for b in bns:
         bn_counters.count_batch(b, r)
 
