@@ -13,7 +13,7 @@ import bench  # noqa: E402
 from fpsg_amd.engine import TrainStep, build_model, build_optimizer, default_options  # noqa: E402
 
 dev = torch.device("cuda:0")
-S, Q, intra, encoder, epr, _ = bench.WORKLOADS["c5"]
+S, Q, intra, encoder, epr, _ = bench.WORKLOADS[sys.argv[1] if len(sys.argv) > 1 else "c5"]
 opt = default_options(device="cuda", intra_recon=intra, pc_encoder=encoder, n_shot=S, n_query=Q)
 torch.manual_seed(0)
 model = build_model(opt).to(dev).train()
