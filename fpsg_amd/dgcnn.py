@@ -243,11 +243,13 @@ class DGCNNfeat(nn.Module):
         x_cm = x.contiguous()                       # channel-major for the kNN kernel
         x_pm = x_cm.transpose(1, 2).contiguous()    # point-major for the GEMM / gather
         feats = []
-        for block in (self.conv1, self.conv2, self.conv3, self.conv4):
+        blocks = (self.conv1, self.conv2, self.conv3, self.conv4)
+        for li, block in enumerate(blocks):
             idx32 = knn_int32(x_cm, self.k)
             x_pm = edgeconv_fused(x_pm, idx32, block)             # [B,N,Co]
             feats.append(x_pm)
-            x_cm = x_pm.transpose(1, 2).contiguous()
+            if li + 1 < len(blocks):                              # the next layer's graph is built on these features
+                x_cm = x_pm.transpose(1, 2).contiguous()
         cat = torch.cat(feats, dim=2)                              # [B,N,512]
         conv5, bn5, act5 = self.conv5[0], self.conv5[1], self.conv5[2]
         h = torch.matmul(conv5.weight.squeeze(-1), cat.transpose(1, 2))   # Conv1d(512,emb,1) as a GEMM -> [B,emb,N]
