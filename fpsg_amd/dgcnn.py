@@ -114,6 +114,29 @@ def _reverse_graph(idx32: torch.Tensor):
     return order.to(torch.int32).contiguous(), off.to(torch.int32).contiguous()
 
 
+class _MaxMeanOverPoints(torch.autograd.Function):
+    """``cat(h.max(dim=2)[0], h.mean(dim=2))`` of the embedding ``h [B,C,N]`` (``dgcnn/model.py:86-88``) with ONE gradient
+    tensor in the backward: autograd's own graph fills a zero tensor for the max, expands the mean's gradient into a
+    second one and adds the two (five passes over the 268 MB embedding at 64 clouds); here the mean's share is written
+    once and the max's share scattered into it."""
+
+    @staticmethod
+    def forward(ctx, h):
+        m, idx = h.max(dim=2)
+        ctx.save_for_backward(idx)
+        ctx.n = h.shape[2]
+        return torch.cat((m, h.mean(dim=2)), dim=1)
+
+    @staticmethod
+    def backward(ctx, g):
+        (idx,) = ctx.saved_tensors
+        C = idx.shape[1]
+        gmax, gmean = g[:, :C], g[:, C:]
+        gh = (gmean / ctx.n).unsqueeze(2).expand(-1, -1, ctx.n).contiguous()
+        gh.scatter_add_(2, idx.unsqueeze(2), gmax.unsqueeze(2).contiguous())
+        return gh
+
+
 class _EdgeConvBNMax(torch.autograd.Function):
     """``out[b,n,c] = max_j LeakyReLU(BN(P[b,idx[b,n,j],c] + Q[b,n,c]))`` with training- or
     eval-mode BatchNorm over all ``B*N*k`` edges; ``PQ [B,N,2Co]`` -> ``out [B,N,Co]``."""
@@ -255,5 +278,5 @@ class DGCNNfeat(nn.Module):
         h = torch.matmul(conv5.weight.squeeze(-1), cat.transpose(1, 2))   # Conv1d(512,emb,1) as a GEMM -> [B,emb,N]
         h = bn_act(bn5, h, ("leaky", act5.negative_slope))                # BatchNorm1d + LeakyReLU fused (K5)
         if self.dual_flag:
-            return torch.cat((h.max(dim=2)[0], h.mean(dim=2)), dim=1)
+            return _MaxMeanOverPoints.apply(h) if h.is_cuda else torch.cat((h.max(dim=2)[0], h.mean(dim=2)), dim=1)
         return h.max(dim=2)[0]

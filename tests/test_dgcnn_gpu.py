@@ -160,3 +160,22 @@ def test_fused_edgeconv_is_deterministic(gpu):
         net(xi).square().sum().backward()
         outs.append((xi.grad.clone(), net.conv3[0].weight.grad.clone()))
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
+def test_max_mean_over_points_matches_autograd(gpu):
+    """dgcnn._MaxMeanOverPoints against the plain ``cat(max, mean)`` graph it replaces: value bit for bit, gradient to
+    fp32 round-off (one add of the two shares in a different order); ties in the max go to the same index."""
+    import torch
+    from fpsg_amd.dgcnn import _MaxMeanOverPoints
+    torch.manual_seed(2)
+    h = torch.randn(5, 48, 300, device=gpu)
+    h[0, 0, 7] = h[0, 0, 250] = 10.0                      # a tie: torch.max picks one index, both paths use it
+    w = torch.randn(5, 96, device=gpu)
+    a = h.clone().requires_grad_()
+    out = _MaxMeanOverPoints.apply(a)
+    (out * w).sum().backward()
+    b = h.clone().requires_grad_()
+    ref = torch.cat((b.max(dim=2)[0], b.mean(dim=2)), dim=1)
+    (ref * w).sum().backward()
+    assert torch.equal(out, ref)
+    assert float((a.grad - b.grad).abs().max()) <= 1e-6 * float(b.grad.abs().max())
