@@ -44,6 +44,10 @@ SIGNATURES = {
     "fpsg_edge_feature_fwd": [_c_f32p, _c_i32p, _c_int, _c_int, _c_int, _c_int, _c_f32p, _c_stream],
     "fpsg_edge_feature_bwd": [_c_f32p, _c_i32p, _c_int, _c_int, _c_int, _c_int, _c_f32p, _c_stream],
     "fpsg_edgeconv_blocks": [_c_int, _c_int, _c_int],
+    "fpsg_edgeconv_prep_blocks": [ctypes.c_long],
+    "fpsg_edgeconv_act": [_c_f32p, _c_f32p, _c_f32p, ctypes.c_float, ctypes.c_long, _c_int, _c_f32p, _c_stream],
+    "fpsg_edgeconv_bwd_prep": [_c_f32p, _c_f32p, _c_f32p, _c_f32p, ctypes.c_float, ctypes.c_long, _c_int, _c_f32p, _c_f32p,
+                               _c_stream],
     "fpsg_edgeconv_fwd": [_c_f32p, _c_i32p, _c_f32p, _c_int, _c_int, _c_int, _c_int, _c_f32p, _c_f32p,
                           _c_f32p, _c_f32p, _c_stream],
     "fpsg_edgeconv_bwd": [_c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_i32p, _c_i32p, _c_f32p, _c_int, _c_int,

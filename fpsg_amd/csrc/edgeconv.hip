@@ -260,6 +260,77 @@ inline dim3 ec_grid(int B, int N, int Co) {          // 8 * ceil(B/8) clouds' wo
   return dim3((unsigned)(8 * ((B + 7) / 8) * ec_blocks_per_cloud(N, Co)));
 }
 
+
+// ---- the elementwise halves around the two kernels above (point-major [rows, Co], rows = B*N) -------------------
+// forward tail: out = LeakyReLU(fma(ysel, scale[c], shift[c])) -- BatchNorm's affine form on the selected
+// neighbour sum + the activation, one pass (torch: addcmul + leaky_relu, two).
+constexpr int kEpThreads = 256;
+constexpr int kEpRows = 256;            // rows per workgroup
+
+__global__ __launch_bounds__(kEpThreads) void edgeconv_act_kernel(const float* __restrict__ ysel,
+                                                                  const float* __restrict__ scale,
+                                                                  const float* __restrict__ shift, float slope,
+                                                                  long rows, int Co, float* __restrict__ out) {
+  const int C4 = Co >> 2, c4 = threadIdx.x % C4, rg = threadIdx.x / C4, RG = kEpThreads / C4;
+  const v4f sc = reinterpret_cast<const v4f*>(scale)[c4], sh = reinterpret_cast<const v4f*>(shift)[c4];
+  const long r1 = ((long)blockIdx.x + 1) * kEpRows < rows ? ((long)blockIdx.x + 1) * kEpRows : rows;
+  for (long r = (long)blockIdx.x * kEpRows + rg; r < r1; r += RG) {
+    const v4f y = reinterpret_cast<const v4f*>(ysel + r * Co)[c4];
+    v4f o;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float z = fma_rn(y[u], sc[u], sh[u]);
+      o[u] = z > 0.0f ? z : z * slope;
+    }
+    reinterpret_cast<v4f*>(out + r * Co)[c4] = o;
+  }
+}
+
+// backward head: z re-derived with the forward's arithmetic, dz = g * LeakyReLU'(z), dzs = dz * scale[c] written for
+// the fused backward kernel, and per channel the partial sums of dz and dz * ysel (-> dbeta, dgamma and the BatchNorm
+// coefficients) over the workgroup's rows -> part[blockIdx.x][2][Co] (a thread's rows in order, then the row groups in
+// order: deterministic).  torch: addcmul, leaky_relu_backward, sum, mul, sum, mul = twelve passes; here g and ysel are
+// read once and dzs written once.
+__global__ __launch_bounds__(kEpThreads) void edgeconv_bwd_prep_kernel(const float* __restrict__ g,
+                                                                       const float* __restrict__ ysel,
+                                                                       const float* __restrict__ scale,
+                                                                       const float* __restrict__ shift, float slope,
+                                                                       long rows, int Co, float* __restrict__ dzs,
+                                                                       float* __restrict__ part) {
+  __shared__ float red[2][kEpThreads][4];
+  const int C4 = Co >> 2, c4 = threadIdx.x % C4, rg = threadIdx.x / C4, RG = kEpThreads / C4;
+  const v4f sc = reinterpret_cast<const v4f*>(scale)[c4], sh = reinterpret_cast<const v4f*>(shift)[c4];
+  v4f s0 = {0.0f, 0.0f, 0.0f, 0.0f}, s1 = {0.0f, 0.0f, 0.0f, 0.0f};
+  const long r1 = ((long)blockIdx.x + 1) * kEpRows < rows ? ((long)blockIdx.x + 1) * kEpRows : rows;
+  for (long r = (long)blockIdx.x * kEpRows + rg; r < r1; r += RG) {
+    const v4f y = reinterpret_cast<const v4f*>(ysel + r * Co)[c4];
+    const v4f gv = reinterpret_cast<const v4f*>(g + r * Co)[c4];
+    v4f o;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float z = fma_rn(y[u], sc[u], sh[u]);
+      const float dz = z > 0.0f ? gv[u] : gv[u] * slope;
+      s0[u] += dz;
+      s1[u] = fma_rn(dz, y[u], s1[u]);
+      o[u] = dz * sc[u];
+    }
+    reinterpret_cast<v4f*>(dzs + r * Co)[c4] = o;
+  }
+#pragma unroll
+  for (int u = 0; u < 4; ++u) { red[0][threadIdx.x][u] = s0[u]; red[1][threadIdx.x][u] = s1[u]; }
+  __syncthreads();
+  if (rg == 0) {
+#pragma unroll
+    for (int w = 0; w < 2; ++w) {
+      v4f t = {red[w][c4][0], red[w][c4][1], red[w][c4][2], red[w][c4][3]};
+      for (int q = 1; q < RG; ++q)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) t[u] += red[w][q * C4 + c4][u];
+      reinterpret_cast<v4f*>(part + ((size_t)blockIdx.x * 2 + w) * Co)[c4] = t;
+    }
+  }
+}
+
 }  // namespace
 }  // namespace fpsg
 
@@ -319,4 +390,43 @@ extern "C" int fpsg_edgeconv_bwd(const float* dzs, const uint8_t* jsel, const fl
   if (Co == 64) hipLaunchKernelGGL(edgeconv_bwd_kernel<1>, grid, dim3(kEcThreads), 0, s, dzs, jsel, PQ, s1, rev, off, coef, B, N, k, bpc, ppw, nsl, stats, dPQ);
   else hipLaunchKernelGGL(edgeconv_bwd_kernel<2>, grid, dim3(kEcThreads), 0, s, dzs, jsel, PQ, s1, rev, off, coef, B, N, k, bpc, ppw, nsl, stats, dPQ);
   return launch_status("fpsg_edgeconv_bwd");
+}
+
+extern "C" int fpsg_edgeconv_prep_blocks(long rows) {
+  return rows > 0 ? (int)((rows + fpsg::kEpRows - 1) / fpsg::kEpRows) : 0;
+}
+
+static int edgeconv_ep_check(const char* fn, long rows, int Co) {
+  using namespace fpsg;
+  FPSG_REQUIRE(rows > 0 && (rows + kEpRows - 1) / kEpRows < (1L << 31), FPSG_E_SHAPE, "%s: rows must be positive (got %ld)", fn, rows);
+  FPSG_REQUIRE(Co == 64 || Co == 128 || Co == 256, FPSG_E_SHAPE, "%s: Co must be 64, 128 or 256 (got %d)", fn, Co);
+  return 0;
+}
+
+extern "C" int fpsg_edgeconv_act(const float* ysel, const float* scale, const float* shift, float slope, long rows,
+                                 int Co, float* out, fpsg_stream_t stream) {
+  using namespace fpsg;
+  int rc = edgeconv_ep_check("fpsg_edgeconv_act", rows, Co);
+  if (rc) return rc;
+  FPSG_REQUIRE_PTR(ysel); FPSG_REQUIRE_PTR(scale); FPSG_REQUIRE_PTR(shift); FPSG_REQUIRE_PTR(out);
+  FPSG_REQUIRE(((reinterpret_cast<uintptr_t>(ysel) | reinterpret_cast<uintptr_t>(scale) | reinterpret_cast<uintptr_t>(shift) |
+                 reinterpret_cast<uintptr_t>(out)) & 15) == 0, FPSG_E_ALIGN, "fpsg_edgeconv_act: buffers must be 16-byte aligned");
+  hipLaunchKernelGGL(edgeconv_act_kernel, dim3((unsigned)((rows + kEpRows - 1) / kEpRows)), dim3(kEpThreads), 0,
+                     static_cast<hipStream_t>(stream), ysel, scale, shift, slope, rows, Co, out);
+  return launch_status("fpsg_edgeconv_act");
+}
+
+extern "C" int fpsg_edgeconv_bwd_prep(const float* g, const float* ysel, const float* scale, const float* shift,
+                                      float slope, long rows, int Co, float* dzs, float* part, fpsg_stream_t stream) {
+  using namespace fpsg;
+  int rc = edgeconv_ep_check("fpsg_edgeconv_bwd_prep", rows, Co);
+  if (rc) return rc;
+  FPSG_REQUIRE_PTR(g); FPSG_REQUIRE_PTR(ysel); FPSG_REQUIRE_PTR(scale); FPSG_REQUIRE_PTR(shift); FPSG_REQUIRE_PTR(dzs);
+  FPSG_REQUIRE_PTR(part);
+  FPSG_REQUIRE(((reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(ysel) | reinterpret_cast<uintptr_t>(scale) |
+                 reinterpret_cast<uintptr_t>(shift) | reinterpret_cast<uintptr_t>(dzs) | reinterpret_cast<uintptr_t>(part)) & 15) == 0,
+               FPSG_E_ALIGN, "fpsg_edgeconv_bwd_prep: buffers must be 16-byte aligned");
+  hipLaunchKernelGGL(edgeconv_bwd_prep_kernel, dim3((unsigned)((rows + kEpRows - 1) / kEpRows)), dim3(kEpThreads), 0,
+                     static_cast<hipStream_t>(stream), g, ysel, scale, shift, slope, rows, Co, dzs, part);
+  return launch_status("fpsg_edgeconv_bwd_prep");
 }

@@ -173,9 +173,13 @@ class _EdgeConvBNMax(torch.autograd.Function):
         else:
             mean, var = running_mean, running_var
         rstd = torch.rsqrt(var + eps)
-        scale = gamma * rstd
-        z = torch.addcmul(beta - mean * scale, ysel, scale)        # one pass over [B,N,Co]
-        out = F.leaky_relu(z, slope)
+        scale = (gamma * rstd).contiguous()
+        shift = (beta - mean * scale).contiguous()
+        out = torch.empty_like(ysel)                                # LeakyReLU(fma(ysel, scale, shift)): one pass
+        with torch.cuda.device(dev):
+            rc = lib.fpsg_edgeconv_act(_hip.ptr(ysel), _hip.ptr(scale), _hip.ptr(shift), float(slope), B * N, Co,
+                                       _hip.ptr(out), _hip.stream_of(PQ))
+        _hip.check(rc, "fpsg_edgeconv_act")
         ctx.save_for_backward(PQ, idx32, ysel, jsel, s1 if training else ysel, mean, rstd, gamma, beta)
         ctx.cfg = (training, slope, k)
         return out
@@ -187,13 +191,22 @@ class _EdgeConvBNMax(torch.autograd.Function):
         B, N, Co2 = PQ.shape
         Co = Co2 // 2
         E = B * N * k
-        scale = gamma * rstd
-        z = torch.addcmul(beta - mean * scale, ysel, scale)
-        dz = torch.ops.aten.leaky_relu_backward(g.contiguous(), z, slope, False)
-        dbeta = dz.sum(dim=(0, 1))
+        scale = (gamma * rstd).contiguous()
+        shift = (beta - mean * scale).contiguous()
+        # dz = g * LeakyReLU'(z) with z re-derived by the forward's arithmetic, dzs = dz * scale, and the sums of dz and
+        # dz * ysel per channel: one pass (fpsg_edgeconv_bwd_prep) instead of six elementwise / reduction ops
+        lib = _hip.load()
+        g = g.contiguous()
+        dzs = torch.empty_like(ysel)
+        part = torch.empty((lib.fpsg_edgeconv_prep_blocks(B * N), 2, Co), dtype=torch.float32, device=PQ.device)
+        with torch.cuda.device(PQ.device):
+            rc = lib.fpsg_edgeconv_bwd_prep(_hip.ptr(g), _hip.ptr(ysel), _hip.ptr(scale), _hip.ptr(shift), float(slope),
+                                            B * N, Co, _hip.ptr(dzs), _hip.ptr(part), _hip.stream_of(PQ))
+        _hip.check(rc, "fpsg_edgeconv_bwd_prep")
+        sums = part.double().sum(dim=0)                              # fixed-shape reduction
+        dbeta = sums[0].float()
         # sum dz * yhat = (sum dz*ysel - mean * sum dz) * rstd
-        dgamma = ((dz * ysel).sum(dim=(0, 1)) - mean * dbeta) * rstd
-        dzs = dz * scale
+        dgamma = ((sums[1] - mean.double() * sums[0]) * rstd.double()).float()
         if training:
             coef = torch.stack([scale * dbeta / E, scale * rstd * dgamma / E, mean]).contiguous()
         else:

@@ -163,6 +163,17 @@ int fpsg_edgeconv_fwd(const float* PQ, const int32_t* idx, const float* sgn, int
 int fpsg_edgeconv_bwd(const float* dzs, const uint8_t* jsel, const float* PQ, const float* s1,
                       const int32_t* rev, const int32_t* off, const float* coef, int B, int N, int k,
                       int Co, float* dPQ, fpsg_stream_t stream);
+/* The elementwise halves around them, on point-major [rows = B*N, Co] tensors: fpsg_edgeconv_act = the BatchNorm
+ * affine form + LeakyReLU of the selected neighbour sum, out = lrelu(fma(ysel, scale[c], shift[c])) (one pass instead
+ * of addcmul + leaky_relu); fpsg_edgeconv_bwd_prep = the head of the backward: z re-derived with the same arithmetic,
+ * dz = g * lrelu'(z), dzs = dz * scale[c] for fpsg_edgeconv_bwd, and part [fpsg_edgeconv_prep_blocks(rows)][2][Co] =
+ * per-workgroup sums of dz and dz * ysel (-> dbeta, dgamma, BatchNorm coefficients): g and ysel read once, dzs written
+ * once (six torch ops = twelve passes otherwise).  Co in {64, 128, 256}; 16-byte aligned.  Deterministic. */
+int fpsg_edgeconv_prep_blocks(long rows);
+int fpsg_edgeconv_act(const float* ysel, const float* scale, const float* shift, float slope, long rows, int Co,
+                      float* out, fpsg_stream_t stream);
+int fpsg_edgeconv_bwd_prep(const float* g, const float* ysel, const float* scale, const float* shift, float slope,
+                           long rows, int Co, float* dzs, float* part, fpsg_stream_t stream);
 
 /* ---- K2b: soft-min of the Sinkhorn loop ---------------------------------------------
  * The operator under neuralnet_pytorch.metrics.emd_loss(sinkhorn=True) = geomloss.SamplesLoss()
