@@ -88,7 +88,7 @@ __global__ __launch_bounds__(kEcThreads) void edgeconv_fwd_kernel(
   float sg[VEC], sum[VEC], sumsq[VEC];
   load_vec<VEC>(sgn + c0, sg);
 #pragma unroll
-  for (int v = 0; v < VEC; ++v) { sum[v] = 0.0f; sumsq[v] = 0.0f; }
+  for (int v = 0; v < VEC; ++v) { sg[v] = sg[v] < 0.0f ? -1.0f : 1.0f; sum[v] = 0.0f; sumsq[v] = 0.0f; }   // only the sign counts
 
   const int n_first = (cb.bx * 4 + wave) * ppw;
   for (int pp = 0; pp < ppw; ++pp) {
@@ -264,6 +264,79 @@ inline dim3 ec_grid(int B, int N, int Co) {          // 8 * ceil(B/8) clouds' wo
 // ---- the elementwise halves around the two kernels above (point-major [rows, Co], rows = B*N) -------------------
 // forward tail: out = LeakyReLU(fma(ysel, scale[c], shift[c])) -- BatchNorm's affine form on the selected
 // neighbour sum + the activation, one pass (torch: addcmul + leaky_relu, two).
+// The per-channel scalar work between the kernels, one launch each (as PyTorch ops: ~20 one-vector launches per
+// layer in the forward, ~15 in the backward).  part [blocks][2][Co] -> fp64 sums in block order.
+// forward: batch statistics of the edge activations (count = B*N*k) -> chan [4][Co] = (scale, shift, mean, rstd) with
+// scale = gamma * rstd, shift = beta - mean * scale; running statistics updated as nn.BatchNorm2d does (unbiased
+// variance).  training = 0: chan from the running statistics, part unused.
+// fp64 sums over the blocks for the 4 channels of a workgroup: thread (row slice q = tid / 4, channel tid % 4) adds
+// blocks q, q + 64, ... in order, the 64 slices are then added in order by the first 4 threads (deterministic)
+constexpr int kFinThreads = 256, kFinCh = 4, kFinSlices = kFinThreads / kFinCh;
+__device__ __forceinline__ bool part_sums(const float* __restrict__ part, int blocks, int Co, int& c, double& s0, double& s1) {
+  __shared__ double red[2][kFinThreads];
+  const int q = threadIdx.x / kFinCh, cl = threadIdx.x % kFinCh;
+  c = blockIdx.x * kFinCh + cl;
+  double a0 = 0.0, a1 = 0.0;
+  if (c < Co && part)
+    for (int b = q; b < blocks; b += kFinSlices) { a0 += part[((size_t)b * 2) * Co + c]; a1 += part[((size_t)b * 2 + 1) * Co + c]; }
+  red[0][threadIdx.x] = a0;
+  red[1][threadIdx.x] = a1;
+  __syncthreads();
+  if (q != 0 || c >= Co) return false;
+  s0 = 0.0; s1 = 0.0;
+  for (int r = 0; r < kFinSlices; ++r) { s0 += red[0][r * kFinCh + cl]; s1 += red[1][r * kFinCh + cl]; }
+  return true;
+}
+
+__global__ __launch_bounds__(kFinThreads) void edgeconv_stats_finalize_kernel(const float* __restrict__ part, int blocks, const float* __restrict__ gamma,
+                                               const float* __restrict__ beta, float* __restrict__ run_mean,
+                                               float* __restrict__ run_var, float momentum, float eps, double count,
+                                               int Co, int training, float* __restrict__ chan) {
+  int c;
+  double s0, s1;
+  if (!part_sums(training ? part : nullptr, blocks, Co, c, s0, s1)) return;
+  float mean, var;
+  if (training) {
+    const double m = s0 / count;
+    double v = s1 / count - m * m;
+    v = v > 0.0 ? v : 0.0;
+    mean = (float)m;
+    var = (float)v;
+    if (run_mean) {
+      const float unbiased = var * (float)(count / (count > 1.0 ? count - 1.0 : 1.0));
+      run_mean[c] = fma_rn(momentum, mean, (1.0f - momentum) * run_mean[c]);
+      run_var[c] = fma_rn(momentum, unbiased, (1.0f - momentum) * run_var[c]);
+    }
+  } else {
+    mean = run_mean[c];
+    var = run_var[c];
+  }
+  const float rstd = 1.0f / sqrtf(var + eps);
+  const float scale = gamma[c] * rstd;
+  chan[c] = scale;
+  chan[Co + c] = beta[c] - mean * scale;
+  chan[2 * Co + c] = mean;
+  chan[3 * Co + c] = rstd;
+}
+
+// backward: the sums of dz and dz * ysel -> dbeta, dgamma = (sum dz*ysel - mean * sum dz) * rstd, and the coefficients
+// coef [3][Co] = (scale * dbeta / count, scale * rstd * dgamma / count, mean) of fpsg_edgeconv_bwd (zeros in eval mode)
+__global__ __launch_bounds__(kFinThreads) void edgeconv_bwd_finalize_kernel(const float* __restrict__ part, int blocks, const float* __restrict__ chan,
+                                             double count, int Co, int training, float* __restrict__ dgamma,
+                                             float* __restrict__ dbeta, float* __restrict__ coef) {
+  int c;
+  double s0, s1;
+  if (!part_sums(part, blocks, Co, c, s0, s1)) return;
+  const float scale = chan[c], mean = chan[2 * Co + c], rstd = chan[3 * Co + c];
+  const float db = (float)s0;
+  const float dg = (float)((s1 - (double)mean * s0) * (double)rstd);
+  dbeta[c] = db;
+  dgamma[c] = dg;
+  coef[c] = training ? (float)((double)scale * db / count) : 0.0f;
+  coef[Co + c] = training ? (float)((double)scale * rstd * dg / count) : 0.0f;
+  coef[2 * Co + c] = training ? mean : 0.0f;
+}
+
 constexpr int kEpThreads = 256;
 constexpr int kEpRows = 256;            // rows per workgroup
 
@@ -429,4 +502,28 @@ extern "C" int fpsg_edgeconv_bwd_prep(const float* g, const float* ysel, const f
   hipLaunchKernelGGL(edgeconv_bwd_prep_kernel, dim3((unsigned)((rows + kEpRows - 1) / kEpRows)), dim3(kEpThreads), 0,
                      static_cast<hipStream_t>(stream), g, ysel, scale, shift, slope, rows, Co, dzs, part);
   return launch_status("fpsg_edgeconv_bwd_prep");
+}
+
+extern "C" int fpsg_edgeconv_stats_finalize(const float* part, int blocks, const float* gamma, const float* beta,
+                                            float* running_mean, float* running_var, float momentum, float eps,
+                                            double count, int Co, int training, float* chan, fpsg_stream_t stream) {
+  using namespace fpsg;
+  FPSG_REQUIRE(Co > 0 && count > 0.0, FPSG_E_SHAPE, "fpsg_edgeconv_stats_finalize: Co and count must be positive (got %d, %g)", Co, count);
+  FPSG_REQUIRE_PTR(gamma); FPSG_REQUIRE_PTR(beta); FPSG_REQUIRE_PTR(chan);
+  if (training) { FPSG_REQUIRE_PTR(part); FPSG_REQUIRE(blocks > 0, FPSG_E_SHAPE, "fpsg_edgeconv_stats_finalize: blocks must be positive (got %d)", blocks); }
+  else { FPSG_REQUIRE_PTR(running_mean); FPSG_REQUIRE_PTR(running_var); }
+  hipLaunchKernelGGL(edgeconv_stats_finalize_kernel, dim3((unsigned)((Co + kFinCh - 1) / kFinCh)), dim3(kFinThreads), 0, static_cast<hipStream_t>(stream),
+                     part, blocks, gamma, beta, running_mean, running_var, momentum, eps, count, Co, training, chan);
+  return launch_status("fpsg_edgeconv_stats_finalize");
+}
+
+extern "C" int fpsg_edgeconv_bwd_finalize(const float* part, int blocks, const float* chan, double count, int Co,
+                                          int training, float* dgamma, float* dbeta, float* coef, fpsg_stream_t stream) {
+  using namespace fpsg;
+  FPSG_REQUIRE(Co > 0 && count > 0.0 && blocks > 0, FPSG_E_SHAPE,
+               "fpsg_edgeconv_bwd_finalize: Co, blocks and count must be positive (got %d, %d, %g)", Co, blocks, count);
+  FPSG_REQUIRE_PTR(part); FPSG_REQUIRE_PTR(chan); FPSG_REQUIRE_PTR(dgamma); FPSG_REQUIRE_PTR(dbeta); FPSG_REQUIRE_PTR(coef);
+  hipLaunchKernelGGL(edgeconv_bwd_finalize_kernel, dim3((unsigned)((Co + kFinCh - 1) / kFinCh)), dim3(kFinThreads), 0, static_cast<hipStream_t>(stream),
+                     part, blocks, chan, count, Co, training, dgamma, dbeta, coef);
+  return launch_status("fpsg_edgeconv_bwd_finalize");
 }

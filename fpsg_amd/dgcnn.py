@@ -149,76 +149,63 @@ class _EdgeConvBNMax(torch.autograd.Function):
         Co, k = Co2 // 2, idx32.size(2)
         dev = PQ.device
         lib = _hip.load()
-        sgn = torch.where(gamma.detach() < 0, -1.0, 1.0).to(torch.float32).contiguous()
+        st = _hip.stream_of(PQ)
+        gam, bet = gamma.detach().contiguous(), beta.detach().contiguous()
         ysel = torch.empty((B, N, Co), dtype=torch.float32, device=dev)
         jsel = torch.empty((B, N, Co), dtype=torch.uint8, device=dev)
         s1 = torch.empty((B, N, Co), dtype=torch.float32, device=dev) if training else None
-        part = (torch.empty((lib.fpsg_edgeconv_blocks(B, N, Co), 2, Co), dtype=torch.float32, device=dev)
-                if training else None)
+        blocks = lib.fpsg_edgeconv_blocks(B, N, Co)
+        part = torch.empty((blocks, 2, Co), dtype=torch.float32, device=dev) if training else None
+        chan = torch.empty((4, Co), dtype=torch.float32, device=dev)       # scale, shift, mean, rstd
+        out = torch.empty_like(ysel)
+        opt = lambda t: _hip.ptr(t) if t is not None else None
         with torch.cuda.device(dev):
-            rc = lib.fpsg_edgeconv_fwd(_hip.ptr(PQ), _hip.ptr(idx32), _hip.ptr(sgn), B, N, k, Co,
-                                       _hip.ptr(ysel), _hip.ptr(jsel),
-                                       _hip.ptr(s1) if training else None,
-                                       _hip.ptr(part) if training else None, _hip.stream_of(PQ))
-        _hip.check(rc, "fpsg_edgeconv_fwd")
-        E = B * N * k
-        if training:
-            sums = part.double().sum(dim=0)                       # fixed-shape reduction
-            mean64 = sums[0] / E
-            var64 = (sums[1] / E - mean64 * mean64).clamp_min_(0.0)
-            mean, var = mean64.float(), var64.float()
-            with torch.no_grad():
-                running_mean.mul_(1 - momentum).add_(mean, alpha=momentum)
-                running_var.mul_(1 - momentum).add_(var * (E / max(E - 1, 1)), alpha=momentum)
-        else:
-            mean, var = running_mean, running_var
-        rstd = torch.rsqrt(var + eps)
-        scale = (gamma * rstd).contiguous()
-        shift = (beta - mean * scale).contiguous()
-        out = torch.empty_like(ysel)                                # LeakyReLU(fma(ysel, scale, shift)): one pass
-        with torch.cuda.device(dev):
-            rc = lib.fpsg_edgeconv_act(_hip.ptr(ysel), _hip.ptr(scale), _hip.ptr(shift), float(slope), B * N, Co,
-                                       _hip.ptr(out), _hip.stream_of(PQ))
-        _hip.check(rc, "fpsg_edgeconv_act")
-        ctx.save_for_backward(PQ, idx32, ysel, jsel, s1 if training else ysel, mean, rstd, gamma, beta)
+            # max / min over the neighbours by the sign of gamma, batch sums of the edge activations
+            _hip.check(lib.fpsg_edgeconv_fwd(_hip.ptr(PQ), _hip.ptr(idx32), _hip.ptr(gam), B, N, k, Co, _hip.ptr(ysel),
+                                             _hip.ptr(jsel), opt(s1), opt(part), st), "fpsg_edgeconv_fwd")
+            # statistics -> (scale, shift, mean, rstd), running statistics updated: one launch
+            _hip.check(lib.fpsg_edgeconv_stats_finalize(opt(part), blocks, _hip.ptr(gam), _hip.ptr(bet),
+                                                        _hip.ptr(running_mean), _hip.ptr(running_var), float(momentum),
+                                                        float(eps), float(B * N * k), Co, 1 if training else 0,
+                                                        _hip.ptr(chan), st), "fpsg_edgeconv_stats_finalize")
+            # LeakyReLU(fma(ysel, scale, shift)): one pass
+            _hip.check(lib.fpsg_edgeconv_act(_hip.ptr(ysel), _hip.ptr(chan[0]), _hip.ptr(chan[1]), float(slope), B * N, Co,
+                                             _hip.ptr(out), st), "fpsg_edgeconv_act")
+        ctx.save_for_backward(PQ, idx32, ysel, jsel, s1 if training else ysel, chan)
         ctx.cfg = (training, slope, k)
         return out
 
     @staticmethod
     def backward(ctx, g):
-        PQ, idx32, ysel, jsel, s1, mean, rstd, gamma, beta = ctx.saved_tensors
+        PQ, idx32, ysel, jsel, s1, chan = ctx.saved_tensors
         training, slope, k = ctx.cfg
         B, N, Co2 = PQ.shape
         Co = Co2 // 2
-        E = B * N * k
-        scale = (gamma * rstd).contiguous()
-        shift = (beta - mean * scale).contiguous()
-        # dz = g * LeakyReLU'(z) with z re-derived by the forward's arithmetic, dzs = dz * scale, and the sums of dz and
-        # dz * ysel per channel: one pass (fpsg_edgeconv_bwd_prep) instead of six elementwise / reduction ops
+        dev = PQ.device
         lib = _hip.load()
+        st = _hip.stream_of(PQ)
         g = g.contiguous()
         dzs = torch.empty_like(ysel)
-        part = torch.empty((lib.fpsg_edgeconv_prep_blocks(B * N), 2, Co), dtype=torch.float32, device=PQ.device)
-        with torch.cuda.device(PQ.device):
-            rc = lib.fpsg_edgeconv_bwd_prep(_hip.ptr(g), _hip.ptr(ysel), _hip.ptr(scale), _hip.ptr(shift), float(slope),
-                                            B * N, Co, _hip.ptr(dzs), _hip.ptr(part), _hip.stream_of(PQ))
-        _hip.check(rc, "fpsg_edgeconv_bwd_prep")
-        sums = part.double().sum(dim=0)                              # fixed-shape reduction
-        dbeta = sums[0].float()
-        # sum dz * yhat = (sum dz*ysel - mean * sum dz) * rstd
-        dgamma = ((sums[1] - mean.double() * sums[0]) * rstd.double()).float()
-        if training:
-            coef = torch.stack([scale * dbeta / E, scale * rstd * dgamma / E, mean]).contiguous()
-        else:
-            coef = torch.zeros((3, Co), dtype=torch.float32, device=PQ.device)
+        blocks = lib.fpsg_edgeconv_prep_blocks(B * N)
+        part = torch.empty((blocks, 2, Co), dtype=torch.float32, device=dev)
+        dgamma = torch.empty((Co,), dtype=torch.float32, device=dev)
+        dbeta = torch.empty((Co,), dtype=torch.float32, device=dev)
+        coef = torch.empty((3, Co), dtype=torch.float32, device=dev)
         rev, off = _reverse_graph(idx32)
         dPQ = torch.empty_like(PQ)
-        with torch.cuda.device(PQ.device):
-            rc = _hip.load().fpsg_edgeconv_bwd(_hip.ptr(dzs), _hip.ptr(jsel), _hip.ptr(PQ),
-                                               _hip.ptr(s1) if training else None, _hip.ptr(rev),
-                                               _hip.ptr(off), _hip.ptr(coef), B, N, k, Co,
-                                               _hip.ptr(dPQ), _hip.stream_of(PQ))
-        _hip.check(rc, "fpsg_edgeconv_bwd")
+        with torch.cuda.device(dev):
+            # dz = g * LeakyReLU'(z) with z re-derived by the forward's arithmetic, dzs = dz * scale, and the sums of dz
+            # and dz * ysel per channel: one pass
+            _hip.check(lib.fpsg_edgeconv_bwd_prep(_hip.ptr(g), _hip.ptr(ysel), _hip.ptr(chan[0]), _hip.ptr(chan[1]),
+                                                  float(slope), B * N, Co, _hip.ptr(dzs), _hip.ptr(part), st),
+                       "fpsg_edgeconv_bwd_prep")
+            # dbeta, dgamma and the BatchNorm coefficients of the fused backward: one launch
+            _hip.check(lib.fpsg_edgeconv_bwd_finalize(_hip.ptr(part), blocks, _hip.ptr(chan), float(B * N * k), Co,
+                                                      1 if training else 0, _hip.ptr(dgamma), _hip.ptr(dbeta),
+                                                      _hip.ptr(coef), st), "fpsg_edgeconv_bwd_finalize")
+            _hip.check(lib.fpsg_edgeconv_bwd(_hip.ptr(dzs), _hip.ptr(jsel), _hip.ptr(PQ),
+                                             _hip.ptr(s1) if training else None, _hip.ptr(rev), _hip.ptr(off),
+                                             _hip.ptr(coef), B, N, k, Co, _hip.ptr(dPQ), st), "fpsg_edgeconv_bwd")
         return dPQ, None, dgamma, dbeta, None, None, None, None, None, None
 
 

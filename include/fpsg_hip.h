@@ -146,7 +146,7 @@ int fpsg_emd_approx(const float* xyz1, const float* xyz2, int B, int N, int M, f
  * Replaces the chain get_graph_feature -> Conv2d 1x1 -> BatchNorm2d -> LeakyReLU -> max_k of
  * src/dgcnn/model.py:23-42,53-56,63-76 without materialising [B,2C,N,k].  The caller first
  * forms PQ [B,N,2*Co] = x^T [W1 ; W2-W1]^T (one GEMM): y(n,j) = P[idx[n,j]] + Q[n].
- *   fwd : sgn [Co] = +1 (take max_j) or -1 (take min_j) per channel (= sign of BN gamma);
+ *   fwd : sgn [Co]: >= 0 take max_j, < 0 take min_j per channel (only the sign is used: pass BN's gamma);
  *         ysel [B,N,Co] selected extreme of y over j; jsel [B,N,Co] uint8 its slot j (first on
  *         ties); s1 [B,N,Co] = sum_j y (NULL to skip); part [fpsg_edgeconv_blocks(B,N,Co)][2][Co]
  *         per-workgroup sums of y and y^2 for the BatchNorm statistics (NULL to skip).
@@ -170,6 +170,16 @@ int fpsg_edgeconv_bwd(const float* dzs, const uint8_t* jsel, const float* PQ, co
  * per-workgroup sums of dz and dz * ysel (-> dbeta, dgamma, BatchNorm coefficients): g and ysel read once, dzs written
  * once (six torch ops = twelve passes otherwise).  Co in {64, 128, 256}; 16-byte aligned.  Deterministic. */
 int fpsg_edgeconv_prep_blocks(long rows);
+/* The per-channel scalar work between them, one launch each: fpsg_edgeconv_stats_finalize turns the forward kernel's
+ * partial sums (count = B*N*k edge activations) into chan [4][Co] = (gamma*rstd, beta - mean*gamma*rstd, mean, rstd) and
+ * updates the running statistics as nn.BatchNorm2d does (training = 0: chan from the running statistics);
+ * fpsg_edgeconv_bwd_finalize turns fpsg_edgeconv_bwd_prep's partial sums into dgamma, dbeta and coef [3][Co] of
+ * fpsg_edgeconv_bwd (zeros in eval mode).  fp64 sums in block order. */
+int fpsg_edgeconv_stats_finalize(const float* part, int blocks, const float* gamma, const float* beta,
+                                 float* running_mean, float* running_var, float momentum, float eps, double count, int Co,
+                                 int training, float* chan, fpsg_stream_t stream);
+int fpsg_edgeconv_bwd_finalize(const float* part, int blocks, const float* chan, double count, int Co, int training,
+                               float* dgamma, float* dbeta, float* coef, fpsg_stream_t stream);
 int fpsg_edgeconv_act(const float* ysel, const float* scale, const float* shift, float slope, long rows, int Co,
                       float* out, fpsg_stream_t stream);
 int fpsg_edgeconv_bwd_prep(const float* g, const float* ysel, const float* scale, const float* shift, float slope,
