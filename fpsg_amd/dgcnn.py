@@ -114,6 +114,31 @@ def _reverse_graph(idx32: torch.Tensor):
     return order.to(torch.int32).contiguous(), off.to(torch.int32).contiguous()
 
 
+class _PointwiseOnCat(torch.autograd.Function):
+    """``Conv1d(C, E, 1, bias=False)`` on the point-major concatenation ``cat [B,N,C]`` -> ``[B,E,N]`` (``dgcnn/model.py:83``)
+    as batched GEMMs that take transposed operands by their strides.  Autograd's own backward of
+    ``bmm(W, cat^T)`` returns the gradient of ``cat`` as a transposed view of a ``[B,C,N]`` tensor, and its channel
+    slices -- the gradients of the four EdgeConv outputs -- then reach the point-major consumers through transposing
+    copies (0.5 ms per episode at 64 clouds); here ``d cat = dh^T W`` is produced point-major."""
+
+    @staticmethod
+    def forward(ctx, cat, w):
+        B = cat.shape[0]
+        ctx.save_for_backward(cat, w)
+        return torch.bmm(w.unsqueeze(0).expand(B, -1, -1), cat.transpose(1, 2))
+
+    @staticmethod
+    def backward(ctx, gh):
+        cat, w = ctx.saved_tensors
+        B = cat.shape[0]
+        gcat = gw = None
+        if ctx.needs_input_grad[0]:
+            gcat = torch.bmm(gh.transpose(1, 2), w.unsqueeze(0).expand(B, -1, -1))      # [B,N,C], contiguous
+        if ctx.needs_input_grad[1]:
+            gw = torch.bmm(gh, cat).sum(dim=0)                                           # [E,C]
+        return gcat, gw
+
+
 class _MaxMeanOverPoints(torch.autograd.Function):
     """``cat(h.max(dim=2)[0], h.mean(dim=2))`` of the embedding ``h [B,C,N]`` (``dgcnn/model.py:86-88``) with ONE gradient
     tensor in the backward: autograd's own graph fills a zero tensor for the max, expands the mean's gradient into a
@@ -275,7 +300,7 @@ class DGCNNfeat(nn.Module):
                 x_cm = x_pm.transpose(1, 2).contiguous()
         cat = torch.cat(feats, dim=2)                              # [B,N,512]
         conv5, bn5, act5 = self.conv5[0], self.conv5[1], self.conv5[2]
-        h = torch.matmul(conv5.weight.squeeze(-1), cat.transpose(1, 2))   # Conv1d(512,emb,1) as a GEMM -> [B,emb,N]
+        h = _PointwiseOnCat.apply(cat, conv5.weight.squeeze(-1))       # Conv1d(512,emb,1) -> [B,emb,N]
         h = bn_act(bn5, h, ("leaky", act5.negative_slope))                # BatchNorm1d + LeakyReLU fused (K5)
         if self.dual_flag:
             return _MaxMeanOverPoints.apply(h) if h.is_cuda else torch.cat((h.max(dim=2)[0], h.mean(dim=2)), dim=1)
