@@ -709,16 +709,16 @@ __global__ __launch_bounds__(kBnThreads) void bn_reduce_ext_kernel(const float* 
     // ascending positions per lane: strict compares keep the first occurrence
     if ((L & 3) == 0) {
       const v4f* __restrict__ xp = reinterpret_cast<const v4f*>(x + base);
-      // four vector loads in flight per lane (one load per trip leaves a 2048-point row as eight serial round trips)
-      for (int e0 = lane; e0 < len / 4; e0 += 4 * 64) {
-        v4f q[4];
+      // eight vector loads in flight per lane: a whole 2048-point row (one load per trip leaves it as eight serial round trips)
+      for (int e0 = lane; e0 < len / 4; e0 += 8 * 64) {
+        v4f q[8];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < 8; ++j) {
           const int e = e0 + 64 * j;
           q[j] = e < len / 4 ? xp[e] : (v4f){0.0f, 0.0f, 0.0f, 0.0f};
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < 8; ++j) {
           const int e = e0 + 64 * j;
           if (e < len / 4) {
 #pragma unroll
