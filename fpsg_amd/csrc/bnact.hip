@@ -725,8 +725,13 @@ __global__ __launch_bounds__(kBnThreads) void bn_reduce_ext_kernel(const float* 
             for (int u = 0; u < 4; ++u) {
               const float xv = q[j][u] + b;
               if (STATS) { a0 += xv; a1 = fma_rn(xv, xv, a1); }
-              if (xv > vmax) { vmax = xv; imax = seg * kBnSeg + 4 * e + u; }
-              if (xv < vmin) { vmin = xv; imin = seg * kBnSeg + 4 * e + u; }
+              // selects, not branches: as `if` bodies the two updates became ~60 exec-mask branches per row
+              const int pos = seg * kBnSeg + 4 * e + u;
+              const bool gt = xv > vmax, lt = xv < vmin;
+              vmax = gt ? xv : vmax;
+              imax = gt ? pos : imax;
+              vmin = lt ? xv : vmin;
+              imin = lt ? pos : imin;
             }
           }
         }
