@@ -333,6 +333,21 @@ def trunk_kernel_rooflines(device, entry):
         t = _event_time(fn, 10)
         out[f"K6_{name}_transform"] = hbm(nb, t, f"({n_img},128,112,112) m=4", "1 read + 2.25 writes (or the reverse) of the tensor")
     del V
+    # K6g: the 36 batched products of the layers that stay on the three-kernel form, as the step runs them
+    # (torch.bmm = the library's fp32-MFMA batched GEMM): forward U.V and the weight gradient gM.V^T
+    for C, K, H in ((128, 128, 112), (256, 256, 56), (512, 512, 28)):
+        P = n_img * (H // 4) ** 2
+        U = torch.randn(36, K, C, device=device)
+        V = torch.randn(36, C, P, device=device)
+        gM = torch.randn(36, K, P, device=device)
+        flop = 2.0 * 36 * K * C * P
+        for leg, fn in (("fwd", lambda: torch.bmm(U, V)), ("dw", lambda: torch.bmm(gM, V.transpose(1, 2)))):
+            t = _event_time(fn, 10)
+            out[f"K6g_batched_gemm_{C}to{K}_{leg}"] = entry(
+                "mfma", flop / t / 1e12, F32_PEAK / 1e12, "TFLOP/s", t, f"36 x [{K} x {C}].[{C} x {P}]",
+                "library GEMM (hipBLASLt / rocBLAS through torch.bmm, tuning records of fpsg_amd/tuning); "
+                "Winograd-domain flop", hbm_GBps=(U.numel() + V.numel() + gM.numel()) * 4 / t / 1e9)
+        del U, V, gM
     # K5: BatchNorm + ReLU on the same tensor: forward 2 reads + 1 write, backward 4 reads + 1 write
     bn = nn.BatchNorm2d(128).to(device).train()
     xr = x.requires_grad_()
