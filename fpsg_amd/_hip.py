@@ -44,6 +44,8 @@ SIGNATURES = {
     "fpsg_edge_feature_fwd": [_c_f32p, _c_i32p, _c_int, _c_int, _c_int, _c_int, _c_f32p, _c_stream],
     "fpsg_edge_feature_bwd": [_c_f32p, _c_i32p, _c_int, _c_int, _c_int, _c_int, _c_f32p, _c_stream],
     "fpsg_edgeconv_blocks": [_c_int, _c_int, _c_int],
+    "fpsg_edgeconv_reverse_graph_fits": [_c_int, _c_int],
+    "fpsg_edgeconv_reverse_graph": [_c_i32p, _c_int, _c_int, _c_int, _c_i32p, _c_i32p, _c_stream],
     "fpsg_edgeconv_prep_blocks": [ctypes.c_long],
     "fpsg_edgeconv_stats_finalize": [_c_f32p, _c_int, _c_f32p, _c_f32p, _c_f32p, _c_f32p, ctypes.c_float, ctypes.c_float,
                                      ctypes.c_double, _c_int, _c_int, _c_f32p, _c_stream],

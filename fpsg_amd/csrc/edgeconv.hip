@@ -527,3 +527,173 @@ extern "C" int fpsg_edgeconv_bwd_finalize(const float* part, int blocks, const f
                      part, blocks, chan, count, Co, training, dgamma, dbeta, coef);
   return launch_status("fpsg_edgeconv_bwd_finalize");
 }
+
+// ------------------------------------------------------------------------------------------------
+// The in-edge lists the backward gathers through: edges e = n*k + j grouped by destination idx[n][j], ascending e
+// inside a group (the summation order of the backward, and of the oracle).  The reference reaches this through
+// autograd's index backward of get_graph_feature's gather (dgcnn/model.py:30-56), which scatters with atomics.
+//
+// One workgroup per cloud, a stable counting sort: wave w owns the contiguous edge range [w*per_wave, ...), counts its
+// destinations in its own row of 16-bit counters (two per LDS word), the rows are scanned per destination (wave 0's
+// edges first) and over the destinations, then every wave places its edges in order, 64 at a time.  Lanes of one group
+// that share a destination are served lowest lane first: pending lanes race for a tag with ds_min on the lane id, the
+// winner takes the next slot of the destination and releases the tag.  The tag table is hashed (256-1024 entries per wave):
+// a lane that loses to another destination's lane just waits a round.  No result depends on timing.
+namespace fpsg {
+namespace {
+
+constexpr int kRgWaves = 16;
+constexpr int kRgThreads = 64 * kRgWaves;
+constexpr int kRgMinTags = 256, kRgMaxTags = 1024;   // per-wave tag table: as large as the LDS allows (fewer lost rounds)
+constexpr int kRgMaxPairs = 2;                 // destination pairs per thread in the scan: N <= 4096
+
+inline size_t rg_lds_bytes(int N, int tags) {
+  return ((size_t)(N + 1) + kRgWaves + (size_t)kRgWaves * tags + (size_t)kRgWaves * ((N + 1) / 2)) * 4;
+}
+inline int rg_tags(int N) {
+  int tags = kRgMaxTags;
+  while (tags > kRgMinTags && rg_lds_bytes(N, tags) > 160 * 1024) tags >>= 1;
+  return tags;
+}
+
+__global__ __launch_bounds__(kRgThreads) void reverse_graph_kernel(const int32_t* __restrict__ idx, int N, int k,
+                                                                   int per_wave, int n_tags,
+                                                                   int32_t* __restrict__ rev,
+                                                                   int32_t* __restrict__ off) {
+  extern __shared__ __attribute__((aligned(16))) unsigned rg_lds[];
+  const int E = N * k;
+  const int Nh = (N + 1) >> 1;
+  int* loff = reinterpret_cast<int*>(rg_lds);                          // [N + 1] first slot of a destination
+  int* wsum = loff + (N + 1);                                          // [kRgWaves]
+  unsigned* tags = reinterpret_cast<unsigned*>(wsum + kRgWaves);       // [kRgWaves][n_tags]
+  unsigned* cur = tags + kRgWaves * n_tags;                             // [kRgWaves][Nh]: count, then cursor (u16 x 2)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int32_t* __restrict__ ix = idx + (size_t)blockIdx.x * E;
+  int32_t* __restrict__ rv = rev + (size_t)blockIdx.x * E;
+  int32_t* __restrict__ of = off + (size_t)blockIdx.x * (N + 1);
+
+  for (int i = tid; i < kRgWaves * Nh; i += kRgThreads) cur[i] = 0;
+  for (int i = tid; i < kRgWaves * n_tags; i += kRgThreads) tags[i] = 0xffffffffu;
+  __syncthreads();
+
+  // ---- counts of this wave's edge range
+  unsigned* mycur = cur + wave * Nh;
+  const int e0 = wave * per_wave;
+  const int e1 = e0 + per_wave < E ? e0 + per_wave : E;
+  for (int e = e0 + lane; e < e1; e += 256) {          // four loads in flight
+    int d[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) d[u] = e + 64 * u < e1 ? ix[e + 64 * u] : -1;
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if ((unsigned)d[u] < (unsigned)N) atomicAdd(&mycur[d[u] >> 1], 1u << ((d[u] & 1) * 16));
+  }
+  __syncthreads();
+
+  // ---- per destination: the waves' counts become each wave's first rank; in-degrees scanned over the destinations
+  const int pp = (Nh + kRgThreads - 1) / kRgThreads;                  // pairs per thread (<= kRgMaxPairs)
+  int deg[2 * kRgMaxPairs];
+  int local = 0;
+#pragma unroll
+  for (int u = 0; u < kRgMaxPairs; ++u) {
+    unsigned run = 0;                                                  // both halves at once: no carry below 65536
+    const int pair = tid * pp + u;
+    if (u < pp && pair < Nh) {
+      for (int w = 0; w < kRgWaves; ++w) {
+        const unsigned c = cur[w * Nh + pair];
+        cur[w * Nh + pair] = run;
+        run += c;
+      }
+    }
+    deg[2 * u] = (int)(run & 0xffffu);
+    deg[2 * u + 1] = (int)(run >> 16);
+    local += deg[2 * u] + deg[2 * u + 1];
+  }
+  int incl = local;
+#pragma unroll
+  for (int s = 1; s < 64; s <<= 1) {
+    const int o = __shfl_up(incl, s, 64);
+    if (lane >= s) incl += o;
+  }
+  if (lane == 63) wsum[wave] = incl;
+  __syncthreads();
+  int base = incl - local;
+  int total = 0;
+  for (int w = 0; w < kRgWaves; ++w) {
+    const int t = wsum[w];
+    base += w < wave ? t : 0;
+    total += t;
+  }
+#pragma unroll
+  for (int u = 0; u < kRgMaxPairs; ++u) {
+    const int pair = tid * pp + u;
+    if (u < pp && pair < Nh) {
+      const int d = 2 * pair;
+      loff[d] = base; of[d] = base;
+      base += deg[2 * u];
+      if (d + 1 < N) { loff[d + 1] = base; of[d + 1] = base; }
+      base += deg[2 * u + 1];
+    }
+  }
+  if (tid == 0) of[N] = total;
+  __syncthreads();
+
+  // ---- placement, this wave's edges in ascending order
+  unsigned* mytag = tags + wave * n_tags;
+  int d_next = e0 + lane < e1 ? ix[e0 + lane] : -1;
+  for (int g = e0; g < e1; g += 64) {
+    const int e = g + lane;
+    const int d = d_next;
+    d_next = e + 64 < e1 ? ix[e + 64] : -1;          // the next group's load flies under this group's rounds
+    bool pending = (unsigned)d < (unsigned)N;
+    const int h = d & (n_tags - 1);
+    while (__ballot(pending) != 0ull) {
+      if (pending) __hip_atomic_fetch_min(&mytag[h], (unsigned)lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      const bool win = pending && __hip_atomic_load(&mytag[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) == (unsigned)lane;
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      if (win) {
+        const int sh = (d & 1) * 16;
+        const unsigned old = atomicAdd(&mycur[d >> 1], 1u << sh);
+        rv[loff[d] + (int)((old >> sh) & 0xffffu)] = e;
+        __hip_atomic_store(&mytag[h], 0xffffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        pending = false;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+}
+
+}  // namespace
+}  // namespace fpsg
+
+extern "C" int fpsg_edgeconv_reverse_graph_fits(int N, int k) {
+  return N > 0 && k > 0 && (long)N * k <= 65535 && (N + 1) / 2 <= fpsg::kRgThreads * fpsg::kRgMaxPairs &&
+         fpsg::rg_lds_bytes(N, fpsg::kRgMinTags) <= 160 * 1024;
+}
+
+extern "C" int fpsg_edgeconv_reverse_graph(const int32_t* idx, int B, int N, int k, int32_t* rev, int32_t* off,
+                                           fpsg_stream_t stream) {
+  using namespace fpsg;
+  FPSG_REQUIRE(B > 0 && N > 0 && k > 0, FPSG_E_SHAPE, "fpsg_edgeconv_reverse_graph: B,N,k must be positive (got %d,%d,%d)", B, N, k);
+  FPSG_REQUIRE(fpsg_edgeconv_reverse_graph_fits(N, k), FPSG_E_LIMIT,
+               "fpsg_edgeconv_reverse_graph: N*k = %ld edges per cloud (limit 65535: 16-bit ranks) or N = %d too large for the LDS",
+               (long)N * k, N);
+  FPSG_REQUIRE_PTR(idx); FPSG_REQUIRE_PTR(rev); FPSG_REQUIRE_PTR(off);
+  const int n_tags = rg_tags(N);
+  const size_t lds = rg_lds_bytes(N, n_tags);
+  if (lds > 65536) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(reverse_graph_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) { set_error("fpsg_edgeconv_reverse_graph: %s", hipGetErrorString(e)); return (int)e; }
+  }
+  const int E = N * k;
+  const int per_wave = ((E + kRgWaves - 1) / kRgWaves + 63) & ~63;
+  hipLaunchKernelGGL(reverse_graph_kernel, dim3((unsigned)B), dim3(kRgThreads), lds, static_cast<hipStream_t>(stream),
+                     idx, N, k, per_wave, n_tags, rev, off);
+  return launch_status("fpsg_edgeconv_reverse_graph");
+}

@@ -100,10 +100,8 @@ def _edge_block(c_in: int, c_out: int) -> nn.Sequential:
                          nn.LeakyReLU(negative_slope=0.2))
 
 
-def _reverse_graph(idx32: torch.Tensor):
-    """Edges ``e = n*k + j`` grouped by destination ``idx[n,j]`` (stable sort => ascending ``e``
-    inside a group, so the backward's summation order is fixed): ``rev [B,N*k]`` int32 and
-    ``off [B,N+1]`` int32."""
+def _reverse_graph_sorted(idx32: torch.Tensor):
+    """The in-edge lists by a stable torch sort (any size)."""
     B, N, k = idx32.shape
     keys = idx32.reshape(B, N * k)
     if N < 32768:
@@ -112,6 +110,24 @@ def _reverse_graph(idx32: torch.Tensor):
     bounds = torch.arange(N + 1, device=idx32.device, dtype=torch.int32).to(vals.dtype).expand(B, N + 1).contiguous()
     off = torch.searchsorted(vals.contiguous(), bounds)
     return order.to(torch.int32).contiguous(), off.to(torch.int32).contiguous()
+
+
+def _reverse_graph(idx32: torch.Tensor):
+    """Edges ``e = n*k + j`` grouped by destination ``idx[n,j]``, ascending ``e`` inside a group (so the backward's
+    summation order is fixed): ``rev [B,N*k]`` int32 and ``off [B,N+1]`` int32.  One launch of
+    ``fpsg_edgeconv_reverse_graph`` (a stable counting sort, one workgroup per cloud) when a cloud's edges fit its
+    16-bit ranks (N*k <= 65535: 2048 x 20 does), the stable torch sort otherwise; identical results."""
+    B, N, k = idx32.shape
+    lib = _hip.load()
+    if not lib.fpsg_edgeconv_reverse_graph_fits(N, k):
+        return _reverse_graph_sorted(idx32)
+    idx32 = _hip.dev_tensor(idx32, torch.int32, "idx")
+    rev = torch.empty((B, N * k), dtype=torch.int32, device=idx32.device)
+    off = torch.empty((B, N + 1), dtype=torch.int32, device=idx32.device)
+    with torch.cuda.device(idx32.device):
+        _hip.check(lib.fpsg_edgeconv_reverse_graph(_hip.ptr(idx32), B, N, k, _hip.ptr(rev), _hip.ptr(off),
+                                                   _hip.stream_of(idx32)), "fpsg_edgeconv_reverse_graph")
+    return rev, off
 
 
 class _PointwiseOnCat(torch.autograd.Function):

@@ -163,6 +163,17 @@ int fpsg_edgeconv_fwd(const float* PQ, const int32_t* idx, const float* sgn, int
 int fpsg_edgeconv_bwd(const float* dzs, const uint8_t* jsel, const float* PQ, const float* s1,
                       const int32_t* rev, const int32_t* off, const float* coef, int B, int N, int k,
                       int Co, float* dPQ, fpsg_stream_t stream);
+
+/* The in-edge lists fpsg_edgeconv_bwd gathers through, from the neighbour lists idx [B][N][k] (values in [0,N)):
+ * rev [B][N*k] = the edges e = n*k + j grouped by destination idx[n][j], ascending e inside a group (the backward's
+ * summation order); off [B][N+1] = first slot of every destination's group, off[N] = N*k.  Replaces what autograd's
+ * index backward of get_graph_feature's gather (src/dgcnn/model.py:30-56) does with atomics.  One workgroup per cloud,
+ * a stable counting sort in LDS; deterministic.  Limits: N*k <= 65535 and N small enough for the LDS --
+ * fpsg_edgeconv_reverse_graph_fits(N,k) answers 1 when both hold (the Python mirror sorts with torch otherwise).
+ * Entries of idx outside [0,N) are skipped (their slots of rev stay unwritten). */
+int fpsg_edgeconv_reverse_graph_fits(int N, int k);
+int fpsg_edgeconv_reverse_graph(const int32_t* idx, int B, int N, int k, int32_t* rev, int32_t* off,
+                                fpsg_stream_t stream);
 /* The elementwise halves around them, on point-major [rows = B*N, Co] tensors: fpsg_edgeconv_act = the BatchNorm
  * affine form + LeakyReLU of the selected neighbour sum, out = lrelu(fma(ysel, scale[c], shift[c])) (one pass instead
  * of addcmul + leaky_relu); fpsg_edgeconv_bwd_prep = the head of the backward: z re-derived with the same arithmetic,

@@ -179,3 +179,73 @@ def test_max_mean_over_points_matches_autograd(gpu):
     (ref * w).sum().backward()
     assert torch.equal(out, ref)
     assert float((a.grad - b.grad).abs().max()) <= 1e-6 * float(b.grad.abs().max())
+
+
+def _in_edges_by_hand(idx):
+    """rev / off of one cloud by the definition: for every destination, its edges e = n*k + j in ascending e."""
+    N, k = idx.shape
+    flat = idx.reshape(-1)
+    valid = (flat >= 0) & (flat < N)
+    order = np.argsort(np.where(valid, flat, N), kind="stable")
+    counts = np.bincount(flat[valid], minlength=N)
+    off = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
+    return order[: off[-1]].astype(np.int32), off
+
+
+@pytest.mark.parametrize("B,N,k,kind", [(3, 2048, 20, "random"), (2, 2048, 20, "hubs"), (2, 512, 20, "same"),
+                                        (2, 1, 1, "random"), (3, 77, 9, "random"), (2, 1025, 1, "random"),
+                                        (1, 3276, 20, "random"), (2, 300, 64, "hubs"), (2, 2047, 32, "random")])
+def test_reverse_graph_is_the_stable_grouping(gpu, B, N, k, kind):
+    """fpsg_edgeconv_reverse_graph against the definition (numpy stable argsort) and against the torch-sort form of the
+    mirror: random lists, hub destinations (in-degree in the hundreds), every source choosing the same k points
+    (in-degree N), odd N, single points, the 65535-edge limit -- bit for bit, twice (no dependence on timing)."""
+    from fpsg_amd import _hip
+    from fpsg_amd.dgcnn import _reverse_graph, _reverse_graph_sorted
+    rng = np.random.default_rng(N * 31 + k)
+    if kind == "random":
+        idx = rng.integers(0, N, size=(B, N, k))
+    elif kind == "hubs":
+        idx = np.minimum(rng.geometric(0.02, size=(B, N, k)) - 1, N - 1)         # low indices are chosen by hundreds
+    else:
+        idx = np.broadcast_to(np.arange(k)[None, None, :] % N, (B, N, k)).copy()
+    idx = idx.astype(np.int32)
+    assert _hip.load().fpsg_edgeconv_reverse_graph_fits(N, k) == 1
+    t = torch.from_numpy(idx).to(gpu)
+    rev, off = _reverse_graph(t)
+    rev2, off2 = _reverse_graph(t)
+    srev, soff = _reverse_graph_sorted(t)
+    assert torch.equal(rev, rev2) and torch.equal(off, off2)
+    assert torch.equal(rev, srev) and torch.equal(off, soff)
+    for b in range(B):
+        erev, eoff = _in_edges_by_hand(idx[b])
+        assert np.array_equal(off[b].cpu().numpy(), eoff)
+        assert np.array_equal(rev[b].cpu().numpy(), erev)
+
+
+def test_reverse_graph_limits_and_bad_entries(gpu):
+    from fpsg_amd import _hip
+    from fpsg_amd.dgcnn import _reverse_graph, _reverse_graph_sorted
+    lib = _hip.load()
+    assert lib.fpsg_edgeconv_reverse_graph_fits(2048, 20) == 1
+    assert lib.fpsg_edgeconv_reverse_graph_fits(4096, 20) == 0          # 81,920 edges: beyond the 16-bit ranks
+    assert lib.fpsg_edgeconv_reverse_graph_fits(0, 20) == 0
+    idx = torch.randint(0, 4096, (1, 4096, 20), dtype=torch.int32, device=gpu)
+    rev = torch.empty(1, 4096 * 20, dtype=torch.int32, device=gpu)
+    off = torch.empty(1, 4097, dtype=torch.int32, device=gpu)
+    rc = lib.fpsg_edgeconv_reverse_graph(idx.data_ptr(), 1, 4096, 20, rev.data_ptr(), off.data_ptr(), None)
+    assert rc == -4 and b"65535" in lib.fpsg_last_error()
+    a, b = _reverse_graph(idx)                                          # the mirror sorts instead
+    c, d = _reverse_graph_sorted(idx)
+    assert torch.equal(a, c) and torch.equal(b, d)
+    # entries outside [0, N) are skipped: the valid edges are grouped as before, off[N] counts them
+    bad = torch.randint(0, 100, (2, 100, 8), dtype=torch.int32, device=gpu)
+    bad[0, 3, 2] = -1
+    bad[1, 50, 0] = 100
+    rev = torch.full((2, 800), -7, dtype=torch.int32, device=gpu)
+    off = torch.empty(2, 101, dtype=torch.int32, device=gpu)
+    assert lib.fpsg_edgeconv_reverse_graph(bad.data_ptr(), 2, 100, 8, rev.data_ptr(), off.data_ptr(), None) == 0
+    for bi in range(2):
+        erev, eoff = _in_edges_by_hand(bad[bi].cpu().numpy())
+        assert eoff[-1] == 799
+        assert np.array_equal(off[bi].cpu().numpy(), eoff)
+        assert np.array_equal(rev[bi, :799].cpu().numpy(), erev) and int(rev[bi, 799]) == -7
