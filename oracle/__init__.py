@@ -172,6 +172,25 @@ def edge_feature_bwd(gout, idx):
     return gx
 
 
+def in_edge_lists(idx):
+    """The order in which oracle_edge_feature_bwd's scatter loop (fpsg_oracle.c, ascending (n, j)) reaches every
+    destination, as lists: idx [N,k] of one cloud -> (rev, off) with rev[off[d]:off[d+1]] = the edges e = n*k + j
+    whose idx[n,j] == d, ascending e.  Entries outside [0,N) belong to no list.  (The reference reaches the same
+    sums through autograd's index backward of src/dgcnn/model.py:30-56, whose atomics fix no order.)"""
+    idx = np.asarray(idx)
+    N, k = idx.shape
+    lists = [[] for _ in range(N)]
+    for n in range(N):
+        for j in range(k):
+            d = int(idx[n, j])
+            if 0 <= d < N:
+                lists[d].append(n * k + j)
+    off = np.zeros(N + 1, np.int32)
+    off[1:] = np.cumsum([len(l) for l in lists])
+    rev = np.array([e for l in lists for e in l], np.int32)
+    return rev, off
+
+
 # --------------------------------------------------------------------------------- EMD
 def emd_approx(xyz1, xyz2, want_grad=False):
     """Approximate-assignment EMD (PARITY UNPINNED, see fpsg_oracle.c): cost [B] and, if

@@ -181,22 +181,11 @@ def test_max_mean_over_points_matches_autograd(gpu):
     assert float((a.grad - b.grad).abs().max()) <= 1e-6 * float(b.grad.abs().max())
 
 
-def _in_edges_by_hand(idx):
-    """rev / off of one cloud by the definition: for every destination, its edges e = n*k + j in ascending e."""
-    N, k = idx.shape
-    flat = idx.reshape(-1)
-    valid = (flat >= 0) & (flat < N)
-    order = np.argsort(np.where(valid, flat, N), kind="stable")
-    counts = np.bincount(flat[valid], minlength=N)
-    off = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
-    return order[: off[-1]].astype(np.int32), off
-
-
 @pytest.mark.parametrize("B,N,k,kind", [(3, 2048, 20, "random"), (2, 2048, 20, "hubs"), (2, 512, 20, "same"),
                                         (2, 1, 1, "random"), (3, 77, 9, "random"), (2, 1025, 1, "random"),
                                         (1, 3276, 20, "random"), (2, 300, 64, "hubs"), (2, 2047, 32, "random")])
-def test_reverse_graph_is_the_stable_grouping(gpu, B, N, k, kind):
-    """fpsg_edgeconv_reverse_graph against the definition (numpy stable argsort) and against the torch-sort form of the
+def test_reverse_graph_is_the_stable_grouping(gpu, oracle, B, N, k, kind):
+    """fpsg_edgeconv_reverse_graph against the oracle (the order of its sequential scatter loop) and against the torch-sort form of the
     mirror: random lists, hub destinations (in-degree in the hundreds), every source choosing the same k points
     (in-degree N), odd N, single points, the 65535-edge limit -- bit for bit, twice (no dependence on timing)."""
     from fpsg_amd import _hip
@@ -217,12 +206,12 @@ def test_reverse_graph_is_the_stable_grouping(gpu, B, N, k, kind):
     assert torch.equal(rev, rev2) and torch.equal(off, off2)
     assert torch.equal(rev, srev) and torch.equal(off, soff)
     for b in range(B):
-        erev, eoff = _in_edges_by_hand(idx[b])
+        erev, eoff = oracle.in_edge_lists(idx[b])
         assert np.array_equal(off[b].cpu().numpy(), eoff)
         assert np.array_equal(rev[b].cpu().numpy(), erev)
 
 
-def test_reverse_graph_limits_and_bad_entries(gpu):
+def test_reverse_graph_limits_and_bad_entries(gpu, oracle):
     from fpsg_amd import _hip
     from fpsg_amd.dgcnn import _reverse_graph, _reverse_graph_sorted
     lib = _hip.load()
@@ -245,7 +234,7 @@ def test_reverse_graph_limits_and_bad_entries(gpu):
     off = torch.empty(2, 101, dtype=torch.int32, device=gpu)
     assert lib.fpsg_edgeconv_reverse_graph(bad.data_ptr(), 2, 100, 8, rev.data_ptr(), off.data_ptr(), None) == 0
     for bi in range(2):
-        erev, eoff = _in_edges_by_hand(bad[bi].cpu().numpy())
+        erev, eoff = oracle.in_edge_lists(bad[bi].cpu().numpy())
         assert eoff[-1] == 799
         assert np.array_equal(off[bi].cpu().numpy(), eoff)
         assert np.array_equal(rev[bi, :799].cpu().numpy(), erev) and int(rev[bi, 799]) == -7

@@ -98,3 +98,25 @@ def test_sinkhorn_restatement_vs_independent_float64(oracle):
     # the divergence of a cloud with itself is zero, and it is symmetric
     assert abs(sinkhorn_divergence_f64(x, x)).max() < 1e-12
     np.testing.assert_allclose(sinkhorn_divergence_f64(x, y), sinkhorn_divergence_f64(y, x), rtol=1e-10)
+
+
+def test_in_edge_lists_are_the_stable_grouping_of_the_edges():
+    """oracle.in_edge_lists (the visiting order of the oracle's sequential scatter) = a stable sort of the edge
+    numbers by destination; entries outside [0, N) belong to no list."""
+    import oracle
+    rng = np.random.default_rng(3)
+    idx = rng.integers(0, 50, size=(50, 7)).astype(np.int32)
+    idx[4, 2] = -1
+    idx[9, 0] = 50
+    rev, off = oracle.in_edge_lists(idx)
+    flat = idx.reshape(-1)
+    valid = (flat >= 0) & (flat < 50)
+    order = np.argsort(np.where(valid, flat, 50), kind="stable")[: int(valid.sum())]
+    assert np.array_equal(rev, order.astype(np.int32))
+    assert off[0] == 0 and off[-1] == valid.sum()
+    assert np.array_equal(np.diff(off), np.bincount(flat[valid], minlength=50))
+    # and it is the order in which oracle_edge_feature_bwd adds: one channel, gradient 1 on the "difference" half of
+    # edge e only -> the destination's sum is 1 exactly for the edges in its list
+    gx_lists = [list(rev[off[d]:off[d + 1]]) for d in range(50)]
+    assert sorted(e for l in gx_lists for e in l) == sorted(np.nonzero(valid)[0].tolist())
+    assert all(l == sorted(l) for l in gx_lists)
