@@ -286,7 +286,8 @@ __global__ __launch_bounds__(kBnThreads) void bn_small_kernel(
     float slope, float* __restrict__ out, float* __restrict__ chan, float* __restrict__ batch_mean,
     float* __restrict__ batch_var_unbiased, float* __restrict__ dgamma, float* __restrict__ dbeta,
     float* __restrict__ dpb, float* __restrict__ run_mean, float* __restrict__ run_var, float momentum,
-    int staged /* the first sweep's values are kept in LDS (dynamic: N*L floats forward, 2*N*L backward) */) {
+    int staged /* the first sweep's values are kept in LDS (dynamic: N*L floats forward, 2*N*L backward) */,
+    int tpr_log2 /* threads per row: the smallest power of two >= the row's vectors (elements), at most the workgroup */) {
   // The second sweep re-reads what the first one read.  With tens of thousands of 16-64 KB channels
   // in flight (the decoder's grouped BatchNorm: 24,624 channels) the 4 MB L2 of an XCD does not hold
   // them -- PMC: 3.7 reads per write in the backward instead of 2 -- so each thread parks its own
@@ -305,14 +306,18 @@ __global__ __launch_bounds__(kBnThreads) void bn_small_kernel(
   if (MODE == 1 || !training) { sc = chan[c]; sh = chan[C + c]; mu = chan[2 * C + c]; rs = chan[3 * C + c]; }
   const bool two_sweeps = MODE == 1 || training;
   const bool keep = staged && vec && two_sweeps;
+  // Rows shorter than the workgroup are taken several at a time (a 14 x 14 map is 49 vectors, an FC layer's row one
+  // element: with one row per pass most threads idle through N dependent load round trips).
+  const int tpr = 1 << tpr_log2, rpi = kBnThreads >> tpr_log2;
+  const int e0 = threadIdx.x & (tpr - 1), n0 = threadIdx.x >> tpr_log2;
   if (two_sweeps) {
     float a0 = 0.0f, a1 = 0.0f;
-    for (int n = 0; n < N; ++n) {
+    for (int n = n0; n < N; n += rpi) {
       const size_t base = ((size_t)n * C + c) * L;
       if (vec) {
         const v4f* __restrict__ xp = reinterpret_cast<const v4f*>(x + base);
         const v4f* __restrict__ gp = reinterpret_cast<const v4f*>(MODE == 1 ? dy + base : x + base);
-        for (int e = threadIdx.x; e < L4; e += kBnThreads) {
+        for (int e = e0; e < L4; e += tpr) {
           v4f xv = xp[e];
 #pragma unroll
           for (int u = 0; u < 4; ++u) xv[u] += b;
@@ -333,7 +338,7 @@ __global__ __launch_bounds__(kBnThreads) void bn_small_kernel(
           if (keep) sx[(size_t)n * L4 + e] = xv;
         }
       } else {
-        for (int e = threadIdx.x; e < L; e += kBnThreads) {
+        for (int e = e0; e < L; e += tpr) {
           const float xv = x[base + e] + b;
           if (MODE == 0) {
             a0 += xv; a1 = fma_rn(xv, xv, a1);
@@ -376,13 +381,13 @@ __global__ __launch_bounds__(kBnThreads) void bn_small_kernel(
   }
   const float k1 = bc[0], k2 = bc[1], k3 = bc[2];
   float acc = 0.0f, unused = 0.0f;
-  for (int n = 0; n < N; ++n) {
+  for (int n = n0; n < N; n += rpi) {
     const size_t base = ((size_t)n * C + c) * L;
     if (vec) {
       const v4f* __restrict__ xp = reinterpret_cast<const v4f*>(x + base);
       const v4f* __restrict__ gp = reinterpret_cast<const v4f*>(MODE == 1 ? dy + base : x + base);
       v4f* __restrict__ op = reinterpret_cast<v4f*>(out + base);
-      for (int e = threadIdx.x; e < L4; e += kBnThreads) {
+      for (int e = e0; e < L4; e += tpr) {
         v4f xv;
         if (keep) {
           xv = sx[(size_t)n * L4 + e];
@@ -411,7 +416,7 @@ __global__ __launch_bounds__(kBnThreads) void bn_small_kernel(
         op[e] = r;
       }
     } else {
-      for (int e = threadIdx.x; e < L; e += kBnThreads) {
+      for (int e = e0; e < L; e += tpr) {
         const float xv = x[base + e] + b;
         if (MODE == 0) {
           out[base + e] = act_fwd<ACT>(fma_rn(xv, sc, sh), slope);
@@ -441,9 +446,12 @@ void launch_small(int act, const float* x, const float* dy, const float* gamma, 
   const size_t need = (size_t)N * L * sizeof(float) * (MODE == 1 ? 2 : 1);
   const int staged = ((L & 3) == 0 && need <= 64 * 1024 && (MODE == 1 || training)) ? 1 : 0;
   const size_t lds = staged ? need : 0;
+  const int row_items = (L & 3) == 0 ? L / 4 : L;
+  int tpr_log2 = 0;
+  while ((1 << tpr_log2) < row_items && (1 << tpr_log2) < kBnThreads) ++tpr_log2;
 #define FPSG_SMALL(A) hipLaunchKernelGGL((bn_small_kernel<MODE, A>), grid, dim3(kBnThreads), lds, s, x, dy, gamma, beta, \
                                          pb, N, C, L, training, eps, slope, out, chan, bm, bv, dgamma, dbeta, dpb, rmean, \
-                                         rvar, momentum, staged)
+                                         rvar, momentum, staged, tpr_log2)
   if (act == kActRelu) FPSG_SMALL(kActRelu);
   else if (act == kActLeaky) FPSG_SMALL(kActLeaky);
   else FPSG_SMALL(kActNone);
