@@ -30,6 +30,8 @@ import torch
 import torch.distributed as dist
 import torch.nn as nn
 
+from .optim import layout_order
+
 
 def env_world() -> tuple[int, int, int]:
     return (int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")),
@@ -87,7 +89,8 @@ class FlatGradBuckets:
         self._bucket_size: list[int] = []
         off, start, count = 0, 0, 0
         self.views: dict[int, torch.Tensor] = {}
-        for p in reversed(params):               # the layout of fpsg_amd.optim.flat_layout
+        order = layout_order(params)             # the layout of fpsg_amd.optim.flat_layout
+        for p in order:
             n = p.numel()
             # same memory format as the parameter (e.g. channels_last conv weights): the fused
             # optimizer requires param and grad layouts to match
@@ -113,7 +116,7 @@ class FlatGradBuckets:
         self._streams: dict = {}     # every stream a gradient was produced on in this backward
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in params]
         # segment table of the flat layout (K7's format): absorb() adds an episode's gradient tensors in one launch
-        self._layout_params = list(reversed(params))
+        self._layout_params = order
         self._seg_off = self._gtab = None
         if dev.type == "cuda" and dt == torch.float32:
             offs, o = [], 0

@@ -25,11 +25,39 @@ from torch.optim import Optimizer
 from . import _hip
 
 
+def layout_order(params):
+    """The parameters in the order of the flat buffers: reverse registration order (the order in which gradients
+    become ready in backward), except that a *stack group* -- parameters tagged ``_fpsg_stack = (group, index, n)``
+    by a module that evaluates them as one stacked tensor (``PCDecoder``: the same layer of its 16 patch MLPs) -- is
+    placed whole, in index order, where its first member falls.  Densely packed, the members of a group are then the
+    rows of a contiguous ``[n, ...]`` tensor inside the flat buffer: stacking them is a view.  A group that is
+    incomplete among ``params`` (or whose members differ in shape) is not kept together."""
+    params = list(params)
+    groups = {}
+    for p in params:
+        tag = getattr(p, "_fpsg_stack", None)
+        if tag is not None:
+            groups.setdefault(tag[0], []).append((tag[1], p))
+    out, placed = [], set()
+    for p in reversed(params):
+        if id(p) in placed:
+            continue
+        members = [p]
+        tag = getattr(p, "_fpsg_stack", None)
+        if tag is not None:
+            g = sorted(groups[tag[0]], key=lambda t: t[0])
+            if len(g) == tag[2] and [i for i, _ in g] == list(range(tag[2])) and all(m.shape == p.shape for _, m in g):
+                members = [m for _, m in g]
+        for m in members:
+            out.append(m)
+            placed.add(id(m))
+    return out
+
+
 def flat_layout(params):
-    """``[(param, offset, numel)]`` of the flat buffers: reverse registration order (the order in
-    which gradients become ready in backward), densely packed."""
+    """``[(param, offset, numel)]`` of the flat buffers: ``layout_order``, densely packed."""
     out, off = [], 0
-    for p in reversed(list(params)):
+    for p in layout_order(params):
         out.append((p, off, p.numel()))
         off += p.numel()
     return out, off

@@ -319,8 +319,46 @@ class _StackFrozen(torch.autograd.Function):
         return (None,) + tuple(g.unbind(0))
 
 
+class _StackView(torch.autograd.Function):
+    """``torch.stack(tensors)`` of tensors that ARE the consecutive rows of one contiguous block (a stack group of
+    ``fpsg_amd.optim.layout_order`` inside the optimizer's flat parameter buffer): a view of that block, no copy; the
+    gradient is unbound to the parameters as ``torch.stack``'s is."""
+
+    @staticmethod
+    def forward(ctx, *tensors):
+        t0 = tensors[0].detach()
+        return t0.as_strided((len(tensors),) + tuple(t0.shape), (t0.numel(),) + tuple(t0.stride()), t0.storage_offset())
+
+    @staticmethod
+    def backward(ctx, g):
+        return tuple(g.unbind(0))
+
+
+_rows_of_one_block = {}      # (first pointer, last pointer, count, numel) -> bool, so the check runs once per layout
+
+
+def _are_rows_of_one_block(tensors) -> bool:
+    t0, n = tensors[0], tensors[0].numel()
+    key = (t0.data_ptr(), tensors[-1].data_ptr(), len(tensors), n)
+    hit = _rows_of_one_block.get(key)
+    if hit is None:
+        base, o0 = t0.untyped_storage().data_ptr(), t0.storage_offset()
+        hit = len(tensors) > 1 and all(
+            t.shape == t0.shape and t.dtype == t0.dtype and t.is_contiguous()
+            and t.untyped_storage().data_ptr() == base and t.storage_offset() == o0 + i * n
+            for i, t in enumerate(tensors))
+        if len(_rows_of_one_block) > 4096:
+            _rows_of_one_block.clear()
+        _rows_of_one_block[key] = hit
+    return hit
+
+
 def _stack(key, tensors):
     tensors = list(tensors)
+    if tensors[0].is_cuda and _are_rows_of_one_block(tensors):
+        if torch.is_grad_enabled() and any(t.requires_grad for t in tensors):
+            return _StackView.apply(*tensors)
+        return _StackView.forward(None, *tensors)
     if tensors[0].is_cuda and torch.is_grad_enabled() and any(t.requires_grad for t in tensors):
         return _StackFrozen.apply(key, *tensors)
     return torch.stack(tensors)
@@ -397,6 +435,22 @@ class PCDecoder(nn.Module):
             PrimitiveCluster(conf, MLPDeformer(conf), self.num_pts_per_cluster, self.num_nodes)
             for _ in range(self.num_clusters)
         ])
+        self._tag_stack_groups()
+
+    def _tag_stack_groups(self):
+        """Marks the parameters ``pack_parameters`` stacks -- the same tensor of every deformer, of every node -- as
+        stack groups (``fpsg_amd.optim.layout_order``): the flat optimizer then stores each group as one contiguous
+        ``[n, ...]`` block, and stacking it is a view.  The modules, their parameters and the state-dict keys stay
+        the reference's (``cluster_pool.<i>.deformer.*``, ``cluster_pool.<i>.node_pool.<j>.*``)."""
+        clusters = list(self.cluster_pool)
+        families = {"deformer": [c.deformer for c in clusters],
+                    "node": [n for c in clusters for n in c.node_pool]}
+        for fam, mods in families.items():
+            names = [name for name, _ in mods[0].named_parameters()]
+            for name in names:
+                members = [dict(m.named_parameters())[name] for m in mods]
+                for i, p in enumerate(members):
+                    p._fpsg_stack = ((id(self), fam, name), i, len(members))
 
     def sample_grids(self, batch: int, device, generator=None):
         """Nested list ``[cluster][node] -> [B, ori_dim, P]`` drawn in the reference's order."""

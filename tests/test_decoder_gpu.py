@@ -167,3 +167,57 @@ def test_stacked_weights_are_copied_once_per_step(gpu, monkeypatch):
         for a, b in zip(g0, g1):
             assert torch.equal(a, b)
     assert winograd.frozen_cache() is None
+
+
+def test_stacked_weights_are_views_of_the_flat_parameters(gpu, monkeypatch):
+    """With the flat optimizer the same layer of the 16 patch MLPs is ONE contiguous block of the parameter buffer
+    (stack groups of fpsg_amd.optim.layout_order): pack_parameters() stacks nothing -- its tensors are views into
+    FlatAdam.flat_param -- and two optimizer steps give the outputs, parameters and running statistics of a copy of
+    the decoder whose parameters are laid out plainly and stacked by copies.  Reference-format state dicts load in
+    place."""
+    from fpsg_amd.optim import FlatAdam
+    dec, hidden, grids = _make(3, 21)
+    a = dec.to(gpu).train()
+    b = copy.deepcopy(a)                                  # torch drops the stack-group tags from copied parameters
+    assert not any(hasattr(p, "_fpsg_stack") for p in b.parameters())
+    oa, ob = FlatAdam(a.parameters(), lr=1e-3), FlatAdam(b.parameters(), lr=1e-3)
+    gg = [[g.to(gpu) for g in c] for c in grids]
+    stacks = {"n": 0}
+    orig = torch.stack
+
+    def counted(ts, *args, **kw):
+        stacks["n"] += 1
+        return orig(ts, *args, **kw)
+
+    monkeypatch.setattr(torch, "stack", counted)
+    lo, hi = oa.flat_param.data_ptr(), oa.flat_param.data_ptr() + oa.flat_param.numel() * 4
+    pack = a.pack_parameters()
+    assert stacks["n"] == 0
+    for key in ("n1", "n2", "n3", "n4"):
+        w, bias = pack[key]
+        assert lo <= w.data_ptr() < hi and w.is_contiguous() and w.size(0) == 16
+        assert w.data_ptr() == a.cluster_pool[0].node_pool[0].__getattr__("conv" + key[1]).weight.data_ptr()
+    b.pack_parameters()
+    assert stacks["n"] >= 24                               # the plain layout stacks by copies
+
+    for it in range(2):
+        outs = []
+        for net, opt in ((a, oa), (b, ob)):
+            opt.zero_grad(set_to_none=True)
+            h = (hidden.to(gpu) * (1 + it)).requires_grad_()
+            out = net(h, grid=gg, pack=net.pack_parameters())
+            (out * out).sum().backward()
+            opt.step()
+            outs.append((out.detach(), h.grad))
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]), it
+    for (na, pa), (nb, pb) in zip(a.named_parameters(), b.named_parameters()):
+        assert na == nb and torch.equal(pa, pb), na
+    for (na, ba), (nb, bb) in zip(a.named_buffers(), b.named_buffers()):
+        assert torch.equal(ba, bb), na
+    # a reference-format checkpoint loads in place: the parameters stay rows of the flat block
+    sd = {k: torch.randn_like(v) if v.is_floating_point() else v for k, v in b.state_dict().items()}
+    ptr = a.cluster_pool[1].node_pool[2].conv1.weight.data_ptr()
+    a.load_state_dict(sd)
+    assert a.cluster_pool[1].node_pool[2].conv1.weight.data_ptr() == ptr
+    w, _ = a.pack_parameters()["n1"]
+    assert torch.equal(w[6], sd["cluster_pool.1.node_pool.2.conv1.weight"].squeeze(-1).to(gpu))

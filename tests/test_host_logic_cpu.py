@@ -138,3 +138,37 @@ def test_deferred_running_statistics_keep_order_and_values():
     a, _, _ = run(True)
     assert torch.equal(a, (a0 * 0.9 + adds[0]) * 0.9 + adds[3])
     assert bn_counters._stats is None
+
+
+def test_flat_layout_keeps_the_decoder_stack_groups_together():
+    """fpsg_amd.optim.layout_order: reverse registration order, but the same tensor of the 16 patch MLPs (a stack
+    group tagged by PCDecoder) sits in one run, in patch order -- so that densely packed it is a contiguous
+    [16, ...] block; every parameter appears once; an incomplete group falls back to the plain order."""
+    import copy
+    from fpsg_amd.engine import default_options
+    from fpsg_amd.optim import flat_layout, layout_order
+    from fpsg_amd.point_cloud_net import PCDecoder
+    dec = PCDecoder(conf=default_options(device="cpu"))
+    ps = list(dec.parameters())
+    order = layout_order(ps)
+    assert len(order) == len(ps) and {id(p) for p in order} == {id(p) for p in ps}
+    layout, total = flat_layout(ps)
+    assert total == sum(p.numel() for p in ps) and [id(p) for p, _, _ in layout] == [id(p) for p in order]
+    off_of = {id(p): off for p, off, _ in layout}
+    nodes = [n for c in dec.cluster_pool for n in c.node_pool]
+    defs = [c.deformer for c in dec.cluster_pool]
+    for mods in (nodes, defs):
+        for name, p0 in mods[0].named_parameters():
+            offs = [off_of[id(dict(m.named_parameters())[name])] for m in mods]
+            assert offs == [offs[0] + i * p0.numel() for i in range(len(mods))], name
+    # state-dict keys are the reference's
+    assert "cluster_pool.0.node_pool.1.conv1.weight" in dec.state_dict()
+    # a group with a member missing (a frozen parameter) is laid out in the plain order
+    some = [p for p in ps if p is not nodes[3].conv2.weight]
+    plain = layout_order(some)
+    idx = [i for i, p in enumerate(plain)
+           if hasattr(p, "_fpsg_stack") and p._fpsg_stack[0][1:] == ("node", "conv2.weight")]
+    assert len(idx) == len(nodes) - 1 and idx != list(range(idx[0], idx[0] + len(idx)))
+    # copies lose the tags (torch's Parameter.__deepcopy__): they are simply laid out in the plain order
+    clone = copy.deepcopy(dec)
+    assert [id(p) for p in layout_order(list(clone.parameters()))] == [id(p) for p in reversed(list(clone.parameters()))]
