@@ -92,6 +92,7 @@ SIGNATURES = {
                                          _c_stream],
     "fpsg_wino_grad_output_transform": [_c_int, _c_f32p, _c_int, _c_int, _c_int, _c_int, _c_f32p, _c_stream],
     "fpsg_wino_filter_transform": [_c_int, _c_f32p, _c_int, _c_int, _c_int, _c_f32p, _c_stream],
+    "fpsg_wino_filter_transform_batch": [ctypes.c_void_p, _c_int, ctypes.c_long, _c_stream],
     "fpsg_wino_filter_grad_transform": [_c_int, _c_f32p, _c_int, _c_int, _c_f32p, _c_stream],
     "fpsg_wino_conv_fused": [_c_f32p, _c_f32p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_f32p, _c_stream],
     "fpsg_wino_input_transform_act": [_c_int, _c_f32p, _c_f32p, _c_f32p, _c_int, _c_int, _c_int, _c_int, _c_f32p, _c_stream],

@@ -308,10 +308,9 @@ __global__ __launch_bounds__(kWinoThreads) void wino_grad_output_kernel(const fl
 // U = G g G^T per (k, c); flip != 0: the filter of the data gradient, g'[c][k] = rot180(g[k][c]),
 // written as U [A*A, C, K].
 template <int M>
-__global__ void wino_filter_kernel(const float* __restrict__ w, int K, int C, int flip, float* __restrict__ U) {
+__device__ __forceinline__ void wino_filter_one(const float* __restrict__ w, int K, int C, int flip, float* __restrict__ U,
+                                                long e) {
   constexpr int A = Wino<M>::A;
-  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= (long)K * C) return;
   // threads run along the fastest axis of the OUTPUT (c, or k when transposing) so that the A*A
   // plane writes are coalesced; the transposing form then reads its 36-byte filters K*36 bytes apart
   const int k = flip ? (int)(e % K) : (int)(e / C), c = flip ? (int)(e / K) : (int)(e % C);
@@ -335,6 +334,29 @@ __global__ void wino_filter_kernel(const float* __restrict__ w, int K, int C, in
 #pragma unroll
     for (int j = 0; j < A; ++j) up[(size_t)(A * i + j) * plane] = o[j];
   }
+}
+
+template <int M>
+__global__ void wino_filter_kernel(const float* __restrict__ w, int K, int C, int flip, float* __restrict__ U) {
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (long)K * C) return;
+  wino_filter_one<M>(w, K, C, flip, U, e);
+}
+
+// Every filter transform of a step in one launch.  jobs [n][6] int64: w pointer, U pointer, K, C, 2*m + flip, first
+// workgroup of the job (ascending; job j owns the workgroups [first_j, first_{j+1})).
+constexpr int kFilterJobFields = 6;
+__global__ __launch_bounds__(256) void wino_filter_batch_kernel(const long long* __restrict__ jobs, int n_jobs) {
+  int j = 0;
+  while (j + 1 < n_jobs && (long long)blockIdx.x >= jobs[(j + 1) * kFilterJobFields + 5]) ++j;    // wave-uniform
+  const long long* job = jobs + (size_t)j * kFilterJobFields;
+  const float* w = reinterpret_cast<const float*>(job[0]);
+  float* U = reinterpret_cast<float*>(job[1]);
+  const int K = (int)job[2], C = (int)job[3], mf = (int)job[4];
+  const long e = ((long)blockIdx.x - (long)job[5]) * 256 + threadIdx.x;
+  if (e >= (long)K * C) return;
+  if ((mf >> 1) == 2) wino_filter_one<2>(w, K, C, mf & 1, U, e);
+  else wino_filter_one<4>(w, K, C, mf & 1, U, e);
 }
 
 // dw = G^T dU G per (k, c)
@@ -471,6 +493,16 @@ extern "C" int fpsg_wino_filter_transform(int m, const float* w, int K, int C, i
   if (m == 2) hipLaunchKernelGGL(wino_filter_kernel<2>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), w, K, C, flip_transpose, U);
   else hipLaunchKernelGGL(wino_filter_kernel<4>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), w, K, C, flip_transpose, U);
   return launch_status("fpsg_wino_filter_transform");
+}
+
+extern "C" int fpsg_wino_filter_transform_batch(const int64_t* jobs, int n_jobs, long total_blocks, fpsg_stream_t stream) {
+  using namespace fpsg;
+  FPSG_REQUIRE(n_jobs > 0 && total_blocks > 0 && total_blocks < (1L << 31), FPSG_E_SHAPE,
+               "fpsg_wino_filter_transform_batch: n_jobs and total_blocks must be positive (got %d, %ld)", n_jobs, total_blocks);
+  FPSG_REQUIRE_PTR(jobs);
+  hipLaunchKernelGGL(wino_filter_batch_kernel, dim3((unsigned)total_blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     reinterpret_cast<const long long*>(jobs), n_jobs);
+  return launch_status("fpsg_wino_filter_transform_batch");
 }
 
 extern "C" int fpsg_wino_filter_grad_transform(int m, const float* dU, int K, int C, float* dw, fpsg_stream_t stream) {

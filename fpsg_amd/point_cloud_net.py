@@ -334,15 +334,15 @@ class _StackView(torch.autograd.Function):
         return tuple(g.unbind(0))
 
 
-_rows_of_one_block = {}      # (first pointer, last pointer, count, numel) -> bool, so the check runs once per layout
+_rows_of_one_block = {}      # (every tensor's address, shape) -> bool: the full check runs once per parameter layout
 
 
 def _are_rows_of_one_block(tensors) -> bool:
-    t0, n = tensors[0], tensors[0].numel()
-    key = (t0.data_ptr(), tensors[-1].data_ptr(), len(tensors), n)
+    t0 = tensors[0]
+    key = (tuple(t.data_ptr() for t in tensors), t0.shape)
     hit = _rows_of_one_block.get(key)
     if hit is None:
-        base, o0 = t0.untyped_storage().data_ptr(), t0.storage_offset()
+        n, base, o0 = t0.numel(), t0.untyped_storage().data_ptr(), t0.storage_offset()
         hit = len(tensors) > 1 and all(
             t.shape == t0.shape and t.dtype == t0.dtype and t.is_contiguous()
             and t.untyped_storage().data_ptr() == base and t.storage_offset() == o0 + i * n

@@ -105,20 +105,96 @@ def _call(name, *args):
 _frozen_cache = None     # {(data_ptr, m, flip): U} while a ``weights_frozen`` block is active
 
 
+class _FilterBank:
+    """The transformed filters of the layers a training step uses, in persistent buffers, all refreshed by ONE launch
+    at the start of a ``weights_frozen`` block (``fpsg_wino_filter_transform_batch``) instead of one launch per layer
+    and direction when first needed -- 24 launches of a few microseconds for the VGG trunk, which is what a one-episode
+    step (configs[1], hipGraph) notices.  An entry is registered the first time a filter is asked for inside a block
+    (outside a capture); it holds an alias of the weight, so the memory it reads stays allocated.  Buffers live across
+    steps: a step's backward has finished with them (same stream) before the next block's refresh overwrites them.
+    A hipGraph captured inside a block holds no filter launches and reads the bank's buffers -- every replay runs
+    inside a block that refreshed them -- so an entry a capture has seen is pinned for the life of the process; the
+    others are dropped when a whole block goes by without asking for them (another model's weights, a parameter that
+    was moved into a flat buffer)."""
+
+    MAX_ENTRIES = 96
+
+    def __init__(self):
+        self.entries = {}        # (data_ptr, m, flip) -> [weight alias, U, K, C, used in this block, pinned]
+        self.table = None        # device int64 [n, 6] of the registered jobs
+        self.total_blocks = 0
+        self.valid = False       # refreshed in the current outermost block
+
+    def register(self, key, w, U):
+        if len(self.entries) < self.MAX_ENTRIES:
+            self.entries[key] = [w, U, w.shape[0], w.shape[1], True, False]
+            self.table = None
+
+    def lookup(self, key, w, capturing):
+        ent = self.entries.get(key) if self.valid else None
+        if ent is None or ent[2] != w.shape[0] or ent[3] != w.shape[1] or ent[1].device != w.device:
+            return None
+        ent[4] = True
+        ent[5] = ent[5] or capturing
+        return ent[1]
+
+    def refresh(self):
+        self.valid = False
+        stale = [k for k, e in self.entries.items() if not (e[4] or e[5])]
+        for k in stale:
+            del self.entries[k]
+        if stale:
+            self.table = None
+        if not self.entries:
+            return
+        dev = next(iter(self.entries.values()))[1].device
+        if any(e[1].device != dev for e in self.entries.values()):       # one device per process in this framework
+            self.entries = {k: e for k, e in self.entries.items() if e[5]}
+            self.table = None
+            return
+        if self.table is None:
+            rows, first = [], 0
+            for (ptr, m, flip), (w, U, K, C, _, _) in self.entries.items():
+                rows.append([ptr, U.data_ptr(), K, C, 2 * m + (1 if flip else 0), first])
+                first += (K * C + 255) // 256
+            self.table = torch.tensor(rows, dtype=torch.int64).to(dev)
+            self.total_blocks = first
+        for e in self.entries.values():
+            e[4] = False
+        with torch.cuda.device(dev):
+            _call("fpsg_wino_filter_transform_batch", _hip.ptr(self.table), self.table.shape[0], self.total_blocks,
+                  torch.cuda.current_stream(dev).cuda_stream)
+        self.valid = True
+
+
+_bank = _FilterBank()
+
+
+def filter_bank_enabled() -> bool:
+    """``FPSG_FILTER_BANK=0``: every filter transform in its own launch, when first needed (A/B measurements)."""
+    return os.environ.get("FPSG_FILTER_BANK", "1") != "0"
+
+
 class weights_frozen:
     """Context manager: the convolution weights do not change inside the block (the episodes of
-    one optimizer step), so each transformed filter is computed once and reused.  Not used while
-    a hipGraph is being captured (a replay must transform the then-current weights)."""
+    one optimizer step), so each transformed filter is computed once and reused: the filters registered by earlier
+    steps all at once when the block opens (``_FilterBank``), others when first needed.  The step-scoped cache is not
+    used while a hipGraph is being captured (a replay must not reuse that step's tensors); the bank is."""
 
     def __enter__(self):
         global _frozen_cache
         self._outer = _frozen_cache
         _frozen_cache = {} if _frozen_cache is None else _frozen_cache
+        if self._outer is None and filter_bank_enabled() and torch.cuda.is_available() \
+                and not torch.cuda.is_current_stream_capturing():
+            _bank.refresh()
         return self
 
     def __exit__(self, *exc):
         global _frozen_cache
         _frozen_cache = self._outer
+        if self._outer is None:
+            _bank.valid = False
         return False
 
 
@@ -131,10 +207,14 @@ def frozen_cache():
 
 
 def _filter(m, w, flip):
-    cache = _frozen_cache
-    if cache is not None and torch.cuda.is_current_stream_capturing():
-        cache = None
     key = (w.data_ptr(), m, bool(flip))
+    capturing = w.is_cuda and torch.cuda.is_current_stream_capturing()
+    banked = _bank.lookup(key, w, capturing)
+    if banked is not None:
+        return banked
+    cache = _frozen_cache
+    if cache is not None and capturing:
+        cache = None
     if cache is not None and key in cache:
         return cache[key]
     K, C = w.shape[0], w.shape[1]
@@ -143,6 +223,8 @@ def _filter(m, w, flip):
     _call("fpsg_wino_filter_transform", m, _hip.ptr(w), K, C, 1 if flip else 0, _hip.ptr(U), _hip.stream_of(w))
     if cache is not None:
         cache[key] = U
+        if filter_bank_enabled():
+            _bank.register(key, w.detach(), U)      # refreshed with the others from the next block on
     return U
 
 

@@ -345,6 +345,11 @@ int fpsg_wino_grad_output_transform(int m, const float* dy, int N, int K, int H,
                                     fpsg_stream_t stream);
 int fpsg_wino_filter_transform(int m, const float* w, int K, int C, int flip_transpose, float* U,
                                fpsg_stream_t stream);
+/* Every filter transform of an optimizer step in one launch (the weights change once per step): jobs [n_jobs][6]
+ * int64 in DEVICE memory -- w pointer [K][C][3][3], U pointer (layout of fpsg_wino_filter_transform), K, C,
+ * 2*m + flip_transpose, first workgroup of the job -- with the jobs' workgroups (256 filters each, ceil(K*C/256) per
+ * job) numbered consecutively; total_blocks = their sum.  Same arithmetic per filter as the single form. */
+int fpsg_wino_filter_transform_batch(const int64_t* jobs, int n_jobs, long total_blocks, fpsg_stream_t stream);
 int fpsg_wino_filter_grad_transform(int m, const float* dU, int K, int C, float* dw, fpsg_stream_t stream);
 
 /* K6 in one kernel for 64 input channels (F(4x4,3x3); conv1_2 / conv2_1 of the trunk and their data

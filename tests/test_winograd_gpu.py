@@ -465,3 +465,59 @@ def test_fused_weight_gradient_matches_three_kernel_form(gpu, shape, act):
     w64 = w.double().cpu().requires_grad_()
     F.conv2d(a.double().cpu(), w64, None, 1, 1).backward(gy.double().cpu())
     assert _errs(gw, w64.grad) <= 2e-5
+
+
+def test_filter_bank_refreshes_every_registered_filter_in_one_launch(gpu, monkeypatch):
+    """winograd._FilterBank: filters asked for inside a weights_frozen block are registered; the next block transforms
+    them all with one fpsg_wino_filter_transform_batch launch into the same buffers -- bit-identical to the single
+    form, after the weights changed in place too; entries a block never asks for are dropped, and FPSG_FILTER_BANK=0
+    keeps the single launches."""
+    from fpsg_amd import _hip, winograd
+    lib = _hip.load()
+    winograd._bank.__init__()
+    torch.manual_seed(3)
+    ws = [torch.randn(K, C, 3, 3, device=gpu) for K, C in ((64, 64), (128, 64), (130, 70), (512, 256))]
+    combos = [(4, ws[0], False), (4, ws[0], True), (2, ws[1], False), (4, ws[2], True), (2, ws[3], True), (4, ws[3], False)]
+
+    def single(m, w, flip):
+        K, C = w.shape[:2]
+        U = torch.empty(((m + 2) ** 2, C, K) if flip else ((m + 2) ** 2, K, C), device=gpu)
+        assert lib.fpsg_wino_filter_transform(m, w.data_ptr(), K, C, int(flip), U.data_ptr(), None) == 0
+        return U
+
+    calls = {"single": 0, "batch": 0}
+    orig = winograd._call
+
+    def counting(name, *a):
+        if name == "fpsg_wino_filter_transform":
+            calls["single"] += 1
+        if name == "fpsg_wino_filter_transform_batch":
+            calls["batch"] += 1
+        return orig(name, *a)
+
+    monkeypatch.setattr(winograd, "_call", counting)
+    with winograd.weights_frozen():                       # block 1: single launches, registration
+        first = [winograd._filter(m, w, f) for m, w, f in combos]
+    assert calls == {"single": 6, "batch": 0} and len(winograd._bank.entries) == 6
+    for w in ws:
+        w.mul_(1.5).add_(0.1)                             # "optimizer step": same memory, new values
+    with winograd.weights_frozen():                       # block 2: one launch, the same buffers
+        assert calls["batch"] == 1
+        again = [winograd._filter(m, w, f) for m, w, f in combos]
+        assert calls["single"] == 6
+        for (m, w, f), U0, U1 in zip(combos, first, again):
+            assert U1.data_ptr() == U0.data_ptr()
+            assert torch.equal(U1, single(m, w, f))
+    with winograd.weights_frozen():                       # block 3 asks for two of them only
+        winograd._filter(*combos[0]); winograd._filter(*combos[5])
+    with winograd.weights_frozen():                       # block 4: the others are gone
+        assert len(winograd._bank.entries) == 2 and calls["batch"] == 3
+        assert torch.equal(winograd._filter(*combos[5]), single(*combos[5]))
+    assert winograd._bank.lookup((ws[0].data_ptr(), 4, False), ws[0], False) is None      # outside a block: not valid
+    winograd._bank.__init__()
+    monkeypatch.setenv("FPSG_FILTER_BANK", "0")
+    n0 = calls["single"]
+    for _ in range(2):
+        with winograd.weights_frozen():
+            winograd._filter(*combos[0])
+    assert calls["single"] == n0 + 2 and not winograd._bank.entries
