@@ -160,6 +160,83 @@ __device__ __forceinline__ void score_tile(const float (&a)[C4T], const float (&
   }
 }
 
+// ---- phase B, threshold form --------------------------------------------------------------
+// The k best of a row's 64*VPL scores without k rounds of wave-wide argmax.  A threshold T0 that k lane maxima reach
+// is a lower bound of the k-th best score, so the k best are among the scores >= T0 -- ~30 of 2048 for k = 20 on
+// ordinary data.  They are compacted (64-bit keys: orderable score << 32 | ~index,
+// the order of the round form: score descending, then index ascending; -0 counts as +0) into the wave's LDS strip,
+// ranked by counting, and the first k land in lanes 0..k-1.  Returns false (nothing written) when more than 64
+// scores pass -- many equal scores, or fewer than k lanes with a finite maximum: the caller then runs the rounds.
+__device__ __forceinline__ unsigned long long readlane_u64(unsigned long long x, int l) {
+  return ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(x >> 32), l) << 32) |
+         (unsigned)__builtin_amdgcn_readlane((int)x, l);
+}
+
+// number of lanes of this lane's row of 16 whose key is larger (keys distinct inside a row): 15 DPP row rotations
+template <int N>
+__device__ __forceinline__ int row_rank_step(unsigned key, int rank) {
+  if constexpr (N < 16) {
+    const unsigned o = (unsigned)__builtin_amdgcn_update_dpp((int)key, (int)key, 0x120 + N, 0xF, 0xF, false);   // row_ror:N
+    return row_rank_step<N + 1>(key, rank + (o > key ? 1 : 0));
+  } else {
+    return rank;
+  }
+}
+
+template <int VPL>
+__device__ __forceinline__ bool select_by_threshold(const float (&v)[VPL], float lane_max, int k, int c0, int lane,
+                                                    unsigned long long* __restrict__ strip, int& mine, float& mval) {
+  // T0: in each of the four rows of 16 lanes the ceil(k/4)-th largest lane maximum, then the smallest of the four:
+  // k lanes (at least) hold a score >= T0.  Ranks inside a row come from integer keys made distinct by the lane
+  // number in the low 4 bits; a near-tie may then pick a neighbouring rank -- T0 is still one of the lane maxima, and
+  // the count checks below send the row to the rounds when fewer than k or more than 64 scores pass.
+  const int need = (k + 3) >> 2;
+  const unsigned rk = (orderable(lane_max + 0.0f) & ~15u) | (unsigned)(15 - (lane & 15));
+  const int rank = row_rank_step<1>(rk, 0);
+  const unsigned long long pick = __ballot(rank == need - 1);         // one lane per row (need <= 16)
+  float T0 = __builtin_inff();
+#pragma unroll
+  for (int row = 0; row < 4; ++row) {
+    const unsigned bits = (unsigned)(pick >> (16 * row)) & 0xffffu;
+    const int src = 16 * row + (bits ? __builtin_ctz(bits) : 0);
+    T0 = __builtin_fminf(T0, __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lane_max), src)));
+  }
+  // compaction: per score slot one ballot; empty slots cost a compare and a scalar branch
+  int total = 0;                                                      // wave-uniform
+#pragma unroll
+  for (int t = 0; t < VPL; ++t) {
+    const bool in = v[t] >= T0;
+    const unsigned long long m = __ballot(in);
+    if (m != 0ull) {
+      const int n = __builtin_popcountll(m);
+      if (total + n > 64) return false;
+      if (in) {
+        const int pos = total + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+        strip[pos] = ((unsigned long long)orderable(v[t] + 0.0f) << 32) | (unsigned)~(unsigned)(c0 + t * 64 + lane);
+      }
+      total += n;
+    }
+  }
+  if (total < k) return false;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  const unsigned long long key = lane < total ? strip[lane] : 0ull;     // one wave's LDS operations execute in order
+  int r = 0;
+  for (int l = 0; l < total; ++l) r += readlane_u64(key, l) > key ? 1 : 0;
+  __builtin_amdgcn_wave_barrier();
+  if (lane < total && r < k) strip[r] = key;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  const unsigned long long mk = lane < k ? strip[lane] : 0ull;
+  __builtin_amdgcn_wave_barrier();
+  const unsigned ov = (unsigned)(mk >> 32);
+  mval = lane < k ? __uint_as_float((ov & 0x80000000u) ? (ov & 0x7fffffffu) : ~ov) : -__builtin_inff();
+  mine = lane < k ? (int)~(unsigned)mk : 0;
+  return true;
+}
+
 // LDS: pd[kQ][ldp] floats (+ qa[C4*4][16] floats for the generic-C path).
 // C4T > 0: compile-time channel steps (C <= 4*C4T), register-resident operands.
 // C4T == 0: any C, operands re-read per step (slow path for unusual channel counts).
@@ -317,7 +394,17 @@ __global__ __launch_bounds__(64 * NW) void knn_kernel(const float* __restrict__ 
       }
     }
     const int rounds = k < cw ? k : cw;   // a short last chunk may hold fewer than k columns
-    for (int round = 0; round < rounds; ++round) {
+    bool by_threshold = rounds == k && k <= 32;     // larger k: too many scores pass for the 64-entry strip
+#pragma unroll
+    for (int rr = 0; rr < kRowsPerWave; ++rr) {
+      if (by_threshold) {
+        float lm = gmax[rr][0];
+#pragma unroll
+        for (int g = 1; g < NG; ++g) lm = __builtin_fmaxf(lm, gmax[rr][g]);
+        by_threshold = select_by_threshold<VPL>(v[rr], lm, k, c0, lane, scratch, mine[rr], mval[rr]);
+      }
+    }
+    for (int round = 0; round < (by_threshold ? 0 : rounds); ++round) {
 #pragma unroll
       for (int rr = 0; rr < kRowsPerWave; ++rr) {
         float bv = gmax[rr][0];
