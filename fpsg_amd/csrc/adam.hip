@@ -24,11 +24,7 @@ __global__ __launch_bounds__(kAdamThreads) void adam_kernel(float* __restrict__ 
                                                             float inv_sqrt_bc2, float gscale) {
   const size_t stride = (size_t)gridDim.x * kAdamThreads;
   const float omb1 = 1.0f - b1, omb2 = 1.0f - b2;
-  for (size_t i = (size_t)blockIdx.x * kAdamThreads + threadIdx.x; i < n4; i += stride) {
-    v4f pv = reinterpret_cast<const v4f*>(p)[i];
-    const v4f gv = reinterpret_cast<const v4f*>(g)[i];
-    v4f mv = reinterpret_cast<const v4f*>(m)[i];
-    v4f vv = reinterpret_cast<const v4f*>(v)[i];
+  auto update = [&](v4f& pv, const v4f& gv, v4f& mv, v4f& vv) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const float gg = gv[u] * gscale;
@@ -37,6 +33,26 @@ __global__ __launch_bounds__(kAdamThreads) void adam_kernel(float* __restrict__ 
       const float denom = fma_rn(__fsqrt_rn(vv[u]), inv_sqrt_bc2, eps);
       pv[u] = fma_rn(-step_size, mv[u] / denom, pv[u]);
     }
+  };
+  // two vectors of each stream per pass: eight 16-byte loads in flight per thread before the first use
+  size_t i = (size_t)blockIdx.x * kAdamThreads + threadIdx.x;
+  for (; i + stride < n4; i += 2 * stride) {
+    const size_t j = i + stride;
+    v4f pa = reinterpret_cast<const v4f*>(p)[i], pb = reinterpret_cast<const v4f*>(p)[j];
+    const v4f ga = reinterpret_cast<const v4f*>(g)[i], gb = reinterpret_cast<const v4f*>(g)[j];
+    v4f ma = reinterpret_cast<const v4f*>(m)[i], mb = reinterpret_cast<const v4f*>(m)[j];
+    v4f va = reinterpret_cast<const v4f*>(v)[i], vb = reinterpret_cast<const v4f*>(v)[j];
+    update(pa, ga, ma, va);
+    update(pb, gb, mb, vb);
+    reinterpret_cast<v4f*>(p)[i] = pa; reinterpret_cast<v4f*>(m)[i] = ma; reinterpret_cast<v4f*>(v)[i] = va;
+    reinterpret_cast<v4f*>(p)[j] = pb; reinterpret_cast<v4f*>(m)[j] = mb; reinterpret_cast<v4f*>(v)[j] = vb;
+  }
+  if (i < n4) {
+    v4f pv = reinterpret_cast<const v4f*>(p)[i];
+    const v4f gv = reinterpret_cast<const v4f*>(g)[i];
+    v4f mv = reinterpret_cast<const v4f*>(m)[i];
+    v4f vv = reinterpret_cast<const v4f*>(v)[i];
+    update(pv, gv, mv, vv);
     reinterpret_cast<v4f*>(p)[i] = pv;
     reinterpret_cast<v4f*>(m)[i] = mv;
     reinterpret_cast<v4f*>(v)[i] = vv;
@@ -127,11 +143,13 @@ __global__ __launch_bounds__(kAdamThreads) void flat_accumulate_kernel(float* __
     const long long i = (long long)(4 * j);
     const int cnt = j < n4 ? 4 : (int)(n - 4 * n4);
     if (cnt == 0) break;
+    // the flat buffer's vector first: its load flies while the table is searched
+    v4f f = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (accumulate && cnt == 4) f = reinterpret_cast<const v4f*>(flat)[j];
     float gg[4];
     const bool any = gather_grad4(gtab, so, nseg, i, cnt, gg);
     if (accumulate && !any) continue;
     if (cnt == 4) {
-      v4f f = accumulate ? reinterpret_cast<const v4f*>(flat)[j] : (v4f){0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
       for (int u = 0; u < 4; ++u) f[u] += gg[u];
       reinterpret_cast<v4f*>(flat)[j] = f;
@@ -146,18 +164,23 @@ __global__ __launch_bounds__(kAdamThreads) void adam_ptr_kernel(float* __restric
                                                                 float* __restrict__ m, float* __restrict__ v, size_t n4,
                                                                 size_t n, float step_size, float b1, float b2,
                                                                 float eps, float inv_sqrt_bc2, float gscale) {
+  const long long* so = seg_off;
   const size_t stride = (size_t)gridDim.x * kAdamThreads;
   const float omb1 = 1.0f - b1, omb2 = 1.0f - b2;
   for (size_t j = (size_t)blockIdx.x * kAdamThreads + threadIdx.x; j < n4 + 1; j += stride) {
     const long long i = (long long)(4 * j);
     const int cnt = j < n4 ? 4 : (int)(n - 4 * n4);          // the last "vector" is the tail
     if (cnt == 0) break;
+    // the flat streams first: their loads fly while the table is searched and the gradient fetched
+    v4f pv = {0.0f, 0.0f, 0.0f, 0.0f}, mv = pv, vv = pv;
+    if (cnt == 4) {
+      pv = reinterpret_cast<const v4f*>(p)[j];
+      mv = reinterpret_cast<const v4f*>(m)[j];
+      vv = reinterpret_cast<const v4f*>(v)[j];
+    }
     float gg[4];
-    gather_grad4(gtab, seg_off, nseg, i, cnt, gg);
+    gather_grad4(gtab, so, nseg, i, cnt, gg);
     if (cnt == 4) {                                            // flat buffers: aligned vectors
-      v4f pv = reinterpret_cast<const v4f*>(p)[j];
-      v4f mv = reinterpret_cast<const v4f*>(m)[j];
-      v4f vv = reinterpret_cast<const v4f*>(v)[j];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const float gq = gg[u] * gscale;
