@@ -73,6 +73,8 @@ SIGNATURES = {
                         _c_stream],
     "fpsg_bn_act_bwd": [_c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_int, _c_int, _c_int, _c_int, _c_int,
                         ctypes.c_float, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_stream],
+    "fpsg_bn_act_bwd_parts": [_c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_int, _c_int, _c_int, _c_int, _c_int,
+                        ctypes.c_float, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_int, _c_stream],
     "fpsg_bn_pool_workspace_floats": [_c_int, _c_int, _c_int, _c_int],
     "fpsg_bn_act_pool_fwd": [_c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, ctypes.c_float, _c_int, _c_int, _c_int, _c_int,
                              _c_int, ctypes.c_float, _c_int, ctypes.c_float, _c_f32p, _c_f32p, _c_f32p, _c_f32p,
@@ -92,6 +94,8 @@ SIGNATURES = {
                                          _c_stream],
     "fpsg_wino_grad_output_transform": [_c_int, _c_f32p, _c_int, _c_int, _c_int, _c_int, _c_f32p, _c_stream],
     "fpsg_wino_filter_transform": [_c_int, _c_f32p, _c_int, _c_int, _c_int, _c_f32p, _c_stream],
+    "fpsg_wino_output_transform_bwd_stats": [_c_int, _c_f32p, _c_int, _c_int, _c_int, _c_int, _c_f32p, _c_f32p, _c_f32p,
+                                             _c_f32p, _c_f32p, _c_stream],
     "fpsg_wino_filter_transform_batch": [ctypes.c_void_p, _c_int, ctypes.c_long, _c_stream],
     "fpsg_wino_filter_grad_transform": [_c_int, _c_f32p, _c_int, _c_int, _c_f32p, _c_stream],
     "fpsg_wino_conv_fused": [_c_f32p, _c_f32p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_f32p, _c_stream],

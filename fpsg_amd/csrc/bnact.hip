@@ -179,7 +179,10 @@ __global__ __launch_bounds__(64) void bn_bwd_finalize_kernel(const float* __rest
                                        float* __restrict__ dbeta, float* __restrict__ coef /*[3][C]*/) {
   const int c = blockIdx.x, lane = threadIdx.x;
   double s0 = 0.0, s1 = 0.0;
-  if (lane < S) { s0 = part[((size_t)c * S + lane) * 2]; s1 = part[((size_t)c * S + lane) * 2 + 1]; }
+  for (int q = lane; q < S; q += 64) {          // S <= 64 for K5's own pass; a convolution epilogue may deliver more
+    s0 += part[((size_t)c * S + q) * 2];
+    s1 += part[((size_t)c * S + q) * 2 + 1];
+  }
   wave_sum2(s0, s1);
   if (lane != 0) return;
   dbeta[c] = (float)s0;
@@ -984,6 +987,33 @@ extern "C" int fpsg_bn_act_bwd(const float* x, const float* pre_bias, const floa
   if (dpre_bias) {
     hipLaunchKernelGGL(bn_dxsum_kernel, dim3(C), dim3(64), 0, s, dxpart, N, C, (L + kBnSeg - 1) / kBnSeg, dpre_bias);
     return launch_status("fpsg_bn_act_bwd(dpre_bias)");
+  }
+  return 0;
+}
+
+extern "C" int fpsg_bn_act_bwd_parts(const float* x, const float* pre_bias, const float* dy, const float* chan, int N,
+                                     int C, int L, int training, int act, float slope, float* dx, float* dgamma,
+                                     float* dbeta, float* dpre_bias, float* coef, float* ws, const float* parts,
+                                     int n_parts, fpsg_stream_t stream) {
+  using namespace fpsg;
+  int rc = check_dims("fpsg_bn_act_bwd_parts", N, C, L, act);
+  if (rc) return rc;
+  FPSG_REQUIRE_PTR(x); FPSG_REQUIRE_PTR(dy); FPSG_REQUIRE_PTR(chan); FPSG_REQUIRE_PTR(dx); FPSG_REQUIRE_PTR(parts);
+  FPSG_REQUIRE_PTR(dgamma); FPSG_REQUIRE_PTR(dbeta); FPSG_REQUIRE_PTR(coef);
+  FPSG_REQUIRE(n_parts > 0, FPSG_E_SHAPE, "fpsg_bn_act_bwd_parts: n_parts must be positive (got %d)", n_parts);
+  FPSG_REQUIRE(dpre_bias == nullptr || ws != nullptr, FPSG_E_NULL, "fpsg_bn_act_bwd_parts: dpre_bias needs the workspace");
+  FPSG_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(dx)) & 15) == 0,
+               FPSG_E_ALIGN, "fpsg_bn_act_bwd_parts: x, dy and dx must be 16-byte aligned");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, s, parts, chan, C, n_parts,
+                     (double)N * (double)L, training, dgamma, dbeta, coef);
+  if ((rc = launch_status("fpsg_bn_act_bwd_parts(finalize)"))) return rc;
+  float* dxpart = dpre_bias ? ws + (size_t)C * kBnSlices * 2 : nullptr;
+  launch_apply<1>(act, x, dy, chan, coef, pre_bias, N, C, L, slope, dx, dxpart, s);
+  if ((rc = launch_status("fpsg_bn_act_bwd_parts(apply)"))) return rc;
+  if (dpre_bias) {
+    hipLaunchKernelGGL(bn_dxsum_kernel, dim3(C), dim3(64), 0, s, dxpart, N, C, (L + kBnSeg - 1) / kBnSeg, dpre_bias);
+    return launch_status("fpsg_bn_act_bwd_parts(dpre_bias)");
   }
   return 0;
 }

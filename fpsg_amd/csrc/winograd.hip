@@ -202,11 +202,18 @@ __global__ __launch_bounds__(kWinoThreads) void wino_input_kernel(const float* _
 // sum(y + bias[k]) and sum((y + bias[k])^2) over the workgroup's 256 tiles -> parts[k][blockIdx.x][2] (per thread 16
 // pixels in row order, then the wave's fixed tree, then the four waves in order: deterministic).  K5's
 // statistics pass over y (one read of the tensor) is then not needed (fpsg_bn_stats with parts).
-template <int M, bool STATS>
+// BWD (with STATS): y is the gradient of relu(bn(xpre + bias)) -- the data gradient of the convolution that consumed
+// that activation -- and the sums are the ones BatchNorm's backward needs, in the arithmetic of K5's own pass
+// (bn_reduce_kernel, MODE 1): dz = y * [fma(x, scale, shift) > 0], sum(dz) and sum(dz * (x - mean) * rstd) with
+// x = xpre + bias[k]; chan = [4][K] scale, shift, mean, rstd.  K5's backward then starts at its finalize
+// (fpsg_bn_act_bwd_parts) and reads neither tensor for the sums.
+template <int M, bool STATS, bool BWD = false>
 __global__ __launch_bounds__(kWinoThreads) void wino_output_kernel(const float* __restrict__ Mt, int K, int H, int W,
                                                                     int Th, int Tw, long P, float* __restrict__ y,
                                                                     const float* __restrict__ bias,
-                                                                    float* __restrict__ parts) {
+                                                                    float* __restrict__ parts,
+                                                                    const float* __restrict__ xpre = nullptr,
+                                                                    const float* __restrict__ chan = nullptr) {
   constexpr int A = Wino<M>::A;
   typedef float vout __attribute__((ext_vector_type(M)));
   __shared__ float red[2 * (kWinoThreads / kWave)];
@@ -226,8 +233,16 @@ __global__ __launch_bounds__(kWinoThreads) void wino_output_kernel(const float* 
     for (int i = 0; i < A; ++i) m[i] = mp[(size_t)(A * i + j) * plane];
     Wino<M>::out(m, s[j]);
   }
-  float* yp = y + (((size_t)ti.n * K + k) * H + M * ti.th) * W + M * ti.tw;
+  const size_t yoff = (((size_t)ti.n * K + k) * H + M * ti.th) * W + M * ti.tw;
+  float* yp = y + yoff;
   const float b = (STATS && bias) ? bias[k] : 0.0f;
+  float sc = 0.0f, sh = 0.0f, mu = 0.0f, rs = 0.0f;
+  vout xrow[M];
+  if constexpr (BWD) {
+    sc = chan[k]; sh = chan[K + k]; mu = chan[2 * K + k]; rs = chan[3 * K + k];
+#pragma unroll
+    for (int i = 0; i < M; ++i) xrow[i] = *reinterpret_cast<const vout*>(xpre + yoff + (size_t)i * W);   // dead lanes: the last tile
+  }
   float a0 = 0.0f, a1 = 0.0f;
 #pragma unroll
   for (int i = 0; i < M; ++i) {
@@ -239,7 +254,15 @@ __global__ __launch_bounds__(kWinoThreads) void wino_output_kernel(const float* 
 #pragma unroll
     for (int j = 0; j < M; ++j) ov[j] = o[j];
     if (live) *reinterpret_cast<vout*>(yp + (size_t)i * W) = ov;
-    if (STATS) {
+    if constexpr (BWD) {
+#pragma unroll
+      for (int j = 0; j < M; ++j) {
+        const float xv = xrow[i][j] + b;
+        const float dz = (live && fma_rn(xv, sc, sh) > 0.0f) ? o[j] : 0.0f;
+        a0 += dz;
+        a1 = fma_rn(dz, (xv - mu) * rs, a1);
+      }
+    } else if (STATS) {
 #pragma unroll
       for (int j = 0; j < M; ++j) {
         const float v = live ? o[j] + b : 0.0f;
@@ -469,6 +492,25 @@ extern "C" int fpsg_wino_output_transform_stats(int m, const float* M, int N, in
   if (m == 2) hipLaunchKernelGGL((wino_output_kernel<2, true>), grid, dim3(kWinoThreads), 0, hs, M, K, H, W, H / m, W / m, P, y, bias, parts);
   else hipLaunchKernelGGL((wino_output_kernel<4, true>), grid, dim3(kWinoThreads), 0, hs, M, K, H, W, H / m, W / m, P, y, bias, parts);
   return launch_status("fpsg_wino_output_transform_stats");
+}
+
+extern "C" int fpsg_wino_output_transform_bwd_stats(int m, const float* M, int N, int K, int H, int W, float* y,
+                                                    const float* xpre, const float* pre_bias, const float* chan,
+                                                    float* parts, fpsg_stream_t stream) {
+  using namespace fpsg;
+  int rc = check_image("fpsg_wino_output_transform_bwd_stats", m, N, K, H, W);
+  if (rc) return rc;
+  FPSG_REQUIRE_PTR(M); FPSG_REQUIRE_PTR(y); FPSG_REQUIRE_PTR(parts); FPSG_REQUIRE_PTR(xpre); FPSG_REQUIRE_PTR(chan);
+  FPSG_REQUIRE(((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(xpre)) & 15) == 0, FPSG_E_ALIGN,
+               "fpsg_wino_output_transform_bwd_stats: y and xpre must be 16-byte aligned");
+  FPSG_REQUIRE(!misaligned4(pre_bias) && !misaligned4(parts) && !misaligned4(chan), FPSG_E_ALIGN,
+               "fpsg_wino_output_transform_bwd_stats: pre_bias / chan / parts not 4-byte aligned");
+  const long P = (long)N * (H / m) * (W / m);
+  dim3 grid((unsigned)((P + kWinoThreads - 1) / kWinoThreads), K);
+  hipStream_t hs = static_cast<hipStream_t>(stream);
+  if (m == 2) hipLaunchKernelGGL((wino_output_kernel<2, true, true>), grid, dim3(kWinoThreads), 0, hs, M, K, H, W, H / m, W / m, P, y, pre_bias, parts, xpre, chan);
+  else hipLaunchKernelGGL((wino_output_kernel<4, true, true>), grid, dim3(kWinoThreads), 0, hs, M, K, H, W, H / m, W / m, P, y, pre_bias, parts, xpre, chan);
+  return launch_status("fpsg_wino_output_transform_bwd_stats");
 }
 
 extern "C" int fpsg_wino_grad_output_transform(int m, const float* dy, int N, int K, int H, int W, float* dM,

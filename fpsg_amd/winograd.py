@@ -241,6 +241,28 @@ def stats_enabled() -> bool:
     return os.environ.get("FPSG_CONV_STATS", "1") != "0"
 
 
+_BN_SMALL_MAX = 16384     # fpsg_bn_act_bwd does tensors of at most this many values per channel in one fused kernel
+
+
+def bwd_stats_enabled() -> bool:
+    """The output transform of a data-gradient convolution also accumulates the two sums the backward of the
+    BatchNorm + ReLU in front of that convolution starts from (K5's backward then does not read the two tensors for
+    them).  ``FPSG_CONV_BWD_STATS=0`` switches it off (A/B)."""
+    return os.environ.get("FPSG_CONV_BWD_STATS", "1") != "0"
+
+
+def _output_bwd_stats(m, M, N, H, W, xpre, pre_bias, chan):
+    """-> (ga, parts [K, S, 2]): the output transform of ``M`` and, per channel and workgroup, sum(dz) and
+    sum(dz * xhat) for dz = ga * [bn(xpre + pre_bias) > 0] (``fpsg_wino_output_transform_bwd_stats``)."""
+    K = M.shape[1]
+    y = torch.empty((N, K, H, W), dtype=torch.float32, device=M.device)
+    S = _hip.load().fpsg_wino_stats_parts(m, N, H, W)
+    parts = torch.empty((K, S, 2), dtype=torch.float32, device=M.device)
+    _call("fpsg_wino_output_transform_bwd_stats", m, _hip.ptr(M), N, K, H, W, _hip.ptr(y), _hip.ptr(xpre),
+          _hip.ptr(pre_bias) if pre_bias is not None else None, _hip.ptr(chan), _hip.ptr(parts), _hip.stream_of(M))
+    return y, parts
+
+
 def _output(m, M, N, H, W, stats_bias=None, want_parts=False):
     """``want_parts``: -> (y, parts [K, S, 2]) with the per-workgroup partial sums of ``y + stats_bias`` and its square."""
     K = M.shape[1]
@@ -435,8 +457,12 @@ class _BNReluConv3x3(torch.autograd.Function):
         gw = None
         with torch.cuda.device(dev):
             # convolution backward: gradient of the (never stored) activation, and of the filter
+            bwd_parts = None
             if _can_fuse(m, K, C, N * H * W):
                 ga = _fused(gout, _filter(m, w, True))
+            elif bwd_stats_enabled() and N * H * W > _BN_SMALL_MAX:
+                # the output transform that writes ga also delivers the sums K5's backward starts from
+                ga, bwd_parts = _output_bwd_stats(m, torch.bmm(_filter(m, w, True), _input(m, gout)), N, H, W, y, pre_bias, chan)
             else:
                 ga = _output(m, torch.bmm(_filter(m, w, True), _input(m, gout)), N, H, W)
             if ctx.needs_input_grad[9]:
@@ -454,9 +480,15 @@ class _BNReluConv3x3(torch.autograd.Function):
             dpb = torch.empty((C,), dtype=torch.float32, device=dev) if want_dpb else None
             coef = torch.empty((3, C), dtype=torch.float32, device=dev)
             ws = torch.empty((lib.fpsg_bn_workspace_floats(N, C, H * W),), dtype=torch.float32, device=dev)
-            _call("fpsg_bn_act_bwd", _hip.ptr(y), _hip.ptr(pre_bias) if pre_bias is not None else None, _hip.ptr(ga),
-                  _hip.ptr(chan), N, C, H * W, 1 if training else 0, 1, 0.0, _hip.ptr(dy), _hip.ptr(dgamma),
-                  _hip.ptr(dbeta), _hip.ptr(dpb) if want_dpb else None, _hip.ptr(coef), _hip.ptr(ws), _hip.stream_of(y))
+            if bwd_parts is not None:
+                _call("fpsg_bn_act_bwd_parts", _hip.ptr(y), _hip.ptr(pre_bias) if pre_bias is not None else None,
+                      _hip.ptr(ga), _hip.ptr(chan), N, C, H * W, 1 if training else 0, 1, 0.0, _hip.ptr(dy),
+                      _hip.ptr(dgamma), _hip.ptr(dbeta), _hip.ptr(dpb) if want_dpb else None, _hip.ptr(coef),
+                      _hip.ptr(ws), _hip.ptr(bwd_parts), bwd_parts.shape[1], _hip.stream_of(y))
+            else:
+                _call("fpsg_bn_act_bwd", _hip.ptr(y), _hip.ptr(pre_bias) if pre_bias is not None else None, _hip.ptr(ga),
+                      _hip.ptr(chan), N, C, H * W, 1 if training else 0, 1, 0.0, _hip.ptr(dy), _hip.ptr(dgamma),
+                      _hip.ptr(dbeta), _hip.ptr(dpb) if want_dpb else None, _hip.ptr(coef), _hip.ptr(ws), _hip.stream_of(y))
         return (dy, dpb, dgamma if has_g else None, dbeta if has_b else None, None, None, None, None, None, gw, None,
                 None, None, None)
 

@@ -278,6 +278,12 @@ int fpsg_bn_stats(const float* x, const float* pre_bias, const float* gamma, con
 int fpsg_bn_act_bwd(const float* x, const float* pre_bias, const float* dy, const float* chan, int N, int C,
                     int L, int training, int act, float slope, float* dx, float* dgamma, float* dbeta,
                     float* dpre_bias, float* coef, float* ws, fpsg_stream_t stream);
+/* fpsg_bn_act_bwd with the two sums per channel delivered by the kernel that produced dy
+ * (fpsg_wino_output_transform_bwd_stats): parts [C][n_parts][2].  ws may be NULL unless dpre_bias is wanted. */
+int fpsg_bn_act_bwd_parts(const float* x, const float* pre_bias, const float* dy, const float* chan, int N,
+                          int C, int L, int training, int act, float slope, float* dx, float* dgamma,
+                          float* dbeta, float* dpre_bias, float* coef, float* ws, const float* parts,
+                          int n_parts, fpsg_stream_t stream);
 
 /* K5 followed by MaxPool2d(kernel 2, stride 2): the conv + BatchNorm + ReLU + max-pool groups
  * that end the five stages of the VGG16-BN trunk (src/models/image_net.py:14).  x [N,C,H,W]
@@ -341,6 +347,15 @@ int fpsg_wino_output_transform(int m, const float* M, int N, int K, int H, int W
 int fpsg_wino_stats_parts(int m, int N, int H, int W);
 int fpsg_wino_output_transform_stats(int m, const float* M, int N, int K, int H, int W, float* y, const float* bias,
                                      float* parts, fpsg_stream_t stream);
+/* The output transform of a DATA-GRADIENT convolution whose result is the gradient of relu(bn(xpre + pre_bias)):
+ * besides y it delivers the two sums BatchNorm's backward starts from -- sum(dz) and sum(dz * (x - mean) * rstd) with
+ * dz = y * [fma(x, scale, shift) > 0], x = xpre + pre_bias[k] -- per output channel and workgroup into
+ * parts [K][fpsg_wino_stats_parts(m,N,H,W)][2] (deterministic), in the arithmetic of fpsg_bn_act_bwd's own pass.
+ * xpre [N,K,H,W]: the pre-BatchNorm tensor; chan [4][K]: scale, shift, mean, rstd (fpsg_bn_stats / _act_fwd).
+ * fpsg_bn_act_bwd_parts then skips its pass over (x, dy). */
+int fpsg_wino_output_transform_bwd_stats(int m, const float* M, int N, int K, int H, int W, float* y,
+                                         const float* xpre, const float* pre_bias, const float* chan,
+                                         float* parts, fpsg_stream_t stream);
 int fpsg_wino_grad_output_transform(int m, const float* dy, int N, int K, int H, int W, float* dM,
                                     fpsg_stream_t stream);
 int fpsg_wino_filter_transform(int m, const float* w, int K, int C, int flip_transpose, float* U,

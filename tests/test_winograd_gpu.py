@@ -189,12 +189,14 @@ def test_full_size_layers_against_the_library_and_linearity(gpu, layer):
 
 @pytest.mark.parametrize("C,K,H,N", [(64, 64, 112, 6), (64, 128, 56, 6), (128, 128, 56, 6), (256, 256, 28, 24)])
 @pytest.mark.parametrize("mode", ["train", "eval"])
-def test_bn_relu_folded_into_next_conv_equals_two_ops(gpu, C, K, H, N, mode):
+def test_bn_relu_folded_into_next_conv_equals_two_ops(gpu, monkeypatch, C, K, H, N, mode):
     """``bn_relu_conv3x3(y, pre_bias, bn, w)`` -- BatchNorm + ReLU applied by the convolution's own input
     transform (fpsg_wino_input_transform_act; fpsg_wino_conv_fused_act for 64 input channels) -- against the
     two ops it replaces, ``conv3x3(bn_act(bn, y, relu, pre_bias), w)``: the activation values are formed with
-    the same arithmetic, so output, running statistics and all gradients agree bit for bit."""
+    the same arithmetic, so output, running statistics and all gradients agree bit for bit (with the BatchNorm
+    backward's sums from K5's own pass in both: FPSG_CONV_BWD_STATS=0; the epilogue sums have their own test)."""
     import copy
+    monkeypatch.setenv("FPSG_CONV_BWD_STATS", "0")
     from fpsg_amd.fused_bn import bn_act
     from fpsg_amd.winograd import bn_relu_conv3x3, conv3x3
     torch.manual_seed(C + K + H)
@@ -241,6 +243,7 @@ def test_trunk_with_and_without_the_fold(gpu, monkeypatch):
     monkeypatch.setattr(winograd._BNReluConv3x3, "forward", staticmethod(counted))
 
     monkeypatch.setenv("FPSG_CONV_STATS", "0")       # same statistics kernels in both arms (see the next test)
+    monkeypatch.setenv("FPSG_CONV_BWD_STATS", "0")
 
     def run(fold):
         monkeypatch.setenv("FPSG_BN_FOLD", fold)
@@ -521,3 +524,69 @@ def test_filter_bank_refreshes_every_registered_filter_in_one_launch(gpu, monkey
         with winograd.weights_frozen():
             winograd._filter(*combos[0])
     assert calls["single"] == n0 + 2 and not winograd._bank.entries
+
+
+@pytest.mark.parametrize("m,shape", [(4, (6, 128, 56, 56)), (2, (5, 48, 50, 30)), (4, (37, 32, 28, 28)), (4, (3, 7, 8, 12))])
+def test_output_transform_delivers_batchnorm_backward_sums(gpu, m, shape):
+    """fpsg_wino_output_transform_bwd_stats: y equals the plain output transform bit for bit, and the per-workgroup
+    partial sums add up (float64) to sum(dz) and sum(dz * xhat) with dz = y * [bn(xpre + bias) > 0], as
+    fpsg_bn_act_bwd's own pass would form them (1e-5 of the sums' scale); last workgroup partly empty included."""
+    from fpsg_amd import _hip
+    from fpsg_amd import winograd as wg
+    lib = _hip.load()
+    N, K, H, W = shape
+    torch.manual_seed(H + K)
+    P = N * (H // m) * (W // m)
+    M = torch.randn((m + 2) ** 2, K, P, device=gpu)
+    xpre = torch.randn(N, K, H, W, device=gpu)
+    pb = torch.randn(K, device=gpu) * 0.1
+    scale, shift = torch.randn(K, device=gpu) * 0.5 + 1, torch.randn(K, device=gpu) * 0.3
+    mean, rstd = torch.randn(K, device=gpu) * 0.1, torch.rand(K, device=gpu) + 0.5
+    chan = torch.stack([scale, shift, mean, rstd]).contiguous()
+    y0 = wg._output(m, M, N, H, W)
+    y1, parts = wg._output_bwd_stats(m, M, N, H, W, xpre, pb, chan)
+    assert torch.equal(y0, y1)
+    assert parts.shape == (K, lib.fpsg_wino_stats_parts(m, N, H, W), 2)
+    x = (xpre + pb.view(1, K, 1, 1)).double()
+    z = x * scale.view(1, K, 1, 1).double() + shift.view(1, K, 1, 1).double()
+    dz = torch.where(z > 0, y0.double(), torch.zeros_like(z))
+    xhat = (x - mean.view(1, K, 1, 1).double()) * rstd.view(1, K, 1, 1).double()
+    s0, s1 = dz.sum(dim=(0, 2, 3)), (dz * xhat).sum(dim=(0, 2, 3))
+    got = parts.double().sum(dim=1)
+    tol0 = 1e-5 * float(dz.abs().sum(dim=(0, 2, 3)).max())
+    tol1 = 1e-5 * float((dz * xhat).abs().sum(dim=(0, 2, 3)).max())
+    assert float((got[:, 0] - s0).abs().max()) <= tol0 and float((got[:, 1] - s1).abs().max()) <= tol1
+
+
+@pytest.mark.parametrize("C,K,H,N", [(128, 128, 56, 6), (32, 48, 28, 24), (128, 64, 36, 16)])
+def test_batchnorm_backward_sums_from_the_data_gradient_convolution(gpu, monkeypatch, C, K, H, N):
+    """BatchNorm -> ReLU -> conv as one node: its backward with the sums of the BatchNorm backward delivered by the
+    data-gradient convolution's output transform (default) against K5's own pass over (x, dy)
+    (FPSG_CONV_BWD_STATS=0): every gradient to 2e-5 of its scale (the sums are grouped differently)."""
+    import copy
+    from fpsg_amd.winograd import bn_relu_conv3x3
+    torch.manual_seed(C + H)
+    y = torch.randn(N, C, H, H, device=gpu)
+    w = torch.randn(K, C, 3, 3, device=gpu) * (2.0 / (9 * C)) ** 0.5
+    pb = torch.randn(C, device=gpu) * 0.05
+    bn = torch.nn.BatchNorm2d(C).to(gpu).train()
+    with torch.no_grad():
+        bn.weight.copy_(torch.randn(C) * 0.3 + 1)
+        bn.bias.copy_(torch.randn(C) * 0.1)
+    g = torch.randn(N, K, H, H, device=gpu)
+    res = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("FPSG_CONV_BWD_STATS", flag)
+        mod = copy.deepcopy(bn)
+        yi, wi, pbi = y.clone().requires_grad_(), w.clone().requires_grad_(), pb.clone().requires_grad_()
+        out = bn_relu_conv3x3(yi, pbi, mod, wi)
+        out.backward(g)
+        res.append((out.detach(), yi.grad, wi.grad, mod.weight.grad, mod.bias.grad, pbi.grad))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][2], res[1][2])
+    for a, b_ in zip(res[0][:-1], res[1][:-1]):
+        scale = float(b_.abs().max()) + 1e-30
+        assert float((a - b_).abs().max()) <= 2e-5 * scale, float((a - b_).abs().max()) / scale
+    # the gradient of a bias in front of a training-mode BatchNorm is zero: both forms leave only the round-off of
+    # sum(dx) over N*H*W values
+    bound = 1e-6 * float(res[1][1].abs().sum(dim=(0, 2, 3)).max())
+    assert float(res[0][-1].abs().max()) <= bound and float(res[1][-1].abs().max()) <= bound
