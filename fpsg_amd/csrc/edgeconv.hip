@@ -270,21 +270,27 @@ inline dim3 ec_grid(int B, int N, int Co) {          // 8 * ceil(B/8) clouds' wo
 // scale = gamma * rstd, shift = beta - mean * scale; running statistics updated as nn.BatchNorm2d does (unbiased
 // variance).  training = 0: chan from the running statistics, part unused.
 // fp64 sums over the blocks for the 4 channels of a workgroup: thread (row slice q = tid / 4, channel tid % 4) adds
-// blocks q, q + 64, ... in order, the 64 slices are then added in order by the first 4 threads (deterministic)
-constexpr int kFinThreads = 256, kFinCh = 4, kFinSlices = kFinThreads / kFinCh;
+// blocks q, q + slices, ... in order (slices = threads / 4), the slices are then added in order by the first 4
+// threads (deterministic)
+constexpr int kFinThreads = 1024, kFinBwdThreads = 256, kFinCh = 4;   // forward: 8,192 partial blocks per layer at 64 clouds
+                                                                      // (32 loads per thread); backward: 512
+template <int THREADS>
 __device__ __forceinline__ bool part_sums(const float* __restrict__ part, int blocks, int Co, int& c, double& s0, double& s1) {
-  __shared__ double red[2][kFinThreads];
+  constexpr int kSlices = THREADS / kFinCh;
+  __shared__ double red[2][THREADS];
   const int q = threadIdx.x / kFinCh, cl = threadIdx.x % kFinCh;
   c = blockIdx.x * kFinCh + cl;
   double a0 = 0.0, a1 = 0.0;
-  if (c < Co && part)
-    for (int b = q; b < blocks; b += kFinSlices) { a0 += part[((size_t)b * 2) * Co + c]; a1 += part[((size_t)b * 2 + 1) * Co + c]; }
+  if (c < Co && part) {
+#pragma unroll 4
+    for (int b = q; b < blocks; b += kSlices) { a0 += part[((size_t)b * 2) * Co + c]; a1 += part[((size_t)b * 2 + 1) * Co + c]; }
+  }
   red[0][threadIdx.x] = a0;
   red[1][threadIdx.x] = a1;
   __syncthreads();
   if (q != 0 || c >= Co) return false;
   s0 = 0.0; s1 = 0.0;
-  for (int r = 0; r < kFinSlices; ++r) { s0 += red[0][r * kFinCh + cl]; s1 += red[1][r * kFinCh + cl]; }
+  for (int r = 0; r < kSlices; ++r) { s0 += red[0][r * kFinCh + cl]; s1 += red[1][r * kFinCh + cl]; }
   return true;
 }
 
@@ -294,7 +300,7 @@ __global__ __launch_bounds__(kFinThreads) void edgeconv_stats_finalize_kernel(co
                                                int Co, int training, float* __restrict__ chan) {
   int c;
   double s0, s1;
-  if (!part_sums(training ? part : nullptr, blocks, Co, c, s0, s1)) return;
+  if (!part_sums<kFinThreads>(training ? part : nullptr, blocks, Co, c, s0, s1)) return;
   float mean, var;
   if (training) {
     const double m = s0 / count;
@@ -321,12 +327,12 @@ __global__ __launch_bounds__(kFinThreads) void edgeconv_stats_finalize_kernel(co
 
 // backward: the sums of dz and dz * ysel -> dbeta, dgamma = (sum dz*ysel - mean * sum dz) * rstd, and the coefficients
 // coef [3][Co] = (scale * dbeta / count, scale * rstd * dgamma / count, mean) of fpsg_edgeconv_bwd (zeros in eval mode)
-__global__ __launch_bounds__(kFinThreads) void edgeconv_bwd_finalize_kernel(const float* __restrict__ part, int blocks, const float* __restrict__ chan,
+__global__ __launch_bounds__(kFinBwdThreads) void edgeconv_bwd_finalize_kernel(const float* __restrict__ part, int blocks, const float* __restrict__ chan,
                                              double count, int Co, int training, float* __restrict__ dgamma,
                                              float* __restrict__ dbeta, float* __restrict__ coef) {
   int c;
   double s0, s1;
-  if (!part_sums(part, blocks, Co, c, s0, s1)) return;
+  if (!part_sums<kFinBwdThreads>(part, blocks, Co, c, s0, s1)) return;
   const float scale = chan[c], mean = chan[2 * Co + c], rstd = chan[3 * Co + c];
   const float db = (float)s0;
   const float dg = (float)((s1 - (double)mean * s0) * (double)rstd);
@@ -523,7 +529,7 @@ extern "C" int fpsg_edgeconv_bwd_finalize(const float* part, int blocks, const f
   FPSG_REQUIRE(Co > 0 && count > 0.0 && blocks > 0, FPSG_E_SHAPE,
                "fpsg_edgeconv_bwd_finalize: Co, blocks and count must be positive (got %d, %d, %g)", Co, blocks, count);
   FPSG_REQUIRE_PTR(part); FPSG_REQUIRE_PTR(chan); FPSG_REQUIRE_PTR(dgamma); FPSG_REQUIRE_PTR(dbeta); FPSG_REQUIRE_PTR(coef);
-  hipLaunchKernelGGL(edgeconv_bwd_finalize_kernel, dim3((unsigned)((Co + kFinCh - 1) / kFinCh)), dim3(kFinThreads), 0, static_cast<hipStream_t>(stream),
+  hipLaunchKernelGGL(edgeconv_bwd_finalize_kernel, dim3((unsigned)((Co + kFinCh - 1) / kFinCh)), dim3(kFinBwdThreads), 0, static_cast<hipStream_t>(stream),
                      part, blocks, chan, count, Co, training, dgamma, dbeta, coef);
   return launch_status("fpsg_edgeconv_bwd_finalize");
 }
