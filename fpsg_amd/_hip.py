@@ -41,6 +41,7 @@ SIGNATURES = {
                               _c_int, _c_int, _c_int, _c_f32p, _c_f32p, _c_stream],
     "fpsg_knn_workspace_floats": [_c_int, _c_int, _c_int],
     "fpsg_knn": [_c_f32p, _c_int, _c_int, _c_int, _c_int, _c_i32p, _c_f32p, _c_stream],
+    "fpsg_knn_ex": [_c_f32p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_i32p, _c_f32p, _c_int, _c_stream],
     "fpsg_edge_feature_fwd": [_c_f32p, _c_i32p, _c_int, _c_int, _c_int, _c_int, _c_f32p, _c_stream],
     "fpsg_edge_feature_bwd": [_c_f32p, _c_i32p, _c_int, _c_int, _c_int, _c_int, _c_f32p, _c_stream],
     "fpsg_edgeconv_blocks": [_c_int, _c_int, _c_int],

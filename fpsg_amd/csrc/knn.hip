@@ -19,7 +19,7 @@
 //            go to the lower index), then only the winner's group -- wave-uniform, so a
 //            scalar branch -- is rescanned.  No LDS traffic inside the rounds.
 // Results are bit-identical to oracle_knn (same fma chains, same tie rule).
-#include "fpsg_common.h"
+#include "knn_internal.h"
 
 namespace fpsg {
 namespace {
@@ -80,10 +80,7 @@ __global__ __launch_bounds__(256) void knn_prep_kernel(const float* __restrict__
   }
 }
 
-__device__ __forceinline__ unsigned orderable(float f) {
-  const unsigned u = __float_as_uint(f);
-  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-}
+__device__ __forceinline__ unsigned orderable(float f) { return knn_orderable(f); }
 
 // ---- wave-wide reductions with DPP row operations (gfx9 encodings) ----------------------
 template <int CTRL, int ROW_MASK>
@@ -527,25 +524,21 @@ inline bool knn_uses_pm(int C) { return C % 16 == 0 && C > 32 && C <= 128; }
 
 extern "C" size_t fpsg_knn_workspace_floats(int B, int C, int N) {
   if (B <= 0 || C <= 0 || N <= 0) return 0;
-  return (size_t)B * N + (fpsg::knn_uses_pm(C) ? (size_t)B * N * C : 0);
+  const size_t bn = (((size_t)B * N + 3) / 4) * 4;      // the feature copy starts 16-byte aligned
+  const size_t tile_copy = fpsg::knn_uses_pm(C) ? (size_t)B * N * C : 0;
+  const size_t stream_copy = (size_t)B * N * fpsg::knn_stream_cpad(C);
+  return bn + (tile_copy > stream_copy ? tile_copy : stream_copy);
 }
 
-extern "C" int fpsg_knn(const float* x, int B, int C, int N, int k, int32_t* idx,
-                        float* ws, fpsg_stream_t stream) {
-  using namespace fpsg;
-  FPSG_REQUIRE(B > 0 && C > 0 && N > 0 && k > 0, FPSG_E_SHAPE,
-               "fpsg_knn: B,C,N,k must be positive (got %d,%d,%d,%d)", B, C, N, k);
-  FPSG_REQUIRE(k <= 64 && k <= N, FPSG_E_LIMIT, "fpsg_knn: need k <= min(64, N) (k=%d, N=%d)", k, N);
-  FPSG_REQUIRE(C <= 440 && (long)N <= (1L << 24), FPSG_E_LIMIT,
-               "fpsg_knn: C=%d exceeds 440 (16 x C query tile beside the 128 KiB score tile) or N=%d > 2^24", C, N);
-  FPSG_REQUIRE(B <= 65535, FPSG_E_LIMIT, "fpsg_knn: B=%d exceeds 65535", B);
-  FPSG_REQUIRE_PTR(x); FPSG_REQUIRE_PTR(idx); FPSG_REQUIRE_PTR(ws);
-  hipStream_t s = static_cast<hipStream_t>(stream);
+namespace fpsg {
+namespace {
+// the score-tile kernel (any C <= 440, k <= 64): x channel-major
+int knn_tile(const float* x, int B, int C, int N, int k, int32_t* idx, float* ws, hipStream_t s) {
   float* xx = ws;
   float* xk = nullptr;
   // the point-major copy needs 16-byte aligned rows; otherwise the channel-major operands are read as before
-  if (knn_uses_pm(C) && (reinterpret_cast<uintptr_t>(ws) & 15) == 0 && (((size_t)B * N) & 3) == 0) {
-    xk = ws + (size_t)B * N;
+  if (knn_uses_pm(C) && (reinterpret_cast<uintptr_t>(ws) & 15) == 0) {
+    xk = ws + (((size_t)B * N + 3) / 4) * 4;
     hipLaunchKernelGGL(knn_prep_kernel, dim3((N + kPrepPts - 1) / kPrepPts, B), dim3(256),
                        (size_t)kPrepPts * (C + 4) * sizeof(float), s, x, C, N, xx, xk);
   } else {
@@ -557,4 +550,39 @@ extern "C" int fpsg_knn(const float* x, int B, int C, int N, int k, int32_t* idx
   if (vpl <= 8) return launch_knn_c<8>(x, xx, xk, B, C, N, k, idx, s);
   if (vpl <= 16) return launch_knn_c<16>(x, xx, xk, B, C, N, k, idx, s);
   return launch_knn_c<32>(x, xx, xk, B, C, N, k, idx, s);   // N > 2048: chunks of 2048 columns
+}
+}  // namespace
+}  // namespace fpsg
+
+extern "C" int fpsg_knn_ex(const float* x, int layout, int B, int C, int N, int k, int32_t* idx, float* ws,
+                           int flags, fpsg_stream_t stream) {
+  using namespace fpsg;
+  FPSG_REQUIRE(B > 0 && C > 0 && N > 0 && k > 0, FPSG_E_SHAPE,
+               "fpsg_knn: B,C,N,k must be positive (got %d,%d,%d,%d)", B, C, N, k);
+  FPSG_REQUIRE(k <= 64 && k <= N, FPSG_E_LIMIT, "fpsg_knn: need k <= min(64, N) (k=%d, N=%d)", k, N);
+  FPSG_REQUIRE(C <= 440 && (long)N <= (1L << 24), FPSG_E_LIMIT,
+               "fpsg_knn: C=%d exceeds 440 (16 x C query tile beside the 128 KiB score tile) or N=%d > 2^24", C, N);
+  FPSG_REQUIRE(B <= 65535, FPSG_E_LIMIT, "fpsg_knn: B=%d exceeds 65535", B);
+  FPSG_REQUIRE(layout == FPSG_KNN_CHANNEL_MAJOR || layout == FPSG_KNN_POINT_MAJOR, FPSG_E_SHAPE,
+               "fpsg_knn: layout %d is neither FPSG_KNN_CHANNEL_MAJOR nor FPSG_KNN_POINT_MAJOR", layout);
+  FPSG_REQUIRE_PTR(x); FPSG_REQUIRE_PTR(idx); FPSG_REQUIRE_PTR(ws);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const bool stream_ok = knn_stream_serves(C, k) && (reinterpret_cast<uintptr_t>(ws) & 15) == 0 &&
+                         !(flags & FPSG_KNN_FORCE_TILE);
+  if (stream_ok) {
+    float* xx = ws;
+    float* xk = ws + (((size_t)B * N + 3) / 4) * 4;
+    int rc = knn_stream_prepare(x, layout == FPSG_KNN_POINT_MAJOR, B, C, N, xx, xk, s);
+    if (rc) return rc;
+    return knn_stream_launch(xk, xx, B, C, N, k, (flags & FPSG_KNN_FORCE_SLOW) ? 1 : 0, idx, s);
+  }
+  FPSG_REQUIRE(layout == FPSG_KNN_CHANNEL_MAJOR, FPSG_E_LIMIT,
+               "fpsg_knn: point-major features are served for C <= 128 and k <= 24 with a 16-byte aligned workspace "
+               "(C=%d, k=%d)", C, k);
+  return knn_tile(x, B, C, N, k, idx, ws, s);
+}
+
+extern "C" int fpsg_knn(const float* x, int B, int C, int N, int k, int32_t* idx,
+                        float* ws, fpsg_stream_t stream) {
+  return fpsg_knn_ex(x, FPSG_KNN_CHANNEL_MAJOR, B, C, N, k, idx, ws, 0, stream);
 }

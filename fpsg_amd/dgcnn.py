@@ -4,8 +4,8 @@ Mirrors reference ``src/dgcnn/model.py``: ``knn :13-20``, ``get_graph_feature :2
 ``DGCNNfeat :45-88`` (same constructor, same ``conv1..conv5`` ``nn.Sequential`` layout, hence
 the same state-dict keys ``conv<i>.0.weight``, ``conv<i>.1.{weight,bias,running_*}``).
 
-  * ``knn`` -> ``fpsg_knn`` (K3): MFMA distance tiles + in-LDS top-k; the [B,N,N] matrix of
-    the reference is never materialised.  Returns int64 ``[B,N,k]`` like ``topk``.
+  * ``knn`` -> ``fpsg_knn`` / ``fpsg_knn_ex`` (K3): MFMA distance tiles + a streaming top-k on the accumulator
+    layout; the [B,N,N] matrix of the reference is never materialised.  Returns int64 ``[B,N,k]`` like ``topk``.
   * ``get_graph_feature`` -> ``fpsg_edge_feature_fwd/bwd`` (K4a): one gather pass writing
     ``[B,2C,N,k]`` (drop-in form; no hard-coded ``torch.device('cuda')``: the device is the
     input's).
@@ -29,22 +29,35 @@ from .bn_counters import count_batch
 from .fused_bn import bn_act
 
 
-def knn_int32(x: torch.Tensor, k: int) -> torch.Tensor:
-    """``x [B,C,N]`` fp32 on a ROCm device -> int32 ``[B,N,k]`` neighbour indices."""
+KNN_CHANNEL_MAJOR, KNN_POINT_MAJOR = 0, 1          # FPSG_KNN_* of include/fpsg_hip.h
+KNN_FORCE_TILE, KNN_FORCE_SLOW = 1, 2
+
+
+def knn_int32(x: torch.Tensor, k: int, point_major: bool = False, flags: int = 0) -> torch.Tensor:
+    """``x [B,C,N]`` (``point_major``: ``[B,N,C]``, what the fused EdgeConv layers produce) fp32 on a ROCm device
+    -> int32 ``[B,N,k]`` neighbour indices.  ``flags``: ``KNN_FORCE_TILE`` / ``KNN_FORCE_SLOW`` (tests, A/B)."""
     if x.dim() != 3:
         raise ValueError(f"expected x [B,C,N], got {tuple(x.shape)}")
     x = _hip.dev_tensor(x.detach() if x.requires_grad else x, torch.float32, "x")
-    B, C, N = x.shape
+    if point_major:
+        B, N, C = x.shape
+    else:
+        B, C, N = x.shape
     if not 0 < k <= min(N, 64):
         raise ValueError(f"k={k} must be in [1, min(N, 64)] (N={N})")
     idx = torch.empty((B, N, k), dtype=torch.int32, device=x.device)
     lib = _hip.load()
     ws = torch.empty((lib.fpsg_knn_workspace_floats(B, C, N),), dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
-        rc = lib.fpsg_knn(_hip.ptr(x), B, C, N, k, _hip.ptr(idx), _hip.ptr(ws),
-                                  _hip.stream_of(x))
+        rc = lib.fpsg_knn_ex(_hip.ptr(x), KNN_POINT_MAJOR if point_major else KNN_CHANNEL_MAJOR, B, C, N, k,
+                             _hip.ptr(idx), _hip.ptr(ws), flags, _hip.stream_of(x))
     _hip.check(rc, "fpsg_knn")
     return idx
+
+
+def knn_serves_point_major(C: int, k: int) -> bool:
+    """Whether ``fpsg_knn_ex`` takes ``[B,N,C]`` features as they are (the streaming kernel's range)."""
+    return C <= 128 and k <= 24
 
 
 def knn(x: torch.Tensor, k: int) -> torch.Tensor:
@@ -304,16 +317,16 @@ class DGCNNfeat(nn.Module):
         if not self.fused:
             return self._forward_unfused(x)
         B, _, N = x.shape
-        x_cm = x.contiguous()                       # channel-major for the kNN kernel
-        x_pm = x_cm.transpose(1, 2).contiguous()    # point-major for the GEMM / gather
+        x_pm = x.transpose(1, 2).contiguous()       # point-major for the GEMM / gather; the graph kernel takes it too
         feats = []
         blocks = (self.conv1, self.conv2, self.conv3, self.conv4)
-        for li, block in enumerate(blocks):
-            idx32 = knn_int32(x_cm, self.k)
-            x_pm = edgeconv_fused(x_pm, idx32, block)             # [B,N,Co]
+        for block in blocks:
+            if knn_serves_point_major(x_pm.size(2), self.k):
+                idx32 = knn_int32(x_pm, self.k, point_major=True)
+            else:
+                idx32 = knn_int32(x_pm.transpose(1, 2).contiguous(), self.k)
+            x_pm = edgeconv_fused(x_pm, idx32, block)             # [B,N,Co]; the next layer's graph is built on these
             feats.append(x_pm)
-            if li + 1 < len(blocks):                              # the next layer's graph is built on these features
-                x_cm = x_pm.transpose(1, 2).contiguous()
         cat = torch.cat(feats, dim=2)                              # [B,N,512]
         conv5, bn5, act5 = self.conv5[0], self.conv5[1], self.conv5[2]
         h = _PointwiseOnCat.apply(cat, conv5.weight.squeeze(-1))       # Conv1d(512,emb,1) -> [B,emb,N]

@@ -104,17 +104,31 @@ int fpsg_chamfer_bwd_scan(const float* xyz1, const float* xyz2,
 
 /* ---- K3: kNN graph ----------------------------------------------------------------
  * Replaces `knn(x, k)` of src/dgcnn/model.py:13-20 (torch.matmul into a [B,N,N] matrix +
- * torch.topk).  x [B,C,N] fp32 channel-major; idx [B,N,k] int32: for every point the k
+ * torch.topk).  x [B,C,N] fp32 channel-major (the reference's layout); idx [B,N,k] int32: for every point the k
  * points with the largest  pd_ij = (-|x_j|^2 + 2 x_i.x_j) - |x_i|^2, nearest first (self
  * included), equal values -> lower index first.  ws: caller scratch of fpsg_knn_workspace_floats(B,C,N) floats,
- * 16-byte aligned (squared norms; for C = 48..128, a multiple of 16, also a point-major k-interleaved copy of x
- * that lets a lane fetch its MFMA operands of four channel steps with one 16-byte load).
- * Limits: k <= min(64, N), C <= 440.  Any N: the score tile in LDS covers 2048 candidates at a
- * time, longer clouds are processed in chunks whose sorted top-k lists are merged.
+ * 16-byte aligned (squared norms + a zero-padded, point-major, k-interleaved copy of x whose 16-byte pieces are the
+ * MFMA operands of four channel steps).
+ * Two kernels, identical results (bit for bit the oracle's):
+ *   - C <= 128 and k <= 24: the streaming kernel (knn_stream.hip) -- a workgroup owns 128 queries, the cloud's
+ *     candidates pass once through LDS, a row keeps only the scores above a running lower bound of its k-th best;
+ *   - otherwise (C <= 440, k <= 64): the score-tile kernel (knn.hip) -- 16 queries per workgroup, their scores
+ *     against 2048 candidates at a time in LDS, longer clouds in chunks whose sorted top-k lists are merged.
+ * fpsg_knn_ex: `layout` says how x is stored -- FPSG_KNN_CHANNEL_MAJOR [B,C,N] or FPSG_KNN_POINT_MAJOR [B,N,C]
+ * (what the fused EdgeConv layers produce; only where the streaming kernel serves, FPSG_E_LIMIT otherwise);
+ * `flags`: FPSG_KNN_FORCE_TILE selects the score-tile kernel, FPSG_KNN_FORCE_SLOW makes every wave of the streaming
+ * kernel take its slow exact path (the one a row buffer that cannot be compacted falls back to) -- both for tests
+ * and A/B timing.  fpsg_knn(x, ...) = fpsg_knn_ex(x, FPSG_KNN_CHANNEL_MAJOR, ..., 0).
  */
+#define FPSG_KNN_CHANNEL_MAJOR 0
+#define FPSG_KNN_POINT_MAJOR   1
+#define FPSG_KNN_FORCE_TILE    1
+#define FPSG_KNN_FORCE_SLOW    2
 size_t fpsg_knn_workspace_floats(int B, int C, int N);
 int fpsg_knn(const float* x, int B, int C, int N, int k, int32_t* idx, float* ws,
              fpsg_stream_t stream);
+int fpsg_knn_ex(const float* x, int layout, int B, int C, int N, int k, int32_t* idx, float* ws,
+                int flags, fpsg_stream_t stream);
 
 /* ---- K4a: EdgeConv edge features (materialising form) ------------------------------
  * Replaces `get_graph_feature(x, k, idx)` of src/dgcnn/model.py:23-42.

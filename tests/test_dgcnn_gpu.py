@@ -41,6 +41,49 @@ def test_knn_ties_and_duplicates(gpu, oracle):
     assert np.array_equal(got, oracle.knn(x, 20))
 
 
+# the streaming kernel's range (C <= 128, k <= 24), sizes around its tiles: 16-candidate tiles, 32-/64-/512-candidate
+# stages, 128-query workgroups, more than 8 clouds (the cloud -> XCD mapping), k odd / 1 / 24
+STREAM_SHAPES = [(1, 3, 16, 5), (1, 3, 31, 20), (2, 3, 129, 20), (9, 3, 300, 20), (1, 3, 513, 7), (3, 3, 1024, 24),
+                 (1, 64, 64, 20), (2, 64, 65, 1), (1, 64, 1000, 20), (1, 48, 257, 9), (1, 128, 33, 20), (2, 128, 200, 13),
+                 (1, 100, 777, 20), (1, 17, 2048, 20), (10, 64, 256, 20)]
+
+
+@pytest.mark.parametrize("B,C,N,k", STREAM_SHAPES)
+def test_knn_kernels_and_layouts_agree_with_oracle(gpu, oracle, B, C, N, k):
+    """The streaming kernel (default in this range), its slow exact path, the score-tile kernel and the point-major
+    entry all give the oracle's lists."""
+    from fpsg_amd.dgcnn import KNN_FORCE_SLOW, KNN_FORCE_TILE, knn_int32
+    rng = np.random.default_rng(B * 11 + C * 5 + N + k)
+    x = rng.standard_normal((B, C, N)).astype(np.float32)
+    exp = oracle.knn(x, k)
+    xt = torch.from_numpy(x).to(gpu)
+    assert np.array_equal(knn_int32(xt, k).cpu().numpy(), exp)
+    assert np.array_equal(knn_int32(xt, k, flags=KNN_FORCE_SLOW).cpu().numpy(), exp)
+    assert np.array_equal(knn_int32(xt, k, flags=KNN_FORCE_TILE).cpu().numpy(), exp)
+    assert np.array_equal(knn_int32(xt.transpose(1, 2).contiguous(), k, point_major=True).cpu().numpy(), exp)
+
+
+def test_knn_many_equal_scores_take_the_slow_path(gpu, oracle):
+    """Hundreds of coincident points: a row's buffer cannot be compacted under its watermark, so the wave falls back to
+    its masked arg-max sweeps -- same lists as the oracle (lowest index first among equal scores)."""
+    from fpsg_amd.dgcnn import knn_int32
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((2, 64, 640)).astype(np.float32)
+    x[:, :, 100:400] = x[:, :, 100:101]                 # 300 copies of one point
+    x[1, :, :] = 0.0                                    # a cloud collapsed to one point: every score equal
+    got = knn_int32(torch.from_numpy(x).to(gpu), 20).cpu().numpy()
+    assert np.array_equal(got, oracle.knn(x, 20))
+
+
+def test_knn_point_major_is_refused_outside_the_streaming_range(gpu):
+    from fpsg_amd.dgcnn import knn_int32
+    from fpsg_amd._hip import FpsgHipError
+    with pytest.raises(FpsgHipError):
+        knn_int32(torch.rand(1, 64, 200, device=gpu), 20, point_major=True)      # C = 200
+    with pytest.raises(FpsgHipError):
+        knn_int32(torch.rand(1, 64, 16, device=gpu), 32, point_major=True)       # k = 32
+
+
 @pytest.mark.parametrize("tag", ["c3_n256", "c3_n2048", "c64_n256", "c64_n2048"])
 def test_knn_matches_reference_function(gpu, gold, tag):
     """Against reference knn() outputs: identical neighbour sets except fp32 near-ties
