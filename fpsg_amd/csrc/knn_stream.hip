@@ -11,18 +11,20 @@
 // against candidate c, so a register holds 4 rows x 16 candidates and every vector instruction serves 4 rows):
 //   * a score that reaches its row's threshold T is appended (score bits, index) to the row's 120-entry buffer in
 //     LDS, its slot taken with an LDS atomic;
-//   * T is a lower bound of the row's k-th best score: every lane tracks the two best scores it has seen for each of
-//     its rows (v_max / v_med3); if at least ceil(k/2) of a row's 16 lanes hold a second-best >= w, then k scores
-//     are >= w.  The largest such w comes from 15 DPP row rotations, at fixed tiles (x1.5 in the number of
-//     candidates seen) and whenever a buffer passes its watermark; the same event drops the buffered entries below
-//     the new T (16 lanes per row, 4 rows at a time).  Between two checks (2 tiles) a row receives at most 32
-//     entries, and a check leaves at most 88: a slot index cannot pass the buffer's end;
-//   * after the sweep a row's buffer holds every score >= its final T (about 2.3 k of them): they are ranked by
+//   * T is a lower bound of the row's k-th best score, raised by events: the 16 lanes of a row split its buffered
+//     entries, each finds the two best of its share (v_max / v_med3); if at least ceil(k/2) lanes hold a second-best
+//     >= w, then k buffered scores are >= w.  The largest such w comes from 15 DPP row rotations, and the same pass
+//     drops the entries below the new T (4 rows at a time).  Events run at fixed tiles (x2.25 in the number of
+//     candidates seen: five per 2048-point cloud) and whenever a buffer passes its watermark.  Between two checks
+//     (2 tiles) a row receives at most 32 entries, and a check leaves at most 88: a slot index cannot pass the
+//     buffer's end;
+//   * after the sweep a row's buffer holds every score >= its final T (about 1.4 k of them): they are ranked by
 //     counting on 64-bit keys (orderable score << 32 | ~index: score descending, then index ascending -- the order of
 //     the oracle's rounds) and the first k are written.
-// If a compaction cannot bring a buffer under the watermark (hundreds of equal scores), the wave finishes the sweep
-// without selecting and then runs k masked arg-max sweeps over the cloud straight from global memory: slow, exact.
-// Results are bit-identical to oracle_knn either way.
+// If a compaction cannot bring a buffer under the watermark (a loose early threshold, hundreds of equal scores), the
+// row's entries are ranked on the spot, its k best stay and the k-th score becomes its threshold.  A second, independent
+// selection is kept for tests (FPSG_KNN_FORCE_SLOW): k masked arg-max sweeps over the cloud straight from global
+// memory.  Results are bit-identical to oracle_knn either way.
 #include "knn_internal.h"
 
 namespace fpsg {
@@ -42,7 +44,8 @@ template <> struct StreamCfg<32> { static constexpr int TC = 32; };    // 16 KB
 template <int C4T>
 constexpr size_t stream_lds_bytes() {
   constexpr int TC = StreamCfg<C4T>::TC;
-  return (size_t)2 * TC * 4 * C4T * 4 + (size_t)2 * TC * 4 + (size_t)kSRows * 4 + (size_t)kSRows * kCap * 8;
+  return (size_t)2 * TC * 4 * C4T * 4 + (size_t)2 * TC * 4 + (size_t)kSRows * 4 + (size_t)kSW * 4 +
+         (size_t)kSRows * kCap * 8;
 }
 
 // ---- prepare: squared norms + the k-interleaved, zero-padded point-major copy ------------------------------------
@@ -124,6 +127,13 @@ __device__ __forceinline__ int row16_count_ge(float w, int acc) {
   }
 }
 
+// v_max_f32 as it is: the builtin adds two canonicalising moves per call, and NaN scores are outside the contract
+__device__ __forceinline__ float raw_max(float a, float b) {
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
 __device__ __forceinline__ unsigned long long knn_key(float score, unsigned j) {
   return ((unsigned long long)knn_orderable(score + 0.0f) << 32) | (unsigned)~j;
 }
@@ -145,7 +155,8 @@ __global__ __launch_bounds__(64 * kSW) void knn_stream_kernel(const float* __res
   float* stage = lds;                                           // [2][TC * CP]
   float* sxx = stage + 2 * TC * CP;                             // [2][TC]
   unsigned* cnt = reinterpret_cast<unsigned*>(sxx + 2 * TC);    // [kSRows]
-  Entry* buf = reinterpret_cast<Entry*>(cnt + kSRows);          // [kSRows][kCap]
+  unsigned* tsl = cnt + kSRows;                                 // [kSW]: a wave's word for the exact compaction
+  Entry* buf = reinterpret_cast<Entry*>(tsl + kSW);             // [kSRows][kCap]
 
   // clouds -> XCDs: workgroup ids go round-robin over the 8 XCDs, so the row blocks of one cloud take ids of one
   // residue class and its features are served by one L2
@@ -191,11 +202,11 @@ __global__ __launch_bounds__(64 * kSW) void knn_stream_kernel(const float* __res
   const int row0 = wave * 16 + 4 * kk;                          // this lane's rows: row0 + rr
   if (lane < 16) cnt[wave * 16 + lane] = 0u;
 
-  float T[4], m1[4], m2[4];
+  float T[4];
 #pragma unroll
-  for (int rr = 0; rr < 4; ++rr) { T[rr] = NEG; m1[rr] = NEG; m2[rr] = NEG; }
+  for (int rr = 0; rr < 4; ++rr) T[rr] = NEG;
   const int jsel = (k + 1) >> 1;
-  bool failed = (flags & 1) != 0;                               // wave-uniform
+  const bool failed = (flags & 1) != 0;                         // wave-uniform: the slow exact path (tests, A/B)
 
   // ---- stage transfer --------------------------------------------------------------------------------------------
   v4f pre[NU];
@@ -233,17 +244,11 @@ __global__ __launch_bounds__(64 * kSW) void knn_stream_kernel(const float* __res
   };
 
   // ---- selection pieces ------------------------------------------------------------------------------------------
-  auto raise_thresholds = [&]() {
-#pragma unroll
-    for (int rr = 0; rr < 4; ++rr) {
-      const float w = m2[rr];
-      const int ge = row16_count_ge<1>(w, 1);
-      const float cand = row16_max(ge >= jsel ? w : NEG);
-      T[rr] = __builtin_fmaxf(T[rr], cand);
-    }
-  };
-  // drop the buffered entries below T: 16 lanes per row, the 4 rows of a register index at a time
-  auto filter_rows = [&]() {
+  // An event raises the rows' thresholds and drops the buffered entries below them: 16 lanes per row, the 4 rows of a
+  // register index at a time.  Lane c of a row holds its entries c, c + 16, ... (distinct candidates, all >= the old
+  // T) and finds the two best of them; if at least ceil(k/2) lanes hold a second-best >= w, then k buffered scores are
+  // >= w, so w is a lower bound of the row's k-th best score.  The largest such w comes from 15 DPP row rotations.
+  auto raise_and_filter = [&]() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -251,17 +256,37 @@ __global__ __launch_bounds__(64 * kSW) void knn_stream_kernel(const float* __res
     for (int rr = 0; rr < 4; ++rr) {
       const int row = row0 + rr;
       const int c = (int)cnt[row];
+      int cmax = __builtin_amdgcn_readlane(c, 0);                    // the longest of the four rows: wave-uniform
+      cmax = max(cmax, __builtin_amdgcn_readlane(c, 16));
+      cmax = max(cmax, __builtin_amdgcn_readlane(c, 32));
+      cmax = max(cmax, __builtin_amdgcn_readlane(c, 48));
       Entry* rb = buf + row * kCap;
       Entry e[kFilterIters];
+      float sc[kFilterIters];
+      float a1 = NEG, a2 = NEG;
+#pragma unroll
+      for (int i = 0; i < kFilterIters; ++i) {
+        sc[i] = NEG;
+        if (16 * i < cmax) {
+          const int p = col + 16 * i;
+          const bool valid = p < c;
+          e[i] = rb[valid ? p : 0];
+          sc[i] = valid ? __uint_as_float(e[i].s) : NEG;
+          a2 = __builtin_amdgcn_fmed3f(a1, a2, sc[i]);
+          a1 = raw_max(a1, sc[i]);
+        }
+      }
+      const int ge = row16_count_ge<1>(a2, 1);
+      T[rr] = __builtin_fmaxf(T[rr], row16_max(ge >= jsel ? a2 : NEG));
       int keep[kFilterIters];
       int n = 0;
 #pragma unroll
       for (int i = 0; i < kFilterIters; ++i) {
-        const int p = col + 16 * i;
-        const bool valid = p < c;
-        e[i] = rb[valid ? p : 0];
-        keep[i] = (valid && __uint_as_float(e[i].s) >= T[rr]) ? 1 : 0;
-        n += keep[i];
+        keep[i] = 0;
+        if (16 * i < cmax) {
+          keep[i] = (col + 16 * i < c && sc[i] >= T[rr]) ? 1 : 0;
+          n += keep[i];
+        }
       }
       int inc = n;                                   // inclusive scan over the row's 16 lanes
       inc += dpp_i0<0x111>(inc);                     // row_shr:1
@@ -272,8 +297,10 @@ __global__ __launch_bounds__(64 * kSW) void knn_stream_kernel(const float* __res
       __builtin_amdgcn_wave_barrier();               // every read of this row precedes the writes (in-order LDS queue)
 #pragma unroll
       for (int i = 0; i < kFilterIters; ++i) {
-        if (keep[i]) rb[pos] = e[i];
-        pos += keep[i];
+        if (16 * i < cmax) {
+          if (keep[i]) rb[pos] = e[i];
+          pos += keep[i];
+        }
       }
       if (col == 15) cnt[row] = (unsigned)inc;
     }
@@ -281,34 +308,107 @@ __global__ __launch_bounds__(64 * kSW) void knn_stream_kernel(const float* __res
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   };
+  // the c buffered entries of a row -> 64-bit keys in place and every entry's rank among them (wave-level; lane l
+  // holds entries l and l + 64)
+  auto rank_row = [&](int row, int c, Entry& e0, Entry& e1, unsigned long long& k0, unsigned long long& k1, int& r0,
+                      int& r1) {
+    unsigned long long* rk = reinterpret_cast<unsigned long long*>(buf) + (size_t)row * kCap;
+    const bool h0 = lane < c, h1 = lane + 64 < c;
+    e0 = buf[row * kCap + (h0 ? lane : 0)];
+    e1 = buf[row * kCap + (h1 ? lane + 64 : 0)];
+    k0 = h0 ? knn_key(__uint_as_float(e0.s), e0.j) : 0ull;
+    k1 = h1 ? knn_key(__uint_as_float(e1.s), e1.j) : 0ull;
+    __builtin_amdgcn_wave_barrier();
+    if (h0) rk[lane] = k0;                           // a lane rewrites only its own slots
+    if (h1) rk[lane + 64] = k1;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    r0 = 0;
+    r1 = 0;
+    if (c <= 64) {
+#pragma unroll 4
+      for (int l = 0; l < c; ++l) r0 += rk[l] > k0 ? 1 : 0;
+    } else {
+#pragma unroll 2
+      for (int l = 0; l < c; ++l) {
+        const unsigned long long o = rk[l];
+        r0 += o > k0 ? 1 : 0;
+        r1 += o > k1 ? 1 : 0;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();                 // the keys have been read: the slots may be rewritten
+  };
+  // a row the filter left over the watermark (a loose early threshold, many equal scores): keep exactly its k best
+  // entries and take the k-th score as the row's threshold -- nothing below the k best seen so far can be selected
+  auto exact_compact = [&]() {
+    for (int r = 0; r < 16; ++r) {
+      const int row = wave * 16 + r;
+      const int c = __builtin_amdgcn_readfirstlane((int)cnt[row]);
+      if (c <= kWM) continue;
+      Entry e0, e1;
+      unsigned long long k0, k1;
+      int r0, r1;
+      rank_row(row, c, e0, e1, k0, k1, r0, r1);
+      const bool h0 = lane < c, h1 = lane + 64 < c;
+      Entry* rb = buf + row * kCap;
+      if (h0 && r0 < k) rb[r0] = e0;
+      if (h1 && r1 < k) rb[r1] = e1;
+      if (h0 && r0 == k - 1) tsl[wave] = e0.s;
+      if (h1 && r1 == k - 1) tsl[wave] = e1.s;
+      if (lane == 0) cnt[row] = (unsigned)k;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      const float tn = __uint_as_float(tsl[wave]);
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr)
+        T[rr] = (kk == (r >> 2) && rr == (r & 3)) ? __builtin_fmaxf(T[rr], tn) : T[rr];
+    }
+  };
   auto over_watermark = [&]() -> bool {
     const unsigned c = cnt[wave * 16 + col];
     return __builtin_amdgcn_ballot_w64(c > (unsigned)kWM) != 0ull;
   };
   auto event = [&]() {
-    raise_thresholds();
-    filter_rows();
-    if (over_watermark()) failed = true;             // e.g. hundreds of equal scores: the slow path decides
+    raise_and_filter();
+    if (over_watermark()) exact_compact();
   };
-  // the scores of tile t (accumulator layout) -> tracking, threshold test, append
-  auto select_tile = [&](const v4f& acc, int t, float xxj) {
-    const unsigned j = (unsigned)(16 * t + col);
+  // the scores of tiles t, t + 1 (accumulator layout) -> threshold test, append.  A lane's rows are the same in both
+  // tiles, so one LDS atomic per register index takes the slots of both; the four atomics of a pair are issued
+  // together (one round trip).  Returns whether a row passed its watermark: the lane that took a row's last slot knows
+  // the row's new count.  (Skipping the append of a register index none of whose 128 scores passes was measured: the
+  // four ballots and scalar branches per pair cost more than they save, 324 -> 372 us at C = 3.)
+  auto select_pair = [&](const v4f& acc0, const v4f& acc1, int t, float xx0, float xx1) -> bool {
+    const unsigned j0 = (unsigned)(16 * t + col);
+    float v0[4], v1[4];
+    unsigned pos[4];
+    bool p0[4], p1[4];
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) {
-      const float v = fma_rn(2.0f, acc[rr], -xxj) - xxq[rr];
-      m2[rr] = __builtin_amdgcn_fmed3f(m1[rr], m2[rr], v);
-      m1[rr] = __builtin_fmaxf(m1[rr], v);
-      const bool pass = v >= T[rr];
-      if (!failed && __builtin_amdgcn_ballot_w64(pass) != 0ull) {
-        if (pass) {
-          const unsigned pos = __hip_atomic_fetch_add(&cnt[row0 + rr], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-          Entry en;
-          en.s = __float_as_uint(v);
-          en.j = j;
-          buf[(row0 + rr) * kCap + pos] = en;
-        }
-      }
+      v0[rr] = fma_rn(2.0f, acc0[rr], -xx0) - xxq[rr];
+      v1[rr] = fma_rn(2.0f, acc1[rr], -xx1) - xxq[rr];
+      p0[rr] = v0[rr] >= T[rr];
+      p1[rr] = v1[rr] >= T[rr];
     }
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      pos[rr] = 0u;
+      if (p0[rr] || p1[rr])
+        pos[rr] = __hip_atomic_fetch_add(&cnt[row0 + rr], (p0[rr] ? 1u : 0u) + (p1[rr] ? 1u : 0u), __ATOMIC_RELAXED,
+                                         __HIP_MEMORY_SCOPE_WAVEFRONT);
+    }
+    unsigned top = 0u;                         // the largest new row count this lane knows of
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      Entry* rb = buf + (row0 + rr) * kCap;
+      const unsigned q1 = pos[rr] + (p0[rr] ? 1u : 0u);
+      if (p0[rr]) { Entry en; en.s = __float_as_uint(v0[rr]); en.j = j0; rb[pos[rr]] = en; }
+      if (p1[rr]) { Entry en; en.s = __float_as_uint(v1[rr]); en.j = j0 + 16u; rb[q1] = en; }
+      const unsigned endc = q1 + (p1[rr] ? 1u : 0u);      // pos = 0 for a lane that appended nothing
+      top = endc > top ? endc : top;
+    }
+    return __builtin_amdgcn_ballot_w64(top > (unsigned)kWM) != 0ull;
   };
 
   // ---- the sweep --------------------------------------------------------------------------------------------------
@@ -346,14 +446,12 @@ __global__ __launch_bounds__(64 * kSW) void knn_stream_kernel(const float* __res
       }
       const float xx0 = sxx[sel * TC + 16 * tt + col];
       const float xx1 = sxx[sel * TC + 16 * tt + 16 + col];
-      select_tile(acc0, t0 + tt, xx0);
-      select_tile(acc1, t0 + tt + 1, xx1);           // a tile past the cloud's end scores -inf everywhere
       if (!failed) {
+        const bool over = select_pair(acc0, acc1, t0 + tt, xx0, xx1);   // a tile past the cloud's end scores -inf
         const int t_end = t0 + tt + 1;
-        const bool over = over_watermark();
         if (over || t_end >= next_evt) {
           event();
-          next_evt = ((t_end + 1) * 3 / 2) | 1;
+          next_evt = ((t_end + 1) * 9 / 4) | 1;
         }
       }
     }
@@ -361,44 +459,21 @@ __global__ __launch_bounds__(64 * kSW) void knn_stream_kernel(const float* __res
     __syncthreads();
   }
 
-  if (!failed) event();
   if (!failed) {
+    event();
     // ---- rank the survivors of every row: wave-level, one row at a time ------------------------------------------
-    unsigned long long* kb = reinterpret_cast<unsigned long long*>(buf);
     for (int r = 0; r < 16; ++r) {
       const int row = wave * 16 + r;
       const int i = i0 + r;
       if (i >= N) break;
       const int c = __builtin_amdgcn_readfirstlane((int)cnt[row]);
-      unsigned long long* rk = kb + (size_t)row * kCap;
-      // entries -> keys, in place (a lane rewrites only its own slots)
-      const bool h0 = lane < c, h1 = lane + 64 < c;
-      const Entry e0 = buf[row * kCap + (h0 ? lane : 0)];
-      const Entry e1 = buf[row * kCap + (h1 ? lane + 64 : 0)];
-      const unsigned long long k0 = h0 ? knn_key(__uint_as_float(e0.s), e0.j) : 0ull;
-      const unsigned long long k1 = h1 ? knn_key(__uint_as_float(e1.s), e1.j) : 0ull;
-      __builtin_amdgcn_wave_barrier();
-      if (h0) rk[lane] = k0;
-      if (h1) rk[lane + 64] = k1;
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      int r0 = 0, r1 = 0;
-      if (c <= 64) {
-#pragma unroll 4
-        for (int l = 0; l < c; ++l) r0 += rk[l] > k0 ? 1 : 0;
-      } else {
-#pragma unroll 2
-        for (int l = 0; l < c; ++l) {
-          const unsigned long long o = rk[l];
-          r0 += o > k0 ? 1 : 0;
-          r1 += o > k1 ? 1 : 0;
-        }
-      }
+      Entry e0, e1;
+      unsigned long long k0, k1;
+      int r0, r1;
+      rank_row(row, c, e0, e1, k0, k1, r0, r1);
       int32_t* out = idx + ((size_t)b * N + i) * k;
-      if (h0 && r0 < k) out[r0] = (int32_t)~(unsigned)k0;
-      if (h1 && r1 < k) out[r1] = (int32_t)~(unsigned)k1;
-      __builtin_amdgcn_wave_barrier();
+      if (lane < c && r0 < k) out[r0] = (int32_t)~(unsigned)k0;
+      if (lane + 64 < c && r1 < k) out[r1] = (int32_t)~(unsigned)k1;
     }
     return;
   }

@@ -63,9 +63,9 @@ def test_knn_kernels_and_layouts_agree_with_oracle(gpu, oracle, B, C, N, k):
     assert np.array_equal(knn_int32(xt.transpose(1, 2).contiguous(), k, point_major=True).cpu().numpy(), exp)
 
 
-def test_knn_many_equal_scores_take_the_slow_path(gpu, oracle):
-    """Hundreds of coincident points: a row's buffer cannot be compacted under its watermark, so the wave falls back to
-    its masked arg-max sweeps -- same lists as the oracle (lowest index first among equal scores)."""
+def test_knn_many_equal_scores(gpu, oracle):
+    """Hundreds of coincident points: the threshold filter cannot bring a row's buffer under its watermark, so the row
+    is compacted to its exact k best -- same lists as the oracle (lowest index first among equal scores)."""
     from fpsg_amd.dgcnn import knn_int32
     rng = np.random.default_rng(5)
     x = rng.standard_normal((2, 64, 640)).astype(np.float32)
