@@ -3,24 +3,27 @@
 //
 // A workgroup (8 waves) owns 128 query points of one cloud, a wave 16 of them for the whole sweep.  The cloud's
 // candidates stream ONCE per workgroup through LDS in stages (a 16 KB tile of k-interleaved point-major features, two
-// buffers, one barrier per stage); every wave reads its MFMA B operands from there (conflict-free 16-byte reads: the
-// 16-byte units of a candidate's channel segment are XOR-swizzled by the candidate number) and keeps its A operands --
-// its 16 queries -- in registers.  The 16 x 16 block of scores  pd_ij = (-|x_j|^2 + 2 x_i.x_j) - |x_i|^2  of a tile
-// is produced by v_mfma_f32_16x16x4_f32 (exact channel-ordered fma chain = the oracle's), and NOTHING of size N is
-// kept per row: the selection works on the accumulator layout itself (lane (g, c) holds the scores of rows 4g..4g+3
-// against candidate c, so a register holds 4 rows x 16 candidates and every vector instruction serves 4 rows):
+// buffers, one barrier per stage); every wave reads its candidate operands from there (conflict-free 16-byte reads:
+// the 16-byte units of a candidate's channel segment are XOR-swizzled by the candidate number) and keeps its 16
+// queries in registers.  The 16 x 16 block of scores  pd_ij = (-|x_j|^2 + 2 x_i.x_j) - |x_i|^2  of a tile is produced
+// by v_mfma_f32_16x16x4_f32 (exact channel-ordered fma chain = the oracle's) with the CANDIDATES as the A operand:
+// lane (g, c) then holds the scores of candidates 4g..4g+3 against query c -- a lane serves ONE row, so a row's
+// threshold, slot counter and write position are per-lane values and one LDS atomic serves a lane's 8 scores of a
+// tile pair.  Nothing of size N is kept per row:
 //   * a score that reaches its row's threshold T is appended (score bits, index) to the row's 120-entry buffer in
-//     LDS, its slot taken with an LDS atomic;
-//   * T is a lower bound of the row's k-th best score, raised by events: the 16 lanes of a row split its buffered
-//     entries, each finds the two best of its share (v_max / v_med3); if at least ceil(k/2) lanes hold a second-best
-//     >= w, then k buffered scores are >= w.  The largest such w comes from 15 DPP row rotations, and the same pass
-//     drops the entries below the new T (4 rows at a time).  Events run at fixed tiles (x2.25 in the number of
-//     candidates seen: five per 2048-point cloud) and whenever a buffer passes its watermark.  Between two checks
+//     LDS;
+//   * T is a lower bound of the row's k-th best score, raised by events: the 16 lanes of a DPP row split a row's
+//     buffered entries, each finds the two best of its share (v_max / v_med3); if at least ceil(k/2) lanes hold a
+//     second-best >= w, then k buffered scores are >= w.  The largest such w comes from 15 DPP row rotations on
+//     31-bit keys (subtract + v_alignbit collect the comparison bits without touching a scalar register), and the
+//     same pass drops the entries below the new T (4 rows at a time).  Events run at fixed tiles (x2.25 in the number
+//     of candidates seen: five per 2048-point cloud) and whenever a buffer passes its watermark.  Between two checks
 //     (2 tiles) a row receives at most 32 entries, and a check leaves at most 88: a slot index cannot pass the
 //     buffer's end;
 //   * after the sweep a row's buffer holds every score >= its final T (about 1.4 k of them): they are ranked by
 //     counting on 64-bit keys (orderable score << 32 | ~index: score descending, then index ascending -- the order of
-//     the oracle's rounds) and the first k are written.
+//     the oracle's rounds), four rows at a time (16 lanes and two entries per lane for a row), and the first k are
+//     written.
 // If a compaction cannot bring a buffer under the watermark (a loose early threshold, hundreds of equal scores), the
 // row's entries are ranked on the spot, its k best stay and the k-th score becomes its threshold.  A second, independent
 // selection is kept for tests (FPSG_KNN_FORCE_SLOW): k masked arg-max sweeps over the cloud straight from global
@@ -44,7 +47,7 @@ template <> struct StreamCfg<32> { static constexpr int TC = 32; };    // 16 KB
 template <int C4T>
 constexpr size_t stream_lds_bytes() {
   constexpr int TC = StreamCfg<C4T>::TC;
-  return (size_t)2 * TC * 4 * C4T * 4 + (size_t)2 * TC * 4 + (size_t)kSRows * 4 + (size_t)kSW * 4 +
+  return (size_t)2 * TC * 4 * C4T * 4 + (size_t)2 * TC * 4 + (size_t)kSRows * 4 + (size_t)kSRows * 4 +
          (size_t)kSRows * kCap * 8;
 }
 
@@ -93,35 +96,40 @@ __global__ __launch_bounds__(256) void knn_stream_prep_kernel(const float* __res
 
 // ---- lane exchanges inside a row of 16 lanes ------------------------------------------------------------------------
 template <int CTRL>
-__device__ __forceinline__ float dpp_f(float v) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
+__device__ __forceinline__ unsigned dpp_u(unsigned v) {
+  return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xF, 0xF, true);
 }
 template <int CTRL>
 __device__ __forceinline__ int dpp_i0(int v) {           // lanes without a source receive 0
   return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true);
 }
-__device__ __forceinline__ float row16_max(float v) {     // every lane of a row of 16 receives the row's maximum
-  v = __builtin_fmaxf(v, dpp_f<0xB1>(v));     // quad_perm [1,0,3,2]
-  v = __builtin_fmaxf(v, dpp_f<0x4E>(v));     // quad_perm [2,3,0,1]
-  v = __builtin_fmaxf(v, dpp_f<0x141>(v));    // row_half_mirror
-  v = __builtin_fmaxf(v, dpp_f<0x140>(v));    // row_mirror
+__device__ __forceinline__ unsigned row16_max_u32(unsigned v) {     // every lane of a row of 16 receives the maximum
+  v = max(v, dpp_u<0xB1>(v));     // quad_perm [1,0,3,2]
+  v = max(v, dpp_u<0x4E>(v));     // quad_perm [2,3,0,1]
+  v = max(v, dpp_u<0x141>(v));    // row_half_mirror
+  v = max(v, dpp_u<0x140>(v));    // row_mirror
   return v;
 }
-__device__ __forceinline__ unsigned long long row16_max_u64(unsigned long long v) {
+// over the four lanes c, c + 16, c + 32, c + 48 (one per row of 16): every one receives the maximum
+__device__ __forceinline__ unsigned long long col4_max_u64(unsigned long long v) {
 #define FPSG_STEP(M)                                                                                      \
   {                                                                                                       \
     const unsigned long long o = ((unsigned long long)lane_xor<M>((unsigned)(v >> 32)) << 32) | lane_xor<M>((unsigned)v); \
     v = o > v ? o : v;                                                                                    \
   }
-  FPSG_STEP(1) FPSG_STEP(2) FPSG_STEP(4) FPSG_STEP(8)
+  FPSG_STEP(16) FPSG_STEP(32)
 #undef FPSG_STEP
   return v;
 }
-// number of lanes of the row (this one included) whose value is >= this lane's
+// Bit n-1 of the result (n = 1..15): the key n lanes to the right in this row of 16 (row_ror:n) is SMALLER than this
+// lane's.  Keys below 2^31, so the sign of the difference decides; v_alignbit shifts it into the collection: two vector
+// instructions per rotation and no scalar register in the chain (a compare + add-with-carry costs wait states between
+// the two on gfx950).
 template <int N>
-__device__ __forceinline__ int row16_count_ge(float w, int acc) {
+__device__ __forceinline__ unsigned row16_less_bits(unsigned key, unsigned acc) {
   if constexpr (N < 16) {
-    return row16_count_ge<N + 1>(w, acc + (dpp_f<0x120 + N>(w) >= w ? 1 : 0));      // row_ror:N
+    const unsigned d = dpp_u<0x120 + N>(key) - key;                                   // row_ror:N
+    return row16_less_bits<N + 1>(key, __builtin_amdgcn_alignbit(acc, d, 31));        // (acc << 1) | (d >> 31)
   } else {
     return acc;
   }
@@ -136,6 +144,9 @@ __device__ __forceinline__ float raw_max(float a, float b) {
 
 __device__ __forceinline__ unsigned long long knn_key(float score, unsigned j) {
   return ((unsigned long long)knn_orderable(score + 0.0f) << 32) | (unsigned)~j;
+}
+__device__ __forceinline__ float knn_unorderable(unsigned o) {
+  return __uint_as_float((o & 0x80000000u) ? (o ^ 0x80000000u) : ~o);
 }
 
 struct Entry { unsigned s, j; };       // score bits, candidate index
@@ -154,9 +165,9 @@ __global__ __launch_bounds__(64 * kSW) void knn_stream_kernel(const float* __res
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* stage = lds;                                           // [2][TC * CP]
   float* sxx = stage + 2 * TC * CP;                             // [2][TC]
-  unsigned* cnt = reinterpret_cast<unsigned*>(sxx + 2 * TC);    // [kSRows]
-  unsigned* tsl = cnt + kSRows;                                 // [kSW]: a wave's word for the exact compaction
-  Entry* buf = reinterpret_cast<Entry*>(tsl + kSW);             // [kSRows][kCap]
+  unsigned* cnt = reinterpret_cast<unsigned*>(sxx + 2 * TC);    // [kSRows]: entries in a row's buffer
+  float* trow = reinterpret_cast<float*>(cnt + kSRows);         // [kSRows]: a row's threshold
+  Entry* buf = reinterpret_cast<Entry*>(trow + kSRows);         // [kSRows][kCap]
 
   // clouds -> XCDs: workgroup ids go round-robin over the 8 XCDs, so the row blocks of one cloud take ids of one
   // residue class and its features are served by one L2
@@ -177,35 +188,31 @@ __global__ __launch_bounds__(64 * kSW) void knn_stream_kernel(const float* __res
   const int n_stages = (N + TC - 1) / TC;
   const float NEG = -__builtin_inff();
 
-  // A operands: lane (kk, col) holds channels 4 c4 + kk of query i0 + col
+  // query operands (the MFMA's B side): lane (kk, col) holds channels 4 c4 + kk of query i0 + col
   float a[C4T];
+  const int qrow = i0 + col;
   {
-    const int q = i0 + col;
     if constexpr (C4T >= 4) {
-      const v4f* src = reinterpret_cast<const v4f*>(xkb + (size_t)(q < N ? q : 0) * CP + kk * C4T);
+      const v4f* src = reinterpret_cast<const v4f*>(xkb + (size_t)(qrow < N ? qrow : 0) * CP + kk * C4T);
 #pragma unroll
       for (int m = 0; m < C4T / 4; ++m) {
         v4f v = {0.0f, 0.0f, 0.0f, 0.0f};
-        if (q < N) v = src[m];
+        if (qrow < N) v = src[m];
         a[4 * m] = v.x; a[4 * m + 1] = v.y; a[4 * m + 2] = v.z; a[4 * m + 3] = v.w;
       }
     } else {
-      a[0] = q < N ? xkb[(size_t)q * CP + kk] : 0.0f;
+      a[0] = qrow < N ? xkb[(size_t)qrow * CP + kk] : 0.0f;
     }
   }
-  float xxq[4];
-#pragma unroll
-  for (int rr = 0; rr < 4; ++rr) {
-    const int q = i0 + 4 * kk + rr;
-    xxq[rr] = q < N ? xxb[q] : 0.0f;
-  }
-  const int row0 = wave * 16 + 4 * kk;                          // this lane's rows: row0 + rr
-  if (lane < 16) cnt[wave * 16 + lane] = 0u;
+  const float xxq = qrow < N ? xxb[qrow] : 0.0f;
+  const int lrow = wave * 16 + col;                             // the row this lane's accumulators belong to
+  const int erow0 = wave * 16 + 4 * kk;                         // the rows this lane's DPP row of 16 handles in events
+  if (lane < 16) { cnt[wave * 16 + lane] = 0u; trow[wave * 16 + lane] = NEG; }
+  unsigned* const my_cnt = cnt + lrow;
+  Entry* const my_buf = buf + lrow * kCap;
 
-  float T[4];
-#pragma unroll
-  for (int rr = 0; rr < 4; ++rr) T[rr] = NEG;
-  const int jsel = (k + 1) >> 1;
+  float T = NEG;
+  const unsigned jsel = (unsigned)((k + 1) >> 1);
   const bool failed = (flags & 1) != 0;                         // wave-uniform: the slow exact path (tests, A/B)
 
   // ---- stage transfer --------------------------------------------------------------------------------------------
@@ -243,50 +250,49 @@ __global__ __launch_bounds__(64 * kSW) void knn_stream_kernel(const float* __res
     if (tid < TC) sxx[sel * TC + tid] = prexx;
   };
 
-  // ---- selection pieces ------------------------------------------------------------------------------------------
-  // An event raises the rows' thresholds and drops the buffered entries below them: 16 lanes per row, the 4 rows of a
-  // register index at a time.  Lane c of a row holds its entries c, c + 16, ... (distinct candidates, all >= the old
-  // T) and finds the two best of them; if at least ceil(k/2) lanes hold a second-best >= w, then k buffered scores are
-  // >= w, so w is a lower bound of the row's k-th best score.  The largest such w comes from 15 DPP row rotations.
-  auto raise_and_filter = [&]() {
+  auto lds_sync_wave = [&]() {           // one wave's LDS operations execute in order; this orders them for the compiler
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  };
+
+  // ---- selection pieces ------------------------------------------------------------------------------------------
+  // An event raises the rows' thresholds and drops the buffered entries below them.  Lane (kk, col) works on rows
+  // erow0 + rr: the 16 lanes of its DPP row split a row's entries (lane col holds entries col, col + 16, ...).
+  auto raise_and_filter = [&]() {
+    lds_sync_wave();
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) {
-      const int row = row0 + rr;
+      const int row = erow0 + rr;
       const int c = (int)cnt[row];
-      int cmax = __builtin_amdgcn_readlane(c, 0);                    // the longest of the four rows: wave-uniform
-      cmax = max(cmax, __builtin_amdgcn_readlane(c, 16));
-      cmax = max(cmax, __builtin_amdgcn_readlane(c, 32));
-      cmax = max(cmax, __builtin_amdgcn_readlane(c, 48));
+      const float told = trow[row];
       Entry* rb = buf + row * kCap;
       Entry e[kFilterIters];
       float sc[kFilterIters];
-      float a1 = NEG, a2 = NEG;
+#pragma unroll
+      for (int i = 0; i < kFilterIters; ++i) e[i] = rb[col + 16 * i < c ? col + 16 * i : 0];
+      float a1 = NEG, a2 = NEG;                     // the two best of this lane's share
 #pragma unroll
       for (int i = 0; i < kFilterIters; ++i) {
-        sc[i] = NEG;
-        if (16 * i < cmax) {
-          const int p = col + 16 * i;
-          const bool valid = p < c;
-          e[i] = rb[valid ? p : 0];
-          sc[i] = valid ? __uint_as_float(e[i].s) : NEG;
-          a2 = __builtin_amdgcn_fmed3f(a1, a2, sc[i]);
-          a1 = raw_max(a1, sc[i]);
-        }
+        sc[i] = col + 16 * i < c ? __uint_as_float(e[i].s) : NEG;
+        a2 = __builtin_amdgcn_fmed3f(a1, a2, sc[i]);
+        a1 = raw_max(a1, sc[i]);
       }
-      const int ge = row16_count_ge<1>(a2, 1);
-      T[rr] = __builtin_fmaxf(T[rr], row16_max(ge >= jsel ? a2 : NEG));
+      // 31-bit key of the second best (rounded down: a bound that is a hair lower is still a bound)
+      const unsigned key = knn_orderable(a2 + 0.0f) >> 1;
+      const unsigned less = row16_less_bits<1>(key, 0u);
+      const unsigned ge = 16u - (unsigned)__builtin_popcount(less);         // lanes of the row with key >= mine
+      const unsigned best = row16_max_u32(ge >= jsel ? key : 0u);
+      // (the key of -inf, rounded down, would decode to a NaN: a row whose qualifying lanes hold less than two entries
+      // keeps its threshold)
+      const float tnew = raw_max(told, best > 0x003fffffu ? knn_unorderable(best << 1) : NEG);
       int keep[kFilterIters];
       int n = 0;
 #pragma unroll
       for (int i = 0; i < kFilterIters; ++i) {
-        keep[i] = 0;
-        if (16 * i < cmax) {
-          keep[i] = (col + 16 * i < c && sc[i] >= T[rr]) ? 1 : 0;
-          n += keep[i];
-        }
+        keep[i] = sc[i] >= tnew ? 1 : 0;            // sc = -inf where the lane has no entry; tnew > -inf then
+        keep[i] = (col + 16 * i < c) ? keep[i] : 0;
+        n += keep[i];
       }
       int inc = n;                                   // inclusive scan over the row's 16 lanes
       inc += dpp_i0<0x111>(inc);                     // row_shr:1
@@ -297,21 +303,18 @@ __global__ __launch_bounds__(64 * kSW) void knn_stream_kernel(const float* __res
       __builtin_amdgcn_wave_barrier();               // every read of this row precedes the writes (in-order LDS queue)
 #pragma unroll
       for (int i = 0; i < kFilterIters; ++i) {
-        if (16 * i < cmax) {
-          if (keep[i]) rb[pos] = e[i];
-          pos += keep[i];
-        }
+        if (keep[i]) rb[pos] = e[i];
+        pos += keep[i];
       }
-      if (col == 15) cnt[row] = (unsigned)inc;
+      if (col == 15) { cnt[row] = (unsigned)inc; trow[row] = tnew; }
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    lds_sync_wave();
   };
-  // the c buffered entries of a row -> 64-bit keys in place and every entry's rank among them (wave-level; lane l
-  // holds entries l and l + 64)
-  auto rank_row = [&](int row, int c, Entry& e0, Entry& e1, unsigned long long& k0, unsigned long long& k1, int& r0,
-                      int& r1) {
+  // The buffered entries of four rows -> 64-bit keys in place and every entry's rank among its row's: the 16 lanes of
+  // a DPP row take row rbase + 4 kk + (their register index), lane col entries col and col + 16 (c <= 32).
+  // A row with more entries is ranked by the whole wave (rank_row_wide).
+  auto rank_row_wide = [&](int row, int c, Entry& e0, Entry& e1, unsigned long long& k0, unsigned long long& k1,
+                           int& r0, int& r1) {
     unsigned long long* rk = reinterpret_cast<unsigned long long*>(buf) + (size_t)row * kCap;
     const bool h0 = lane < c, h1 = lane + 64 < c;
     e0 = buf[row * kCap + (h0 ? lane : 0)];
@@ -321,9 +324,7 @@ __global__ __launch_bounds__(64 * kSW) void knn_stream_kernel(const float* __res
     __builtin_amdgcn_wave_barrier();
     if (h0) rk[lane] = k0;                           // a lane rewrites only its own slots
     if (h1) rk[lane + 64] = k1;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    lds_sync_wave();
     r0 = 0;
     r1 = 0;
     if (c <= 64) {
@@ -349,21 +350,15 @@ __global__ __launch_bounds__(64 * kSW) void knn_stream_kernel(const float* __res
       Entry e0, e1;
       unsigned long long k0, k1;
       int r0, r1;
-      rank_row(row, c, e0, e1, k0, k1, r0, r1);
+      rank_row_wide(row, c, e0, e1, k0, k1, r0, r1);
       const bool h0 = lane < c, h1 = lane + 64 < c;
       Entry* rb = buf + row * kCap;
       if (h0 && r0 < k) rb[r0] = e0;
       if (h1 && r1 < k) rb[r1] = e1;
-      if (h0 && r0 == k - 1) tsl[wave] = e0.s;
-      if (h1 && r1 == k - 1) tsl[wave] = e1.s;
+      if (h0 && r0 == k - 1) trow[row] = raw_max(trow[row], __uint_as_float(e0.s));
+      if (h1 && r1 == k - 1) trow[row] = raw_max(trow[row], __uint_as_float(e1.s));
       if (lane == 0) cnt[row] = (unsigned)k;
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      const float tn = __uint_as_float(tsl[wave]);
-#pragma unroll
-      for (int rr = 0; rr < 4; ++rr)
-        T[rr] = (kk == (r >> 2) && rr == (r & 3)) ? __builtin_fmaxf(T[rr], tn) : T[rr];
+      lds_sync_wave();
     }
   };
   auto over_watermark = [&]() -> bool {
@@ -373,42 +368,40 @@ __global__ __launch_bounds__(64 * kSW) void knn_stream_kernel(const float* __res
   auto event = [&]() {
     raise_and_filter();
     if (over_watermark()) exact_compact();
+    T = trow[lrow];
   };
-  // the scores of tiles t, t + 1 (accumulator layout) -> threshold test, append.  A lane's rows are the same in both
-  // tiles, so one LDS atomic per register index takes the slots of both; the four atomics of a pair are issued
-  // together (one round trip).  Returns whether a row passed its watermark: the lane that took a row's last slot knows
-  // the row's new count.  (Skipping the append of a register index none of whose 128 scores passes was measured: the
-  // four ballots and scalar branches per pair cost more than they save, 324 -> 372 us at C = 3.)
-  auto select_pair = [&](const v4f& acc0, const v4f& acc1, int t, float xx0, float xx1) -> bool {
-    const unsigned j0 = (unsigned)(16 * t + col);
-    float v0[4], v1[4];
-    unsigned pos[4];
-    bool p0[4], p1[4];
+  // The scores of tiles t, t + 1: this lane's 8 scores of ITS row (candidates 16 t + 4 kk + r and + 16) -> threshold
+  // test and append.  One LDS atomic takes the lane's slots.  Returns whether a row passed its watermark: the lane that
+  // took a row's last slot knows the row's new count.
+  auto select_pair = [&](const v4f& acc0, const v4f& acc1, int t, const v4f& xx0, const v4f& xx1) -> bool {
+    const unsigned j0 = (unsigned)(16 * t + 4 * kk);
+    float v[8];
+    bool p[8];
 #pragma unroll
-    for (int rr = 0; rr < 4; ++rr) {
-      v0[rr] = fma_rn(2.0f, acc0[rr], -xx0) - xxq[rr];
-      v1[rr] = fma_rn(2.0f, acc1[rr], -xx1) - xxq[rr];
-      p0[rr] = v0[rr] >= T[rr];
-      p1[rr] = v1[rr] >= T[rr];
+    for (int r = 0; r < 4; ++r) {
+      v[r] = fma_rn(2.0f, acc0[r], -xx0[r]) - xxq;
+      v[4 + r] = fma_rn(2.0f, acc1[r], -xx1[r]) - xxq;
     }
+    unsigned n = 0u;
 #pragma unroll
-    for (int rr = 0; rr < 4; ++rr) {
-      pos[rr] = 0u;
-      if (p0[rr] || p1[rr])
-        pos[rr] = __hip_atomic_fetch_add(&cnt[row0 + rr], (p0[rr] ? 1u : 0u) + (p1[rr] ? 1u : 0u), __ATOMIC_RELAXED,
-                                         __HIP_MEMORY_SCOPE_WAVEFRONT);
+    for (int r = 0; r < 8; ++r) {
+      p[r] = v[r] >= T;
+      n += p[r] ? 1u : 0u;
     }
-    unsigned top = 0u;                         // the largest new row count this lane knows of
+    unsigned pos = 0u;
+    if (n != 0u) pos = __hip_atomic_fetch_add(my_cnt, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    const bool over = n != 0u && pos + n > (unsigned)kWM;
 #pragma unroll
-    for (int rr = 0; rr < 4; ++rr) {
-      Entry* rb = buf + (row0 + rr) * kCap;
-      const unsigned q1 = pos[rr] + (p0[rr] ? 1u : 0u);
-      if (p0[rr]) { Entry en; en.s = __float_as_uint(v0[rr]); en.j = j0; rb[pos[rr]] = en; }
-      if (p1[rr]) { Entry en; en.s = __float_as_uint(v1[rr]); en.j = j0 + 16u; rb[q1] = en; }
-      const unsigned endc = q1 + (p1[rr] ? 1u : 0u);      // pos = 0 for a lane that appended nothing
-      top = endc > top ? endc : top;
+    for (int r = 0; r < 8; ++r) {
+      if (p[r]) {
+        Entry en;
+        en.s = __float_as_uint(v[r]);
+        en.j = j0 + (unsigned)(r < 4 ? r : r + 12);
+        my_buf[pos] = en;
+      }
+      pos += p[r] ? 1u : 0u;
     }
-    return __builtin_amdgcn_ballot_w64(top > (unsigned)kWM) != 0ull;
+    return __builtin_amdgcn_ballot_w64(over) != 0ull;
   };
 
   // ---- the sweep --------------------------------------------------------------------------------------------------
@@ -433,20 +426,20 @@ __global__ __launch_bounds__(64 * kSW) void knn_stream_kernel(const float* __res
           const v4f b0 = *reinterpret_cast<const v4f*>(p0 + 4 * (m ^ sw));
           const v4f b1 = *reinterpret_cast<const v4f*>(p1 + 4 * (m ^ sw));
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[4 * m + e], b0[e], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[4 * m + e], b1[e], acc1, 0, 0, 0);
+          for (int e = 0; e < 4; ++e) {             // candidates = A (rows of D), queries = B (columns of D)
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(b0[e], a[4 * m + e], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(b1[e], a[4 * m + e], acc1, 0, 0, 0);
           }
         }
       } else {
         const float b0 = st[(16 * tt + col) * 4 + kk];
         const float b1 = st[(16 * tt + 16 + col) * 4 + kk];
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b0, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b1, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(b0, a[0], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(b1, a[0], acc1, 0, 0, 0);
       }
-      const float xx0 = sxx[sel * TC + 16 * tt + col];
-      const float xx1 = sxx[sel * TC + 16 * tt + 16 + col];
       if (!failed) {
+        const v4f xx0 = *reinterpret_cast<const v4f*>(sxx + sel * TC + 16 * tt + 4 * kk);
+        const v4f xx1 = *reinterpret_cast<const v4f*>(sxx + sel * TC + 16 * tt + 16 + 4 * kk);
         const bool over = select_pair(acc0, acc1, t0 + tt, xx0, xx1);   // a tile past the cloud's end scores -inf
         const int t_end = t0 + tt + 1;
         if (over || t_end >= next_evt) {
@@ -461,32 +454,66 @@ __global__ __launch_bounds__(64 * kSW) void knn_stream_kernel(const float* __res
 
   if (!failed) {
     event();
-    // ---- rank the survivors of every row: wave-level, one row at a time ------------------------------------------
-    for (int r = 0; r < 16; ++r) {
-      const int row = wave * 16 + r;
-      const int i = i0 + r;
-      if (i >= N) break;
-      const int c = __builtin_amdgcn_readfirstlane((int)cnt[row]);
-      Entry e0, e1;
-      unsigned long long k0, k1;
-      int r0, r1;
-      rank_row(row, c, e0, e1, k0, k1, r0, r1);
-      int32_t* out = idx + ((size_t)b * N + i) * k;
-      if (lane < c && r0 < k) out[r0] = (int32_t)~(unsigned)k0;
-      if (lane + 64 < c && r1 < k) out[r1] = (int32_t)~(unsigned)k1;
+    // ---- rank the survivors: four rows at a time, 16 lanes and two entries per lane for a row ---------------------
+    unsigned long long* kb = reinterpret_cast<unsigned long long*>(buf);
+    for (int rr = 0; rr < 4; ++rr) {
+      const int row = erow0 + rr;
+      const int i = i0 + 4 * kk + rr;
+      const int c = (int)cnt[row];
+      const bool wide = __builtin_amdgcn_ballot_w64(c > 32) != 0ull;        // some row of the four: the wave-wide form
+      if (!wide) {
+        unsigned long long* rk = kb + (size_t)row * kCap;
+        const bool h0 = col < c, h1 = col + 16 < c;
+        const Entry e0 = buf[row * kCap + (h0 ? col : 0)];
+        const Entry e1 = buf[row * kCap + (h1 ? col + 16 : 0)];
+        const unsigned long long k0 = h0 ? knn_key(__uint_as_float(e0.s), e0.j) : 0ull;
+        const unsigned long long k1 = h1 ? knn_key(__uint_as_float(e1.s), e1.j) : 0ull;
+        __builtin_amdgcn_wave_barrier();
+        if (h0) rk[col] = k0;
+        if (h1) rk[col + 16] = k1;
+        lds_sync_wave();
+        int cmax = __builtin_amdgcn_readlane(c, 0);
+        cmax = max(cmax, __builtin_amdgcn_readlane(c, 16));
+        cmax = max(cmax, __builtin_amdgcn_readlane(c, 32));
+        cmax = max(cmax, __builtin_amdgcn_readlane(c, 48));
+        int r0 = 0, r1 = 0;
+#pragma unroll 4
+        for (int l = 0; l < cmax; ++l) {
+          const unsigned long long o = l < c ? rk[l] : 0ull;      // a shorter row compares with key 0: no rank change
+          r0 += o > k0 ? 1 : 0;
+          r1 += o > k1 ? 1 : 0;
+        }
+        if (i < N) {
+          int32_t* out = idx + ((size_t)b * N + i) * k;
+          if (h0 && r0 < k) out[r0] = (int32_t)~(unsigned)k0;
+          if (h1 && r1 < k) out[r1] = (int32_t)~(unsigned)k1;
+        }
+      } else {
+        for (int g = 0; g < 4; ++g) {
+          const int wrow = wave * 16 + 4 * g + rr;
+          const int wi = i0 + 4 * g + rr;
+          if (wi >= N) continue;
+          const int wc = __builtin_amdgcn_readfirstlane((int)cnt[wrow]);
+          Entry e0, e1;
+          unsigned long long k0, k1;
+          int r0, r1;
+          rank_row_wide(wrow, wc, e0, e1, k0, k1, r0, r1);
+          int32_t* out = idx + ((size_t)b * N + wi) * k;
+          if (lane < wc && r0 < k) out[r0] = (int32_t)~(unsigned)k0;
+          if (lane + 64 < wc && r1 < k) out[r1] = (int32_t)~(unsigned)k1;
+        }
+      }
     }
     return;
   }
 
   // ---- slow exact path: k masked arg-max sweeps, operands straight from global memory ------------------------------
-  unsigned long long prev[4];
-#pragma unroll
-  for (int rr = 0; rr < 4; ++rr) prev[rr] = ~0ull;
+  unsigned long long prev = ~0ull;
   for (int round = 0; round < k; ++round) {
-    unsigned long long best[4] = {0ull, 0ull, 0ull, 0ull};
+    unsigned long long best = 0ull;
 #pragma unroll 1
     for (int t = 0; t < n_tiles; ++t) {
-      const int j = 16 * t + col;
+      const int j = 16 * t + col;                    // the candidate whose features this lane feeds to the MFMA
       const bool jin = j < N;
       v4f acc = {0.0f, 0.0f, 0.0f, 0.0f};
       if constexpr (C4T >= 4) {
@@ -496,28 +523,25 @@ __global__ __launch_bounds__(64 * kSW) void knn_stream_kernel(const float* __res
           v4f bv = {0.0f, 0.0f, 0.0f, 0.0f};
           if (jin) bv = src[m];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[4 * m + e], bv[e], acc, 0, 0, 0);
+          for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[e], a[4 * m + e], acc, 0, 0, 0);
         }
       } else {
         const float bv = jin ? xkb[(size_t)j * CP + kk] : 0.0f;
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], bv, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(bv, a[0], acc, 0, 0, 0);
       }
-      const float xxj = jin ? xxb[j] : __builtin_inff();
 #pragma unroll
-      for (int rr = 0; rr < 4; ++rr) {
-        const float v = fma_rn(2.0f, acc[rr], -xxj) - xxq[rr];
-        const unsigned long long key = knn_key(v, (unsigned)j);
-        const bool take = key < prev[rr] && key > best[rr];
-        best[rr] = take ? key : best[rr];
+      for (int r = 0; r < 4; ++r) {
+        const int jc = 16 * t + 4 * kk + r;          // the candidate of accumulator r
+        const float xxj = jc < N ? xxb[jc] : __builtin_inff();
+        const float v = fma_rn(2.0f, acc[r], -xxj) - xxq;
+        const unsigned long long key = knn_key(v, (unsigned)jc);
+        const bool take = key < prev && key > best;
+        best = take ? key : best;
       }
     }
-#pragma unroll
-    for (int rr = 0; rr < 4; ++rr) {
-      const unsigned long long w = row16_max_u64(best[rr]);
-      prev[rr] = w;
-      const int i = i0 + 4 * kk + rr;
-      if (col == 0 && i < N) idx[((size_t)b * N + i) * k + round] = (int32_t)~(unsigned)w;
-    }
+    const unsigned long long w = col4_max_u64(best);
+    prev = w;
+    if (kk == 0 && qrow < N) idx[((size_t)b * N + qrow) * k + round] = (int32_t)~(unsigned)w;
   }
 }
 
