@@ -463,14 +463,19 @@ def run_workload(wl, args, rank, world, device, steps, warmup, probe=None, graph
     if probe is not None:
         probe.enabled = False
     t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    ranks_seen = 1
     if world > 1:
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        one = torch.ones(1, dtype=torch.float32, device=device)        # every rank adds 1 through the same collective path
+        torch.distributed.all_reduce(one)
+        ranks_seen = int(one.item())
     elapsed = float(t.item())
     eps_per_s = steps * epr * world / elapsed
     flops = direct_equivalent_flops(S, Q, intra, encoder)
     return {"value": eps_per_s, "elapsed": elapsed, "steps": steps, "warmup": warmup, "epr": epr, "graph": bool(graph),
             "loss": float(out[-1]["ttl_loss"].sum().item()), "desc": desc, "S": S, "Q": Q, "intra": intra,
             "encoder": encoder, "params": sum(p.numel() for p in model.parameters()), "step": step,
+            "ranks_seen": ranks_seen,
             "mfu": {"direct_equivalent_tflop_per_episode": flops / 1e12,
                     "direct_equivalent_tflops": eps_per_s / world * flops / 1e12,
                     "fraction_of_fp32_peak": eps_per_s / world * flops / F32_PEAK,
@@ -553,6 +558,11 @@ def main():
             "hbm_peak_allocated_gb": round(torch.cuda.max_memory_allocated(device) / 1e9, 2),
             "mfu_direct_equivalent": main_run["mfu"],
         }
+        if torch.distributed.is_initialized():
+            # what the process group itself reports (N > 1: RCCL over xGMI), so the line shows that N ranks took part
+            res["distributed"] = {"world_size": torch.distributed.get_world_size(),
+                                  "backend": torch.distributed.get_backend(),
+                                  "ranks_that_reported": main_run.get("ranks_seen")}
         if n_l:
             achieved_flops = flops / sec
             res["roofline"] = {

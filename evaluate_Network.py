@@ -3,7 +3,7 @@
 
 Same command line and report lines as reference ``src/evaluate_Network.py`` (``main :65-123``):
 loads ``<model_path>/<name>/<eval_model>``, runs ``ImgPCProtoNet._return_reconstruction`` on
-every test episode (HIP Chamfer K1 + HIP approximate EMD K2) and prints
+every test episode (HIP Chamfer K1 + the HIP Sinkhorn divergence K2b, the form ``emd_wrapper`` calls) and prints
 ``Class: <c> -- Rec CD: <mean>; Rec EMD: <mean>``.  With ``--npy_folder`` the generated and
 ground-truth clouds (+ a side-by-side PNG) of every item are dumped instead, which is the
 reference's commented-out "OPTION 2" (``:111``).

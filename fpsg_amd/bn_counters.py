@@ -11,11 +11,20 @@ operations on the same values, so the results are bit-identical."""
 from __future__ import annotations
 
 import contextlib
+import threading
 
 import torch
 
-_pending = None      # id(tensor) -> [tensor, count] while a ``deferred()`` block is open
-_stats = None        # [(tensors, scale, addends, alpha)] in call order while a block is open
+
+class _State(threading.local):
+    """Per thread: a ``deferred()`` block collects the updates of the forward passes of ITS thread only (the process
+    also runs the episode prefetcher and the RCCL watchdog; a second thread's training-mode forward must neither join
+    nor lose this block's updates)."""
+    pending = None       # id(tensor) -> [tensor, count] while a ``deferred()`` block is open
+    stats = None         # [(tensors, scale, addends, alpha)] in call order while a block is open
+
+
+_tls = _State()
 
 
 def count_batch(bn, times: int = 1) -> None:
@@ -23,12 +32,12 @@ def count_batch(bn, times: int = 1) -> None:
     t = bn.num_batches_tracked
     if t is None:
         return
-    if _pending is None:
+    if _tls.pending is None:
         t += times
         return
-    entry = _pending.get(id(t))
+    entry = _tls.pending.get(id(t))
     if entry is None:
-        _pending[id(t)] = [t, times]
+        _tls.pending[id(t)] = [t, times]
     else:
         entry[1] += times
 
@@ -38,25 +47,24 @@ def update_running(tensors, scale: float, addends, alpha: float = 1.0) -> None:
     multi-tensor ops ``_foreach_mul_`` / ``_foreach_add_(alpha=)`` -- now, or batched with the other updates of the
     enclosing ``deferred()`` block."""
     tensors, addends = list(tensors), list(addends)
-    if _stats is None:
+    if _tls.stats is None:
         torch._foreach_mul_(tensors, scale)
         torch._foreach_add_(tensors, addends, alpha=alpha)
     else:
-        _stats.append((tensors, float(scale), addends, float(alpha)))
+        _tls.stats.append((tensors, float(scale), addends, float(alpha)))
 
 
 @contextlib.contextmanager
 def deferred():
-    global _pending, _stats
-    if _pending is not None:         # nested: the outer block applies everything
+    if _tls.pending is not None:     # nested: the outer block applies everything
         yield
         return
-    _pending, _stats = {}, []
+    _tls.pending, _tls.stats = {}, []
     try:
         yield
     finally:
-        items, _pending = list(_pending.values()), None
-        stats, _stats = _stats, None
+        items, _tls.pending = list(_tls.pending.values()), None
+        stats, _tls.stats = _tls.stats, None
         by_count = {}
         for t, c in items:
             by_count.setdefault((c, t.device), []).append(t)

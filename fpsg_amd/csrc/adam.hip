@@ -113,7 +113,7 @@ __device__ __forceinline__ bool gather_grad4(const float* const* __restrict__ gt
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       if (u >= cnt) break;
-      while (i + u >= seg_off[sg + 1]) ++sg;
+      while (sg + 1 < nseg && i + u >= seg_off[sg + 1]) ++sg;      // never past the table, whatever seg_off[nseg] says
       const float* g = gtab[sg];
       any = any || g != nullptr;
       gg[u] = g ? g[i + u - seg_off[sg]] : 0.0f;
@@ -164,7 +164,6 @@ __global__ __launch_bounds__(kAdamThreads) void adam_ptr_kernel(float* __restric
                                                                 float* __restrict__ m, float* __restrict__ v, size_t n4,
                                                                 size_t n, float step_size, float b1, float b2,
                                                                 float eps, float inv_sqrt_bc2, float gscale) {
-  const long long* so = seg_off;
   const size_t stride = (size_t)gridDim.x * kAdamThreads;
   const float omb1 = 1.0f - b1, omb2 = 1.0f - b2;
   for (size_t j = (size_t)blockIdx.x * kAdamThreads + threadIdx.x; j < n4 + 1; j += stride) {
@@ -179,7 +178,7 @@ __global__ __launch_bounds__(kAdamThreads) void adam_ptr_kernel(float* __restric
       vv = reinterpret_cast<const v4f*>(v)[j];
     }
     float gg[4];
-    gather_grad4(gtab, so, nseg, i, cnt, gg);
+    gather_grad4(gtab, seg_off, nseg, i, cnt, gg);
     if (cnt == 4) {                                            // flat buffers: aligned vectors
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
@@ -220,6 +219,9 @@ extern "C" int fpsg_adam_step_segments(float* param, const float* const* grad_pt
                "fpsg_adam_step_segments: betas must lie in [0,1) and eps be non-negative");
   FPSG_REQUIRE_PTR(param); FPSG_REQUIRE_PTR(exp_avg); FPSG_REQUIRE_PTR(exp_avg_sq);
   FPSG_REQUIRE(grad_ptrs != nullptr && seg_off != nullptr, FPSG_E_NULL, "fpsg_adam_step_segments: null table");
+  FPSG_REQUIRE(((reinterpret_cast<uintptr_t>(param) | reinterpret_cast<uintptr_t>(exp_avg) |
+                 reinterpret_cast<uintptr_t>(exp_avg_sq)) & 15) == 0,
+               FPSG_E_ALIGN, "fpsg_adam_step_segments: param, exp_avg and exp_avg_sq must be 16-byte aligned");
   const double bc1 = 1.0 - pow((double)beta1, (double)step);
   const double bc2 = 1.0 - pow((double)beta2, (double)step);
   const float step_size = (float)((double)lr / bc1);

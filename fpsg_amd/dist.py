@@ -266,6 +266,18 @@ class FlatGradBuckets:
         gradient in the armed backward, and turns the sum into the mean over episodes."""
         if self._armed:
             cur = torch.cuda.current_stream(self.flat.device) if self.flat.is_cuda else None
+            late = len(self.buckets) - self._next_launch
+            fired = sum(self._bucket_size) - sum(self._pending)
+            if late and fired and not getattr(self, "_warned_late", False):
+                # a backward ran here, yet some buckets never completed: parameters without a gradient hold their bucket
+                # -- and, because launches go out in index order, every later one -- back until now (no overlap with the
+                # backward).  Results are unaffected.
+                self._warned_late = True
+                import warnings
+                silent = [b for b in range(self._next_launch, len(self.buckets)) if self._pending[b] > 0]
+                warnings.warn(f"FlatGradBuckets: {late} of {len(self.buckets)} gradient buckets were all-reduced only "
+                              f"after the backward (buckets {silent} hold parameters that received no gradient); "
+                              "freeze such parameters (requires_grad=False) to restore the overlap")
             self._launch_ready(cur, flush=True)      # the rest, in index order (e.g. parameters unused by this step's graph)
             for h in self._handles:
                 h.wait()
@@ -285,6 +297,72 @@ def broadcast_parameters(model: nn.Module, src: int = 0) -> None:
         return
     for t in list(model.parameters()) + list(model.buffers()):
         dist.broadcast(t.data, src=src)
+
+
+class BufferSync:
+    """Reconciles the BatchNorm buffers of the replicas before rank 0 evaluates or saves.
+
+    The reference trains on one GPU, so its checkpoint's running statistics have seen every episode
+    (``trainNetwork.py:140-148,192-197``).  Under episode-level data parallelism each rank's BatchNorm layers see 1/W
+    of the episodes; there is no SyncBN (per-episode batch statistics are the reference's semantics), so the running
+    statistics drift apart.  ``sync()`` replaces every floating-point buffer (``running_mean``, ``running_var``) by its
+    mean over the ranks -- an exponential average is linear in its inputs, so this is the running average a single
+    process would hold had each of its updates been the mean of the W ranks' batch statistics -- and every integer
+    buffer (``num_batches_tracked``) by its value at the last sync plus the SUM of the ranks' increments since, the
+    count a single process would have reached.  One flat all-reduce per dtype; a no-op without a process group."""
+
+    def __init__(self, model: nn.Module, group=None):
+        self.group = group
+        bufs = [b for b in model.buffers() if b is not None]
+        self.floats = [b for b in bufs if b.is_floating_point()]
+        self.ints = [b for b in bufs if not b.is_floating_point()]
+        self._base = [b.detach().clone() for b in self.ints]
+
+    def rebase(self) -> None:
+        """After the buffers were overwritten from outside (a checkpoint load)."""
+        self._base = [b.detach().clone() for b in self.ints]
+
+    @torch.no_grad()
+    def sync(self) -> None:
+        if not dist.is_initialized():
+            return
+        world = dist.get_world_size(self.group)
+        if self.floats:
+            flat = torch.cat([b.detach().reshape(-1).to(torch.float32) for b in self.floats])
+            dist.all_reduce(flat, group=self.group)
+            flat /= world
+            off = 0
+            for b in self.floats:
+                n = b.numel()
+                b.copy_(flat[off:off + n].view(b.shape))
+                off += n
+        if self.ints:
+            delta = torch.cat([(b.detach() - base).reshape(-1).to(torch.int64) for b, base in zip(self.ints, self._base)])
+            dist.all_reduce(delta, group=self.group)
+            off = 0
+            for b, base in zip(self.ints, self._base):
+                n = b.numel()
+                b.copy_((base.reshape(-1).to(torch.int64) + delta[off:off + n]).view(b.shape).to(b.dtype))
+                off += n
+            self.rebase()
+
+
+def gather_objects(obj, group=None) -> list:
+    """``[obj of rank 0, obj of rank 1, ...]`` on every rank (``[obj]`` without a process group)."""
+    if not dist.is_initialized():
+        return [obj]
+    out = [None] * dist.get_world_size(group)
+    dist.all_gather_object(out, obj, group=group)
+    return out
+
+
+def broadcast_object(obj, src: int = 0, group=None):
+    """Rank ``src``'s ``obj`` on every rank."""
+    if not dist.is_initialized():
+        return obj
+    box = [obj]
+    dist.broadcast_object_list(box, src=src, group=group)
+    return box[0]
 
 
 def all_reduce_scalars(values: Iterable[float], device) -> list[float]:

@@ -153,6 +153,7 @@ class TrainStep:
                 p.grad = gr
         for k in self._KEYS:
             static[k].copy_(sample[k], non_blocking=True)
+        winograd.check_bank_before_replay()
         g.replay()
         return {n: v.clone() for n, v in static_out.items()}
 

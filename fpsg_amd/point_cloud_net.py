@@ -339,7 +339,10 @@ _rows_of_one_block = {}      # (every tensor's address, shape) -> bool: the full
 
 def _are_rows_of_one_block(tensors) -> bool:
     t0 = tensors[0]
-    key = (tuple(t.data_ptr() for t in tensors), t0.shape)
+    # the storage's identity and t0's place in it are part of the key: another model's parameters, allocated at the same
+    # addresses after the first flat buffer was freed, must not inherit a cached "yes"
+    key = (tuple(t.data_ptr() for t in tensors), t0.shape, t0.untyped_storage().data_ptr(), t0.storage_offset(),
+           t0.untyped_storage().nbytes())
     hit = _rows_of_one_block.get(key)
     if hit is None:
         n, base, o0 = t0.numel(), t0.untyped_storage().data_ptr(), t0.storage_offset()

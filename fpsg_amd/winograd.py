@@ -121,8 +121,7 @@ class _FilterBank:
 
     def __init__(self):
         self.entries = {}        # (data_ptr, m, flip) -> [weight alias, U, K, C, used in this block, pinned]
-        self.table = None        # device int64 [n, 6] of the registered jobs
-        self.total_blocks = 0
+        self.table = None        # [(device, int64 [n, 6] of the registered jobs there, workgroups)]
         self.valid = False       # refreshed in the current outermost block
 
     def register(self, key, w, U):
@@ -138,7 +137,13 @@ class _FilterBank:
         ent[5] = ent[5] or capturing
         return ent[1]
 
+    def has_pinned(self) -> bool:
+        return any(e[5] for e in self.entries.values())
+
     def refresh(self):
+        """Transforms every registered filter into its buffer: one launch per device that holds entries (one device
+        per process in this framework; a second device gets its own table rather than a stale buffer -- a captured
+        hipGraph reads the pinned buffers, so none of them may be left behind)."""
         self.valid = False
         stale = [k for k, e in self.entries.items() if not (e[4] or e[5])]
         for k in stale:
@@ -147,27 +152,33 @@ class _FilterBank:
             self.table = None
         if not self.entries:
             return
-        dev = next(iter(self.entries.values()))[1].device
-        if any(e[1].device != dev for e in self.entries.values()):       # one device per process in this framework
-            self.entries = {k: e for k, e in self.entries.items() if e[5]}
-            self.table = None
-            return
         if self.table is None:
-            rows, first = [], 0
+            per_dev = {}
             for (ptr, m, flip), (w, U, K, C, _, _) in self.entries.items():
+                rows, first = per_dev.setdefault(U.device, [[], 0])
                 rows.append([ptr, U.data_ptr(), K, C, 2 * m + (1 if flip else 0), first])
-                first += (K * C + 255) // 256
-            self.table = torch.tensor(rows, dtype=torch.int64).to(dev)
-            self.total_blocks = first
+                per_dev[U.device][1] = first + (K * C + 255) // 256
+            self.table = [(dev, torch.tensor(rows, dtype=torch.int64).to(dev), blocks)
+                          for dev, (rows, blocks) in per_dev.items()]
         for e in self.entries.values():
             e[4] = False
-        with torch.cuda.device(dev):
-            _call("fpsg_wino_filter_transform_batch", _hip.ptr(self.table), self.table.shape[0], self.total_blocks,
-                  torch.cuda.current_stream(dev).cuda_stream)
+        for dev, table, blocks in self.table:
+            with torch.cuda.device(dev):
+                _call("fpsg_wino_filter_transform_batch", _hip.ptr(table), table.shape[0], blocks,
+                      torch.cuda.current_stream(dev).cuda_stream)
         self.valid = True
 
 
 _bank = _FilterBank()
+
+
+def check_bank_before_replay() -> None:
+    """A hipGraph captured inside a ``weights_frozen`` block holds no filter-transform launches: it reads the bank's
+    pinned buffers, which are only right when the block the replay runs in has refreshed them.  Raises otherwise (a
+    replay outside a block would silently use the previous step's filters)."""
+    if _bank.has_pinned() and not _bank.valid:
+        raise RuntimeError("hipGraph replay outside a refreshed winograd.weights_frozen() block: the captured "
+                           "episode reads transformed filters that were not recomputed for the current weights")
 
 
 def filter_bank_enabled() -> bool:
@@ -185,7 +196,8 @@ class weights_frozen:
         global _frozen_cache
         self._outer = _frozen_cache
         _frozen_cache = {} if _frozen_cache is None else _frozen_cache
-        if self._outer is None and filter_bank_enabled() and torch.cuda.is_available() \
+        # (a graph captured with the bank reads its pinned buffers whatever FPSG_FILTER_BANK says later)
+        if self._outer is None and (filter_bank_enabled() or _bank.has_pinned()) and torch.cuda.is_available() \
                 and not torch.cuda.is_current_stream_capturing():
             _bank.refresh()
         return self

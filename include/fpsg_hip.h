@@ -456,7 +456,8 @@ int fpsg_adam_step(float* param, const float* grad, float* exp_avg, float* exp_a
  * [seg_off[s], seg_off[s+1]) (seg_off: nseg+1 int64 on the device, seg_off[0] = 0, seg_off[nseg] = n)
  * and its gradient is the contiguous fp32 tensor at grad_ptrs[s] (device array of nseg device
  * pointers; NULL = no gradient = zero).  Saves the gather of the gradients into a flat buffer when a
- * step is one episode on one rank (the reference's own loop, trainNetwork.py:140-148).
+ * step is one episode on one rank (the reference's own loop, trainNetwork.py:140-148).  param, exp_avg and
+ * exp_avg_sq 16-byte aligned (FPSG_E_ALIGN otherwise); the gradient tensors may start anywhere.
  */
 int fpsg_adam_step_segments(float* param, const float* const* grad_ptrs, const long long* seg_off, int nseg,
                             float* exp_avg, float* exp_avg_sq, size_t n, float lr, float beta1, float beta2,

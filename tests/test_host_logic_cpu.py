@@ -108,7 +108,7 @@ def test_deferred_batch_counters_match_immediate_increments():
         bn_counters.count_batch(c)
         assert int(a.num_batches_tracked) == 1 and int(b.num_batches_tracked) == 5     # not yet
     assert int(a.num_batches_tracked) == 3 and int(b.num_batches_tracked) == 6
-    assert bn_counters._pending is None
+    assert bn_counters._tls.pending is None
 
 
 def test_deferred_running_statistics_keep_order_and_values():
@@ -137,7 +137,7 @@ def test_deferred_running_statistics_keep_order_and_values():
         assert torch.equal(x, y)
     a, _, _ = run(True)
     assert torch.equal(a, (a0 * 0.9 + adds[0]) * 0.9 + adds[3])
-    assert bn_counters._stats is None
+    assert bn_counters._tls.stats is None
 
 
 def test_flat_layout_keeps_the_decoder_stack_groups_together():
@@ -172,3 +172,20 @@ def test_flat_layout_keeps_the_decoder_stack_groups_together():
     # copies lose the tags (torch's Parameter.__deepcopy__): they are simply laid out in the plain order
     clone = copy.deepcopy(dec)
     assert [id(p) for p in layout_order(list(clone.parameters()))] == [id(p) for p in reversed(list(clone.parameters()))]
+
+
+def test_deferred_bookkeeping_is_per_thread():
+    """a second thread's training-mode forward while a deferred() block is open neither joins the block
+    nor loses its own update."""
+    import threading
+    import torch
+    from fpsg_amd import bn_counters
+    a, b = torch.nn.BatchNorm1d(3), torch.nn.BatchNorm1d(3)
+    with bn_counters.deferred():
+        bn_counters.count_batch(a)
+        t = threading.Thread(target=lambda: bn_counters.count_batch(b, 2))
+        t.start()
+        t.join()
+        assert int(b.num_batches_tracked) == 2          # applied at once: the other thread has no open block
+        assert int(a.num_batches_tracked) == 0          # still pending in this thread's block
+    assert int(a.num_batches_tracked) == 1 and int(b.num_batches_tracked) == 2

@@ -590,3 +590,42 @@ def test_batchnorm_backward_sums_from_the_data_gradient_convolution(gpu, monkeyp
     # sum(dx) over N*H*W values
     bound = 1e-6 * float(res[1][1].abs().sum(dim=(0, 2, 3)).max())
     assert float(res[0][-1].abs().max()) <= bound and float(res[1][-1].abs().max()) <= bound
+
+
+def test_graph_replay_reads_refreshed_filters_and_refuses_a_stale_bank(gpu, monkeypatch):
+    """a hipGraph captured inside a weights_frozen block holds no filter-transform launches and reads the
+    bank's pinned buffers.  After the weights change (an optimizer step), a replay inside a new block equals the eager
+    convolution with the NEW weights -- also when FPSG_FILTER_BANK was switched off after the capture -- and a replay
+    outside a refreshed block is refused by the check TrainStep runs before g.replay()."""
+    from fpsg_amd import winograd
+    winograd._bank.__init__()
+    torch.manual_seed(11)
+    w = torch.randn(128, 128, 3, 3, device=gpu) * 0.05
+    x = torch.randn(2, 128, 32, 32, device=gpu)
+    static_x = x.clone()
+    with winograd.weights_frozen():                                   # block 1: registers the filter
+        winograd.conv3x3(static_x, w)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    g = torch.cuda.CUDAGraph()
+    with winograd.weights_frozen():                                   # block 2: refresh, then capture
+        with torch.cuda.stream(side):
+            winograd.conv3x3(static_x, w)                             # warm-up on the capture stream
+            with torch.cuda.graph(g, stream=side):
+                static_y = winograd.conv3x3(static_x, w)
+    torch.cuda.current_stream().wait_stream(side)
+    assert winograd._bank.has_pinned()
+    ref0 = torch.nn.functional.conv2d(x.double(), w.double(), padding=1)
+    w.mul_(-0.7).add_(0.01)                                           # "optimizer.step()": same memory, new values
+    ref1 = torch.nn.functional.conv2d(x.double(), w.double(), padding=1)
+    with pytest.raises(RuntimeError, match="replay outside"):
+        winograd.check_bank_before_replay()                           # no block open: the buffers hold the old filters
+    for env in ("1", "0"):                                            # the bank refreshes pinned entries either way
+        monkeypatch.setenv("FPSG_FILTER_BANK", env)
+        with winograd.weights_frozen():
+            winograd.check_bank_before_replay()
+            g.replay()
+            torch.cuda.synchronize()
+            got = static_y.double()
+        assert float((got - ref1).abs().max()) < 1e-3 * float(ref1.abs().max())
+        assert float((got - ref0).abs().max()) > 0.1 * float(ref0.abs().max())       # and it is not the old result

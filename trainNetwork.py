@@ -6,7 +6,9 @@ Same command line, log lines and checkpoint files as reference ``src/trainNetwor
 PyTorch-ROCm networks).  Extras: ``--synthetic`` data, and data-parallel episodes when
 launched with ``python -m torch.distributed.run --nproc-per-node N trainNetwork.py ...``
 (every optimizer step then covers ``--episodes_per_step`` episodes, default one per rank;
-gradients are averaged with an RCCL all-reduce; rank 0 logs, evaluates and saves).
+gradients are averaged with an RCCL all-reduce; the BatchNorm buffers of the ranks are reconciled before an
+evaluation or a save (``fpsg_amd.dist.BufferSync``); every rank evaluates a shard of the test items; rank 0 logs and
+saves).
 
     python trainNetwork.py --synthetic --n_shot 1 --n_query 1 --epoch 2 --n_episode 10 \
         --pc_encoder_path tests/golden/pretrained_pcencoder_pointnet.pt --model_path /tmp/ckpt
@@ -27,17 +29,25 @@ from fpsg_amd.engine import TrainStep, build_model, build_optimizer, to_device
 from fpsg_amd.episodes import EpisodePrefetcher
 
 
-def evaluate(model, dl_test, n_query, n_shot, device, log):
-    """Per-class Chamfer report (reference :157-189); returns the per-item values."""
+def evaluate(model, dl_test, n_query, n_shot, device, log, rank: int = 0, world: int = 1):
+    """Per-class Chamfer report (reference :157-189); returns the per-item values.
+
+    With ``world`` ranks every rank evaluates the test items ``rank, rank + world, ...`` (every rank walks the same
+    loader, so the items and their order are the single-process ones) and the values are gathered: no rank sits in a
+    collective while another evaluates, and the report lines are those of one process."""
     model.eval()
+    mine = []
+    with torch.no_grad():
+        for n, sample in enumerate(dl_test):
+            if n % world != rank:
+                continue
+            out = model.loss(to_device(sample, device))
+            mine.append((n, sample["class"][0], out["query_rec_loss"].item() / n_query))
     per_class = defaultdict(list)
     every = []
-    with torch.no_grad():
-        for sample in dl_test:
-            out = model.loss(to_device(sample, device))
-            cd = out["query_rec_loss"].item() / n_query
-            per_class[sample["class"][0]].append(cd)
-            every.append(cd)
+    for _, name, cd in sorted(itertools.chain.from_iterable(fdist.gather_objects(mine))):
+        per_class[name].append(cd)
+        every.append(cd)
     for name in sorted(per_class):
         vals = per_class[name]
         spread = statistics.stdev(vals) if len(vals) > 1 else 0.0
@@ -69,32 +79,42 @@ def main(opt):
 
     model = build_model(opt)
     start_epoch = 1
+    state_path = None
     if opt.resume > 0:
         start_epoch = opt.resume
         resume_path = os.path.join(checkpoint_path, f"model_epoch_{start_epoch}.pt")
         if not os.path.exists(resume_path):
             raise RuntimeError(f"{resume_path} does not exist, loading failed")
-        print(f"Resume previous training, start from epoch {start_epoch}, loading previous model")
         model.load_state_dict(torch.load(resume_path, map_location="cpu", weights_only=True))
+        # Extension (SURVEY.md 8f-N3): the reference saves weights only, so a resumed run restarts
+        # Adam's moments and the LR schedule.  A sidecar file keeps them; the weights file keeps
+        # the reference's format and name.  Rank 0 decides whether the sidecar is used (ranks that saw different
+        # directories would run different epoch counts and hang in the collectives).
+        state_path = os.path.join(checkpoint_path, f"train_state_epoch_{start_epoch}.pt")
+        if not fdist.broadcast_object(os.path.exists(state_path) if is_main else None):
+            state_path = None
     model = model.to(device).train()
     fdist.broadcast_parameters(model)
 
     optimizer, scheduler = build_optimizer(model, opt)
-    if opt.resume > 0:
-        # Extension (SURVEY.md 8f-N3): the reference saves weights only, so a resumed run restarts
-        # Adam's moments and the LR schedule.  A sidecar file keeps them; the weights file keeps
-        # the reference's format and name.
-        state_path = os.path.join(checkpoint_path, f"train_state_epoch_{start_epoch}.pt")
-        if os.path.exists(state_path):
-            state = torch.load(state_path, map_location=device, weights_only=True)
-            optimizer.load_state_dict(state["optimizer"])
-            scheduler.load_state_dict(state["scheduler"])
-            # the sidecar holds the state AFTER epoch N's scheduler.step(): training continues with epoch
-            # N+1 (the weights-only resume of the reference re-runs epoch N from fresh moments; doing that
-            # here would step the LR schedule twice for epoch N and reuse post-epoch-N moments)
-            start_epoch = int(state.get("epoch", start_epoch)) + 1
-            print(f"Restored optimizer / scheduler state from {state_path}; continuing with epoch {start_epoch}")
+    if state_path is not None:
+        state = torch.load(state_path, map_location=device, weights_only=True)
+        optimizer.load_state_dict(state["optimizer"])
+        scheduler.load_state_dict(state["scheduler"])
+        # the sidecar holds the state AFTER epoch N's scheduler.step(): training continues with epoch
+        # N+1 (the weights-only resume of the reference re-runs epoch N from fresh moments; doing that
+        # here would step the LR schedule twice for epoch N and reuse post-epoch-N moments)
+        start_epoch = int(state.get("epoch", start_epoch)) + 1
+    start_epoch = int(fdist.broadcast_object(start_epoch))
+    if opt.resume > 0 and is_main:
+        how = (f"optimizer / scheduler state restored from {state_path}" if state_path is not None
+               else "weights only, fresh optimizer state as in the reference")
+        print(f"Resume previous training from model_epoch_{opt.resume}.pt ({how}): next epoch is {start_epoch}")
+    if start_epoch > opt.epoch:
+        raise RuntimeError(f"nothing to do: the resumed run would start at epoch {start_epoch} but --epoch is "
+                           f"{opt.epoch}")
     step = TrainStep(model, optimizer, world=world)
+    buffers = fdist.BufferSync(model)
     eps_per_step = opt.episodes_per_step or world
     local_n = len(range(rank, eps_per_step, world))
 
@@ -139,19 +159,25 @@ def main(opt):
             print(f"  [{done / dt:.2f} episodes/s over {world} GPU(s)]")
         scheduler.step()
 
-        if is_main and (epoch % opt.eval_interval == 0 or epoch == opt.epoch):
-            every = evaluate(model, dl_test, n_query, opt.n_shot, device, log)
+        evaluating = epoch % opt.eval_interval == 0 or epoch == opt.epoch
+        saving = epoch % opt.save_interval == 0 or epoch == opt.epoch
+        if evaluating or saving or epoch % opt.sample_interval == 0:
+            buffers.sync()          # the BatchNorm running statistics of all ranks' episodes, as one process holds them
+        if evaluating:
+            if world > 1:
+                torch.manual_seed(2000003 * epoch)      # every rank walks the same test items (the shards partition them)
+            every = evaluate(model, dl_test, n_query, opt.n_shot, device, log, rank, world)
             spread = statistics.stdev(every) if len(every) > 1 else 0.0
             log(f"Avg testing results across all classes Epoch -- {epoch} are: "
                 f"Query_rec: {sum(every) / max(len(every), 1)} ({spread})")
-            for sample in dl_test:
+            for sample in dl_test if is_main else ():
                 model.eval()
                 model.draw_reconstruction(to_device(sample, device),
                                           os.path.join(checkpoint_imgs, f"sample_img_{epoch}_test.png"))
                 model.train()
                 break
 
-        if is_main and (epoch % opt.save_interval == 0 or epoch == opt.epoch):
+        if is_main and saving:
             torch.save(model.state_dict(), os.path.join(checkpoint_path, f"model_epoch_{epoch}.pt"))
             torch.save({"optimizer": optimizer.state_dict(), "scheduler": scheduler.state_dict(),
                         "epoch": epoch}, os.path.join(checkpoint_path, f"train_state_epoch_{epoch}.pt"))
