@@ -22,6 +22,10 @@ namespace fpsg {
 namespace {
 
 constexpr int kEcThreads = 256;  // 4 waves
+#ifndef FPSG_EC_IN_FLIGHT
+#define FPSG_EC_IN_FLIGHT 4
+#endif
+constexpr int kInFlight = FPSG_EC_IN_FLIGHT;   // in-edges whose rows a wave of the backward has in flight
 
 template <int VEC>
 struct VecT;
@@ -197,12 +201,11 @@ __global__ __launch_bounds__(kEcThreads) void edgeconv_bwd_kernel(
     for (int tb = e0; tb < e1; tb += 64) {
       const int here = (e1 - tb) < 64 ? (e1 - tb) : 64;
       const int mine = lane < here ? revb[tb + lane] : 0;        // one coalesced read of up to 64 edge ids
-      for (int t = 0; t < here; t += 2) {
-        const bool two = t + 1 < here;
-        int n[2], j[2];
-        size_t rown[2];
+      for (int t = 0; t < here; t += kInFlight) {
+        int n[kInFlight], j[kInFlight];
+        size_t rown[kInFlight];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < kInFlight; ++u) {
           const int e = __builtin_amdgcn_readlane(mine, (t + u) < here ? (t + u) : t);
           int nn = e / k;
           nn = nn < 0 ? 0 : (nn >= N ? N - 1 : nn);
@@ -210,17 +213,17 @@ __global__ __launch_bounds__(kEcThreads) void edgeconv_bwd_kernel(
           j[u] = e - nn * k;
           rown[u] = (size_t)b * N + nn;
         }
-        float g[2][VEC], qn[2][VEC];
-        unsigned js[2];
+        float g[kInFlight][VEC], qn[kInFlight][VEC];
+        unsigned js[kInFlight];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {                              // both edges' rows in flight
+        for (int u = 0; u < kInFlight; ++u) {                      // the rows of kInFlight edges in flight
           load_vec<VEC>(dzs + rown[u] * Co + c0, g[u]);
           js[u] = load_js(rown[u]);
           if (stats) load_vec<VEC>(pq + (size_t)n[u] * 2 * Co + Co + c0, qn[u]);
         }
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          if (u == 1 && !two) break;
+        for (int u = 0; u < kInFlight; ++u) {                      // summed in edge order
+          if (t + u >= here) break;
 #pragma unroll
           for (int v = 0; v < VEC; ++v) acc[v] += ((int)((js[u] >> (8 * v)) & 0xffu) == j[u]) ? g[u][v] : 0.0f;
           if (stats) {

@@ -30,7 +30,7 @@ import torch
 from PIL import Image
 from torch.utils.data import Dataset
 
-from .episodes import extract_episode
+from .episodes import extract_episode, take_rows
 
 SHAPENET_ID2NAME = {
     "02691156": "airplane", "02773838": "bag", "02801938": "basket", "02808440": "bathtub",
@@ -222,9 +222,9 @@ class _FewShotFiles(Dataset):
         key, shown = self.class_of(self.data_corpus[int(index)])
         ans = extract_episode(self.n_support, self.n_query, {
             "class": shown, "img_data": self.reference[key]["imgs"], "pc_data": self.reference[key]["pcs"]})
-        ad = torch.randperm(self.img_corpus.size(0))[:self.n_support].to(self.img_corpus.device)
-        ans["xad"] = self.img_corpus[ad]
-        ans["pcad"] = self.pc_corpus[ad]
+        ad = torch.randperm(self.img_corpus.size(0))[:self.n_support]
+        ans["xad"] = take_rows(self.img_corpus, ad)
+        ans["pcad"] = take_rows(self.pc_corpus, ad)
         return ans
 
 

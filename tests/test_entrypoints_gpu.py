@@ -36,7 +36,8 @@ def test_train_then_evaluate(gpu, tmp_path):
     out2 = _run(["trainNetwork.py", "--synthetic", "--n_shot", "1", "--n_query", "1", "--epoch", "3", "--resume", "2",
                  "--n_episode", "2", "--pc_dist", "emd", "--model_path", ck, "--name", "t"])
     assert "Resume previous training, start from epoch 2" in out2 and "Epoch -- 3" in out2
-    assert "train_state_epoch_2.pt" in files and "Restored optimizer / scheduler state" in out2
+    assert "train_state_epoch_2.pt" in files and "optimizer / scheduler state restored" in out2
+    assert "the next epoch is 3" in out2
 
 
 def test_dgcnn_encoder_and_ae_mode(gpu, tmp_path):

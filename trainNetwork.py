@@ -81,6 +81,8 @@ def main(opt):
     start_epoch = 1
     state_path = None
     if opt.resume > 0:
+        if is_main:
+            print(f"Resume previous training, start from epoch {opt.resume}, loading previous model")   # reference :106
         start_epoch = opt.resume
         resume_path = os.path.join(checkpoint_path, f"model_epoch_{start_epoch}.pt")
         if not os.path.exists(resume_path):
@@ -109,7 +111,7 @@ def main(opt):
     if opt.resume > 0 and is_main:
         how = (f"optimizer / scheduler state restored from {state_path}" if state_path is not None
                else "weights only, fresh optimizer state as in the reference")
-        print(f"Resume previous training from model_epoch_{opt.resume}.pt ({how}): next epoch is {start_epoch}")
+        print(f"Resumed from model_epoch_{opt.resume}.pt ({how}): the next epoch is {start_epoch}")
     if start_epoch > opt.epoch:
         raise RuntimeError(f"nothing to do: the resumed run would start at epoch {start_epoch} but --epoch is "
                            f"{opt.epoch}")
