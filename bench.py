@@ -147,21 +147,7 @@ def make_episodes(S, Q, count, seed, device):
             for i in range(count)]
 
 
-def usable_cores() -> int:
-    """Cores this process may really use: affinity mask and cgroup CPU quota, not the host's
-    core count (the GPU box exposes every host core but grants a 16-core share)."""
-    n = os.cpu_count() or 1
-    try:
-        n = min(n, len(os.sched_getaffinity(0)))
-    except AttributeError:
-        pass
-    try:
-        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
-        if quota != "max":
-            n = min(n, max(1, int(int(quota) / int(period))))
-    except (OSError, ValueError):
-        pass
-    return max(1, min(n, int(os.environ.get("FPSG_CPU_THREADS", "16"))))
+from fpsg_amd.cli import usable_cores  # noqa: E402  (affinity mask + cgroup quota, capped by FPSG_CPU_THREADS)
 
 
 def cpu_baseline(S, Q, intra, encoder, budget_s):

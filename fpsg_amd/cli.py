@@ -16,6 +16,8 @@ from __future__ import annotations
 
 import argparse
 
+import os
+
 import torch
 from torch.utils.data import DataLoader
 
@@ -127,7 +129,35 @@ def build_loaders(opt, ds, ds_test):
     return dl, dl_test
 
 
+def usable_cores() -> int:
+    """Cores this process may really use: affinity mask and cgroup CPU quota, not the host's core count (a container
+    on a GPU node sees every host core but is granted a share of them).  ``FPSG_CPU_THREADS`` caps it (default 16)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, int(os.environ.get("FPSG_CPU_THREADS", "16"))))
+
+
+def limit_host_threads(world: int = 1) -> int:
+    """PyTorch sizes its intra-op pool by the HOST's core count; with a 16-core share of a 200-core node every host
+    op that parallelises (the row gathers of episode assembly, normalisation, collate) then thrashes -- the gather
+    of one 32-shot episode took 30 ms instead of 3.  One call per process, before the first parallel op."""
+    n = max(1, usable_cores() // max(world, 1))
+    if torch.get_num_threads() > n:
+        torch.set_num_threads(n)
+    return n
+
+
 def pick_device(opt) -> torch.device:
+    limit_host_threads()
     if opt.device.startswith("cuda") and not torch.cuda.is_available():
         raise SystemExit("--device cuda requested but no ROCm GPU is visible "
                          "(the Chamfer / EMD / kNN ops are HIP kernels; there is no CPU fallback)")

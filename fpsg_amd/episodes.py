@@ -63,12 +63,14 @@ class _PinnedRing:
 def take_rows(corpus: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
     """``corpus[idx]`` (rows of a corpus, as ``modelnet.py:117-120`` indexes them).  On the host ``index_select`` is a
     row-wise memcpy -- the advanced-indexing kernel behind ``corpus[idx]`` moves the 69 images of a 32-shot episode
-    (42 MB) 5-30x slower, which made episode assembly the bottleneck of host-resident corpora; and when the calling
+    (42 MB) several times slower once the intra-op pool matches the cores the process really has
+    (``cli.limit_host_threads``), which made episode assembly the bottleneck of host-resident corpora; and when the calling
     thread has a pinned staging ring open (``EpisodePrefetcher``) the rows land in pinned memory at once, ready for an
     asynchronous upload (no second 42 MB ``pin_memory()`` copy)."""
-    idx = idx.to(corpus.device)
+    if corpus.device.type != "cpu":
+        return corpus[idx.to(corpus.device)]               # resident corpora: the device's gather kernel
     ring = getattr(_staging, "ring", None)
-    if ring is not None and corpus.device.type == "cpu":
+    if ring is not None:
         out = ring.take((idx.numel(),) + tuple(corpus.shape[1:]), corpus.dtype)
         return torch.index_select(corpus, 0, idx, out=out)
     return torch.index_select(corpus, 0, idx)

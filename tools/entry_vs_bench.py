@@ -17,6 +17,7 @@ from fpsg_amd.episodes import EpisodePrefetcher, SyntheticFewShot, collate_episo
 
 def main():
     dev = torch.device("cuda:0")
+    print("host threads:", torch.get_num_threads(), "->", cli.limit_host_threads(), flush=True)
     gemm_tuning.enable()
     opt = default_options(device="cuda", intra_recon=True)
     model = build_model(opt).to(dev).train()

@@ -60,6 +60,7 @@ def main(opt):
     cli.validate(opt)
     n_query = opt.n_shot if opt.n_query == 0 else opt.n_query
     rank, world, device = fdist.init_distributed("cuda" if opt.device.startswith("cuda") else "cpu")
+    cli.limit_host_threads(world)
     if world == 1:
         device = cli.pick_device(opt)
     elif device.type == "cuda":
