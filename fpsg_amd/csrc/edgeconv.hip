@@ -18,6 +18,11 @@
 // dQ[m] = dzs[m] - k A - Bc (S1[m] - k mu)   (A, Bc: the BatchNorm statistic terms).
 #include "fpsg_common.h"
 
+#include <stdlib.h>
+#include <string.h>
+
+#include <type_traits>
+
 namespace fpsg {
 namespace {
 
@@ -146,6 +151,113 @@ __global__ __launch_bounds__(kEcThreads) void edgeconv_fwd_kernel(
   }
 }
 
+// The forward with SEVERAL neighbours per load instruction (round 3; Co = 64 and 128).  At Co = 64 a neighbour's P row
+// is 256 bytes: one float per lane and 20 small loads per point.  With 4 channels per lane (16-byte loads) a row takes
+// LPE = Co / 4 lanes and a wave instruction reads the rows of G = 64 / LPE neighbours.  Group g walks neighbours
+// g, g + G, ... in order; the groups' partial results are then merged: sums pairwise in a fixed order (deterministic;
+// last bits differ from the one-neighbour order), the selected extreme by (value, then lower slot) -- exactly the
+// "first strictly better wins" rule of the sequential walk.
+template <int LPE>
+__global__ __launch_bounds__(kEcThreads) void edgeconv_fwd_grouped_kernel(
+    const float* __restrict__ PQ, const int32_t* __restrict__ idx, const float* __restrict__ sgn,
+    int B, int N, int k, int bpc, int ppw, float* __restrict__ ysel, uint8_t* __restrict__ jsel, float* __restrict__ s1,
+    float* __restrict__ part) {
+  constexpr int G = 64 / LPE;
+  constexpr int Co = 4 * LPE;
+  __shared__ float red[4][2][Co];
+  const CloudBlock cb = cloud_block(bpc);
+  if (cb.b >= B) return;
+  const int b = cb.b;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int grp = lane / LPE, cl = lane - grp * LPE;
+  const int c0 = cl * 4;
+  const float* __restrict__ base = PQ + (size_t)b * N * 2 * Co;
+  float sg[4], sum[4], sumsq[4];
+  load_vec<4>(sgn + c0, sg);
+#pragma unroll
+  for (int v = 0; v < 4; ++v) { sg[v] = sg[v] < 0.0f ? -1.0f : 1.0f; sum[v] = 0.0f; sumsq[v] = 0.0f; }
+
+  auto merge = [&](auto xor_tag, float (&best)[4], int (&bj)[4], float (&tot)[4]) {
+    constexpr int M = decltype(xor_tag)::value;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const float ob = __uint_as_float(lane_xor<M>(__float_as_uint(best[v])));
+      const int oj = (int)lane_xor<M>((unsigned)bj[v]);
+      const bool take = ob > best[v] || (ob == best[v] && oj < bj[v]);
+      bj[v] = take ? oj : bj[v];
+      best[v] = take ? ob : best[v];
+      tot[v] += __uint_as_float(lane_xor<M>(__float_as_uint(tot[v])));
+    }
+  };
+
+  const int n_first = (cb.bx * 4 + wave) * ppw;
+  for (int pp = 0; pp < ppw; ++pp) {
+    const int n = n_first + pp;
+    if (n >= N) break;  // wave-uniform
+    const size_t row = (size_t)b * N + n;
+    int my = lane < k ? idx[row * k + lane] : 0;
+    my = my < 0 ? 0 : (my >= N ? N - 1 : my);
+    float q[4], best[4], tot[4];
+    int bj[4];
+    load_vec<4>(base + (size_t)n * 2 * Co + Co + c0, q);
+#pragma unroll
+    for (int v = 0; v < 4; ++v) { best[v] = -__builtin_inff(); bj[v] = 0x7fffffff; tot[v] = 0.0f; }
+    for (int j0 = 0; j0 < k; j0 += G * kInFlight) {
+      float p[kInFlight][4];
+      int jj[kInFlight];
+#pragma unroll
+      for (int u = 0; u < kInFlight; ++u) {
+        jj[u] = j0 + u * G + grp;
+        const int m = __shfl(my, jj[u] < k ? jj[u] : 0, 64);
+        load_vec<4>(base + (size_t)m * 2 * Co + c0, p[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < kInFlight; ++u) {
+        if (jj[u] < k) {
+#pragma unroll
+          for (int v = 0; v < 4; ++v) {
+            const float y = p[u][v] + q[v];
+            tot[v] += y;
+            sumsq[v] = fma_rn(y, y, sumsq[v]);
+            const float t = y * sg[v];          // +-y: one code path for max and min
+            const bool gt = t > best[v];
+            bj[v] = gt ? jj[u] : bj[v];
+            best[v] = gt ? t : best[v];
+          }
+        }
+      }
+    }
+    if constexpr (G == 4) merge(std::integral_constant<int, 16>{}, best, bj, tot);
+    merge(std::integral_constant<int, 32>{}, best, bj, tot);
+    if (grp == 0) {
+      float out[4];
+#pragma unroll
+      for (int v = 0; v < 4; ++v) { out[v] = best[v] * sg[v]; sum[v] += tot[v]; }
+      store_vec<4>(ysel + row * Co + c0, out);
+      if (s1) store_vec<4>(s1 + row * Co + c0, tot);
+      *reinterpret_cast<uint32_t*>(jsel + row * Co + c0) =
+          (uint32_t)(bj[0] & 0xff) | ((uint32_t)(bj[1] & 0xff) << 8) | ((uint32_t)(bj[2] & 0xff) << 16) | ((uint32_t)(bj[3] & 0xff) << 24);
+    }
+  }
+  if (!part) return;
+#pragma unroll
+  for (int v = 0; v < 4; ++v) {            // sum of squares: every group holds a share
+    if constexpr (G == 4) sumsq[v] += __uint_as_float(lane_xor<16>(__float_as_uint(sumsq[v])));
+    sumsq[v] += __uint_as_float(lane_xor<32>(__float_as_uint(sumsq[v])));
+  }
+  if (grp == 0) {
+#pragma unroll
+    for (int v = 0; v < 4; ++v) { red[wave][0][c0 + v] = sum[v]; red[wave][1][c0 + v] = sumsq[v]; }
+  }
+  __syncthreads();
+  float* dst = part + ((size_t)b * bpc + cb.bx) * 2 * Co;
+  for (int e = threadIdx.x; e < 2 * Co; e += kEcThreads) {
+    const int which = e / Co, c = e - which * Co;
+    dst[e] = (red[0][which][c] + red[1][which][c]) + (red[2][which][c] + red[3][which][c]);
+  }
+}
+
 // dzs [B,N,Co] = dz*scale; jsel; PQ; s1 (or null when coef A=Bc=0); rev [B,N*k] edge ids
 // (n*k+j) grouped by destination, ascending inside a group; off [B,N+1] group offsets;
 // coef [3][Co] = A, Bc, mu.  Output dPQ [B,N,2*Co].
@@ -254,9 +366,123 @@ __global__ __launch_bounds__(kEcThreads) void edgeconv_bwd_kernel(
   }
 }
 
+// The same backward with SEVERAL in-edges per load instruction (round 3).  The one-edge form reads a 256-byte row per
+// load at Co = 64 (one float per lane): 60 small loads per point, and the kernel is bound by the number of memory
+// transactions, not by bytes.  Here a lane always holds 4 channels (16-byte loads), so a row of a 64 * 4 / G-channel
+// slice takes LPE = 64 / G lanes and a wave instruction reads the rows of G in-edges: G = 4 at Co = 64, G = 2 at
+// Co = 128 and for the 128-channel slices of Co = 256.  Group g sums in-edges g, g + G, ... in order; the groups are
+// then added pairwise ((g0 + g1) + (g2 + g3)) with lane exchanges: a fixed order, so still deterministic (it differs
+// from the one-edge order in the last bits).
+template <int LPE>
+__global__ __launch_bounds__(kEcThreads) void edgeconv_bwd_grouped_kernel(
+    const float* __restrict__ dzs, const uint8_t* __restrict__ jsel, const float* __restrict__ PQ,
+    const float* __restrict__ s1, const int32_t* __restrict__ rev, const int32_t* __restrict__ off,
+    const float* __restrict__ coef, int B, int N, int k, int bpc, int ppw, int nsl, int stats, float* __restrict__ dPQ) {
+  constexpr int G = 64 / LPE;                 // in-edges per load instruction
+  constexpr int SLICE = 4 * LPE;              // channels of a workgroup's slice
+  const int Co = SLICE * nsl;
+  const int id = blockIdx.x, xcd = id & 7, slot = id >> 3;
+  const int pair = xcd + 8 * (slot / bpc);            // = slice-major inside a cloud: pair = b * nsl + sl
+  const int bx = slot % bpc;
+  const int b = pair / nsl, sl = pair - b * nsl;
+  if (b >= B) return;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int grp = lane / LPE, cl = lane - grp * LPE;
+  const int c0 = sl * SLICE + cl * 4;
+  float A[4], Bc[4], mu[4];
+  load_vec<4>(coef + c0, A);
+  load_vec<4>(coef + Co + c0, Bc);
+  load_vec<4>(coef + 2 * Co + c0, mu);
+  const float* __restrict__ pq = PQ + (size_t)b * N * 2 * Co;
+  const int32_t* __restrict__ revb = rev + (size_t)b * N * k;
+  const int32_t* __restrict__ offb = off + (size_t)b * (N + 1);
+  const int m_first = (bx * 4 + wave) * ppw;
+  const size_t row0 = (size_t)b * N;
+
+  for (int pp = 0; pp < ppw; ++pp) {
+    const int m = m_first + pp;
+    if (m >= N) break;
+    const size_t rowm = row0 + m;
+    int e0 = offb[m], e1 = offb[m + 1];
+    e0 = e0 < 0 ? 0 : e0;
+    e1 = e1 > N * k ? N * k : e1;  // never walk outside the edge list
+    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f}, accq[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (int tb = e0; tb < e1; tb += 64) {
+      const int here = (e1 - tb) < 64 ? (e1 - tb) : 64;
+      const int mine = lane < here ? revb[tb + lane] : 0;        // one coalesced read of up to 64 edge ids
+      for (int t = 0; t < here; t += G * kInFlight) {
+        bool on[kInFlight];
+        int j[kInFlight];
+        size_t rown[kInFlight];
+#pragma unroll
+        for (int u = 0; u < kInFlight; ++u) {
+          const int te = t + u * G + grp;                          // this lane group's edge of the round
+          on[u] = te < here;
+          const int e = __shfl(mine, on[u] ? te : 0, 64);
+          int nn = e / k;
+          nn = nn < 0 ? 0 : (nn >= N ? N - 1 : nn);
+          j[u] = e - nn * k;
+          rown[u] = row0 + nn;
+        }
+        float g[kInFlight][4], qn[kInFlight][4];
+        unsigned js[kInFlight];
+#pragma unroll
+        for (int u = 0; u < kInFlight; ++u) {                      // the rows of G * kInFlight in-edges in flight
+          load_vec<4>(dzs + rown[u] * Co + c0, g[u]);
+          js[u] = *reinterpret_cast<const uint32_t*>(jsel + rown[u] * Co + c0);
+          if (stats) load_vec<4>(pq + (rown[u] - row0) * 2 * Co + Co + c0, qn[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < kInFlight; ++u) {                      // a group's edges in order
+#pragma unroll
+          for (int v = 0; v < 4; ++v) {
+            acc[v] += (on[u] && (int)((js[u] >> (8 * v)) & 0xffu) == j[u]) ? g[u][v] : 0.0f;
+            if (stats) accq[v] += on[u] ? qn[u][v] : 0.0f;
+          }
+        }
+      }
+    }
+    // the groups' sums, pairwise
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      if constexpr (G == 4) {
+        acc[v] += __uint_as_float(lane_xor<16>(__float_as_uint(acc[v])));
+        accq[v] += __uint_as_float(lane_xor<16>(__float_as_uint(accq[v])));
+      }
+      acc[v] += __uint_as_float(lane_xor<32>(__float_as_uint(acc[v])));
+      accq[v] += __uint_as_float(lane_xor<32>(__float_as_uint(accq[v])));
+    }
+    if (grp == 0) {
+      float dp[4], dq[4];
+      load_vec<4>(dzs + rowm * Co + c0, dq);
+      if (stats) {
+        float pm[4], sm[4];
+        load_vec<4>(pq + (size_t)m * 2 * Co + c0, pm);
+        load_vec<4>(s1 + rowm * Co + c0, sm);
+        const float cnt = (float)(e1 - e0), kf = (float)k;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          dp[v] = acc[v] - cnt * (A[v] + Bc[v] * (pm[v] - mu[v])) - Bc[v] * accq[v];
+          dq[v] = dq[v] - kf * A[v] - Bc[v] * (sm[v] - kf * mu[v]);
+        }
+      } else {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) dp[v] = acc[v];
+      }
+      store_vec<4>(dPQ + rowm * 2 * Co + c0, dp);
+      store_vec<4>(dPQ + rowm * 2 * Co + Co + c0, dq);
+    }
+  }
+}
+
 // Points per wave.  An XCD keeps ~256 of these 4-wave workgroups resident; they should belong to as few
 // clouds as fit its 4 MB L2 together (the k-fold gathers of a cloud touch 2 MB of P rows at Co = 256,
 // 0.5 MB at Co = 64): one cloud = 256 workgroups at Co = 256, 128 at Co = 128, 64 at Co = 64 (N = 2048).
+inline bool edgeconv_bwd_one_edge() {
+  const char* e = getenv("FPSG_EDGECONV_BWD");
+  return e != nullptr && strcmp(e, "one_edge") == 0;
+}
 inline int ec_points_per_wave(int Co) { return Co == 256 ? 2 : Co == 128 ? 4 : 8; }
 inline int ec_blocks_per_cloud(int N, int Co) { return (N + 4 * ec_points_per_wave(Co) - 1) / (4 * ec_points_per_wave(Co)); }
 inline dim3 ec_grid(int B, int N, int Co) {          // 8 * ceil(B/8) clouds' worth of workgroups, see cloud_block
@@ -437,7 +663,10 @@ extern "C" int fpsg_edgeconv_fwd(const float* PQ, const int32_t* idx, const floa
   hipStream_t s = static_cast<hipStream_t>(stream);
   const dim3 grid = ec_grid(B, N, Co);
   const int bpc = ec_blocks_per_cloud(N, Co), ppw = ec_points_per_wave(Co);
-  if (Co == 64) hipLaunchKernelGGL(edgeconv_fwd_kernel<1>, grid, dim3(kEcThreads), 0, s, PQ, idx, sgn, B, N, k, bpc, ppw, ysel, jsel, s1, part);
+  const bool one = edgeconv_bwd_one_edge();       // FPSG_EDGECONV_BWD=one_edge also selects the one-neighbour forward
+  if (Co == 64 && !one) hipLaunchKernelGGL(edgeconv_fwd_grouped_kernel<16>, grid, dim3(kEcThreads), 0, s, PQ, idx, sgn, B, N, k, bpc, ppw, ysel, jsel, s1, part);
+  else if (Co == 128 && !one) hipLaunchKernelGGL(edgeconv_fwd_grouped_kernel<32>, grid, dim3(kEcThreads), 0, s, PQ, idx, sgn, B, N, k, bpc, ppw, ysel, jsel, s1, part);
+  else if (Co == 64) hipLaunchKernelGGL(edgeconv_fwd_kernel<1>, grid, dim3(kEcThreads), 0, s, PQ, idx, sgn, B, N, k, bpc, ppw, ysel, jsel, s1, part);
   else if (Co == 128) hipLaunchKernelGGL(edgeconv_fwd_kernel<2>, grid, dim3(kEcThreads), 0, s, PQ, idx, sgn, B, N, k, bpc, ppw, ysel, jsel, s1, part);
   else hipLaunchKernelGGL(edgeconv_fwd_kernel<4>, grid, dim3(kEcThreads), 0, s, PQ, idx, sgn, B, N, k, bpc, ppw, ysel, jsel, s1, part);
   return launch_status("fpsg_edgeconv_fwd");
@@ -459,6 +688,7 @@ extern "C" int fpsg_edgeconv_bwd(const float* dzs, const uint8_t* jsel, const fl
                    (reinterpret_cast<uintptr_t>(dPQ) & 15) == 0 && (reinterpret_cast<uintptr_t>(s1) & 15) == 0 &&
                    (reinterpret_cast<uintptr_t>(coef) & 15) == 0,
                FPSG_E_ALIGN, "fpsg_edgeconv_bwd: float buffers must be 16-byte aligned");
+  FPSG_REQUIRE((reinterpret_cast<uintptr_t>(jsel) & 3) == 0, FPSG_E_ALIGN, "fpsg_edgeconv_bwd: jsel must be 4-byte aligned");
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int stats = s1 != nullptr;
   // channel slices: 128 channels at Co = 256 (two slices), whole rows otherwise
@@ -469,8 +699,13 @@ extern "C" int fpsg_edgeconv_bwd(const float* dzs, const uint8_t* jsel, const fl
   const int ppw = Co == 64 ? 4 : 2;
   const int bpc = (N + 4 * ppw - 1) / (4 * ppw);
   const dim3 grid((unsigned)(8 * ((B * nsl + 7) / 8) * bpc));
-  if (Co == 64) hipLaunchKernelGGL(edgeconv_bwd_kernel<1>, grid, dim3(kEcThreads), 0, s, dzs, jsel, PQ, s1, rev, off, coef, B, N, k, bpc, ppw, nsl, stats, dPQ);
-  else hipLaunchKernelGGL(edgeconv_bwd_kernel<2>, grid, dim3(kEcThreads), 0, s, dzs, jsel, PQ, s1, rev, off, coef, B, N, k, bpc, ppw, nsl, stats, dPQ);
+  if (edgeconv_bwd_one_edge()) {      // FPSG_EDGECONV_BWD=one_edge: round 2's form, one in-edge per load (A/B timing)
+    if (Co == 64) hipLaunchKernelGGL(edgeconv_bwd_kernel<1>, grid, dim3(kEcThreads), 0, s, dzs, jsel, PQ, s1, rev, off, coef, B, N, k, bpc, ppw, nsl, stats, dPQ);
+    else hipLaunchKernelGGL(edgeconv_bwd_kernel<2>, grid, dim3(kEcThreads), 0, s, dzs, jsel, PQ, s1, rev, off, coef, B, N, k, bpc, ppw, nsl, stats, dPQ);
+  } else {
+    if (Co == 64) hipLaunchKernelGGL(edgeconv_bwd_grouped_kernel<16>, grid, dim3(kEcThreads), 0, s, dzs, jsel, PQ, s1, rev, off, coef, B, N, k, bpc, ppw, nsl, stats, dPQ);
+    else hipLaunchKernelGGL(edgeconv_bwd_grouped_kernel<32>, grid, dim3(kEcThreads), 0, s, dzs, jsel, PQ, s1, rev, off, coef, B, N, k, bpc, ppw, nsl, stats, dPQ);
+  }
   return launch_status("fpsg_edgeconv_bwd");
 }
 

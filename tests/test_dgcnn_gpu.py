@@ -281,3 +281,75 @@ def test_reverse_graph_limits_and_bad_entries(gpu, oracle):
         assert eoff[-1] == 799
         assert np.array_equal(off[bi].cpu().numpy(), eoff)
         assert np.array_equal(rev[bi, :799].cpu().numpy(), erev) and int(rev[bi, 799]) == -7
+
+
+@pytest.mark.parametrize("Co,stats", [(64, True), (128, True), (256, True), (64, False)])
+def test_edgeconv_backward_forms_agree(gpu, monkeypatch, Co, stats):
+    """fpsg_edgeconv_bwd: the form with several in-edges per load instruction (default) against the one-edge form of
+    round 2 (FPSG_EDGECONV_BWD=one_edge) on a graph with hubs and isolated points -- equal up to the order of the fp32
+    sums (a lane group sums every G-th in-edge, then the groups are added), and bit-identical from run to run."""
+    from fpsg_amd import _hip
+    from fpsg_amd.dgcnn import _reverse_graph
+    lib = _hip.load()
+    torch.manual_seed(Co)
+    B, N, k = 3, 300, 20
+    idx = torch.randint(0, N, (B, N, k), dtype=torch.int32, device=gpu)
+    idx[:, :, :5] = torch.randint(0, 7, (B, N, 5), dtype=torch.int32, device=gpu)      # hubs: in-degree of hundreds
+    idx[0, :, :] = 5                                                                       # one point takes every edge
+    rev, off = _reverse_graph(idx)
+    dzs = torch.randn(B, N, Co, device=gpu)
+    jsel = torch.randint(0, k, (B, N, Co), dtype=torch.uint8, device=gpu)
+    PQ = torch.randn(B, N, 2 * Co, device=gpu)
+    s1 = torch.randn(B, N, Co, device=gpu) if stats else None
+    coef = torch.randn(3, Co, device=gpu) * 0.1
+    st = torch.cuda.current_stream().cuda_stream
+
+    def run():
+        out = torch.full_like(PQ, float("nan"))
+        _hip.check(lib.fpsg_edgeconv_bwd(dzs.data_ptr(), jsel.data_ptr(), PQ.data_ptr(), s1.data_ptr() if stats else None,
+                                         rev.data_ptr(), off.data_ptr(), coef.data_ptr(), B, N, k, Co, out.data_ptr(), st),
+                   "fpsg_edgeconv_bwd")
+        return out
+
+    a, a2 = run(), run()
+    monkeypatch.setenv("FPSG_EDGECONV_BWD", "one_edge")
+    b = run()
+    assert torch.equal(a, a2) and bool(torch.isfinite(a).all())
+    scale = float(b.abs().max())
+    assert float((a - b).abs().max()) <= 2e-5 * scale, float((a - b).abs().max()) / scale
+
+
+@pytest.mark.parametrize("Co", [64, 128])
+def test_edgeconv_forward_forms_agree(gpu, monkeypatch, Co):
+    """fpsg_edgeconv_fwd: several neighbours per load instruction (default at Co = 64 / 128) against the one-neighbour
+    form: the selected values and slots are identical (ties: lowest slot, duplicates in the lists included), the sums
+    equal up to the order of the fp32 additions."""
+    from fpsg_amd import _hip
+    lib = _hip.load()
+    torch.manual_seed(Co + 1)
+    B, N, k = 3, 333, 20
+    idx = torch.randint(0, N, (B, N, k), dtype=torch.int32, device=gpu)
+    idx[:, :, 7] = idx[:, :, 2]                        # repeated neighbours: equal values in different slots
+    idx[1, :, :] = idx[1, :, :1]                       # every slot the same point: all equal, slot 0 must win
+    PQ = torch.randn(B, N, 2 * Co, device=gpu)
+    sgn = torch.where(torch.randn(Co, device=gpu) < 0, -1.0, 1.0)
+    st = torch.cuda.current_stream().cuda_stream
+
+    def run():
+        ysel = torch.empty(B, N, Co, device=gpu)
+        jsel = torch.empty(B, N, Co, dtype=torch.uint8, device=gpu)
+        s1 = torch.empty(B, N, Co, device=gpu)
+        part = torch.empty(lib.fpsg_edgeconv_blocks(B, N, Co), 2, Co, device=gpu)
+        _hip.check(lib.fpsg_edgeconv_fwd(PQ.data_ptr(), idx.data_ptr(), sgn.data_ptr(), B, N, k, Co, ysel.data_ptr(),
+                                         jsel.data_ptr(), s1.data_ptr(), part.data_ptr(), st), "fpsg_edgeconv_fwd")
+        return ysel, jsel, s1, part
+
+    a = run()
+    a2 = run()
+    monkeypatch.setenv("FPSG_EDGECONV_BWD", "one_edge")
+    b = run()
+    assert all(torch.equal(x, y) for x, y in zip(a, a2))
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    assert bool((a[1][1] == 0).all())
+    assert float((a[2] - b[2]).abs().max()) <= 1e-5 * float(b[2].abs().max())
+    assert float((a[3] - b[3]).abs().max()) <= 1e-5 * float(b[3].abs().max())
