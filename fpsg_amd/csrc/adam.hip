@@ -18,6 +18,26 @@ namespace {
 
 constexpr int kAdamThreads = 256;
 
+// Non-temporal accesses to the four streams (each larger than the Infinity Cache, touched once per step) were
+// measured: 450 vs 457 us, no difference -- plain accesses (FPSG_ADAM_NT=1 builds the other form).
+#ifndef FPSG_ADAM_NT
+#define FPSG_ADAM_NT 0
+#endif
+__device__ __forceinline__ v4f ld4(const float* p, size_t i) {
+#if FPSG_ADAM_NT
+  return __builtin_nontemporal_load(reinterpret_cast<const v4f*>(p) + i);
+#else
+  return reinterpret_cast<const v4f*>(p)[i];
+#endif
+}
+__device__ __forceinline__ void st4(float* p, size_t i, v4f v) {
+#if FPSG_ADAM_NT
+  __builtin_nontemporal_store(v, reinterpret_cast<v4f*>(p) + i);
+#else
+  reinterpret_cast<v4f*>(p)[i] = v;
+#endif
+}
+
 __global__ __launch_bounds__(kAdamThreads) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                             float* __restrict__ m, float* __restrict__ v, size_t n4,
                                                             size_t n, float step_size, float b1, float b2, float eps,
@@ -38,24 +58,24 @@ __global__ __launch_bounds__(kAdamThreads) void adam_kernel(float* __restrict__ 
   size_t i = (size_t)blockIdx.x * kAdamThreads + threadIdx.x;
   for (; i + stride < n4; i += 2 * stride) {
     const size_t j = i + stride;
-    v4f pa = reinterpret_cast<const v4f*>(p)[i], pb = reinterpret_cast<const v4f*>(p)[j];
-    const v4f ga = reinterpret_cast<const v4f*>(g)[i], gb = reinterpret_cast<const v4f*>(g)[j];
-    v4f ma = reinterpret_cast<const v4f*>(m)[i], mb = reinterpret_cast<const v4f*>(m)[j];
-    v4f va = reinterpret_cast<const v4f*>(v)[i], vb = reinterpret_cast<const v4f*>(v)[j];
+    v4f pa = ld4(p, i), pb = ld4(p, j);
+    const v4f ga = ld4(g, i), gb = ld4(g, j);
+    v4f ma = ld4(m, i), mb = ld4(m, j);
+    v4f va = ld4(v, i), vb = ld4(v, j);
     update(pa, ga, ma, va);
     update(pb, gb, mb, vb);
-    reinterpret_cast<v4f*>(p)[i] = pa; reinterpret_cast<v4f*>(m)[i] = ma; reinterpret_cast<v4f*>(v)[i] = va;
-    reinterpret_cast<v4f*>(p)[j] = pb; reinterpret_cast<v4f*>(m)[j] = mb; reinterpret_cast<v4f*>(v)[j] = vb;
+    st4(p, i, pa); st4(m, i, ma); st4(v, i, va);
+    st4(p, j, pb); st4(m, j, mb); st4(v, j, vb);
   }
   if (i < n4) {
-    v4f pv = reinterpret_cast<const v4f*>(p)[i];
-    const v4f gv = reinterpret_cast<const v4f*>(g)[i];
-    v4f mv = reinterpret_cast<const v4f*>(m)[i];
-    v4f vv = reinterpret_cast<const v4f*>(v)[i];
+    v4f pv = ld4(p, i);
+    const v4f gv = ld4(g, i);
+    v4f mv = ld4(m, i);
+    v4f vv = ld4(v, i);
     update(pv, gv, mv, vv);
-    reinterpret_cast<v4f*>(p)[i] = pv;
-    reinterpret_cast<v4f*>(m)[i] = mv;
-    reinterpret_cast<v4f*>(v)[i] = vv;
+    st4(p, i, pv);
+    st4(m, i, mv);
+    st4(v, i, vv);
   }
   // tail (n not a multiple of 4)
   if (blockIdx.x == 0) {

@@ -26,6 +26,24 @@
 namespace fpsg {
 namespace {
 
+// V, dM (written once, read once by the batched GEMM) and M (read once): when such a tensor is larger than the 256 MB
+// Infinity Cache -- the 128-channel layers at 112 x 112 and 37 images: 534 MB -- non-temporal stores / loads keep it
+// from sweeping the cache (input transform 168 -> 125 us, 58 -> 77 % of 8 TB/s; grad-output 157 -> 124; output 156 ->
+// 140); a tensor that fits stays cached for its consumer, and the same hint costs 15-75 % there
+// (profiles/r03/k6_transforms_nontemporal.txt).  A template parameter: behind a run-time branch the compiler merges the
+// two stores and drops the hint.
+constexpr size_t kStreamBytes = (size_t)300 << 20;
+template <bool NT>
+__device__ __forceinline__ void stream_store(float* p, float v) {
+  if constexpr (NT) __builtin_nontemporal_store(v, p);
+  else *p = v;
+}
+template <bool NT>
+__device__ __forceinline__ float stream_load(const float* p) {
+  if constexpr (NT) return __builtin_nontemporal_load(p);
+  else return *p;
+}
+
 constexpr int kWinoThreads = 256;
 
 // One-dimensional transforms of F(m, 3), m = 2 and 4 (interpolation points 0, +-1 [, +-2], inf;
@@ -118,7 +136,7 @@ __device__ __forceinline__ TileIndex tile_of(long p, int Th, int Tw) {
 // reads a = relu(fma(x + pre_bias[c], scale[c], shift[c])) instead (exactly the value K5's apply pass
 // would have stored; padding stays zero) -- the BatchNorm + ReLU apply pass between two convolutions of a
 // VGG stage (one read + one write of the activation tensor) is folded into this load.
-template <int M, bool ACT>
+template <int M, bool ACT, bool NT = false>
 __global__ __launch_bounds__(kWinoThreads) void wino_input_kernel(const float* __restrict__ x, int C, int H, int W,
                                                                    int Th, int Tw, long P, float* __restrict__ V,
                                                                    const float* __restrict__ chan,
@@ -194,7 +212,7 @@ __global__ __launch_bounds__(kWinoThreads) void wino_input_kernel(const float* _
     for (int j = 0; j < A; ++j) row[j] = t[j][i];
     Wino<M>::in(row, v);
 #pragma unroll
-    for (int j = 0; j < A; ++j) vp[(size_t)(A * i + j) * plane] = v[j];
+    for (int j = 0; j < A; ++j) stream_store<NT>(vp + (size_t)(A * i + j) * plane, v[j]);
   }
 }
 
@@ -207,7 +225,7 @@ __global__ __launch_bounds__(kWinoThreads) void wino_input_kernel(const float* _
 // (bn_reduce_kernel, MODE 1): dz = y * [fma(x, scale, shift) > 0], sum(dz) and sum(dz * (x - mean) * rstd) with
 // x = xpre + bias[k]; chan = [4][K] scale, shift, mean, rstd.  K5's backward then starts at its finalize
 // (fpsg_bn_act_bwd_parts) and reads neither tensor for the sums.
-template <int M, bool STATS, bool BWD = false>
+template <int M, bool STATS, bool BWD = false, bool NT = false>
 __global__ __launch_bounds__(kWinoThreads) void wino_output_kernel(const float* __restrict__ Mt, int K, int H, int W,
                                                                     int Th, int Tw, long P, float* __restrict__ y,
                                                                     const float* __restrict__ bias,
@@ -230,7 +248,7 @@ __global__ __launch_bounds__(kWinoThreads) void wino_output_kernel(const float* 
   for (int j = 0; j < A; ++j) {
     float m[A];
 #pragma unroll
-    for (int i = 0; i < A; ++i) m[i] = mp[(size_t)(A * i + j) * plane];
+    for (int i = 0; i < A; ++i) m[i] = stream_load<NT>(mp + (size_t)(A * i + j) * plane);
     Wino<M>::out(m, s[j]);
   }
   const size_t yoff = (((size_t)ti.n * K + k) * H + M * ti.th) * W + M * ti.tw;
@@ -289,7 +307,7 @@ __global__ __launch_bounds__(kWinoThreads) void wino_output_kernel(const float* 
 }
 
 // dM = A dY A^T per tile
-template <int M>
+template <int M, bool NT = false>
 __global__ __launch_bounds__(kWinoThreads) void wino_grad_output_kernel(const float* __restrict__ dy, int K, int H,
                                                                          int W, int Th, int Tw, long P,
                                                                          float* __restrict__ dM) {
@@ -324,7 +342,7 @@ __global__ __launch_bounds__(kWinoThreads) void wino_grad_output_kernel(const fl
     for (int j = 0; j < M; ++j) row[j] = r[j][i];
     Wino<M>::gout(row, o);
 #pragma unroll
-    for (int j = 0; j < A; ++j) mp[(size_t)(A * i + j) * plane] = o[j];
+    for (int j = 0; j < A; ++j) stream_store<NT>(mp + (size_t)(A * i + j) * plane, o[j]);
   }
 }
 
@@ -438,6 +456,7 @@ extern "C" int fpsg_wino_input_transform(int m, const float* x, int N, int C, in
   const long P = (long)N * (H / m) * (W / m);
   dim3 grid((unsigned)((P + kWinoThreads - 1) / kWinoThreads), C);
   if (m == 2) hipLaunchKernelGGL((wino_input_kernel<2, false>), grid, dim3(kWinoThreads), 0, static_cast<hipStream_t>(stream), x, C, H, W, H / m, W / m, P, V, nullptr, nullptr);
+  else if ((size_t)36 * C * P * sizeof(float) > kStreamBytes) hipLaunchKernelGGL((wino_input_kernel<4, false, true>), grid, dim3(kWinoThreads), 0, static_cast<hipStream_t>(stream), x, C, H, W, H / m, W / m, P, V, nullptr, nullptr);
   else hipLaunchKernelGGL((wino_input_kernel<4, false>), grid, dim3(kWinoThreads), 0, static_cast<hipStream_t>(stream), x, C, H, W, H / m, W / m, P, V, nullptr, nullptr);
   return launch_status("fpsg_wino_input_transform");
 }
@@ -453,6 +472,7 @@ extern "C" int fpsg_wino_input_transform_act(int m, const float* x, const float*
   const long P = (long)N * (H / m) * (W / m);
   dim3 grid((unsigned)((P + kWinoThreads - 1) / kWinoThreads), C);
   if (m == 2) hipLaunchKernelGGL((wino_input_kernel<2, true>), grid, dim3(kWinoThreads), 0, static_cast<hipStream_t>(stream), x, C, H, W, H / m, W / m, P, V, chan, pre_bias);
+  else if ((size_t)36 * C * P * sizeof(float) > kStreamBytes) hipLaunchKernelGGL((wino_input_kernel<4, true, true>), grid, dim3(kWinoThreads), 0, static_cast<hipStream_t>(stream), x, C, H, W, H / m, W / m, P, V, chan, pre_bias);
   else hipLaunchKernelGGL((wino_input_kernel<4, true>), grid, dim3(kWinoThreads), 0, static_cast<hipStream_t>(stream), x, C, H, W, H / m, W / m, P, V, chan, pre_bias);
   return launch_status("fpsg_wino_input_transform_act");
 }
@@ -468,6 +488,7 @@ extern "C" int fpsg_wino_output_transform(int m, const float* M, int N, int K, i
   dim3 grid((unsigned)((P + kWinoThreads - 1) / kWinoThreads), K);
   hipStream_t hs = static_cast<hipStream_t>(stream);
   if (m == 2) hipLaunchKernelGGL((wino_output_kernel<2, false>), grid, dim3(kWinoThreads), 0, hs, M, K, H, W, H / m, W / m, P, y, nullptr, nullptr);
+  else if ((size_t)36 * K * P * sizeof(float) > kStreamBytes) hipLaunchKernelGGL((wino_output_kernel<4, false, false, true>), grid, dim3(kWinoThreads), 0, hs, M, K, H, W, H / m, W / m, P, y, nullptr, nullptr);
   else hipLaunchKernelGGL((wino_output_kernel<4, false>), grid, dim3(kWinoThreads), 0, hs, M, K, H, W, H / m, W / m, P, y, nullptr, nullptr);
   return launch_status("fpsg_wino_output_transform");
 }
@@ -490,6 +511,7 @@ extern "C" int fpsg_wino_output_transform_stats(int m, const float* M, int N, in
   dim3 grid((unsigned)((P + kWinoThreads - 1) / kWinoThreads), K);
   hipStream_t hs = static_cast<hipStream_t>(stream);
   if (m == 2) hipLaunchKernelGGL((wino_output_kernel<2, true>), grid, dim3(kWinoThreads), 0, hs, M, K, H, W, H / m, W / m, P, y, bias, parts);
+  else if ((size_t)36 * K * P * sizeof(float) > kStreamBytes) hipLaunchKernelGGL((wino_output_kernel<4, true, false, true>), grid, dim3(kWinoThreads), 0, hs, M, K, H, W, H / m, W / m, P, y, bias, parts);
   else hipLaunchKernelGGL((wino_output_kernel<4, true>), grid, dim3(kWinoThreads), 0, hs, M, K, H, W, H / m, W / m, P, y, bias, parts);
   return launch_status("fpsg_wino_output_transform_stats");
 }
@@ -509,6 +531,7 @@ extern "C" int fpsg_wino_output_transform_bwd_stats(int m, const float* M, int N
   dim3 grid((unsigned)((P + kWinoThreads - 1) / kWinoThreads), K);
   hipStream_t hs = static_cast<hipStream_t>(stream);
   if (m == 2) hipLaunchKernelGGL((wino_output_kernel<2, true, true>), grid, dim3(kWinoThreads), 0, hs, M, K, H, W, H / m, W / m, P, y, pre_bias, parts, xpre, chan);
+  else if ((size_t)36 * K * P * sizeof(float) > kStreamBytes) hipLaunchKernelGGL((wino_output_kernel<4, true, true, true>), grid, dim3(kWinoThreads), 0, hs, M, K, H, W, H / m, W / m, P, y, pre_bias, parts, xpre, chan);
   else hipLaunchKernelGGL((wino_output_kernel<4, true, true>), grid, dim3(kWinoThreads), 0, hs, M, K, H, W, H / m, W / m, P, y, pre_bias, parts, xpre, chan);
   return launch_status("fpsg_wino_output_transform_bwd_stats");
 }
@@ -520,7 +543,12 @@ extern "C" int fpsg_wino_grad_output_transform(int m, const float* dy, int N, in
   if (rc) return rc;
   FPSG_REQUIRE_PTR(dy); FPSG_REQUIRE_PTR(dM);
   FPSG_REQUIRE((reinterpret_cast<uintptr_t>(dy) & 15) == 0, FPSG_E_ALIGN, "fpsg_wino_grad_output_transform: dy must be 16-byte aligned");
-  FPSG_WINO_IMAGE_LAUNCH(wino_grad_output_kernel, K, dy, K, H, W, H / m, W / m, P, dM);
+  const long P = (long)N * (H / m) * (W / m);
+  dim3 grid((unsigned)((P + kWinoThreads - 1) / kWinoThreads), K);
+  hipStream_t hs = static_cast<hipStream_t>(stream);
+  if (m == 2) hipLaunchKernelGGL((wino_grad_output_kernel<2>), grid, dim3(kWinoThreads), 0, hs, dy, K, H, W, H / m, W / m, P, dM);
+  else if ((size_t)36 * K * P * sizeof(float) > kStreamBytes) hipLaunchKernelGGL((wino_grad_output_kernel<4, true>), grid, dim3(kWinoThreads), 0, hs, dy, K, H, W, H / m, W / m, P, dM);
+  else hipLaunchKernelGGL((wino_grad_output_kernel<4>), grid, dim3(kWinoThreads), 0, hs, dy, K, H, W, H / m, W / m, P, dM);
   return launch_status("fpsg_wino_grad_output_transform");
 }
 
