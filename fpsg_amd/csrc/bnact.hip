@@ -64,7 +64,7 @@ __device__ __forceinline__ void block_reduce2(float& a, float& b, float* red /*[
 // Work items of channel c: (n, seg) pairs, seg over ceil(L / kBnSeg) segments of a row.
 // Block (s, c) takes items s, s + S, ...
 // MODE 0: sums of x and x^2.   MODE 1: sums of dz and dz*xhat (dz = dy * act'(x*scale+shift)).
-template <int MODE, int ACT>
+template <int MODE, int ACT, bool NT = false>
 __global__ __launch_bounds__(kBnThreads) void bn_reduce_kernel(
     const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ chan /*[4][C]: scale, shift, mean, rstd*/,
     const float* __restrict__ pb, int N, int C, int L, int S, float slope, float* __restrict__ part /*[C][S][2]*/) {
@@ -85,14 +85,14 @@ __global__ __launch_bounds__(kBnThreads) void bn_reduce_kernel(
       const v4f* __restrict__ xp = reinterpret_cast<const v4f*>(x + base);
       const v4f* __restrict__ gp = reinterpret_cast<const v4f*>(MODE == 1 ? dy + base : x + base);
       for (int e = threadIdx.x; e < len / 4; e += kBnThreads) {
-        v4f xv = xp[e];
+        v4f xv = ld_stream<NT>(xp + e);
 #pragma unroll
         for (int u = 0; u < 4; ++u) xv[u] += b;
         if (MODE == 0) {
 #pragma unroll
           for (int u = 0; u < 4; ++u) { a0 += xv[u]; a1 = fma_rn(xv[u], xv[u], a1); }
         } else {
-          const v4f gv = gp[e];
+          const v4f gv = ld_stream<NT>(gp + e);
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
             const float dz = gv[u] * act_grad<ACT>(fma_rn(xv[u], sc, sh), slope);
@@ -201,7 +201,8 @@ __global__ __launch_bounds__(64) void bn_bwd_finalize_kernel(const float* __rest
 
 // MODE 0: y = act(x*scale + shift).   MODE 1: dx = k1*dz + k2*x + k3.
 // grid (N*C rows, segments of the row)
-template <int MODE, int ACT>
+// NT: the tensors are larger than the Infinity Cache (fpsg_common.h: beyond_cache)
+template <int MODE, int ACT, bool NT = false>
 __global__ __launch_bounds__(kBnThreads) void bn_apply_kernel(const float* __restrict__ x,
                                                               const float* __restrict__ dy,
                                                               const float* __restrict__ chan,
@@ -225,7 +226,7 @@ __global__ __launch_bounds__(kBnThreads) void bn_apply_kernel(const float* __res
     const v4f* __restrict__ gp = reinterpret_cast<const v4f*>(MODE == 1 ? dy + base : x + base);
     v4f* __restrict__ op = reinterpret_cast<v4f*>(out + base);
     for (int e = threadIdx.x; e < len / 4; e += kBnThreads) {
-      v4f xv = xp[e];
+      v4f xv = ld_stream<NT>(xp + e);
 #pragma unroll
       for (int u = 0; u < 4; ++u) xv[u] += b;
       v4f r;
@@ -233,7 +234,7 @@ __global__ __launch_bounds__(kBnThreads) void bn_apply_kernel(const float* __res
 #pragma unroll
         for (int u = 0; u < 4; ++u) r[u] = act_fwd<ACT>(fma_rn(xv[u], sc, sh), slope);
       } else {
-        const v4f gv = gp[e];
+        const v4f gv = ld_stream<NT>(gp + e);
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           const float dz = gv[u] * act_grad<ACT>(fma_rn(xv[u], sc, sh), slope);
@@ -241,7 +242,7 @@ __global__ __launch_bounds__(kBnThreads) void bn_apply_kernel(const float* __res
         }
         acc += (r[0] + r[1]) + (r[2] + r[3]);
       }
-      op[e] = r;
+      st_stream<NT>(op + e, r);
     }
   } else {
     for (int e = threadIdx.x; e < len; e += kBnThreads) {
@@ -470,18 +471,26 @@ template <int MODE>
 void launch_reduce(int act, const float* x, const float* dy, const float* chan, const float* pb, int N, int C, int L,
                    int S, float slope, float* part, hipStream_t s) {
   dim3 grid(S, C);
-  if (act == kActRelu) hipLaunchKernelGGL((bn_reduce_kernel<MODE, kActRelu>), grid, dim3(kBnThreads), 0, s, x, dy, chan, pb, N, C, L, S, slope, part);
-  else if (act == kActLeaky) hipLaunchKernelGGL((bn_reduce_kernel<MODE, kActLeaky>), grid, dim3(kBnThreads), 0, s, x, dy, chan, pb, N, C, L, S, slope, part);
-  else hipLaunchKernelGGL((bn_reduce_kernel<MODE, kActNone>), grid, dim3(kBnThreads), 0, s, x, dy, chan, pb, N, C, L, S, slope, part);
+#define FPSG_RED(A, T) hipLaunchKernelGGL((bn_reduce_kernel<MODE, A, T>), grid, dim3(kBnThreads), 0, s, x, dy, chan, pb, N, C, L, S, slope, part)
+  if (beyond_cache((size_t)N * C * L * sizeof(float))) {
+    if (act == kActRelu) FPSG_RED(kActRelu, true); else if (act == kActLeaky) FPSG_RED(kActLeaky, true); else FPSG_RED(kActNone, true);
+  } else {
+    if (act == kActRelu) FPSG_RED(kActRelu, false); else if (act == kActLeaky) FPSG_RED(kActLeaky, false); else FPSG_RED(kActNone, false);
+  }
+#undef FPSG_RED
 }
 
 template <int MODE>
 void launch_apply(int act, const float* x, const float* dy, const float* chan, const float* coef, const float* pb,
                   int N, int C, int L, float slope, float* out, float* dxpart, hipStream_t s) {
   dim3 grid((unsigned)((size_t)N * C), (L + kBnSeg - 1) / kBnSeg);
-  if (act == kActRelu) hipLaunchKernelGGL((bn_apply_kernel<MODE, kActRelu>), grid, dim3(kBnThreads), 0, s, x, dy, chan, coef, pb, C, L, slope, out, dxpart);
-  else if (act == kActLeaky) hipLaunchKernelGGL((bn_apply_kernel<MODE, kActLeaky>), grid, dim3(kBnThreads), 0, s, x, dy, chan, coef, pb, C, L, slope, out, dxpart);
-  else hipLaunchKernelGGL((bn_apply_kernel<MODE, kActNone>), grid, dim3(kBnThreads), 0, s, x, dy, chan, coef, pb, C, L, slope, out, dxpart);
+#define FPSG_APP(A, T) hipLaunchKernelGGL((bn_apply_kernel<MODE, A, T>), grid, dim3(kBnThreads), 0, s, x, dy, chan, coef, pb, C, L, slope, out, dxpart)
+  if (beyond_cache((size_t)N * C * L * sizeof(float))) {
+    if (act == kActRelu) FPSG_APP(kActRelu, true); else if (act == kActLeaky) FPSG_APP(kActLeaky, true); else FPSG_APP(kActNone, true);
+  } else {
+    if (act == kActRelu) FPSG_APP(kActRelu, false); else if (act == kActLeaky) FPSG_APP(kActLeaky, false); else FPSG_APP(kActNone, false);
+  }
+#undef FPSG_APP
 }
 
 // ---- pooled variants: act(BN(x + pb)) followed by MaxPool2d(kernel 2, stride 2) -------------
@@ -514,7 +523,7 @@ __device__ __forceinline__ int window_argmax(const float (&z)[4], float slope, f
   return sel;
 }
 
-template <int MODE, int ACT, int VW>
+template <int MODE, int ACT, int VW, bool NT>
 __device__ __forceinline__ void pool_item(const float* __restrict__ xpl, const float* __restrict__ gpl,
                                           float* __restrict__ opl, int W, int r0, int r1, float b, float sc,
                                           float sh, float mu, float rs, float k1, float k2, float k3, float slope,
@@ -528,8 +537,8 @@ __device__ __forceinline__ void pool_item(const float* __restrict__ xpl, const f
     const int rr = e / vpr, v = e - rr * vpr;
     const int r = r0 + rr;
     const size_t o0 = (size_t)(2 * r) * W + 2 * VW * v;
-    const in_t t0 = *reinterpret_cast<const in_t*>(xpl + o0);
-    const in_t t1 = *reinterpret_cast<const in_t*>(xpl + o0 + W);
+    const in_t t0 = ld_stream<NT>(reinterpret_cast<const in_t*>(xpl + o0));
+    const in_t t1 = ld_stream<NT>(reinterpret_cast<const in_t*>(xpl + o0 + W));
     float x0[2 * VW], x1[2 * VW];
 #pragma unroll
     for (int u = 0; u < 2 * VW; ++u) { x0[u] = t0[u] + b; x1[u] = t1[u] + b; }
@@ -568,14 +577,14 @@ __device__ __forceinline__ void pool_item(const float* __restrict__ xpl, const f
       in_t o0v, o1v;
 #pragma unroll
       for (int u = 0; u < 2 * VW; ++u) { o0v[u] = d0[u]; o1v[u] = d1[u]; }
-      *reinterpret_cast<in_t*>(opl + o0) = o0v;
-      *reinterpret_cast<in_t*>(opl + o0 + W) = o1v;
+      st_stream<NT>(reinterpret_cast<in_t*>(opl + o0), o0v);
+      st_stream<NT>(reinterpret_cast<in_t*>(opl + o0 + W), o1v);
     }
   }
 }
 
 // MODE 0 / 2: grid (N*C planes, items of a plane).  `out`: pooled y (MODE 0) or dx (MODE 2).
-template <int MODE, int ACT, int VW>
+template <int MODE, int ACT, int VW, bool NT = false>
 __global__ __launch_bounds__(kBnThreads) void bn_pool_apply_kernel(
     const float* __restrict__ x, const float* __restrict__ dyp, const float* __restrict__ chan,
     const float* __restrict__ coef, const float* __restrict__ pb, int C, int H, int W, int RP, float slope,
@@ -592,7 +601,7 @@ __global__ __launch_bounds__(kBnThreads) void bn_pool_apply_kernel(
   const float* xpl = x + (size_t)plane * H * W;
   const float* gpl = MODE == 2 ? dyp + (size_t)plane * Hp * Wp : nullptr;
   float* opl = MODE == 0 ? out + (size_t)plane * Hp * Wp : out + (size_t)plane * H * W;
-  pool_item<MODE, ACT, VW>(xpl, gpl, opl, W, r0, r1, b, sc, sh, 0.0f, 0.0f, k1, k2, k3, slope, acc, unused);
+  pool_item<MODE, ACT, VW, NT>(xpl, gpl, opl, W, r0, r1, b, sc, sh, 0.0f, 0.0f, k1, k2, k3, slope, acc, unused);
   if (MODE == 2 && dxpart) {
     block_reduce2(acc, unused, red);
     if (threadIdx.x == 0) dxpart[(size_t)plane * gridDim.y + it] = acc;
@@ -600,7 +609,7 @@ __global__ __launch_bounds__(kBnThreads) void bn_pool_apply_kernel(
 }
 
 // backward sums: grid (S slices, C channels); block (s, c) takes items s, s + S, ... of channel c
-template <int ACT, int VW>
+template <int ACT, int VW, bool NT = false>
 __global__ __launch_bounds__(kBnThreads) void bn_pool_reduce_kernel(
     const float* __restrict__ x, const float* __restrict__ dyp, const float* __restrict__ chan,
     const float* __restrict__ pb, int N, int C, int H, int W, int RP, int S, float slope,
@@ -617,7 +626,7 @@ __global__ __launch_bounds__(kBnThreads) void bn_pool_reduce_kernel(
     const int n = item / per_plane, it = item - n * per_plane;
     const int r0 = it * RP, r1 = (r0 + RP) < Hp ? (r0 + RP) : Hp;
     const size_t plane = (size_t)n * C + c;
-    pool_item<1, ACT, VW>(x + plane * H * W, dyp + plane * Hp * Wp, nullptr, W, r0, r1, b, sc, sh, mu, rs, 0.0f, 0.0f,
+    pool_item<1, ACT, VW, NT>(x + plane * H * W, dyp + plane * Hp * Wp, nullptr, W, r0, r1, b, sc, sh, mu, rs, 0.0f, 0.0f,
                           0.0f, slope, a0, a1);
   }
   block_reduce2(a0, a1, red);
@@ -640,7 +649,10 @@ void launch_pool_apply(int act, const float* x, const float* dyp, const float* c
   dim3 grid((unsigned)((size_t)N * C), (H / 2 + RP - 1) / RP);
 #define FPSG_PA(A, V) hipLaunchKernelGGL((bn_pool_apply_kernel<MODE, A, V>), grid, dim3(kBnThreads), 0, s, x, dyp, chan, \
                                          coef, pb, C, H, W, RP, slope, out, dxpart)
-  if ((W & 3) == 0) {
+  if ((W & 3) == 0 && act == kActRelu && beyond_cache((size_t)N * C * H * W * sizeof(float))) {      // VGG's first stage
+    hipLaunchKernelGGL((bn_pool_apply_kernel<MODE, kActRelu, 2, true>), grid, dim3(kBnThreads), 0, s, x, dyp, chan, coef, pb,
+                       C, H, W, RP, slope, out, dxpart);
+  } else if ((W & 3) == 0) {
     if (act == kActRelu) FPSG_PA(kActRelu, 2); else if (act == kActLeaky) FPSG_PA(kActLeaky, 2); else FPSG_PA(kActNone, 2);
   } else {
     if (act == kActRelu) FPSG_PA(kActRelu, 1); else if (act == kActLeaky) FPSG_PA(kActLeaky, 1); else FPSG_PA(kActNone, 1);
@@ -654,7 +666,10 @@ void launch_pool_reduce(int act, const float* x, const float* dyp, const float* 
   dim3 grid(S, C);
 #define FPSG_PR(A, V) hipLaunchKernelGGL((bn_pool_reduce_kernel<A, V>), grid, dim3(kBnThreads), 0, s, x, dyp, chan, pb, \
                                          N, C, H, W, RP, S, slope, part)
-  if ((W & 3) == 0) {
+  if ((W & 3) == 0 && act == kActRelu && beyond_cache((size_t)N * C * H * W * sizeof(float))) {
+    hipLaunchKernelGGL((bn_pool_reduce_kernel<kActRelu, 2, true>), grid, dim3(kBnThreads), 0, s, x, dyp, chan, pb, N, C, H, W,
+                       RP, S, slope, part);
+  } else if ((W & 3) == 0) {
     if (act == kActRelu) FPSG_PR(kActRelu, 2); else if (act == kActLeaky) FPSG_PR(kActLeaky, 2); else FPSG_PR(kActNone, 2);
   } else {
     if (act == kActRelu) FPSG_PR(kActRelu, 1); else if (act == kActLeaky) FPSG_PR(kActLeaky, 1); else FPSG_PR(kActNone, 1);
@@ -699,7 +714,7 @@ __device__ __forceinline__ void ext_merge(float& vmax, int& imax, float& vmin, i
 // (a 2048-point row is 8 KB: a wave streams it with 8 vector loads per lane and reduces the
 // extremes with shuffles, no LDS, no barrier); the block's sums go to part[c][s].
 // STATS = 0 (eval mode): extremes only.
-template <int STATS>
+template <int STATS, bool NT = false>
 __global__ __launch_bounds__(kBnThreads) void bn_reduce_ext_kernel(const float* __restrict__ x,
                                                                    const float* __restrict__ pb, int N, int C, int L,
                                                                    int S, float* __restrict__ part /*[C][S][2]*/,
@@ -726,7 +741,7 @@ __global__ __launch_bounds__(kBnThreads) void bn_reduce_ext_kernel(const float* 
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           const int e = e0 + 64 * j;
-          q[j] = e < len / 4 ? xp[e] : (v4f){0.0f, 0.0f, 0.0f, 0.0f};
+          q[j] = e < len / 4 ? ld_stream<NT>(xp + e) : (v4f){0.0f, 0.0f, 0.0f, 0.0f};
         }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -832,6 +847,7 @@ __global__ __launch_bounds__(64) void bn_max_bwd_coef_kernel(const float* __rest
 }
 
 // dx = k1*dz*[l == sel] + k2*(x+b) + k3 ; grid (N*C rows, segments)
+template <bool NT>
 __global__ __launch_bounds__(kBnThreads) void bn_max_apply_kernel(const float* __restrict__ x,
                                                                   const float* __restrict__ pb,
                                                                   const float* __restrict__ dz,
@@ -851,12 +867,12 @@ __global__ __launch_bounds__(kBnThreads) void bn_max_apply_kernel(const float* _
     const v4f* __restrict__ xp = reinterpret_cast<const v4f*>(x + base);
     v4f* __restrict__ op = reinterpret_cast<v4f*>(dx + base);
     for (int e = threadIdx.x; e < len / 4; e += kBnThreads) {
-      const v4f xv = xp[e];
+      const v4f xv = ld_stream<NT>(xp + e);
       v4f r;
 #pragma unroll
       for (int u = 0; u < 4; ++u) r[u] = fma_rn(k1, (4 * e + u == sel) ? d : 0.0f, fma_rn(k2, xv[u] + b, k3));
       acc += (r[0] + r[1]) + (r[2] + r[3]);
-      op[e] = r;
+      st_stream<NT>(op + e, r);
     }
   } else {
     for (int e = threadIdx.x; e < len; e += kBnThreads) {
@@ -1117,7 +1133,8 @@ extern "C" int fpsg_bn_act_max_fwd(const float* x, const float* pre_bias, const 
   RowExt* ext = reinterpret_cast<RowExt*>(ws + (size_t)C * kBnSlices * 2);
   dim3 grid(C, S);
   if (training) {
-    hipLaunchKernelGGL(bn_reduce_ext_kernel<1>, grid, dim3(kBnThreads), 0, s, x, pre_bias, N, C, L, S, ws, ext);
+    if (beyond_cache((size_t)N * C * L * sizeof(float))) hipLaunchKernelGGL((bn_reduce_ext_kernel<1, true>), grid, dim3(kBnThreads), 0, s, x, pre_bias, N, C, L, S, ws, ext);
+    else hipLaunchKernelGGL(bn_reduce_ext_kernel<1>, grid, dim3(kBnThreads), 0, s, x, pre_bias, N, C, L, S, ws, ext);
     if ((rc = launch_status("fpsg_bn_act_max_fwd(stats)"))) return rc;
     hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3(C), dim3(64), 0, s, ws, gamma, beta, C, S,
                        (double)N * (double)L, eps, chan, batch_mean, batch_var_unbiased, running_mean, running_var,
@@ -1160,7 +1177,7 @@ extern "C" int fpsg_bn_act_max_bwd(const float* x, const float* pre_bias, const 
 #undef FPSG_MAXB
   if ((rc = launch_status("fpsg_bn_act_max_bwd(coef)"))) return rc;
   dim3 grid((unsigned)((size_t)N * C), segs);
-  hipLaunchKernelGGL(bn_max_apply_kernel, grid, dim3(kBnThreads), 0, s, x, pre_bias, dz, idx, coef, C, L, dx,
+  hipLaunchKernelGGL(beyond_cache((size_t)N * C * L * sizeof(float)) ? bn_max_apply_kernel<true> : bn_max_apply_kernel<false>, grid, dim3(kBnThreads), 0, s, x, pre_bias, dz, idx, coef, C, L, dx,
                      dpre_bias ? dxpart : nullptr);
   if ((rc = launch_status("fpsg_bn_act_max_bwd(apply)"))) return rc;
   if (dpre_bias) {

@@ -22,6 +22,7 @@ constexpr int kDyLd = kPx + 4;          // LDS row stride of the dy tile: 2 lane
 constexpr int kXLd = kPx + 4;           // row stride of the input patch (66 used)
 constexpr int kFirstThreads = 256;
 
+template <bool NT>
 __global__ __launch_bounds__(kFirstThreads) void conv_first_dw_kernel(const float* __restrict__ x,
                                                                       const float* __restrict__ dy, int H, int W,
                                                                       int segs_per_row, long n_segs,
@@ -55,7 +56,7 @@ __global__ __launch_bounds__(kFirstThreads) void conv_first_dw_kernel(const floa
       for (int it = 0; it < 4; ++it) {
         const int ch = it * 16 + (tid >> 4);
         v4f v = {0.0f, 0.0f, 0.0f, 0.0f};
-        if (in) v = *reinterpret_cast<const v4f*>(dy + (((size_t)n * 64 + ch) * H + h) * W + w0 + q4);
+        if (in) v = ld_stream<NT>(reinterpret_cast<const v4f*>(dy + (((size_t)n * 64 + ch) * H + h) * W + w0 + q4));
         *reinterpret_cast<v4f*>(dyt + ch * kDyLd + q4) = v;
       }
     }
@@ -117,7 +118,7 @@ __global__ __launch_bounds__(1024) void conv_first_dw_reduce_kernel(const float*
 // (c, a, b) order by an fma chain starting from 0 (the oracle of tests/test_winograd_gpu.py restates exactly this).
 // STATS: per channel the partial sums of y + bias[k] and its square over the workgroup's 1024 pixels ->
 // parts[k][blockIdx.x][2] for the BatchNorm that follows (fpsg_bn_stats with parts).  Deterministic.
-template <bool STATS>
+template <bool STATS, bool NT = false>
 __global__ __launch_bounds__(kFirstThreads) void conv_first_fwd_kernel(const float* __restrict__ x,
                                                                        const float* __restrict__ wt /*[64][27]*/, int H,
                                                                        int W, long Q, float* __restrict__ y,
@@ -194,7 +195,7 @@ __global__ __launch_bounds__(kFirstThreads) void conv_first_fwd_kernel(const flo
         }
       }
     }
-    if (live) *reinterpret_cast<v4f*>(yp + (size_t)k * plane) = (v4f){o[0], o[1], o[2], o[3]};
+    if (live) st_stream<NT>(reinterpret_cast<v4f*>(yp + (size_t)k * plane), (v4f){o[0], o[1], o[2], o[3]});
     if (STATS) {
       const float bk = bias ? bias[k] : 0.0f;
       float s0 = 0.0f, s1 = 0.0f;
@@ -242,7 +243,9 @@ extern "C" int fpsg_conv_first_dw(const float* x, const float* dy, int N, int C,
   const int segs_per_row = (W + kPx - 1) / kPx;
   const long n_segs = (long)N * H * segs_per_row;
   const int blocks = n_segs < 2048 ? (int)n_segs : 2048;   // 8 workgroups per CU: staging of one overlaps the MFMAs of others
-  hipLaunchKernelGGL(conv_first_dw_kernel, dim3(blocks), dim3(kFirstThreads), 0, s, x, dy, H, W, segs_per_row, n_segs, ws);
+  // (non-temporal loads of dy were measured here: 144 -> 185 us -- its 64-byte pieces per channel row lose the L2's
+  // merging of neighbouring workgroups' requests; plain loads)
+  hipLaunchKernelGGL(conv_first_dw_kernel<false>, dim3(blocks), dim3(kFirstThreads), 0, s, x, dy, H, W, segs_per_row, n_segs, ws);
   int rc = launch_status("fpsg_conv_first_dw(partials)");
   if (rc) return rc;
   hipLaunchKernelGGL(conv_first_dw_reduce_kernel, dim3(64), dim3(1024), 0, s, ws, blocks, dw);
@@ -270,8 +273,13 @@ extern "C" int fpsg_conv_first_fwd(const float* x, const float* w, int N, int C,
   const long blocks = (Q + kFirstThreads - 1) / kFirstThreads;
   FPSG_REQUIRE(blocks < (1L << 31), FPSG_E_LIMIT, "fpsg_conv_first_fwd: %ld workgroups beyond the grid limit", blocks);
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (parts)
+  const bool nt = beyond_cache((size_t)N * 64 * H * W * sizeof(float));      // y: 475 MB at 37 images, written once
+  if (parts && nt)
+    hipLaunchKernelGGL((conv_first_fwd_kernel<true, true>), dim3((unsigned)blocks), dim3(kFirstThreads), 0, s, x, w, H, W, Q, y, bias, parts);
+  else if (parts)
     hipLaunchKernelGGL(conv_first_fwd_kernel<true>, dim3((unsigned)blocks), dim3(kFirstThreads), 0, s, x, w, H, W, Q, y, bias, parts);
+  else if (nt)
+    hipLaunchKernelGGL((conv_first_fwd_kernel<false, true>), dim3((unsigned)blocks), dim3(kFirstThreads), 0, s, x, w, H, W, Q, y, nullptr, nullptr);
   else
     hipLaunchKernelGGL(conv_first_fwd_kernel<false>, dim3((unsigned)blocks), dim3(kFirstThreads), 0, s, x, w, H, W, Q, y, nullptr, nullptr);
   return launch_status("fpsg_conv_first_fwd");

@@ -70,6 +70,7 @@ struct Dec1Args {
 };
 
 // LDS: pts [3][BP] | hl [kD1Tile][B]
+template <bool NT>
 __global__ __launch_bounds__(kD1Threads) void dec1_fwd_kernel(Dec1Args a, float* __restrict__ out,
                                                              float* __restrict__ chan, float* __restrict__ bmean,
                                                              float* __restrict__ bvar) {
@@ -145,12 +146,13 @@ __global__ __launch_bounds__(kD1Threads) void dec1_fwd_kernel(Dec1Args a, float*
         const float h = fma_rn(w2, Z[u], fma_rn(w1, Y[u], w0 * X[u])) + hb;
         o[u] = __builtin_fmaxf(fma_rn(h, scale, shift), 0.0f);
       }
-      orow[e4] = o;
+      st_stream<NT>(orow + e4, o);
     }
   }
 }
 
 // LDS: pts [3][BP] | hl [kD1Tile][B] | red [kD1Waves][64][12]
+template <bool NT>
 __global__ __launch_bounds__(kD1Threads) void dec1_bwd_kernel(Dec1Args a, const float* __restrict__ dout,
                                                              const float* __restrict__ chan,
                                                              float* __restrict__ dhlat, float* __restrict__ dw,
@@ -240,7 +242,7 @@ __global__ __launch_bounds__(kD1Threads) void dec1_bwd_kernel(Dec1Args a, const 
       const size_t gd = (size_t)g * a.D + d0 + wave * kD1ChPerWave + cc;
       const float hb = hl[(wave * kD1ChPerWave + cc) * a.B + b];
       v4f dy = {0, 0, 0, 0};
-      if (in) dy = reinterpret_cast<const v4f*>(dout + gd * BP)[e4];
+      if (in) dy = ld_stream<NT>(reinterpret_cast<const v4f*>(dout + gd * BP) + e4);
       float part = 0.0f;
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
@@ -323,12 +325,14 @@ extern "C" int fpsg_dec1_fwd(const float* hlat, const float* w, int ldw, int wof
                FPSG_E_ALIGN, "fpsg_dec1_fwd: pts / out must be 16-byte aligned");
   Dec1Args a{hlat, w, pts, gamma, beta, running_mean, running_var, G, D, B, P, ldw, wofs, training, eps};
   const size_t lds_bytes = dec1_lds_bytes(B, P, false);
+  // the output (403 MB at 32 clouds) is written once: past the Infinity Cache when it exceeds it
+  auto kern = beyond_cache((size_t)G * D * B * P * sizeof(float)) ? dec1_fwd_kernel<true> : dec1_fwd_kernel<false>;
   if (lds_bytes > 65536) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(dec1_fwd_kernel),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) { set_error("fpsg_dec1_fwd: %s", hipGetErrorString(e)); return (int)e; }
   }
-  hipLaunchKernelGGL(dec1_fwd_kernel, dim3((unsigned)fpsg_dec1_tiles(D), (unsigned)G), dim3(kD1Threads), lds_bytes,
+  hipLaunchKernelGGL(kern, dim3((unsigned)fpsg_dec1_tiles(D), (unsigned)G), dim3(kD1Threads), lds_bytes,
                      static_cast<hipStream_t>(stream), a, out, chan, batch_mean, batch_var_unbiased);
   return launch_status("fpsg_dec1_fwd");
 }
@@ -346,12 +350,14 @@ extern "C" int fpsg_dec1_bwd(const float* dout, const float* hlat, const float* 
                FPSG_E_ALIGN, "fpsg_dec1_bwd: pts / dout must be 16-byte aligned");
   Dec1Args a{hlat, w, pts, nullptr, nullptr, nullptr, nullptr, G, D, B, P, ldw, wofs, training, 0.0f};
   const size_t lds_bytes = dec1_lds_bytes(B, P, true);
+  // the output gradient's second (last) read of a row
+  auto kern = beyond_cache((size_t)G * D * B * P * sizeof(float)) ? dec1_bwd_kernel<true> : dec1_bwd_kernel<false>;
   if (lds_bytes > 65536) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(dec1_bwd_kernel),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) { set_error("fpsg_dec1_bwd: %s", hipGetErrorString(e)); return (int)e; }
   }
-  hipLaunchKernelGGL(dec1_bwd_kernel, dim3((unsigned)fpsg_dec1_tiles(D), (unsigned)G), dim3(kD1Threads), lds_bytes,
+  hipLaunchKernelGGL(kern, dim3((unsigned)fpsg_dec1_tiles(D), (unsigned)G), dim3(kD1Threads), lds_bytes,
                      static_cast<hipStream_t>(stream), a, dout, chan, dhlat, dw, dpts_part, dgamma, dbeta);
   return launch_status("fpsg_dec1_bwd");
 }

@@ -49,6 +49,26 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 
 constexpr int kWave = 64;
 
+// Streams through tensors larger than the 256 MB Infinity Cache (touched once per pass) use non-temporal loads and
+// stores: the data does not sweep the cache, and the passes run 13-25 % faster (profiles/r03/nontemporal_streams.txt);
+// a tensor that fits the cache stays there for its consumer and must NOT get the hint (15-75 % slower).  NT is a
+// template parameter of the kernels (behind a run-time branch the compiler merges the two accesses and drops the
+// hint); the launchers pick the instantiation with `beyond_cache(bytes of the largest tensor of the pass)`.
+#ifndef FPSG_NT_BYTES
+#define FPSG_NT_BYTES ((size_t)300 << 20)
+#endif
+inline bool beyond_cache(size_t bytes) { return bytes > (size_t)FPSG_NT_BYTES; }
+template <bool NT, typename T>
+__device__ __forceinline__ T ld_stream(const T* p) {
+  if constexpr (NT) return __builtin_nontemporal_load(p);
+  else return *p;
+}
+template <bool NT, typename T>
+__device__ __forceinline__ void st_stream(T* p, T v) {
+  if constexpr (NT) __builtin_nontemporal_store(v, p);
+  else *p = v;
+}
+
 __device__ __forceinline__ float fma_rn(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 __device__ __forceinline__ v2f fma_rn(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
 

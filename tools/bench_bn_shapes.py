@@ -16,7 +16,7 @@ def timed(fn, reps=30):
     for _ in range(reps): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps * 1e3
-for shape in ((64, 64, 2048), (64, 128, 2048), (37, 64, 2048), (37, 128, 112, 112)):
+for shape in ((64, 64, 2048), (64, 128, 2048), (37, 64, 2048), (37, 128, 112, 112), (37, 64, 224, 224), (64, 1024, 2048)):
     C = shape[1]
     bn = (nn.BatchNorm1d(C) if len(shape) == 3 else nn.BatchNorm2d(C)).to(dev).train()
     x = torch.randn(*shape, device=dev, requires_grad=True)
