@@ -67,7 +67,7 @@ __device__ __forceinline__ void out4(const float (&m)[6], float (&s)[4]) {
 // tiles -> parts[k][index of the workgroup in its slice][2] for the BatchNorm that follows (fpsg_bn_stats with
 // parts): a lane keeps the sums of its 4 channels over its tile groups, then its row of 16 lanes (fixed DPP tree),
 // then the four waves in order.  Deterministic.
-template <bool ACT, bool STATS>
+template <bool ACT, bool STATS, bool NT = false>
 __global__ __launch_bounds__(kFusedThreads) void wino4_fused_c64_kernel(const float* __restrict__ x,
                                                                         const float* __restrict__ U /*[36][K][64]*/,
                                                                         int K, int H, int W, int Th, int Tw, long P,
@@ -328,7 +328,7 @@ __global__ __launch_bounds__(kFusedThreads) void wino4_fused_c64_kernel(const fl
 #pragma unroll
           for (int c = 0; c < 6; ++c) rowv[c] = s[c][a];
           out4(rowv, o);
-          *reinterpret_cast<v4f*>(yp + (size_t)a * W) = (v4f){o[0], o[1], o[2], o[3]};
+          st_stream<NT>(reinterpret_cast<v4f*>(yp + (size_t)a * W), (v4f){o[0], o[1], o[2], o[3]});
           if (STATS) {
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -399,8 +399,13 @@ static int wino_conv_fused_launch(const char* fn, const float* x, const float* c
   const size_t lds_bytes = (size_t)(kUldsFloats + 3 * 64) * sizeof(float);
   typedef void (*kern_t)(const float*, const float*, int, int, int, int, int, long, int, float*, const float*,
                          const float*, const float*, float*);
-  const kern_t kern = chan ? (parts ? wino4_fused_c64_kernel<true, true> : wino4_fused_c64_kernel<true, false>)
-                           : (parts ? wino4_fused_c64_kernel<false, true> : wino4_fused_c64_kernel<false, false>);
+  // y beyond the Infinity Cache (64 -> 64 @224 at 37 images: 475 MB) is written with non-temporal stores
+  const bool nt = beyond_cache((size_t)N * K * H * W * sizeof(float));
+  const kern_t kern =
+      nt ? (chan ? (parts ? wino4_fused_c64_kernel<true, true, true> : wino4_fused_c64_kernel<true, false, true>)
+                 : (parts ? wino4_fused_c64_kernel<false, true, true> : wino4_fused_c64_kernel<false, false, true>))
+         : (chan ? (parts ? wino4_fused_c64_kernel<true, true> : wino4_fused_c64_kernel<true, false>)
+                 : (parts ? wino4_fused_c64_kernel<false, true> : wino4_fused_c64_kernel<false, false>));
   const hipError_t lds_optin = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (lds_optin != hipSuccess) {
