@@ -75,6 +75,27 @@ def test_knn_many_equal_scores(gpu, oracle):
     assert np.array_equal(got, oracle.knn(x, 20))
 
 
+@pytest.mark.parametrize("order", ["ascending", "descending", "interleaved"])
+def test_knn_adversarial_candidate_orders(gpu, oracle, order):
+    """Points sorted along a line: for most queries every new candidate beats all earlier ones (or none does), the
+    worst case for a streaming threshold -- the buffers hit their watermark every few tiles and the events do the work.
+    Same lists as the oracle."""
+    from fpsg_amd.dgcnn import knn_int32
+    rng = np.random.default_rng(17)
+    N = 1500
+    t = np.sort(rng.random(N).astype(np.float32))
+    if order == "descending":
+        t = t[::-1].copy()
+    elif order == "interleaved":
+        t = np.concatenate([t[::2], t[1::2][::-1]])
+    x = np.stack([t, 0.25 * t, -0.5 * t])[None].astype(np.float32)            # [1,3,N]
+    x = np.concatenate([x, x + rng.standard_normal(x.shape).astype(np.float32) * 1e-3])
+    got = knn_int32(torch.from_numpy(x).to(gpu), 20).cpu().numpy()
+    assert np.array_equal(got, oracle.knn(x, 20))
+    x64 = np.concatenate([x, np.zeros((2, 61, N), np.float32)], axis=1)         # the same through the C = 64 kernel
+    assert np.array_equal(knn_int32(torch.from_numpy(x64).to(gpu), 20).cpu().numpy(), oracle.knn(x64, 20))
+
+
 def test_knn_point_major_is_refused_outside_the_streaming_range(gpu):
     from fpsg_amd.dgcnn import knn_int32
     from fpsg_amd._hip import FpsgHipError
