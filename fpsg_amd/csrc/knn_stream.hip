@@ -377,10 +377,13 @@ __global__ __launch_bounds__(64 * kSW) void knn_stream_kernel(const float* __res
     const unsigned j0 = (unsigned)(16 * t + 4 * kk);
     float v[8];
     bool p[8];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      v[r] = fma_rn(2.0f, acc0[r], -xx0[r]) - xxq;
-      v[4 + r] = fma_rn(2.0f, acc1[r], -xx1[r]) - xxq;
+    {   // two scores per packed instruction (v_pk_fma_f32 / v_pk_add_f32): the same fma and subtraction per element
+      const v2f two = {2.0f, 2.0f}, nq = {-xxq, -xxq};
+      const v2f a = fma_rn(two, (v2f){acc0[0], acc0[1]}, -(v2f){xx0[0], xx0[1]}) + nq;
+      const v2f b2 = fma_rn(two, (v2f){acc0[2], acc0[3]}, -(v2f){xx0[2], xx0[3]}) + nq;
+      const v2f c = fma_rn(two, (v2f){acc1[0], acc1[1]}, -(v2f){xx1[0], xx1[1]}) + nq;
+      const v2f d = fma_rn(two, (v2f){acc1[2], acc1[3]}, -(v2f){xx1[2], xx1[3]}) + nq;
+      v[0] = a.x; v[1] = a.y; v[2] = b2.x; v[3] = b2.y; v[4] = c.x; v[5] = c.y; v[6] = d.x; v[7] = d.y;
     }
     unsigned n = 0u;
 #pragma unroll
