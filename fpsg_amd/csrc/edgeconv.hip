@@ -31,6 +31,7 @@ constexpr int kEcThreads = 256;  // 4 waves
 #define FPSG_EC_IN_FLIGHT 4
 #endif
 constexpr int kInFlight = FPSG_EC_IN_FLIGHT;   // in-edges whose rows a wave of the backward has in flight
+constexpr int kFwdInFlight = 5;                // forward: G = 4 groups x 5 = the 20 neighbours of a point in one round of loads
 
 template <int VEC>
 struct VecT;
@@ -203,17 +204,17 @@ __global__ __launch_bounds__(kEcThreads) void edgeconv_fwd_grouped_kernel(
     load_vec<4>(base + (size_t)n * 2 * Co + Co + c0, q);
 #pragma unroll
     for (int v = 0; v < 4; ++v) { best[v] = -__builtin_inff(); bj[v] = 0x7fffffff; tot[v] = 0.0f; }
-    for (int j0 = 0; j0 < k; j0 += G * kInFlight) {
-      float p[kInFlight][4];
-      int jj[kInFlight];
+    for (int j0 = 0; j0 < k; j0 += G * kFwdInFlight) {
+      float p[kFwdInFlight][4];
+      int jj[kFwdInFlight];
 #pragma unroll
-      for (int u = 0; u < kInFlight; ++u) {
+      for (int u = 0; u < kFwdInFlight; ++u) {
         jj[u] = j0 + u * G + grp;
         const int m = __shfl(my, jj[u] < k ? jj[u] : 0, 64);
         load_vec<4>(base + (size_t)m * 2 * Co + c0, p[u]);
       }
 #pragma unroll
-      for (int u = 0; u < kInFlight; ++u) {
+      for (int u = 0; u < kFwdInFlight; ++u) {
         if (jj[u] < k) {
 #pragma unroll
           for (int v = 0; v < 4; ++v) {
