@@ -13,7 +13,7 @@ __device__ __forceinline__ unsigned knn_orderable(float f) {
 
 // channels after padding for the streaming kernel (0: not served by it)
 inline int knn_stream_cpad(int C) { return C <= 4 ? 4 : (C <= 64 ? 64 : (C <= 128 ? 128 : 0)); }
-// the streaming kernel keeps ~2.3 k candidates per row between two compactions of its 120-entry row buffers
+// the streaming kernel keeps ~1.4 k candidates per row after a compaction of its 124-entry row buffers
 inline bool knn_stream_serves(int C, int k) { return knn_stream_cpad(C) != 0 && k <= 24; }
 
 // xk [B][N][cpad] k-interleaved point-major features, xx [B][N] squared norms (knn_stream_prepare makes both)

@@ -10,7 +10,7 @@
 // lane (g, c) then holds the scores of candidates 4g..4g+3 against query c -- a lane serves ONE row, so a row's
 // threshold, slot counter and write position are per-lane values and one LDS atomic serves a lane's 8 scores of a
 // tile pair.  Nothing of size N is kept per row:
-//   * a score that reaches its row's threshold T is appended (score bits, index) to the row's 120-entry buffer in
+//   * a score that reaches its row's threshold T is appended (score bits, index) to the row's 124-entry buffer in
 //     LDS;
 //   * T is a lower bound of the row's k-th best score, raised by events: the 16 lanes of a DPP row split a row's
 //     buffered entries, each finds the two best of its share (v_max / v_med3); if at least ceil(k/2) lanes hold a
@@ -18,7 +18,7 @@
 //     31-bit keys (subtract + v_alignbit collect the comparison bits without touching a scalar register), and the
 //     same pass drops the entries below the new T (4 rows at a time).  Events run at fixed tiles (x2.25 in the number
 //     of candidates seen: five per 2048-point cloud) and whenever a buffer passes its watermark.  Between two checks
-//     (2 tiles) a row receives at most 32 entries, and a check leaves at most 88: a slot index cannot pass the
+//     (2 tiles) a row receives at most 32 entries, and a check leaves at most 92: a slot index cannot pass the
 //     buffer's end;
 //   * after the sweep a row's buffer holds every score >= its final T (about 1.4 k of them): they are ranked by
 //     counting on 64-bit keys (orderable score << 32 | ~index: score descending, then index ascending -- the order of
@@ -35,7 +35,7 @@ namespace {
 
 constexpr int kSW = 8;                 // waves per workgroup
 constexpr int kSRows = 16 * kSW;       // query rows per workgroup
-constexpr int kCap = 120;              // entries per row buffer
+constexpr int kCap = 124;              // entries per row buffer (row stride 248 dwords: the filter reads of two DPP rows tile the 64 banks)
 constexpr int kWM = kCap - 32;         // a check leaves at most this many entries in a buffer
 constexpr int kFilterIters = (kCap + 15) / 16;
 
