@@ -395,7 +395,11 @@ __global__ __launch_bounds__(kEcThreads) void edgeconv_bwd_grouped_kernel(
   load_vec<4>(coef + c0, A);
   load_vec<4>(coef + Co + c0, Bc);
   load_vec<4>(coef + 2 * Co + c0, mu);
+  // per-cloud bases (wave-uniform) + 32-bit element offsets: the loads take the scalar-base form and the row
+  // offsets of the edges in flight cost one register each instead of two
   const float* __restrict__ pq = PQ + (size_t)b * N * 2 * Co;
+  const float* __restrict__ dzb = dzs + (size_t)b * N * Co;
+  const uint8_t* __restrict__ jsb = jsel + (size_t)b * N * Co;
   const int32_t* __restrict__ revb = rev + (size_t)b * N * k;
   const int32_t* __restrict__ offb = off + (size_t)b * (N + 1);
   const int m_first = (bx * 4 + wave) * ppw;
@@ -415,7 +419,7 @@ __global__ __launch_bounds__(kEcThreads) void edgeconv_bwd_grouped_kernel(
       for (int t = 0; t < here; t += G * kInFlight) {
         bool on[kInFlight];
         int j[kInFlight];
-        size_t rown[kInFlight];
+        unsigned rown[kInFlight];                                  // source point inside the cloud
 #pragma unroll
         for (int u = 0; u < kInFlight; ++u) {
           const int te = t + u * G + grp;                          // this lane group's edge of the round
@@ -424,15 +428,16 @@ __global__ __launch_bounds__(kEcThreads) void edgeconv_bwd_grouped_kernel(
           int nn = e / k;
           nn = nn < 0 ? 0 : (nn >= N ? N - 1 : nn);
           j[u] = e - nn * k;
-          rown[u] = row0 + nn;
+          rown[u] = (unsigned)nn;
         }
         float g[kInFlight][4], qn[kInFlight][4];
         unsigned js[kInFlight];
 #pragma unroll
         for (int u = 0; u < kInFlight; ++u) {                      // the rows of G * kInFlight in-edges in flight
-          load_vec<4>(dzs + rown[u] * Co + c0, g[u]);
-          js[u] = *reinterpret_cast<const uint32_t*>(jsel + rown[u] * Co + c0);
-          if (stats) load_vec<4>(pq + (rown[u] - row0) * 2 * Co + Co + c0, qn[u]);
+          const unsigned o = rown[u] * (unsigned)Co + (unsigned)c0;
+          load_vec<4>(dzb + o, g[u]);
+          js[u] = *reinterpret_cast<const uint32_t*>(jsb + o);
+          if (stats) load_vec<4>(pq + (2u * rown[u] * (unsigned)Co + (unsigned)(Co + c0)), qn[u]);
         }
 #pragma unroll
         for (int u = 0; u < kInFlight; ++u) {                      // a group's edges in order
