@@ -14,7 +14,8 @@ import threading
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfpsg_hip.so")
+# FPSG_HIP_LIB: another build of the same library (same-box A/B of kernel versions, tools/ab_lib.sh); never a fallback
+LIB_PATH = os.environ.get("FPSG_HIP_LIB") or os.path.join(_HERE, "libfpsg_hip.so")
 
 _c_f32p = ctypes.c_void_p
 _c_i32p = ctypes.c_void_p

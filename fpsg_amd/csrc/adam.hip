@@ -159,11 +159,33 @@ __global__ __launch_bounds__(kAdamThreads) void flat_accumulate_kernel(float* __
     so = soff;
   }
   const size_t stride = (size_t)gridDim.x * kAdamThreads;
-  for (size_t j = (size_t)blockIdx.x * kAdamThreads + threadIdx.x; j < n4 + 1; j += stride) {
+  size_t j = (size_t)blockIdx.x * kAdamThreads + threadIdx.x;
+  // whole vectors, kAccU per trip: the flat loads go out first, then the table searches, then the gradient loads --
+  // each group in flight together (one vector per trip was two dependent round trips per 16 bytes)
+  constexpr int kAccU = 4;
+  for (; j + (kAccU - 1) * stride < n4; j += kAccU * stride) {
+    v4f f[kAccU];
+#pragma unroll
+    for (int u = 0; u < kAccU; ++u) {
+      f[u] = (v4f){0.0f, 0.0f, 0.0f, 0.0f};
+      if (accumulate) f[u] = reinterpret_cast<const v4f*>(flat)[j + u * stride];
+    }
+    float gg[kAccU][4];
+    bool any[kAccU];
+#pragma unroll
+    for (int u = 0; u < kAccU; ++u) any[u] = gather_grad4(gtab, so, nseg, (long long)(4 * (j + u * stride)), 4, gg[u]);
+#pragma unroll
+    for (int u = 0; u < kAccU; ++u) {
+      if (accumulate && !any[u]) continue;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) f[u][e] += gg[u][e];
+      reinterpret_cast<v4f*>(flat)[j + u * stride] = f[u];
+    }
+  }
+  for (; j < n4 + 1; j += stride) {
     const long long i = (long long)(4 * j);
     const int cnt = j < n4 ? 4 : (int)(n - 4 * n4);
     if (cnt == 0) break;
-    // the flat buffer's vector first: its load flies while the table is searched
     v4f f = {0.0f, 0.0f, 0.0f, 0.0f};
     if (accumulate && cnt == 4) f = reinterpret_cast<const v4f*>(flat)[j];
     float gg[4];

@@ -30,6 +30,11 @@ namespace {
 constexpr int kBnThreads = 256;
 constexpr int kBnSeg = 4096;      // floats per work item (one contiguous row segment)
 constexpr int kBnSlices = 64;     // partial sums per channel
+// Vector loads a thread has in flight in the streaming loops: its whole share of a segment (4096 floats / 256 threads
+// = 4 vectors).  With one load per trip the loop was a chain of full round trips (`s_waitcnt vmcnt(0)` per vector, which
+// on gfx9 also waits for the previous trip's store): 32 KB in flight per CU, ~5 TB/s at best.  Arithmetic and its order
+// per thread are unchanged.
+constexpr int kBnU = kBnSeg / 4 / kBnThreads;
 
 enum BnAct { kActNone = 0, kActRelu = 1, kActLeaky = 2 };
 
@@ -84,20 +89,35 @@ __global__ __launch_bounds__(kBnThreads) void bn_reduce_kernel(
     if (vec) {
       const v4f* __restrict__ xp = reinterpret_cast<const v4f*>(x + base);
       const v4f* __restrict__ gp = reinterpret_cast<const v4f*>(MODE == 1 ? dy + base : x + base);
-      for (int e = threadIdx.x; e < len / 4; e += kBnThreads) {
-        v4f xv = ld_stream<NT>(xp + e);
+      const int nvec = len / 4;
+      for (int e0 = threadIdx.x; e0 < nvec; e0 += kBnU * kBnThreads) {
+        v4f xq[kBnU], gq[kBnU];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) xv[u] += b;
-        if (MODE == 0) {
+        for (int j = 0; j < kBnU; ++j) {
+          const int e = e0 + j * kBnThreads;
+          xq[j] = gq[j] = (v4f){0.0f, 0.0f, 0.0f, 0.0f};
+          if (e < nvec) {
+            xq[j] = ld_stream<NT>(xp + e);
+            if (MODE == 1) gq[j] = ld_stream<NT>(gp + e);
+          }
+        }
 #pragma unroll
-          for (int u = 0; u < 4; ++u) { a0 += xv[u]; a1 = fma_rn(xv[u], xv[u], a1); }
-        } else {
-          const v4f gv = ld_stream<NT>(gp + e);
+        for (int j = 0; j < kBnU; ++j) {
+          if (e0 + j * kBnThreads < nvec) {
+            v4f xv = xq[j];
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const float dz = gv[u] * act_grad<ACT>(fma_rn(xv[u], sc, sh), slope);
-            a0 += dz;
-            a1 = fma_rn(dz, (xv[u] - mu) * rs, a1);
+            for (int u = 0; u < 4; ++u) xv[u] += b;
+            if (MODE == 0) {
+#pragma unroll
+              for (int u = 0; u < 4; ++u) { a0 += xv[u]; a1 = fma_rn(xv[u], xv[u], a1); }
+            } else {
+#pragma unroll
+              for (int u = 0; u < 4; ++u) {
+                const float dz = gq[j][u] * act_grad<ACT>(fma_rn(xv[u], sc, sh), slope);
+                a0 += dz;
+                a1 = fma_rn(dz, (xv[u] - mu) * rs, a1);
+              }
+            }
           }
         }
       }
@@ -225,24 +245,40 @@ __global__ __launch_bounds__(kBnThreads) void bn_apply_kernel(const float* __res
     const v4f* __restrict__ xp = reinterpret_cast<const v4f*>(x + base);
     const v4f* __restrict__ gp = reinterpret_cast<const v4f*>(MODE == 1 ? dy + base : x + base);
     v4f* __restrict__ op = reinterpret_cast<v4f*>(out + base);
-    for (int e = threadIdx.x; e < len / 4; e += kBnThreads) {
-      v4f xv = ld_stream<NT>(xp + e);
+    const int nvec = len / 4;
+    for (int e0 = threadIdx.x; e0 < nvec; e0 += kBnU * kBnThreads) {
+      v4f xq[kBnU], gq[kBnU];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) xv[u] += b;
-      v4f r;
-      if (MODE == 0) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u) r[u] = act_fwd<ACT>(fma_rn(xv[u], sc, sh), slope);
-      } else {
-        const v4f gv = ld_stream<NT>(gp + e);
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const float dz = gv[u] * act_grad<ACT>(fma_rn(xv[u], sc, sh), slope);
-          r[u] = fma_rn(k1, dz, fma_rn(k2, xv[u], k3));
+      for (int j = 0; j < kBnU; ++j) {
+        const int e = e0 + j * kBnThreads;
+        xq[j] = gq[j] = (v4f){0.0f, 0.0f, 0.0f, 0.0f};
+        if (e < nvec) {
+          xq[j] = ld_stream<NT>(xp + e);
+          if (MODE == 1) gq[j] = ld_stream<NT>(gp + e);
         }
-        acc += (r[0] + r[1]) + (r[2] + r[3]);
       }
-      st_stream<NT>(op + e, r);
+#pragma unroll
+      for (int j = 0; j < kBnU; ++j) {
+        const int e = e0 + j * kBnThreads;
+        if (e < nvec) {
+          v4f xv = xq[j];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) xv[u] += b;
+          v4f r;
+          if (MODE == 0) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) r[u] = act_fwd<ACT>(fma_rn(xv[u], sc, sh), slope);
+          } else {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const float dz = gq[j][u] * act_grad<ACT>(fma_rn(xv[u], sc, sh), slope);
+              r[u] = fma_rn(k1, dz, fma_rn(k2, xv[u], k3));
+            }
+            acc += (r[0] + r[1]) + (r[2] + r[3]);
+          }
+          st_stream<NT>(op + e, r);
+        }
+      }
     }
   } else {
     for (int e = threadIdx.x; e < len; e += kBnThreads) {
@@ -533,12 +569,33 @@ __device__ __forceinline__ void pool_item(const float* __restrict__ xpl, const f
   const int Wp = W >> 1;
   const int vpr = Wp / VW;                 // vectors per pooled row
   const int nvec = (r1 - r0) * vpr;
-  for (int e = threadIdx.x; e < nvec; e += kBnThreads) {
+  // two trips' loads (two row pairs of vectors and their pooled gradients) in flight before the first is used
+  constexpr int PU = 2;
+  for (int e0 = threadIdx.x; e0 < nvec; e0 += PU * kBnThreads) {
+   in_t q0[PU], q1[PU];
+   float gq[PU][VW];
+#pragma unroll
+   for (int j = 0; j < PU; ++j) {
+    const int e = e0 + j * kBnThreads;
+    if (e < nvec) {
+      const int rr = e / vpr, v = e - rr * vpr;
+      const size_t o0 = (size_t)(2 * (r0 + rr)) * W + 2 * VW * v;
+      q0[j] = ld_stream<NT>(reinterpret_cast<const in_t*>(xpl + o0));
+      q1[j] = ld_stream<NT>(reinterpret_cast<const in_t*>(xpl + o0 + W));
+      if (MODE != 0) {
+#pragma unroll
+        for (int w = 0; w < VW; ++w) gq[j][w] = gpl[(size_t)(r0 + rr) * Wp + VW * v + w];
+      }
+    }
+   }
+#pragma unroll
+   for (int j = 0; j < PU; ++j) {
+    const int e = e0 + j * kBnThreads;
+    if (e >= nvec) break;
     const int rr = e / vpr, v = e - rr * vpr;
     const int r = r0 + rr;
     const size_t o0 = (size_t)(2 * r) * W + 2 * VW * v;
-    const in_t t0 = ld_stream<NT>(reinterpret_cast<const in_t*>(xpl + o0));
-    const in_t t1 = ld_stream<NT>(reinterpret_cast<const in_t*>(xpl + o0 + W));
+    const in_t t0 = q0[j], t1 = q1[j];
     float x0[2 * VW], x1[2 * VW];
 #pragma unroll
     for (int u = 0; u < 2 * VW; ++u) { x0[u] = t0[u] + b; x1[u] = t1[u] + b; }
@@ -553,7 +610,7 @@ __device__ __forceinline__ void pool_item(const float* __restrict__ xpl, const f
       if (MODE == 0) {
         po[w] = ymax;
       } else {
-        const float g = gpl[(size_t)r * Wp + VW * v + w];
+        const float g = gq[j][w];
         const float zs = sel == 0 ? z[0] : sel == 1 ? z[1] : sel == 2 ? z[2] : z[3];
         const float dz = g * act_grad<ACT>(zs, slope);
         if (MODE == 1) {
@@ -580,6 +637,7 @@ __device__ __forceinline__ void pool_item(const float* __restrict__ xpl, const f
       st_stream<NT>(reinterpret_cast<in_t*>(opl + o0), o0v);
       st_stream<NT>(reinterpret_cast<in_t*>(opl + o0 + W), o1v);
     }
+   }
   }
 }
 
@@ -866,13 +924,25 @@ __global__ __launch_bounds__(kBnThreads) void bn_max_apply_kernel(const float* _
   if ((L & 3) == 0) {
     const v4f* __restrict__ xp = reinterpret_cast<const v4f*>(x + base);
     v4f* __restrict__ op = reinterpret_cast<v4f*>(dx + base);
-    for (int e = threadIdx.x; e < len / 4; e += kBnThreads) {
-      const v4f xv = ld_stream<NT>(xp + e);
-      v4f r;
+    const int nvec = len / 4;
+    for (int e0 = threadIdx.x; e0 < nvec; e0 += kBnU * kBnThreads) {
+      v4f xq[kBnU];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) r[u] = fma_rn(k1, (4 * e + u == sel) ? d : 0.0f, fma_rn(k2, xv[u] + b, k3));
-      acc += (r[0] + r[1]) + (r[2] + r[3]);
-      st_stream<NT>(op + e, r);
+      for (int j = 0; j < kBnU; ++j) {
+        const int e = e0 + j * kBnThreads;
+        xq[j] = e < nvec ? ld_stream<NT>(xp + e) : (v4f){0.0f, 0.0f, 0.0f, 0.0f};
+      }
+#pragma unroll
+      for (int j = 0; j < kBnU; ++j) {
+        const int e = e0 + j * kBnThreads;
+        if (e < nvec) {
+          v4f r;
+#pragma unroll
+          for (int u = 0; u < 4; ++u) r[u] = fma_rn(k1, (4 * e + u == sel) ? d : 0.0f, fma_rn(k2, xq[j][u] + b, k3));
+          acc += (r[0] + r[1]) + (r[2] + r[3]);
+          st_stream<NT>(op + e, r);
+        }
+      }
     }
   } else {
     for (int e = threadIdx.x; e < len; e += kBnThreads) {

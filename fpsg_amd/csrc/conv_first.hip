@@ -5,9 +5,10 @@
 // product with a 1.86 M-long reduction (37 images of 224x224) and a 1,728-element result: 6.4
 // GFLOP over 475 MB of dy -- HBM-bound by two orders of magnitude.  The library runs it as an
 // NHWC implicit GEMM behind two layout transposes of dy (0.73 ms); here dy is read exactly once:
-//   * a workgroup walks over row segments of 64 pixels; dy[64 ch][64 px] is staged coalesced into
-//     LDS (256-B runs per channel) together with the 3 x 3 x 66 input patch of the segment;
-//   * wave w owns output channels 16w .. 16w+15: 16 steps of v_mfma_f32_16x16x4_f32 per segment
+//   * a workgroup walks over row segments of PX pixels (112 for VGG's 224-pixel rows, else 64); dy[64 ch][PX px]
+//     is staged coalesced into LDS (448-B / 256-B runs per channel) together with the 3 x 3 x (PX+2) input patch of
+//     the segment; the next segment's vectors are already on their way into registers while this one is multiplied;
+//   * wave w owns output channels 16w .. 16w+15: PX/4 steps of v_mfma_f32_16x16x4_f32 per segment
 //     with A = dy (channel x 4 pixels) and B = the im2col patch (4 pixels x 16 taps; taps 27..31
 //     are zero), two tap tiles -> 8 accumulator registers carried over all segments;
 //   * each workgroup writes one [64][32] partial; a second kernel sums the partials in a fixed
@@ -17,21 +18,27 @@
 namespace fpsg {
 namespace {
 
-constexpr int kPx = 64;                 // pixels per segment
-constexpr int kDyLd = kPx + 4;          // LDS row stride of the dy tile: 2 lanes per bank, the minimum
-constexpr int kXLd = kPx + 4;           // row stride of the input patch (66 used)
 constexpr int kFirstThreads = 256;
 
-template <bool NT>
+// PX = pixels per segment: 112 when the rows are whole multiples of it (VGG's 224: two 448-byte runs per channel row,
+// no idle pixels), 64 otherwise.  The NEXT segment's dy vectors and patch elements are fetched into registers before
+// the current segment's MFMAs start, so the HBM latency runs beside the matrix work instead of in front of it.
+template <int PX>
 __global__ __launch_bounds__(kFirstThreads) void conv_first_dw_kernel(const float* __restrict__ x,
                                                                       const float* __restrict__ dy, int H, int W,
-                                                                      int segs_per_row, long n_segs,
+                                                                      int segs_per_row, int n_segs,
                                                                       float* __restrict__ part /*[grid][64][32]*/) {
-  __shared__ float dyt[64 * kDyLd];
-  __shared__ float xt[9 * kXLd];
+  constexpr int LD = PX + 4;                      // LDS row stride: 2 lanes per bank for the A reads, the minimum
+  constexpr int VPR = PX / 4;                     // 16-byte vectors per channel row of the tile
+  constexpr int NV = 64 * VPR / kFirstThreads;    // vectors per thread (4 or 7)
+  constexpr int PE = 9 * (PX + 2);                // patch elements: 3 channels x 3 rows x (PX + 2) columns
+  constexpr int NP = (PE + kFirstThreads - 1) / kFirstThreads;
+  static_assert(64 * VPR % kFirstThreads == 0, "tile vectors divide over the threads");
+  __shared__ float dyt[64 * LD];
+  __shared__ float xt[9 * LD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int kk = lane >> 4, col = lane & 15;
-  // B operand: tap index 16*nt + col -> (c, a, b); its patch element for pixel p is xt[(3c+a)*kXLd + p + b]
+  // B operand: tap index 16*nt + col -> (c, a, b); its patch element for pixel p is xt[(3c+a)*LD + p + b]
   int boff[2];
   bool bval[2];
 #pragma unroll
@@ -39,40 +46,61 @@ __global__ __launch_bounds__(kFirstThreads) void conv_first_dw_kernel(const floa
     const int tap = 16 * nt + col;
     bval[nt] = tap < 27;
     const int t = bval[nt] ? tap : 0;
-    boff[nt] = (t / 3) * kXLd + (t % 3);          // t/3 = 3c + a, t%3 = b
+    boff[nt] = (t / 3) * LD + (t % 3);            // t/3 = 3c + a, t%3 = b
   }
-  v4f acc[2] = {{0.0f, 0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f, 0.0f}};
-  for (long seg = blockIdx.x; seg < n_segs; seg += gridDim.x) {
-    const long row = seg / segs_per_row;            // (n, h)
-    const int w0 = (int)(seg - row * segs_per_row) * kPx;
-    const long n = row / H;
-    const int h = (int)(row - n * H);
-    __syncthreads();                                // the previous segment's tiles are consumed
-    // dy tile: thread -> (channel = it*16 + tid/16, pixels 4*(tid%16) .. +3)
-    {
-      const int q4 = (tid & 15) * 4;
-      const bool in = w0 + q4 < W;                  // W % 4 == 0: a vector is inside or outside as a whole
+  // this thread's slots of a tile: vector v = it*256 + tid -> (channel v / VPR, pixels 4*(v % VPR) ..), patch
+  // element e = it*256 + tid -> (row cr = e / (PX+2), column e % (PX+2))
+  int vch[NV], vq4[NV], pcr[NP], pj[NP];
 #pragma unroll
-      for (int it = 0; it < 4; ++it) {
-        const int ch = it * 16 + (tid >> 4);
-        v4f v = {0.0f, 0.0f, 0.0f, 0.0f};
-        if (in) v = ld_stream<NT>(reinterpret_cast<const v4f*>(dy + (((size_t)n * 64 + ch) * H + h) * W + w0 + q4));
-        *reinterpret_cast<v4f*>(dyt + ch * kDyLd + q4) = v;
-      }
+  for (int it = 0; it < NV; ++it) {
+    const int v = it * kFirstThreads + tid;
+    vch[it] = v / VPR;
+    vq4[it] = (v - vch[it] * VPR) * 4;
+  }
+#pragma unroll
+  for (int it = 0; it < NP; ++it) {
+    const int e = it * kFirstThreads + tid;
+    pcr[it] = e < PE ? e / (PX + 2) : -1;
+    pj[it] = e - (e / (PX + 2)) * (PX + 2);
+  }
+  v4f rv[NV];
+  float rp[NP];
+  auto fetch = [&](int seg) {
+    const int row = seg / segs_per_row;             // (n, h)
+    const int w0 = (seg - row * segs_per_row) * PX;
+    const int n = row / H;
+    const int h = row - n * H;
+#pragma unroll
+    for (int it = 0; it < NV; ++it) {
+      rv[it] = (v4f){0.0f, 0.0f, 0.0f, 0.0f};       // W % 4 == 0: a vector is inside or outside as a whole
+      if (w0 + vq4[it] < W)
+        rv[it] = *reinterpret_cast<const v4f*>(dy + (((size_t)n * 64 + vch[it]) * H + h) * W + w0 + vq4[it]);
     }
-    // input patch: 3 channels x 3 rows x 66 columns (zero outside the image)
-    for (int e = tid; e < 9 * (kPx + 2); e += kFirstThreads) {
-      const int cr = e / (kPx + 2), j = e - cr * (kPx + 2);
-      const int c = cr / 3, r = cr - 3 * c;
-      const int hh = h + r - 1, ww = w0 + j - 1;
-      xt[cr * kXLd + j] = (hh >= 0 && hh < H && ww >= 0 && ww < W) ? x[(((size_t)n * 3 + c) * H + hh) * W + ww] : 0.0f;
+#pragma unroll
+    for (int it = 0; it < NP; ++it) {
+      const int c = pcr[it] / 3, r = pcr[it] - 3 * c;
+      const int hh = h + r - 1, ww = w0 + pj[it] - 1;
+      rp[it] = 0.0f;
+      if (pcr[it] >= 0 && hh >= 0 && hh < H && ww >= 0 && ww < W) rp[it] = x[(((size_t)n * 3 + c) * H + hh) * W + ww];
     }
+  };
+  v4f acc[2] = {{0.0f, 0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f, 0.0f}};
+  int seg = blockIdx.x;
+  if (seg < n_segs) fetch(seg);
+  for (; seg < n_segs; seg += gridDim.x) {
+    __syncthreads();                                // the previous segment's tiles are consumed
+#pragma unroll
+    for (int it = 0; it < NV; ++it) *reinterpret_cast<v4f*>(dyt + vch[it] * LD + vq4[it]) = rv[it];
+#pragma unroll
+    for (int it = 0; it < NP; ++it)
+      if (pcr[it] >= 0) xt[pcr[it] * LD + pj[it]] = rp[it];
     __syncthreads();
-    const float* ap = dyt + (16 * wave + col) * kDyLd + kk;
+    if (seg + (int)gridDim.x < n_segs) fetch(seg + gridDim.x);
+    const float* ap = dyt + (16 * wave + col) * LD + kk;
     const float* bp0 = xt + boff[0] + kk;
     const float* bp1 = xt + boff[1] + kk;
 #pragma unroll
-    for (int s = 0; s < kPx / 4; ++s) {
+    for (int s = 0; s < PX / 4; ++s) {
       const float a = ap[4 * s];
       const float b0 = bval[0] ? bp0[4 * s] : 0.0f;
       const float b1 = bval[1] ? bp1[4 * s] : 0.0f;
@@ -118,6 +146,69 @@ __global__ __launch_bounds__(1024) void conv_first_dw_reduce_kernel(const float*
 // (c, a, b) order by an fma chain starting from 0 (the oracle of tests/test_winograd_gpu.py restates exactly this).
 // STATS: per channel the partial sums of y + bias[k] and its square over the workgroup's 1024 pixels ->
 // parts[k][blockIdx.x][2] for the BatchNorm that follows (fpsg_bn_stats with parts).  Deterministic.
+// the 27 weights (and the bias) of output channel k: k is wave-uniform, so these are scalar loads
+__device__ __forceinline__ void first_load_weights(const float* __restrict__ wt, const float* __restrict__ bias, int k,
+                                                   float (&w)[27], float& b) {
+#pragma unroll
+  for (int i = 0; i < 27; ++i) w[i] = wt[k * 27 + i];
+  b = bias ? bias[k] : 0.0f;
+}
+
+// pins the wait for a channel's scalar loads at this point of the program
+__device__ __forceinline__ void first_wait_weights(const float (&w)[27], float b) {
+  asm volatile("" ::"s"(w[0]), "s"(w[15]), "s"(w[23]), "s"(w[25]), "s"(w[26]), "s"(b));
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+// one output channel of the thread's 4 pixels: taps added in (c, a, b) order by an fma chain starting from 0
+__device__ __forceinline__ void first_channel(const float (&d)[3][3][6], const float (&w)[27], float (&o)[4]) {
+#pragma unroll
+  for (int p = 0; p < 4; ++p) o[p] = 0.0f;
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int b = 0; b < 3; ++b) {
+        const float wv = w[(c * 3 + a) * 3 + b];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) o[p] = fma_rn(wv, d[c][a][b + p], o[p]);
+      }
+}
+
+// a lane's contribution to the BatchNorm sums of y + bias over its 4 pixels (0 for the lanes beyond the tensor)
+__device__ __forceinline__ void first_lane_sums(const float (&o)[4], float bk, bool live, float& s0, float& s1) {
+  s0 = 0.0f;
+  s1 = 0.0f;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const float v = o[p] + bk;
+    s0 += v;
+    s1 = fma_rn(v, v, s1);
+  }
+  if (!live) s0 = s1 = 0.0f;
+}
+
+// Sums of four values over the 64 lanes, delivered in lane 63 (other lanes: partial sums): the row_shr / row_bcast DPP
+// tree -- six dependent adds per value, no LDS crossbar operation, the four chains interleaved so that a DPP operand
+// is never read within two instructions of its write (the first s_nop covers the producers).  Fixed order.
+__device__ __forceinline__ void wave_sum4_to_last(float& a, float& b, float& c, float& d) {
+#define FPSG_DPP_ADD4(ctrl)                          \
+  "v_add_f32_dpp %0, %0, %0 " ctrl "\n"              \
+  "v_add_f32_dpp %1, %1, %1 " ctrl "\n"              \
+  "v_add_f32_dpp %2, %2, %2 " ctrl "\n"              \
+  "v_add_f32_dpp %3, %3, %3 " ctrl "\n"
+  asm volatile("s_nop 1\n"
+               FPSG_DPP_ADD4("row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0")
+               FPSG_DPP_ADD4("row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:0")
+               FPSG_DPP_ADD4("row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:0")
+               FPSG_DPP_ADD4("row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:0")
+               FPSG_DPP_ADD4("row_bcast:15 row_mask:0xa bank_mask:0xf")
+               FPSG_DPP_ADD4("row_bcast:31 row_mask:0xc bank_mask:0xf")
+               : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+#undef FPSG_DPP_ADD4
+}
+
 template <bool STATS, bool NT = false>
 __global__ __launch_bounds__(kFirstThreads) void conv_first_fwd_kernel(const float* __restrict__ x,
                                                                        const float* __restrict__ wt /*[64][27]*/, int H,
@@ -179,35 +270,33 @@ __global__ __launch_bounds__(kFirstThreads) void conv_first_fwd_kernel(const flo
   }
   const size_t plane = (size_t)H * W;
   float* yp = y + ((size_t)n * 64 * H + h) * W + 4 * w4;
-#pragma unroll 2
-  for (int k = 0; k < 64; ++k) {
-    const float* wk = wt + k * 27;
-    float o[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-#pragma unroll
-      for (int a = 0; a < 3; ++a) {
-#pragma unroll
-        for (int b = 0; b < 3; ++b) {
-          const float wv = wk[(c * 3 + a) * 3 + b];
-#pragma unroll
-          for (int p = 0; p < 4; ++p) o[p] = fma_rn(wv, d[c][a][b + p], o[p]);
-        }
-      }
-    }
-    if (live) st_stream<NT>(reinterpret_cast<v4f*>(yp + (size_t)k * plane), (v4f){o[0], o[1], o[2], o[3]});
+  // Two output channels per round; a channel's 27 weights (+ bias) are fetched one channel ahead of their use, so
+  // the scalar loads' latency is covered by the previous channel's 54 packed fmas.
+  float wa[27], wb[27], ba = 0.0f, bb = 0.0f;
+  first_load_weights(wt, STATS ? bias : nullptr, 0, wa, ba);
+  for (int k = 0; k < 64; k += 2) {
+    // (scalar loads return out of order, so a wait for one means a wait for all: the wait for the channel about to
+    // be used comes first -- its loads were issued a channel ago -- and only then the next channel's loads go out)
+    first_wait_weights(wa, ba);
+    first_load_weights(wt, STATS ? bias : nullptr, k + 1, wb, bb);
+    __builtin_amdgcn_sched_barrier(0);
+    float oa[4], ob[4];
+    first_channel(d, wa, oa);
+    if (live) st_stream<NT>(reinterpret_cast<v4f*>(yp + (size_t)k * plane), (v4f){oa[0], oa[1], oa[2], oa[3]});
+    float a0 = 0.0f, a1 = 0.0f, b0 = 0.0f, b1 = 0.0f;
+    if (STATS) first_lane_sums(oa, ba, live, a0, a1);
+    first_wait_weights(wb, bb);
+    first_load_weights(wt, STATS ? bias : nullptr, k + 2 < 64 ? k + 2 : 63, wa, ba);
+    __builtin_amdgcn_sched_barrier(0);
+    first_channel(d, wb, ob);
+    if (live) st_stream<NT>(reinterpret_cast<v4f*>(yp + (size_t)(k + 1) * plane), (v4f){ob[0], ob[1], ob[2], ob[3]});
     if (STATS) {
-      const float bk = bias ? bias[k] : 0.0f;
-      float s0 = 0.0f, s1 = 0.0f;
-#pragma unroll
-      for (int p = 0; p < 4; ++p) {
-        const float v = live ? o[p] + bk : 0.0f;
-        s0 += v;
-        s1 = fma_rn(v, v, s1);
+      first_lane_sums(ob, bb, live, b0, b1);
+      wave_sum4_to_last(a0, a1, b0, b1);
+      if (lane == 63) {
+        *reinterpret_cast<v2f*>(&red[wave][k][0]) = (v2f){a0, a1};
+        *reinterpret_cast<v2f*>(&red[wave][k + 1][0]) = (v2f){b0, b1};
       }
-      s0 = wave_sum(s0);
-      s1 = wave_sum(s1);
-      if (lane == 0) { red[wave][k][0] = s0; red[wave][k][1] = s1; }
     }
   }
   if (STATS) {
@@ -240,12 +329,19 @@ extern "C" int fpsg_conv_first_dw(const float* x, const float* dy, int N, int C,
   FPSG_REQUIRE_PTR(x); FPSG_REQUIRE_PTR(dy); FPSG_REQUIRE_PTR(dw); FPSG_REQUIRE_PTR(ws);
   FPSG_REQUIRE((reinterpret_cast<uintptr_t>(dy) & 15) == 0, FPSG_E_ALIGN, "fpsg_conv_first_dw: dy must be 16-byte aligned");
   hipStream_t s = static_cast<hipStream_t>(stream);
-  const int segs_per_row = (W + kPx - 1) / kPx;
-  const long n_segs = (long)N * H * segs_per_row;
-  const int blocks = n_segs < 2048 ? (int)n_segs : 2048;   // 8 workgroups per CU: staging of one overlaps the MFMAs of others
-  // (non-temporal loads of dy were measured here: 144 -> 185 us -- its 64-byte pieces per channel row lose the L2's
-  // merging of neighbouring workgroups' requests; plain loads)
-  hipLaunchKernelGGL(conv_first_dw_kernel<false>, dim3(blocks), dim3(kFirstThreads), 0, s, x, dy, H, W, segs_per_row, n_segs, ws);
+  const int px = W % 112 == 0 ? 112 : 64;
+  const int segs_per_row = (W + px - 1) / px;
+  const long n_segs_l = (long)N * H * segs_per_row;
+  FPSG_REQUIRE(n_segs_l < (1L << 31), FPSG_E_LIMIT, "fpsg_conv_first_dw: %ld row segments beyond the 32-bit walk", n_segs_l);
+  const int n_segs = (int)n_segs_l;
+  // as many workgroups as are resident at once (LDS: 4 per CU with 112-pixel tiles, 8 with 64-pixel tiles); each walks
+  // over its share of the segments.  (Non-temporal loads of dy were measured here: 144 -> 185 us; plain loads.)
+  const int resident = px == 112 ? 1024 : 2048;
+  const int blocks = n_segs < resident ? n_segs : resident;
+  if (px == 112)
+    hipLaunchKernelGGL(conv_first_dw_kernel<112>, dim3(blocks), dim3(kFirstThreads), 0, s, x, dy, H, W, segs_per_row, n_segs, ws);
+  else
+    hipLaunchKernelGGL(conv_first_dw_kernel<64>, dim3(blocks), dim3(kFirstThreads), 0, s, x, dy, H, W, segs_per_row, n_segs, ws);
   int rc = launch_status("fpsg_conv_first_dw(partials)");
   if (rc) return rc;
   hipLaunchKernelGGL(conv_first_dw_reduce_kernel, dim3(64), dim3(1024), 0, s, ws, blocks, dw);
