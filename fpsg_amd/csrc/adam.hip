@@ -208,7 +208,36 @@ __global__ __launch_bounds__(kAdamThreads) void adam_ptr_kernel(float* __restric
                                                                 float eps, float inv_sqrt_bc2, float gscale) {
   const size_t stride = (size_t)gridDim.x * kAdamThreads;
   const float omb1 = 1.0f - b1, omb2 = 1.0f - b2;
-  for (size_t j = (size_t)blockIdx.x * kAdamThreads + threadIdx.x; j < n4 + 1; j += stride) {
+  size_t j = (size_t)blockIdx.x * kAdamThreads + threadIdx.x;
+  // whole vectors, two per trip: six flat loads out, two table searches, two gradient loads, then the arithmetic
+  // (one vector per trip: the search and the gradient load sat between the flat loads and their use every 16 bytes)
+  for (; j + stride < n4; j += 2 * stride) {
+    v4f pv[2], mv[2], vv[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      pv[u] = reinterpret_cast<const v4f*>(p)[j + u * stride];
+      mv[u] = reinterpret_cast<const v4f*>(m)[j + u * stride];
+      vv[u] = reinterpret_cast<const v4f*>(v)[j + u * stride];
+    }
+    float gg[2][4];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) gather_grad4(gtab, seg_off, nseg, (long long)(4 * (j + u * stride)), 4, gg[u]);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float gq = gg[u][e] * gscale;
+        mv[u][e] = fma_rn(omb1, gq - mv[u][e], mv[u][e]);
+        vv[u][e] = fma_rn(omb2 * gq, gq, b2 * vv[u][e]);
+        const float denom = fma_rn(__fsqrt_rn(vv[u][e]), inv_sqrt_bc2, eps);
+        pv[u][e] = fma_rn(-step_size, mv[u][e] / denom, pv[u][e]);
+      }
+      reinterpret_cast<v4f*>(p)[j + u * stride] = pv[u];
+      reinterpret_cast<v4f*>(m)[j + u * stride] = mv[u];
+      reinterpret_cast<v4f*>(v)[j + u * stride] = vv[u];
+    }
+  }
+  for (; j < n4 + 1; j += stride) {
     const long long i = (long long)(4 * j);
     const int cnt = j < n4 ? 4 : (int)(n - 4 * n4);          // the last "vector" is the tail
     if (cnt == 0) break;

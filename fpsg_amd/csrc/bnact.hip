@@ -352,7 +352,49 @@ __global__ __launch_bounds__(kBnThreads) void bn_small_kernel(
   const int e0 = threadIdx.x & (tpr - 1), n0 = threadIdx.x >> tpr_log2;
   if (two_sweeps) {
     float a0 = 0.0f, a1 = 0.0f;
-    for (int n = n0; n < N; n += rpi) {
+    int n_first = n0;
+    if (vec && L4 <= tpr) {
+      // a row is at most one vector per thread (the decoder's 128-point rows, 14 x 14 maps): the thread's vectors of
+      // kBnU row groups are requested together -- one row group per trip made the sweep N / rpi dependent round
+      // trips to HBM per thread -- and consumed in row order (same sums, bit for bit)
+      const bool has = e0 < L4;
+      for (; n_first + (kBnU - 1) * rpi < N; n_first += kBnU * rpi) {
+        v4f xq[kBnU], gq[kBnU];
+#pragma unroll
+        for (int j = 0; j < kBnU; ++j) {
+          xq[j] = gq[j] = (v4f){0.0f, 0.0f, 0.0f, 0.0f};
+          if (has) {
+            const size_t base = ((size_t)(n_first + j * rpi) * C + c) * L;
+            xq[j] = reinterpret_cast<const v4f*>(x + base)[e0];
+            if (MODE == 1) gq[j] = reinterpret_cast<const v4f*>(dy + base)[e0];
+          }
+        }
+        if (has) {
+#pragma unroll
+          for (int j = 0; j < kBnU; ++j) {
+            const int n = n_first + j * rpi;
+            v4f xv = xq[j];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) xv[u] += b;
+            if (MODE == 0) {
+#pragma unroll
+              for (int u = 0; u < 4; ++u) { a0 += xv[u]; a1 = fma_rn(xv[u], xv[u], a1); }
+            } else {
+              v4f dz;
+#pragma unroll
+              for (int u = 0; u < 4; ++u) {
+                dz[u] = gq[j][u] * act_grad<ACT>(fma_rn(xv[u], sc, sh), slope);
+                a0 += dz[u];
+                a1 = fma_rn(dz[u], (xv[u] - mu) * rs, a1);
+              }
+              if (keep) sd[(size_t)n * L4 + e0] = dz;
+            }
+            if (keep) sx[(size_t)n * L4 + e0] = xv;
+          }
+        }
+      }
+    }
+    for (int n = n_first; n < N; n += rpi) {
       const size_t base = ((size_t)n * C + c) * L;
       if (vec) {
         const v4f* __restrict__ xp = reinterpret_cast<const v4f*>(x + base);

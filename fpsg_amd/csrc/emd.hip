@@ -23,25 +23,28 @@ constexpr int kEmdThreads = 64 * kEmdWaves;
 
 enum EmdMode { kRatioL = 0, kRatioR = 1, kMatch = 2, kGradOther = 3 };
 
+inline int emd_pad4(int n) { return (n + 3) & ~3; }
+
 struct EmdArgs {
-  const float* own;      // [B, No, 3] owner cloud
-  const float* oth;      // [B, Nt, 3] cloud that is swept
-  const float* oth_w;    // [B, Nt] weight of every swept point (remainR | ratioL | ratioR)
-  float* own_remain;     // [B, No]  remainL (kRatioL: read, kMatch: updated) | remainR (kRatioR: updated)
-  float* own_ratio;      // [B, No]  ratioL (kRatioL: written, kMatch: read) | ratioR (kRatioR: written; kGradOther: read)
-  float* own_cost;       // [B, No]  kMatch: per-owner transport cost, accumulated over levels
-  float* own_grad;       // [B, No, 3] or null: kMatch / kGradOther gradient accumulators
-  int No, Nt;
+  const float* own;      // [B, 3, Nop] owner cloud, coordinate-major (SoA copy in the workspace)
+  const float* oth;      // [B, 3, Ntp] cloud that is swept, coordinate-major
+  const float* oth_w;    // [B, Ntp] weight of every swept point (remainR | ratioL | ratioR); 0 in the padding
+  float* own_remain;     // [B, Nop]  remainL (kRatioL: read, kMatch: updated) | remainR (kRatioR: updated)
+  float* own_ratio;      // [B, Nop]  ratioL (kRatioL: written, kMatch: read) | ratioR (kRatioR: written; kGradOther: read)
+  float* own_cost;       // [B, Nop]  kMatch: per-owner transport cost, accumulated over levels
+  float* own_grad;       // [B, No, 3] or null: kMatch / kGradOther gradient accumulators (the caller's layout)
+  int No, Nt;            // points; the workspace rows are padded to multiples of 4 (Nop, Ntp)
   float level;
 };
 
-// One wave = kEmdOwners owner points against the whole swept cloud: lane l takes the candidates
-// l, l+64, l+128, ... straight from global memory (a wave reads contiguous 768-byte runs of the AoS
-// cloud; the cloud stays in L2 -- no LDS staging, no barrier), two candidates per packed FP32
-// instruction, and the per-owner sums are folded over the 64 lanes by a fixed DPP tree
-// (deterministic, no float atomics).  A sweep of one 2048-point pair is 256 workgroups of 4 waves,
-// so even a single pair fills the chip; per pair: distance (3 packed-half instructions) + v_exp_f32 +
-// weights (+ v_sqrt / v_rcp and 4 FMAs in the assignment sweeps): VALU + transcendental bound.
+// One wave = kEmdOwners owner points against the whole swept cloud.  The clouds are read from coordinate-major copies
+// (x[], y[], z[] rows, made once per call by emd_init_kernel): lane l takes the FOUR candidates 4(l + 64 t) .. +3 of
+// trip t with one 16-byte load per coordinate and one for their weights -- 4 load instructions per 8 pairs (the
+// point-major cloud needed 8 dword loads per 4 pairs, and their waits were the sweep's critical path) -- the next trip's
+// vectors are on their way while this one is evaluated; two candidates per packed FP32 instruction; the per-owner
+// sums are folded over the 64 lanes by the row_shr / row_bcast DPP tree (deterministic, no float atomics, no LDS).
+// A sweep of one 2048-point pair is 256 workgroups of 4 waves, so even a single pair fills the chip; per pair: distance
+// (3 packed-half instructions) + v_exp_f32 + weights (+ v_sqrt / v_rcp and 4 FMAs in the assignment sweeps).
 template <int MODE, bool GRAD>
 __global__ __launch_bounds__(kEmdThreads) void emd_sweep_kernel(EmdArgs a) {
   const int b = blockIdx.y;
@@ -49,99 +52,141 @@ __global__ __launch_bounds__(kEmdThreads) void emd_sweep_kernel(EmdArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int o0 = (blockIdx.x * kEmdWaves + wave) * kEmdOwners;
   if (o0 >= a.No) return;                               // whole wave; no barrier in this kernel
-  const float* __restrict__ own = a.own + (size_t)b * a.No * 3;
-  const float* __restrict__ oth = a.oth + (size_t)b * a.Nt * 3;
-  const float* __restrict__ ow = a.oth_w + (size_t)b * a.Nt;
+  const int Nop = (a.No + 3) & ~3, Ntp = (a.Nt + 3) & ~3;
+  const float* __restrict__ own = a.own + (size_t)b * 3 * Nop;
+  const float* __restrict__ othx = a.oth + (size_t)b * 3 * Ntp;
+  const float* __restrict__ othy = othx + Ntp;
+  const float* __restrict__ othz = othy + Ntp;
+  const float* __restrict__ ow = a.oth_w + (size_t)b * Ntp;
   v2f px[kEmdOwners], py[kEmdOwners], pz[kEmdOwners];
   float fac[kEmdOwners];
 #pragma unroll
   for (int r = 0; r < kEmdOwners; ++r) {
     const int oc = (o0 + r) < a.No ? (o0 + r) : a.No - 1;
-    const float x = own[3 * oc], y = own[3 * oc + 1], z = own[3 * oc + 2];
+    const float x = own[oc], y = own[Nop + oc], z = own[2 * Nop + oc];
     px[r] = v2f{x, x}; py[r] = v2f{y, y}; pz[r] = v2f{z, z};
     // factor applied to every pair weight of this owner (assignment sweeps only)
-    fac[r] = (MODE == kMatch || MODE == kGradOther) ? a.own_ratio[(size_t)b * a.No + oc] : 1.0f;
+    fac[r] = (MODE == kMatch || MODE == kGradOther) ? a.own_ratio[(size_t)b * Nop + oc] : 1.0f;
   }
   v2f s[kEmdOwners], c[kEmdOwners], gx[kEmdOwners], gy[kEmdOwners], gz[kEmdOwners];
 #pragma unroll
   for (int r = 0; r < kEmdOwners; ++r) { s[r] = v2f{0, 0}; c[r] = v2f{0, 0}; gx[r] = v2f{0, 0}; gy[r] = v2f{0, 0}; gz[r] = v2f{0, 0}; }
   const v2f lvl = {a.level, a.level};
 
-#pragma unroll 4
-  for (int l0 = lane; l0 < a.Nt; l0 += 128) {           // candidates l0 and l0 + 64 as one packed pair; 4 pairs of loads in flight
-    const int l1 = l0 + 64;
-    const bool in1 = l1 < a.Nt;
-    const int l1c = in1 ? l1 : l0;
-    const v2f cx = {oth[3 * l0], oth[3 * l1c]}, cy = {oth[3 * l0 + 1], oth[3 * l1c + 1]},
-              cz = {oth[3 * l0 + 2], oth[3 * l1c + 2]};
-    const v2f cw = {ow[l0], in1 ? ow[l1] : 0.0f};       // a missing candidate weighs nothing
+  const int ngroups = Ntp >> 2;                         // groups of four candidates
+  auto fetch = [&](int g, v4f& X, v4f& Y, v4f& Z, v4f& Wt) {
+    const bool in = g < ngroups;
+    const int gc = in ? g : 0;                          // a lane beyond the cloud re-reads group 0 with weight 0
+    X = reinterpret_cast<const v4f*>(othx)[gc];
+    Y = reinterpret_cast<const v4f*>(othy)[gc];
+    Z = reinterpret_cast<const v4f*>(othz)[gc];
+    Wt = reinterpret_cast<const v4f*>(ow)[gc];
+    if (!in) Wt = (v4f){0.0f, 0.0f, 0.0f, 0.0f};
+  };
+  v4f X, Y, Z, Wt;
+  fetch(lane, X, Y, Z, Wt);
+  for (int g = lane; g < ngroups; g += 64) {
+    v4f Xn, Yn, Zn, Wn;
+    fetch(g + 64, Xn, Yn, Zn, Wn);                      // (past the end: group 0, weight 0, never used)
 #pragma unroll
-    for (int r = 0; r < kEmdOwners; ++r) {
-      const v2f dx = cx - px[r], dy = cy - py[r], dz = cz - pz[r];
-      const v2f d2 = fma_rn(dz, dz, fma_rn(dy, dy, dx * dx));
-      const v2f e = lvl * d2;
-      const v2f f2 = {fac[r], fac[r]};
-      const v2f w = v2f{__expf(e.x), __expf(e.y)} * cw * f2;
-      s[r] += w;
-      if (MODE == kMatch || MODE == kGradOther) {
-        const v2f dist = {__builtin_sqrtf(d2.x), __builtin_sqrtf(d2.y)};
-        if (MODE == kMatch) c[r] = fma_rn(w, dist, c[r]);
-        if (GRAD) {
-          const v2f f = {w.x / __builtin_fmaxf(dist.x, 1e-20f), w.y / __builtin_fmaxf(dist.y, 1e-20f)};
-          gx[r] = fma_rn(f, -dx, gx[r]);   // owner - other
-          gy[r] = fma_rn(f, -dy, gy[r]);
-          gz[r] = fma_rn(f, -dz, gz[r]);
+    for (int h = 0; h < 2; ++h) {                       // candidates (4g, 4g+1) and (4g+2, 4g+3) as packed pairs
+      const v2f cx = h ? v2f{X[2], X[3]} : v2f{X[0], X[1]};
+      const v2f cy = h ? v2f{Y[2], Y[3]} : v2f{Y[0], Y[1]};
+      const v2f cz = h ? v2f{Z[2], Z[3]} : v2f{Z[0], Z[1]};
+      const v2f cw = h ? v2f{Wt[2], Wt[3]} : v2f{Wt[0], Wt[1]};
+#pragma unroll
+      for (int r = 0; r < kEmdOwners; ++r) {
+        const v2f dx = cx - px[r], dy = cy - py[r], dz = cz - pz[r];
+        const v2f d2 = fma_rn(dz, dz, fma_rn(dy, dy, dx * dx));
+        const v2f e = lvl * d2;
+        const v2f f2 = {fac[r], fac[r]};
+        const v2f w = v2f{__expf(e.x), __expf(e.y)} * cw * f2;
+        s[r] += w;
+        if (MODE == kMatch || MODE == kGradOther) {
+          const v2f dist = {__builtin_sqrtf(d2.x), __builtin_sqrtf(d2.y)};
+          if (MODE == kMatch) c[r] = fma_rn(w, dist, c[r]);
+          if (GRAD) {
+            const v2f f = {w.x / __builtin_fmaxf(dist.x, 1e-20f), w.y / __builtin_fmaxf(dist.y, 1e-20f)};
+            gx[r] = fma_rn(f, -dx, gx[r]);   // owner - other
+            gy[r] = fma_rn(f, -dy, gy[r]);
+            gz[r] = fma_rn(f, -dz, gz[r]);
+          }
         }
       }
     }
+    X = Xn; Y = Yn; Z = Zn; Wt = Wn;
   }
+  static_assert(kEmdOwners == 2, "the reductions below fold two owners' sums per DPP tree");
+  float st[2] = {s[0].x + s[0].y, s[1].x + s[1].y};
+  float ct[2] = {c[0].x + c[0].y, c[1].x + c[1].y};
+  wave_sum4_to_last(st[0], st[1], ct[0], ct[1]);
+  float gt[2][3] = {{0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f}};
+  if (GRAD) {
+#pragma unroll
+    for (int r = 0; r < 2; ++r) { gt[r][0] = gx[r].x + gx[r].y; gt[r][1] = gy[r].x + gy[r].y; gt[r][2] = gz[r].x + gz[r].y; }
+    float pad = 0.0f, pad2 = 0.0f;
+    wave_sum4_to_last(gt[0][0], gt[0][1], gt[0][2], pad);
+    wave_sum4_to_last(gt[1][0], gt[1][1], gt[1][2], pad2);
+  }
+  if (lane != 63) return;                                // the DPP tree delivers the totals in the last lane
 #pragma unroll
   for (int r = 0; r < kEmdOwners; ++r) {
-    const float st = wave_sum(s[r].x + s[r].y);
-    float ct = 0.0f, gxt = 0.0f, gyt = 0.0f, gzt = 0.0f;
-    if (MODE == kMatch) ct = wave_sum(c[r].x + c[r].y);
-    if (GRAD) {
-      gxt = wave_sum(gx[r].x + gx[r].y);
-      gyt = wave_sum(gy[r].x + gy[r].y);
-      gzt = wave_sum(gz[r].x + gz[r].y);
-    }
     const int o = o0 + r;
-    if (lane != 0 || o >= a.No) continue;
-    const size_t oi = (size_t)b * a.No + o;
+    if (o >= a.No) continue;
+    const size_t oi = (size_t)b * Nop + o;
     if (MODE == kRatioL) {
-      a.own_ratio[oi] = a.own_remain[oi] / (st + 1e-9f);
+      a.own_ratio[oi] = a.own_remain[oi] / (st[r] + 1e-9f);
     } else if (MODE == kRatioR) {
       const float rem = a.own_remain[oi];
-      const float sumr = st * rem;
+      const float sumr = st[r] * rem;
       const float consumption = __builtin_fminf(rem / (sumr + 1e-9f), 1.0f);
       a.own_ratio[oi] = consumption * rem;
       a.own_remain[oi] = __builtin_fmaxf(0.0f, rem - sumr);
     } else if (MODE == kMatch) {
-      a.own_cost[oi] += ct;
-      a.own_remain[oi] = __builtin_fmaxf(0.0f, a.own_remain[oi] - st);
+      a.own_cost[oi] += ct[r];
+      a.own_remain[oi] = __builtin_fmaxf(0.0f, a.own_remain[oi] - st[r]);
     }
     if (GRAD && (MODE == kMatch || MODE == kGradOther)) {
-      a.own_grad[3 * oi] += gxt;
-      a.own_grad[3 * oi + 1] += gyt;
-      a.own_grad[3 * oi + 2] += gzt;
+      const size_t gi = ((size_t)b * a.No + o) * 3;
+      a.own_grad[gi] += gt[r][0];
+      a.own_grad[gi + 1] += gt[r][1];
+      a.own_grad[gi + 2] += gt[r][2];
     }
   }
 }
 
-__global__ void emd_init_kernel(float* remainL, float* costrow, float* remainR, float* g1, float* g2,
-                                int B, int N, int M, float multiL, float multiR) {
+// Workspace set-up of a call: the per-point state (padding included: a padded point weighs nothing in every sweep), the
+// coordinate-major copies of both clouds and zeroed gradient accumulators.
+__global__ void emd_init_kernel(const float* __restrict__ xyz1, const float* __restrict__ xyz2, float* remainL,
+                                float* ratioL, float* costrow, float* remainR, float* ratioR, float* soa1, float* soa2,
+                                float* g1, float* g2, int B, int N, int M, int Np, int Mp, float multiL, float multiR) {
   const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t < (size_t)B * N) { remainL[t] = multiL; costrow[t] = 0.0f; }
-  if (t < (size_t)B * M) remainR[t] = multiR;
+  if (t < (size_t)B * Np) {
+    const int b = (int)(t / Np), i = (int)(t - (size_t)b * Np);
+    const bool in = i < N;
+    remainL[t] = in ? multiL : 0.0f;
+    ratioL[t] = 0.0f;
+    costrow[t] = 0.0f;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) soa1[((size_t)b * 3 + d) * Np + i] = in ? xyz1[((size_t)b * N + i) * 3 + d] : 0.0f;
+  }
+  if (t < (size_t)B * Mp) {
+    const int b = (int)(t / Mp), i = (int)(t - (size_t)b * Mp);
+    const bool in = i < M;
+    remainR[t] = in ? multiR : 0.0f;
+    ratioR[t] = 0.0f;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) soa2[((size_t)b * 3 + d) * Mp + i] = in ? xyz2[((size_t)b * M + i) * 3 + d] : 0.0f;
+  }
   if (g1 && t < (size_t)B * N * 3) g1[t] = 0.0f;
   if (g2 && t < (size_t)B * M * 3) g2[t] = 0.0f;
 }
 
 // cost[b] = sum_k costrow[b,k]: one workgroup per cloud, fixed-shape tree (deterministic)
-__global__ __launch_bounds__(256) void emd_cost_kernel(const float* __restrict__ costrow, int N,
+__global__ __launch_bounds__(256) void emd_cost_kernel(const float* __restrict__ costrow, int N, int Np,
                                                        float* __restrict__ cost) {
   __shared__ float red[256];
-  const float* r = costrow + (size_t)blockIdx.x * N;
+  const float* r = costrow + (size_t)blockIdx.x * Np;
   float acc = 0.0f;
   for (int k = threadIdx.x; k < N; k += 256) acc += r[k];
   red[threadIdx.x] = acc;
@@ -164,7 +209,9 @@ int sweep(const EmdArgs& a, int B, hipStream_t s, const char* what) {
 }  // namespace fpsg
 
 extern "C" size_t fpsg_emd_workspace_floats(int B, int N, int M) {
-  return (size_t)B * (3 * (size_t)N + 2 * (size_t)M);
+  if (B <= 0 || N <= 0 || M <= 0) return 0;
+  const size_t Np = (size_t)fpsg::emd_pad4(N), Mp = (size_t)fpsg::emd_pad4(M);
+  return (size_t)B * (6 * Np + 5 * Mp);      // remainL, ratioL, costrow, x1/y1/z1 | remainR, ratioR, x2/y2/z2
 }
 
 extern "C" int fpsg_emd_approx(const float* xyz1, const float* xyz2, int B, int N, int M,
@@ -177,18 +224,22 @@ extern "C" int fpsg_emd_approx(const float* xyz1, const float* xyz2, int B, int 
   FPSG_REQUIRE_PTR(xyz1); FPSG_REQUIRE_PTR(xyz2); FPSG_REQUIRE_PTR(cost); FPSG_REQUIRE_PTR(ws);
   FPSG_REQUIRE(!misaligned4(gxyz1) && !misaligned4(gxyz2), FPSG_E_ALIGN,
                "fpsg_emd_approx: gradient buffers must be 4-byte aligned");
+  FPSG_REQUIRE((reinterpret_cast<uintptr_t>(ws) & 15) == 0, FPSG_E_ALIGN, "fpsg_emd_approx: ws must be 16-byte aligned");
   hipStream_t s = static_cast<hipStream_t>(stream);
+  const int Np = emd_pad4(N), Mp = emd_pad4(M);
   float* remainL = ws;
-  float* ratioL = remainL + (size_t)B * N;
-  float* costrow = ratioL + (size_t)B * N;
-  float* remainR = costrow + (size_t)B * N;
-  float* ratioR = remainR + (size_t)B * M;
+  float* ratioL = remainL + (size_t)B * Np;
+  float* costrow = ratioL + (size_t)B * Np;
+  float* soa1 = costrow + (size_t)B * Np;
+  float* remainR = soa1 + (size_t)B * 3 * Np;
+  float* ratioR = remainR + (size_t)B * Mp;
+  float* soa2 = ratioR + (size_t)B * Mp;
   const float multiL = (M > N) ? (float)(M / N) : 1.0f;
   const float multiR = (N >= M) ? (float)(N / M) : 1.0f;
   {
-    const size_t n = (size_t)B * 3 * (size_t)(N > M ? N : M);
-    hipLaunchKernelGGL(emd_init_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, remainL,
-                       costrow, remainR, gxyz1, gxyz2, B, N, M, multiL, multiR);
+    const size_t n = (size_t)B * 3 * (size_t)(Np > Mp ? Np : Mp);
+    hipLaunchKernelGGL(emd_init_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, xyz1, xyz2, remainL, ratioL,
+                       costrow, remainR, ratioR, soa1, soa2, gxyz1, gxyz2, B, N, M, Np, Mp, multiL, multiR);
     int rc = launch_status("fpsg_emd_approx(init)");
     if (rc) return rc;
   }
@@ -200,25 +251,25 @@ extern "C" int fpsg_emd_approx(const float* xyz1, const float* xyz2, int B, int 
     a.level = level;
     int rc;
     // row normalisers: owners = cloud 1, sweep cloud 2 weighted by remainR
-    a.own = xyz1; a.oth = xyz2; a.oth_w = remainR; a.own_remain = remainL; a.own_ratio = ratioL;
+    a.own = soa1; a.oth = soa2; a.oth_w = remainR; a.own_remain = remainL; a.own_ratio = ratioL;
     a.own_cost = nullptr; a.own_grad = nullptr; a.No = N; a.Nt = M;
     if ((rc = sweep<kRatioL, false>(a, B, s, "fpsg_emd_approx(ratioL)"))) return rc;
     // column consumption: owners = cloud 2, sweep cloud 1 weighted by ratioL
-    a.own = xyz2; a.oth = xyz1; a.oth_w = ratioL; a.own_remain = remainR; a.own_ratio = ratioR;
+    a.own = soa2; a.oth = soa1; a.oth_w = ratioL; a.own_remain = remainR; a.own_ratio = ratioR;
     a.No = M; a.Nt = N;
     if ((rc = sweep<kRatioR, false>(a, B, s, "fpsg_emd_approx(ratioR)"))) return rc;
     // assignment: owners = cloud 1 (factor ratioL), sweep cloud 2 weighted by ratioR
-    a.own = xyz1; a.oth = xyz2; a.oth_w = ratioR; a.own_remain = remainL; a.own_ratio = ratioL;
+    a.own = soa1; a.oth = soa2; a.oth_w = ratioR; a.own_remain = remainL; a.own_ratio = ratioL;
     a.own_cost = costrow; a.own_grad = gxyz1; a.No = N; a.Nt = M;
     rc = gxyz1 ? sweep<kMatch, true>(a, B, s, "fpsg_emd_approx(match+grad)")
                : sweep<kMatch, false>(a, B, s, "fpsg_emd_approx(match)");
     if (rc) return rc;
     if (gxyz2) {  // same weights seen from cloud 2
-      a.own = xyz2; a.oth = xyz1; a.oth_w = ratioL; a.own_remain = nullptr; a.own_ratio = ratioR;
+      a.own = soa2; a.oth = soa1; a.oth_w = ratioL; a.own_remain = nullptr; a.own_ratio = ratioR;
       a.own_cost = nullptr; a.own_grad = gxyz2; a.No = M; a.Nt = N;
       if ((rc = sweep<kGradOther, true>(a, B, s, "fpsg_emd_approx(grad2)"))) return rc;
     }
   }
-  hipLaunchKernelGGL(emd_cost_kernel, dim3(B), dim3(256), 0, s, costrow, N, cost);
+  hipLaunchKernelGGL(emd_cost_kernel, dim3(B), dim3(256), 0, s, costrow, N, Np, cost);
   return launch_status("fpsg_emd_approx(cost)");
 }

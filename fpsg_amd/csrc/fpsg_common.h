@@ -103,4 +103,24 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
+// Sums of four values over the 64 lanes, delivered in lane 63 (other lanes: partial sums): the row_shr / row_bcast DPP
+// tree -- six dependent adds per value, no LDS crossbar operation, the four chains interleaved so that a DPP operand
+// is never read within two instructions of its write (the first s_nop covers the producers).  Fixed order.
+__device__ __forceinline__ void wave_sum4_to_last(float& a, float& b, float& c, float& d) {
+#define FPSG_DPP_ADD4(ctrl)                          \
+  "v_add_f32_dpp %0, %0, %0 " ctrl "\n"              \
+  "v_add_f32_dpp %1, %1, %1 " ctrl "\n"              \
+  "v_add_f32_dpp %2, %2, %2 " ctrl "\n"              \
+  "v_add_f32_dpp %3, %3, %3 " ctrl "\n"
+  asm volatile("s_nop 1\n"
+               FPSG_DPP_ADD4("row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0")
+               FPSG_DPP_ADD4("row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:0")
+               FPSG_DPP_ADD4("row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:0")
+               FPSG_DPP_ADD4("row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:0")
+               FPSG_DPP_ADD4("row_bcast:15 row_mask:0xa bank_mask:0xf")
+               FPSG_DPP_ADD4("row_bcast:31 row_mask:0xc bank_mask:0xf")
+               : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+#undef FPSG_DPP_ADD4
+}
+
 }  // namespace fpsg
