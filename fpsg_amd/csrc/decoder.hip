@@ -195,32 +195,63 @@ __global__ __launch_bounds__(kD1Threads) void dec1_bwd_kernel(Dec1Args a, const 
     c1[cc] = 0.0f; c2[cc] = 0.0f;
   }
   // ---- sweep 1: dbeta = sum dz, dgamma = sum dz * hhat (dz = dout where the activation was positive)
+  // The wave's four channels advance together, two element blocks per trip: eight 16-byte loads of dout in flight per
+  // lane (one channel at a time with one load per trip, a wave walked 4 x BP/256 dependent round trips to HBM with
+  // 1 KB in flight).  Per channel and lane the sums run over the same elements in the same order as before.
+  {
+    const v4f* drow[kD1ChPerWave];
+    const float* hc[kD1ChPerWave];
+    float s[kD1ChPerWave], sh[kD1ChPerWave];
 #pragma unroll
-  for (int cc = 0; cc < kD1ChPerWave; ++cc) {
-    if (!live[cc]) continue;             // wave-uniform
-    const size_t gd = (size_t)g * a.D + d0 + wave * kD1ChPerWave + cc;
-    const float* hc = hl + (wave * kD1ChPerWave + cc) * a.B;
-    const v4f* drow = reinterpret_cast<const v4f*>(dout + gd * BP);
-    float s = 0.0f, sh = 0.0f;
-    for (int e4 = lane; e4 < BP / 4; e4 += 64) {
-      const v4f X = reinterpret_cast<const v4f*>(sp)[e4], Y = reinterpret_cast<const v4f*>(sp + BP)[e4],
-                Z = reinterpret_cast<const v4f*>(sp + 2 * BP)[e4];
-      const v4f dy = drow[e4];
-      const float hb = hc[e4 / pshift4];
+    for (int cc = 0; cc < kD1ChPerWave; ++cc) {
+      const size_t gd = (size_t)g * a.D + (live[cc] ? d0 + wave * kD1ChPerWave + cc : a.D - 1);
+      drow[cc] = reinterpret_cast<const v4f*>(dout + gd * BP);
+      hc[cc] = hl + (wave * kD1ChPerWave + cc) * a.B;
+      s[cc] = 0.0f; sh[cc] = 0.0f;
+    }
+    const int nv = BP / 4;
+    for (int e4a = lane; e4a < nv; e4a += 128) {
+      const int e4b = e4a + 64;
+      const bool inb = e4b < nv;
+      const int e4bc = inb ? e4b : e4a;
+      v4f dya[kD1ChPerWave], dyb[kD1ChPerWave];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const float h = fma_rn(w2[cc], Z[u], fma_rn(w1[cc], Y[u], w0[cc] * X[u])) + hb;
-        const float dz = fma_rn(h, scale[cc], shift[cc]) > 0.0f ? dy[u] : 0.0f;
-        s += dz;
-        sh = fma_rn(dz, (h - mean[cc]) * rstd[cc], sh);
+      for (int cc = 0; cc < kD1ChPerWave; ++cc) {
+        dya[cc] = drow[cc][e4a];
+        dyb[cc] = drow[cc][e4bc];
+      }
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        if (half == 1 && !inb) break;
+        const int e4 = half ? e4b : e4a;
+        const v4f X = reinterpret_cast<const v4f*>(sp)[e4], Y = reinterpret_cast<const v4f*>(sp + BP)[e4],
+                  Z = reinterpret_cast<const v4f*>(sp + 2 * BP)[e4];
+#pragma unroll
+        for (int cc = 0; cc < kD1ChPerWave; ++cc) {
+          if (!live[cc]) continue;           // wave-uniform
+          const v4f dy = half ? dyb[cc] : dya[cc];
+          const float hb = hc[cc][e4 / pshift4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const float h = fma_rn(w2[cc], Z[u], fma_rn(w1[cc], Y[u], w0[cc] * X[u])) + hb;
+            const float dz = fma_rn(h, scale[cc], shift[cc]) > 0.0f ? dy[u] : 0.0f;
+            s[cc] += dz;
+            sh[cc] = fma_rn(dz, (h - mean[cc]) * rstd[cc], sh[cc]);
+          }
+        }
       }
     }
-    const double S = wave_sum_f64((double)s), SH = wave_sum_f64((double)sh);
-    if (lane == 0) {
-      dbeta[gd] = (float)S;
-      dgamma[gd] = (float)SH;
+#pragma unroll
+    for (int cc = 0; cc < kD1ChPerWave; ++cc) {
+      if (!live[cc]) continue;
+      const size_t gd = (size_t)g * a.D + d0 + wave * kD1ChPerWave + cc;
+      const double S = wave_sum_f64((double)s[cc]), SH = wave_sum_f64((double)sh[cc]);
+      if (lane == 0) {
+        dbeta[gd] = (float)S;
+        dgamma[gd] = (float)SH;
+      }
+      if (a.training) { c1[cc] = (float)(S / BP); c2[cc] = (float)(SH / BP); }
     }
-    if (a.training) { c1[cc] = (float)(S / BP); c2[cc] = (float)(SH / BP); }
   }
   // ---- sweep 2: dh in registers; three reductions
   float aw0[kD1ChPerWave], aw1[kD1ChPerWave], aw2[kD1ChPerWave];
@@ -228,10 +259,27 @@ __global__ __launch_bounds__(kD1Threads) void dec1_bwd_kernel(Dec1Args a, const 
   for (int cc = 0; cc < kD1ChPerWave; ++cc) { aw0[cc] = 0.0f; aw1[cc] = 0.0f; aw2[cc] = 0.0f; }
   float* mine = red + (wave * 64 + lane) * 12;
   float* pp = dpts_part + ((size_t)g * gridDim.x + tile) * 3 * BP;
+  // the upstream gradient of the NEXT element block is requested before this block's arithmetic and barriers
+  v4f dyn[kD1ChPerWave];
+  const v4f* drow2[kD1ChPerWave];
+#pragma unroll
+  for (int cc = 0; cc < kD1ChPerWave; ++cc) {
+    const size_t gd = (size_t)g * a.D + (live[cc] ? d0 + wave * kD1ChPerWave + cc : a.D - 1);
+    drow2[cc] = reinterpret_cast<const v4f*>(dout + gd * BP);
+    dyn[cc] = (v4f){0.0f, 0.0f, 0.0f, 0.0f};
+    if (lane < BP / 4) dyn[cc] = ld_stream<NT>(drow2[cc] + lane);
+  }
   for (int e4b = 0; e4b < BP / 4; e4b += 64) {          // all waves walk the element blocks together
     const int e4 = e4b + lane;
     const bool in = e4 < BP / 4;
     const int e4c = in ? e4 : 0;
+    v4f dyc[kD1ChPerWave];
+#pragma unroll
+    for (int cc = 0; cc < kD1ChPerWave; ++cc) dyc[cc] = dyn[cc];
+    if (e4 + 64 < BP / 4) {
+#pragma unroll
+      for (int cc = 0; cc < kD1ChPerWave; ++cc) dyn[cc] = ld_stream<NT>(drow2[cc] + e4 + 64);
+    }
     const v4f X = reinterpret_cast<const v4f*>(sp)[e4c], Y = reinterpret_cast<const v4f*>(sp + BP)[e4c],
               Z = reinterpret_cast<const v4f*>(sp + 2 * BP)[e4c];
     const int b = e4c / pshift4;
@@ -242,7 +290,7 @@ __global__ __launch_bounds__(kD1Threads) void dec1_bwd_kernel(Dec1Args a, const 
       const size_t gd = (size_t)g * a.D + d0 + wave * kD1ChPerWave + cc;
       const float hb = hl[(wave * kD1ChPerWave + cc) * a.B + b];
       v4f dy = {0, 0, 0, 0};
-      if (in) dy = ld_stream<NT>(reinterpret_cast<const v4f*>(dout + gd * BP) + e4);
+      if (in) dy = dyc[cc];
       float part = 0.0f;
 #pragma unroll
       for (int u = 0; u < 4; ++u) {

@@ -588,15 +588,27 @@ __global__ __launch_bounds__(kEpThreads) void edgeconv_act_kernel(const float* _
   const int C4 = Co >> 2, c4 = threadIdx.x % C4, rg = threadIdx.x / C4, RG = kEpThreads / C4;
   const v4f sc = reinterpret_cast<const v4f*>(scale)[c4], sh = reinterpret_cast<const v4f*>(shift)[c4];
   const long r1 = ((long)blockIdx.x + 1) * kEpRows < rows ? ((long)blockIdx.x + 1) * kEpRows : rows;
-  for (long r = (long)blockIdx.x * kEpRows + rg; r < r1; r += RG) {
-    const v4f y = reinterpret_cast<const v4f*>(ysel + r * Co)[c4];
-    v4f o;
+  // four rows' vectors in flight per thread (one per trip was a chain of full round trips)
+  for (long r0 = (long)blockIdx.x * kEpRows + rg; r0 < r1; r0 += 4 * RG) {
+    v4f yq[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const float z = fma_rn(y[u], sc[u], sh[u]);
-      o[u] = z > 0.0f ? z : z * slope;
+    for (int j = 0; j < 4; ++j) {
+      const long r = r0 + (long)j * RG;
+      yq[j] = r < r1 ? reinterpret_cast<const v4f*>(ysel + r * Co)[c4] : (v4f){0.0f, 0.0f, 0.0f, 0.0f};
     }
-    reinterpret_cast<v4f*>(out + r * Co)[c4] = o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const long r = r0 + (long)j * RG;
+      if (r < r1) {
+        v4f o;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const float z = fma_rn(yq[j][u], sc[u], sh[u]);
+          o[u] = z > 0.0f ? z : z * slope;
+        }
+        reinterpret_cast<v4f*>(out + r * Co)[c4] = o;
+      }
+    }
   }
 }
 
@@ -616,19 +628,34 @@ __global__ __launch_bounds__(kEpThreads) void edgeconv_bwd_prep_kernel(const flo
   const v4f sc = reinterpret_cast<const v4f*>(scale)[c4], sh = reinterpret_cast<const v4f*>(shift)[c4];
   v4f s0 = {0.0f, 0.0f, 0.0f, 0.0f}, s1 = {0.0f, 0.0f, 0.0f, 0.0f};
   const long r1 = ((long)blockIdx.x + 1) * kEpRows < rows ? ((long)blockIdx.x + 1) * kEpRows : rows;
-  for (long r = (long)blockIdx.x * kEpRows + rg; r < r1; r += RG) {
-    const v4f y = reinterpret_cast<const v4f*>(ysel + r * Co)[c4];
-    const v4f gv = reinterpret_cast<const v4f*>(g + r * Co)[c4];
-    v4f o;
+  // four rows' vector pairs in flight per thread, consumed in row order (the sums are unchanged bit for bit)
+  for (long r0 = (long)blockIdx.x * kEpRows + rg; r0 < r1; r0 += 4 * RG) {
+    v4f yq[4], gq[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const float z = fma_rn(y[u], sc[u], sh[u]);
-      const float dz = z > 0.0f ? gv[u] : gv[u] * slope;
-      s0[u] += dz;
-      s1[u] = fma_rn(dz, y[u], s1[u]);
-      o[u] = dz * sc[u];
+    for (int j = 0; j < 4; ++j) {
+      const long r = r0 + (long)j * RG;
+      yq[j] = gq[j] = (v4f){0.0f, 0.0f, 0.0f, 0.0f};
+      if (r < r1) {
+        yq[j] = reinterpret_cast<const v4f*>(ysel + r * Co)[c4];
+        gq[j] = reinterpret_cast<const v4f*>(g + r * Co)[c4];
+      }
     }
-    reinterpret_cast<v4f*>(dzs + r * Co)[c4] = o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const long r = r0 + (long)j * RG;
+      if (r < r1) {
+        v4f o;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const float z = fma_rn(yq[j][u], sc[u], sh[u]);
+          const float dz = z > 0.0f ? gq[j][u] : gq[j][u] * slope;
+          s0[u] += dz;
+          s1[u] = fma_rn(dz, yq[j][u], s1[u]);
+          o[u] = dz * sc[u];
+        }
+        reinterpret_cast<v4f*>(dzs + r * Co)[c4] = o;
+      }
+    }
   }
 #pragma unroll
   for (int u = 0; u < 4; ++u) { red[0][threadIdx.x][u] = s0[u]; red[1][threadIdx.x][u] = s1[u]; }
