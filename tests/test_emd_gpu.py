@@ -16,7 +16,8 @@ def _clouds(seed, B, N, M):
     return unit_ball_clouds(rng, B, N), np.tanh(rng.standard_normal((B, M, 3)) * 0.5).astype(np.float32)
 
 
-@pytest.mark.parametrize("B,N,M", [(2, 256, 256), (1, 1024, 1024), (3, 100, 300), (2, 512, 128), (5, 2048, 2048)])
+@pytest.mark.parametrize("B,N,M", [(2, 256, 256), (1, 1024, 1024), (3, 100, 300), (2, 512, 128), (5, 2048, 2048),
+                                   (2, 101, 67), (1, 3, 258)])      # rows padded to multiples of 4, clouds shorter than a wave
 def test_cost_and_grads_vs_oracle(gpu, oracle, B, N, M):
     from fpsg_amd.metrics import emd_approx
     p1, p2 = _clouds(N + M, B, N, M)

@@ -130,7 +130,7 @@ def test_fused_kernel_argument_checks(gpu):
     assert b"C must be 64" in lib.fpsg_last_error()
 
 
-@pytest.mark.parametrize("shape", [(2, 8, 8), (3, 30, 36), (5, 64, 64), (2, 224, 224), (37, 56, 100)])
+@pytest.mark.parametrize("shape", [(2, 8, 8), (3, 30, 36), (5, 64, 64), (2, 224, 224), (37, 56, 100), (3, 10, 112), (1, 7, 336)])
 def test_first_layer_weight_gradient(gpu, shape):
     """K8 (fpsg_conv_first_dw): dw of the 3 -> 64 channel first convolution against conv2d's own
     weight gradient in float64 and against the library's fp32 result."""
