@@ -142,6 +142,32 @@ __device__ __forceinline__ bool gather_grad4(const float* const* __restrict__ gt
   return any;
 }
 
+// The same for a WHOLE vector when the lanes of the wave hold consecutive vectors (grid-stride loops): one table search
+// for the wave's first vector -- on wave-uniform values, so the ten dependent reads are scalar loads -- and a range
+// test per lane; only a wave that straddles a segment boundary (~600 of ~300,000) searches per lane.  Same values.
+__device__ __forceinline__ bool gather_grad4_wave(const float* const* __restrict__ gtab, const long long* __restrict__ seg_off,
+                                                  int nseg, long long i, float (&gg)[4]) {
+  const unsigned lo32 = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)i);
+  const unsigned hi32 = __builtin_amdgcn_readfirstlane((unsigned)((unsigned long long)i >> 32));
+  const long long i0 = (long long)(((unsigned long long)hi32 << 32) | lo32);
+  const int sg0 = segment_of(seg_off, nseg, i0);
+  const long long lo = seg_off[sg0], hi = seg_off[sg0 + 1];
+  const bool inside = i >= lo && i + 4 <= hi;
+  if (__builtin_amdgcn_ballot_w64(!inside) != 0ull) return gather_grad4(gtab, seg_off, nseg, i, 4, gg);
+  const float* g = gtab[sg0];
+  gg[0] = gg[1] = gg[2] = gg[3] = 0.0f;
+  if (!g) return false;
+  const long long base = i - lo;
+  if ((reinterpret_cast<uintptr_t>(g + base) & 15) == 0) {
+    const v4f q = *reinterpret_cast<const v4f*>(g + base);
+    gg[0] = q[0]; gg[1] = q[1]; gg[2] = q[2]; gg[3] = q[3];
+  } else {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) gg[u] = g[base + u];
+  }
+  return true;
+}
+
 // flat[i] (+)= the segment table's gradient: the episode's fresh gradient tensors added into (or, first episode of a
 // step, copied over) the step's flat gradient buffer in ONE stream at HBM rate -- the multi-tensor add it replaces
 // runs ~25 chunked launches at half of it.  accumulate = 0 writes zeros where a parameter has no gradient.
@@ -221,7 +247,7 @@ __global__ __launch_bounds__(kAdamThreads) void adam_ptr_kernel(float* __restric
     }
     float gg[2][4];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) gather_grad4(gtab, seg_off, nseg, (long long)(4 * (j + u * stride)), 4, gg[u]);
+    for (int u = 0; u < 2; ++u) gather_grad4_wave(gtab, seg_off, nseg, (long long)(4 * (j + u * stride)), gg[u]);
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
 #pragma unroll
