@@ -150,7 +150,9 @@ int fpsg_edge_feature_bwd(const float* gout, const int32_t* idx, int B, int C, i
  * matrix is never stored.  cost [B].  gxyz1 [B,N,3] / gxyz2 [B,M,3] may each be NULL;
  * when given they receive d cost / d xyz with the assignment held constant (the
  * convention of the original matchcost gradient).  ws: caller scratch of
- * fpsg_emd_workspace_floats(B,N,M) floats.  Deterministic (no float atomics).
+ * fpsg_emd_workspace_floats(B,N,M) floats, 16-byte aligned (per-point state and
+ * coordinate-major copies of both clouds, rows padded to multiples of 4 points).
+ * Deterministic (no float atomics).
  */
 size_t fpsg_emd_workspace_floats(int B, int N, int M);
 int fpsg_emd_approx(const float* xyz1, const float* xyz2, int B, int N, int M, float* cost,
