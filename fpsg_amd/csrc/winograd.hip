@@ -136,7 +136,10 @@ __device__ __forceinline__ TileIndex tile_of(long p, int Th, int Tw) {
 // reads a = relu(fma(x + pre_bias[c], scale[c], shift[c])) instead (exactly the value K5's apply pass
 // would have stored; padding stays zero) -- the BatchNorm + ReLU apply pass between two convolutions of a
 // VGG stage (one read + one write of the activation tensor) is folded into this load.
-template <int M, bool ACT, bool NT = false>
+// RAG (m = 4 only): H, W even but not multiples of 4 -- the tile grid is ceil(H/4) x ceil(W/4), pixels beyond the
+// image enter as zeros (the last tile row / column is half empty); rows are then only 8-byte aligned, so a tile row is
+// read as two 8-byte halves and the second half of a last-column tile is not read at all.
+template <int M, bool ACT, bool NT = false, bool RAG = false>
 __global__ __launch_bounds__(kWinoThreads) void wino_input_kernel(const float* __restrict__ x, int C, int H, int W,
                                                                    int Th, int Tw, long P, float* __restrict__ V,
                                                                    const float* __restrict__ chan,
@@ -162,12 +165,21 @@ __global__ __launch_bounds__(kWinoThreads) void wino_input_kernel(const float* _
   vin mid[A];
   bool rin[A];
   const float* rp[A];
+  const bool hi_in = !RAG || c0 + 2 < W;                    // (RAG) columns c0 + 2, c0 + 3 of this tile are inside the image
 #pragma unroll
   for (int i = 0; i < A; ++i) {
     const int r = r0 + i;
     rin[i] = r >= 0 && r < H;
     rp[i] = xp + (size_t)(rin[i] ? r : (r < 0 ? 0 : H - 1)) * W + c0;
-    mid[i] = *reinterpret_cast<const vin*>(rp[i]);
+    if constexpr (RAG) {
+      typedef float v2 __attribute__((ext_vector_type(2)));
+      const v2 lo = *reinterpret_cast<const v2*>(rp[i]);
+      v2 hi = {0.0f, 0.0f};
+      if (hi_in) hi = *reinterpret_cast<const v2*>(rp[i] + 2);
+      mid[i][0] = lo[0]; mid[i][1] = lo[1]; mid[i][M - 2] = hi[0]; mid[i][M - 1] = hi[1];
+    } else {
+      mid[i] = *reinterpret_cast<const vin*>(rp[i]);
+    }
   }
   float el[A], er[A];                                       // halo columns of the lanes at a wave edge
 #pragma unroll
@@ -184,7 +196,7 @@ __global__ __launch_bounds__(kWinoThreads) void wino_input_kernel(const float* _
 #pragma unroll
   for (int i = 0; i < A; ++i) {
 #pragma unroll
-    for (int j = 0; j < M; ++j) mid[i][j] = rin[i] ? act(mid[i][j]) : 0.0f;
+    for (int j = 0; j < M; ++j) mid[i][j] = (rin[i] && (!RAG || j < 2 || hi_in)) ? act(mid[i][j]) : 0.0f;
     float lft = __shfl_up(mid[i][M - 1], 1, kWave);
     float rgt = __shfl_down(mid[i][0], 1, kWave);
     if (!left_lane) lft = (has_left && rin[i]) ? act(el[i]) : 0.0f;
@@ -225,7 +237,8 @@ __global__ __launch_bounds__(kWinoThreads) void wino_input_kernel(const float* _
 // (bn_reduce_kernel, MODE 1): dz = y * [fma(x, scale, shift) > 0], sum(dz) and sum(dz * (x - mean) * rstd) with
 // x = xpre + bias[k]; chan = [4][K] scale, shift, mean, rstd.  K5's backward then starts at its finalize
 // (fpsg_bn_act_bwd_parts) and reads neither tensor for the sums.
-template <int M, bool STATS, bool BWD = false, bool NT = false>
+// RAG (m = 4 only, see wino_input_kernel): only the pixels inside the image are written (and counted in the sums).
+template <int M, bool STATS, bool BWD = false, bool NT = false, bool RAG = false>
 __global__ __launch_bounds__(kWinoThreads) void wino_output_kernel(const float* __restrict__ Mt, int K, int H, int W,
                                                                     int Th, int Tw, long P, float* __restrict__ y,
                                                                     const float* __restrict__ bias,
@@ -256,10 +269,26 @@ __global__ __launch_bounds__(kWinoThreads) void wino_output_kernel(const float* 
   const float b = (STATS && bias) ? bias[k] : 0.0f;
   float sc = 0.0f, sh = 0.0f, mu = 0.0f, rs = 0.0f;
   vout xrow[M];
+  const bool hi_in = !RAG || M * ti.tw + 2 < W;             // (RAG) the tile's last two columns are inside the image
+  bool row_in[M];
+#pragma unroll
+  for (int i = 0; i < M; ++i) row_in[i] = !RAG || M * ti.th + i < H;
   if constexpr (BWD) {
     sc = chan[k]; sh = chan[K + k]; mu = chan[2 * K + k]; rs = chan[3 * K + k];
 #pragma unroll
-    for (int i = 0; i < M; ++i) xrow[i] = *reinterpret_cast<const vout*>(xpre + yoff + (size_t)i * W);   // dead lanes: the last tile
+    for (int i = 0; i < M; ++i) {
+      if constexpr (RAG) {
+        typedef float v2 __attribute__((ext_vector_type(2)));
+        v2 lo = {0.0f, 0.0f}, hi = {0.0f, 0.0f};
+        if (row_in[i]) {
+          lo = *reinterpret_cast<const v2*>(xpre + yoff + (size_t)i * W);
+          if (hi_in) hi = *reinterpret_cast<const v2*>(xpre + yoff + (size_t)i * W + 2);
+        }
+        xrow[i][0] = lo[0]; xrow[i][1] = lo[1]; xrow[i][M - 2] = hi[0]; xrow[i][M - 1] = hi[1];
+      } else {
+        xrow[i] = *reinterpret_cast<const vout*>(xpre + yoff + (size_t)i * W);   // dead lanes: the last tile
+      }
+    }
   }
   float a0 = 0.0f, a1 = 0.0f;
 #pragma unroll
@@ -271,19 +300,29 @@ __global__ __launch_bounds__(kWinoThreads) void wino_output_kernel(const float* 
     vout ov;
 #pragma unroll
     for (int j = 0; j < M; ++j) ov[j] = o[j];
-    if (live) *reinterpret_cast<vout*>(yp + (size_t)i * W) = ov;
+    if constexpr (RAG) {
+      typedef float v2 __attribute__((ext_vector_type(2)));
+      if (live && row_in[i]) {
+        *reinterpret_cast<v2*>(yp + (size_t)i * W) = (v2){o[0], o[1]};
+        if (hi_in) *reinterpret_cast<v2*>(yp + (size_t)i * W + 2) = (v2){o[M - 2], o[M - 1]};
+      }
+    } else {
+      if (live) *reinterpret_cast<vout*>(yp + (size_t)i * W) = ov;
+    }
     if constexpr (BWD) {
 #pragma unroll
       for (int j = 0; j < M; ++j) {
+        const bool in = live && row_in[i] && (j < 2 || hi_in);
         const float xv = xrow[i][j] + b;
-        const float dz = (live && fma_rn(xv, sc, sh) > 0.0f) ? o[j] : 0.0f;
+        const float dz = (in && fma_rn(xv, sc, sh) > 0.0f) ? o[j] : 0.0f;
         a0 += dz;
         a1 = fma_rn(dz, (xv - mu) * rs, a1);
       }
     } else if (STATS) {
 #pragma unroll
       for (int j = 0; j < M; ++j) {
-        const float v = live ? o[j] + b : 0.0f;
+        const bool in = live && row_in[i] && (j < 2 || hi_in);
+        const float v = in ? o[j] + b : 0.0f;
         a0 += v;
         a1 = fma_rn(v, v, a1);
       }
@@ -307,7 +346,7 @@ __global__ __launch_bounds__(kWinoThreads) void wino_output_kernel(const float* 
 }
 
 // dM = A dY A^T per tile
-template <int M, bool NT = false>
+template <int M, bool NT = false, bool RAG = false>
 __global__ __launch_bounds__(kWinoThreads) void wino_grad_output_kernel(const float* __restrict__ dy, int K, int H,
                                                                          int W, int Th, int Tw, long P,
                                                                          float* __restrict__ dM) {
@@ -321,9 +360,19 @@ __global__ __launch_bounds__(kWinoThreads) void wino_grad_output_kernel(const fl
   float yv[M][M];
 #pragma unroll
   for (int i = 0; i < M; ++i) {
-    const vin v = *reinterpret_cast<const vin*>(yp + (size_t)i * W);
+    if constexpr (RAG) {                                     // pixels beyond the image: zero gradient
+      typedef float v2 __attribute__((ext_vector_type(2)));
+      v2 lo = {0.0f, 0.0f}, hi = {0.0f, 0.0f};
+      if (M * ti.th + i < H) {
+        lo = *reinterpret_cast<const v2*>(yp + (size_t)i * W);
+        if (M * ti.tw + 2 < W) hi = *reinterpret_cast<const v2*>(yp + (size_t)i * W + 2);
+      }
+      yv[i][0] = lo[0]; yv[i][1] = lo[1]; yv[i][M - 2] = hi[0]; yv[i][M - 1] = hi[1];
+    } else {
+      const vin v = *reinterpret_cast<const vin*>(yp + (size_t)i * W);
 #pragma unroll
-    for (int j = 0; j < M; ++j) yv[i][j] = v[j];
+      for (int j = 0; j < M; ++j) yv[i][j] = v[j];
+    }
   }
   float r[M][A];        // r[j][i]: column j after the transform along rows
 #pragma unroll
@@ -427,11 +476,15 @@ __global__ void wino_filter_grad_kernel(const float* __restrict__ dU, int K, int
   }
 }
 
+// Tiles per image side: ceil -- with m = 4 an even H or W that is not a multiple of 4 gets a half-empty last tile (RAG).
+inline int tiles_of(int H, int m) { return (H + m - 1) / m; }
+inline bool ragged(int m, int H, int W) { return m == 4 && ((H | W) & 3) != 0; }
+
 int check_image(const char* fn, int m, int N, int C, int H, int W) {
   FPSG_REQUIRE(m == 2 || m == 4, FPSG_E_SHAPE, "%s: m must be 2 or 4 (got %d)", fn, m);
-  FPSG_REQUIRE(N > 0 && C > 0 && H > 0 && W > 0 && H % m == 0 && W % m == 0, FPSG_E_SHAPE,
-               "%s: N,C positive and H,W positive multiples of m=%d (got %d,%d,%d,%d)", fn, m, N, C, H, W);
-  const long P = (long)N * (H / m) * (W / m);
+  FPSG_REQUIRE(N > 0 && C > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0, FPSG_E_SHAPE,
+               "%s: N,C positive and H,W positive and even (got %d,%d,%d,%d)", fn, N, C, H, W);
+  const long P = (long)N * ((H + m - 1) / m) * ((W + m - 1) / m);
   FPSG_REQUIRE(C <= 65535 && (P + kWinoThreads - 1) / kWinoThreads < (1L << 31), FPSG_E_LIMIT,
                "%s: C=%d or tile count %ld beyond the grid limits", fn, C, P);
   return 0;
@@ -441,7 +494,7 @@ int check_image(const char* fn, int m, int N, int C, int H, int W) {
 }  // namespace fpsg
 
 #define FPSG_WINO_IMAGE_LAUNCH(KERNEL, CH, ...)                                                              \
-  const long P = (long)N * (H / m) * (W / m);                                                                \
+  const long P = (long)N * tiles_of(H, m) * tiles_of(W, m);                                                                \
   dim3 grid((unsigned)((P + kWinoThreads - 1) / kWinoThreads), CH);                                          \
   if (m == 2) hipLaunchKernelGGL((KERNEL<2>), grid, dim3(kWinoThreads), 0, static_cast<hipStream_t>(stream), __VA_ARGS__); \
   else hipLaunchKernelGGL((KERNEL<4>), grid, dim3(kWinoThreads), 0, static_cast<hipStream_t>(stream), __VA_ARGS__)
@@ -453,11 +506,12 @@ extern "C" int fpsg_wino_input_transform(int m, const float* x, int N, int C, in
   if (rc) return rc;
   FPSG_REQUIRE_PTR(x); FPSG_REQUIRE_PTR(V);
   FPSG_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0, FPSG_E_ALIGN, "fpsg_wino_input_transform: x must be 16-byte aligned");
-  const long P = (long)N * (H / m) * (W / m);
+  const long P = (long)N * tiles_of(H, m) * tiles_of(W, m);
   dim3 grid((unsigned)((P + kWinoThreads - 1) / kWinoThreads), C);
-  if (m == 2) hipLaunchKernelGGL((wino_input_kernel<2, false>), grid, dim3(kWinoThreads), 0, static_cast<hipStream_t>(stream), x, C, H, W, H / m, W / m, P, V, nullptr, nullptr);
-  else if ((size_t)36 * C * P * sizeof(float) > kStreamBytes) hipLaunchKernelGGL((wino_input_kernel<4, false, true>), grid, dim3(kWinoThreads), 0, static_cast<hipStream_t>(stream), x, C, H, W, H / m, W / m, P, V, nullptr, nullptr);
-  else hipLaunchKernelGGL((wino_input_kernel<4, false>), grid, dim3(kWinoThreads), 0, static_cast<hipStream_t>(stream), x, C, H, W, H / m, W / m, P, V, nullptr, nullptr);
+  if (m == 2) hipLaunchKernelGGL((wino_input_kernel<2, false>), grid, dim3(kWinoThreads), 0, static_cast<hipStream_t>(stream), x, C, H, W, tiles_of(H, m), tiles_of(W, m), P, V, nullptr, nullptr);
+  else if (ragged(m, H, W)) hipLaunchKernelGGL((wino_input_kernel<4, false, false, true>), grid, dim3(kWinoThreads), 0, static_cast<hipStream_t>(stream), x, C, H, W, tiles_of(H, m), tiles_of(W, m), P, V, nullptr, nullptr);
+  else if ((size_t)36 * C * P * sizeof(float) > kStreamBytes) hipLaunchKernelGGL((wino_input_kernel<4, false, true>), grid, dim3(kWinoThreads), 0, static_cast<hipStream_t>(stream), x, C, H, W, tiles_of(H, m), tiles_of(W, m), P, V, nullptr, nullptr);
+  else hipLaunchKernelGGL((wino_input_kernel<4, false>), grid, dim3(kWinoThreads), 0, static_cast<hipStream_t>(stream), x, C, H, W, tiles_of(H, m), tiles_of(W, m), P, V, nullptr, nullptr);
   return launch_status("fpsg_wino_input_transform");
 }
 
@@ -469,11 +523,12 @@ extern "C" int fpsg_wino_input_transform_act(int m, const float* x, const float*
   FPSG_REQUIRE_PTR(x); FPSG_REQUIRE_PTR(V); FPSG_REQUIRE_PTR(chan);
   FPSG_REQUIRE(!misaligned4(pre_bias), FPSG_E_ALIGN, "fpsg_wino_input_transform_act: pre_bias not 4-byte aligned");
   FPSG_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0, FPSG_E_ALIGN, "fpsg_wino_input_transform_act: x must be 16-byte aligned");
-  const long P = (long)N * (H / m) * (W / m);
+  const long P = (long)N * tiles_of(H, m) * tiles_of(W, m);
   dim3 grid((unsigned)((P + kWinoThreads - 1) / kWinoThreads), C);
-  if (m == 2) hipLaunchKernelGGL((wino_input_kernel<2, true>), grid, dim3(kWinoThreads), 0, static_cast<hipStream_t>(stream), x, C, H, W, H / m, W / m, P, V, chan, pre_bias);
-  else if ((size_t)36 * C * P * sizeof(float) > kStreamBytes) hipLaunchKernelGGL((wino_input_kernel<4, true, true>), grid, dim3(kWinoThreads), 0, static_cast<hipStream_t>(stream), x, C, H, W, H / m, W / m, P, V, chan, pre_bias);
-  else hipLaunchKernelGGL((wino_input_kernel<4, true>), grid, dim3(kWinoThreads), 0, static_cast<hipStream_t>(stream), x, C, H, W, H / m, W / m, P, V, chan, pre_bias);
+  if (m == 2) hipLaunchKernelGGL((wino_input_kernel<2, true>), grid, dim3(kWinoThreads), 0, static_cast<hipStream_t>(stream), x, C, H, W, tiles_of(H, m), tiles_of(W, m), P, V, chan, pre_bias);
+  else if (ragged(m, H, W)) hipLaunchKernelGGL((wino_input_kernel<4, true, false, true>), grid, dim3(kWinoThreads), 0, static_cast<hipStream_t>(stream), x, C, H, W, tiles_of(H, m), tiles_of(W, m), P, V, chan, pre_bias);
+  else if ((size_t)36 * C * P * sizeof(float) > kStreamBytes) hipLaunchKernelGGL((wino_input_kernel<4, true, true>), grid, dim3(kWinoThreads), 0, static_cast<hipStream_t>(stream), x, C, H, W, tiles_of(H, m), tiles_of(W, m), P, V, chan, pre_bias);
+  else hipLaunchKernelGGL((wino_input_kernel<4, true>), grid, dim3(kWinoThreads), 0, static_cast<hipStream_t>(stream), x, C, H, W, tiles_of(H, m), tiles_of(W, m), P, V, chan, pre_bias);
   return launch_status("fpsg_wino_input_transform_act");
 }
 
@@ -484,18 +539,19 @@ extern "C" int fpsg_wino_output_transform(int m, const float* M, int N, int K, i
   if (rc) return rc;
   FPSG_REQUIRE_PTR(M); FPSG_REQUIRE_PTR(y);
   FPSG_REQUIRE((reinterpret_cast<uintptr_t>(y) & 15) == 0, FPSG_E_ALIGN, "fpsg_wino_output_transform: y must be 16-byte aligned");
-  const long P = (long)N * (H / m) * (W / m);
+  const long P = (long)N * tiles_of(H, m) * tiles_of(W, m);
   dim3 grid((unsigned)((P + kWinoThreads - 1) / kWinoThreads), K);
   hipStream_t hs = static_cast<hipStream_t>(stream);
-  if (m == 2) hipLaunchKernelGGL((wino_output_kernel<2, false>), grid, dim3(kWinoThreads), 0, hs, M, K, H, W, H / m, W / m, P, y, nullptr, nullptr);
-  else if ((size_t)36 * K * P * sizeof(float) > kStreamBytes) hipLaunchKernelGGL((wino_output_kernel<4, false, false, true>), grid, dim3(kWinoThreads), 0, hs, M, K, H, W, H / m, W / m, P, y, nullptr, nullptr);
-  else hipLaunchKernelGGL((wino_output_kernel<4, false>), grid, dim3(kWinoThreads), 0, hs, M, K, H, W, H / m, W / m, P, y, nullptr, nullptr);
+  if (m == 2) hipLaunchKernelGGL((wino_output_kernel<2, false>), grid, dim3(kWinoThreads), 0, hs, M, K, H, W, tiles_of(H, m), tiles_of(W, m), P, y, nullptr, nullptr);
+  else if (ragged(m, H, W)) hipLaunchKernelGGL((wino_output_kernel<4, false, false, false, true>), grid, dim3(kWinoThreads), 0, hs, M, K, H, W, tiles_of(H, m), tiles_of(W, m), P, y, nullptr, nullptr);
+  else if ((size_t)36 * K * P * sizeof(float) > kStreamBytes) hipLaunchKernelGGL((wino_output_kernel<4, false, false, true>), grid, dim3(kWinoThreads), 0, hs, M, K, H, W, tiles_of(H, m), tiles_of(W, m), P, y, nullptr, nullptr);
+  else hipLaunchKernelGGL((wino_output_kernel<4, false>), grid, dim3(kWinoThreads), 0, hs, M, K, H, W, tiles_of(H, m), tiles_of(W, m), P, y, nullptr, nullptr);
   return launch_status("fpsg_wino_output_transform");
 }
 
 extern "C" int fpsg_wino_stats_parts(int m, int N, int H, int W) {
-  if ((m != 2 && m != 4) || N <= 0 || H <= 0 || W <= 0 || H % m || W % m) return 0;
-  const long P = (long)N * (H / m) * (W / m);
+  if ((m != 2 && m != 4) || N <= 0 || H <= 0 || W <= 0 || H % 2 || W % 2) return 0;
+  const long P = (long)N * fpsg::tiles_of(H, m) * fpsg::tiles_of(W, m);
   return (int)((P + fpsg::kWinoThreads - 1) / fpsg::kWinoThreads);
 }
 
@@ -507,12 +563,13 @@ extern "C" int fpsg_wino_output_transform_stats(int m, const float* M, int N, in
   FPSG_REQUIRE_PTR(M); FPSG_REQUIRE_PTR(y); FPSG_REQUIRE_PTR(parts);
   FPSG_REQUIRE((reinterpret_cast<uintptr_t>(y) & 15) == 0, FPSG_E_ALIGN, "fpsg_wino_output_transform_stats: y must be 16-byte aligned");
   FPSG_REQUIRE(!misaligned4(bias) && !misaligned4(parts), FPSG_E_ALIGN, "fpsg_wino_output_transform_stats: bias / parts not 4-byte aligned");
-  const long P = (long)N * (H / m) * (W / m);
+  const long P = (long)N * tiles_of(H, m) * tiles_of(W, m);
   dim3 grid((unsigned)((P + kWinoThreads - 1) / kWinoThreads), K);
   hipStream_t hs = static_cast<hipStream_t>(stream);
-  if (m == 2) hipLaunchKernelGGL((wino_output_kernel<2, true>), grid, dim3(kWinoThreads), 0, hs, M, K, H, W, H / m, W / m, P, y, bias, parts);
-  else if ((size_t)36 * K * P * sizeof(float) > kStreamBytes) hipLaunchKernelGGL((wino_output_kernel<4, true, false, true>), grid, dim3(kWinoThreads), 0, hs, M, K, H, W, H / m, W / m, P, y, bias, parts);
-  else hipLaunchKernelGGL((wino_output_kernel<4, true>), grid, dim3(kWinoThreads), 0, hs, M, K, H, W, H / m, W / m, P, y, bias, parts);
+  if (m == 2) hipLaunchKernelGGL((wino_output_kernel<2, true>), grid, dim3(kWinoThreads), 0, hs, M, K, H, W, tiles_of(H, m), tiles_of(W, m), P, y, bias, parts);
+  else if (ragged(m, H, W)) hipLaunchKernelGGL((wino_output_kernel<4, true, false, false, true>), grid, dim3(kWinoThreads), 0, hs, M, K, H, W, tiles_of(H, m), tiles_of(W, m), P, y, bias, parts);
+  else if ((size_t)36 * K * P * sizeof(float) > kStreamBytes) hipLaunchKernelGGL((wino_output_kernel<4, true, false, true>), grid, dim3(kWinoThreads), 0, hs, M, K, H, W, tiles_of(H, m), tiles_of(W, m), P, y, bias, parts);
+  else hipLaunchKernelGGL((wino_output_kernel<4, true>), grid, dim3(kWinoThreads), 0, hs, M, K, H, W, tiles_of(H, m), tiles_of(W, m), P, y, bias, parts);
   return launch_status("fpsg_wino_output_transform_stats");
 }
 
@@ -527,12 +584,13 @@ extern "C" int fpsg_wino_output_transform_bwd_stats(int m, const float* M, int N
                "fpsg_wino_output_transform_bwd_stats: y and xpre must be 16-byte aligned");
   FPSG_REQUIRE(!misaligned4(pre_bias) && !misaligned4(parts) && !misaligned4(chan), FPSG_E_ALIGN,
                "fpsg_wino_output_transform_bwd_stats: pre_bias / chan / parts not 4-byte aligned");
-  const long P = (long)N * (H / m) * (W / m);
+  const long P = (long)N * tiles_of(H, m) * tiles_of(W, m);
   dim3 grid((unsigned)((P + kWinoThreads - 1) / kWinoThreads), K);
   hipStream_t hs = static_cast<hipStream_t>(stream);
-  if (m == 2) hipLaunchKernelGGL((wino_output_kernel<2, true, true>), grid, dim3(kWinoThreads), 0, hs, M, K, H, W, H / m, W / m, P, y, pre_bias, parts, xpre, chan);
-  else if ((size_t)36 * K * P * sizeof(float) > kStreamBytes) hipLaunchKernelGGL((wino_output_kernel<4, true, true, true>), grid, dim3(kWinoThreads), 0, hs, M, K, H, W, H / m, W / m, P, y, pre_bias, parts, xpre, chan);
-  else hipLaunchKernelGGL((wino_output_kernel<4, true, true>), grid, dim3(kWinoThreads), 0, hs, M, K, H, W, H / m, W / m, P, y, pre_bias, parts, xpre, chan);
+  if (m == 2) hipLaunchKernelGGL((wino_output_kernel<2, true, true>), grid, dim3(kWinoThreads), 0, hs, M, K, H, W, tiles_of(H, m), tiles_of(W, m), P, y, pre_bias, parts, xpre, chan);
+  else if (ragged(m, H, W)) hipLaunchKernelGGL((wino_output_kernel<4, true, true, false, true>), grid, dim3(kWinoThreads), 0, hs, M, K, H, W, tiles_of(H, m), tiles_of(W, m), P, y, pre_bias, parts, xpre, chan);
+  else if ((size_t)36 * K * P * sizeof(float) > kStreamBytes) hipLaunchKernelGGL((wino_output_kernel<4, true, true, true>), grid, dim3(kWinoThreads), 0, hs, M, K, H, W, tiles_of(H, m), tiles_of(W, m), P, y, pre_bias, parts, xpre, chan);
+  else hipLaunchKernelGGL((wino_output_kernel<4, true, true>), grid, dim3(kWinoThreads), 0, hs, M, K, H, W, tiles_of(H, m), tiles_of(W, m), P, y, pre_bias, parts, xpre, chan);
   return launch_status("fpsg_wino_output_transform_bwd_stats");
 }
 
@@ -543,12 +601,13 @@ extern "C" int fpsg_wino_grad_output_transform(int m, const float* dy, int N, in
   if (rc) return rc;
   FPSG_REQUIRE_PTR(dy); FPSG_REQUIRE_PTR(dM);
   FPSG_REQUIRE((reinterpret_cast<uintptr_t>(dy) & 15) == 0, FPSG_E_ALIGN, "fpsg_wino_grad_output_transform: dy must be 16-byte aligned");
-  const long P = (long)N * (H / m) * (W / m);
+  const long P = (long)N * tiles_of(H, m) * tiles_of(W, m);
   dim3 grid((unsigned)((P + kWinoThreads - 1) / kWinoThreads), K);
   hipStream_t hs = static_cast<hipStream_t>(stream);
-  if (m == 2) hipLaunchKernelGGL((wino_grad_output_kernel<2>), grid, dim3(kWinoThreads), 0, hs, dy, K, H, W, H / m, W / m, P, dM);
-  else if ((size_t)36 * K * P * sizeof(float) > kStreamBytes) hipLaunchKernelGGL((wino_grad_output_kernel<4, true>), grid, dim3(kWinoThreads), 0, hs, dy, K, H, W, H / m, W / m, P, dM);
-  else hipLaunchKernelGGL((wino_grad_output_kernel<4>), grid, dim3(kWinoThreads), 0, hs, dy, K, H, W, H / m, W / m, P, dM);
+  if (m == 2) hipLaunchKernelGGL((wino_grad_output_kernel<2>), grid, dim3(kWinoThreads), 0, hs, dy, K, H, W, tiles_of(H, m), tiles_of(W, m), P, dM);
+  else if (ragged(m, H, W)) hipLaunchKernelGGL((wino_grad_output_kernel<4, false, true>), grid, dim3(kWinoThreads), 0, hs, dy, K, H, W, tiles_of(H, m), tiles_of(W, m), P, dM);
+  else if ((size_t)36 * K * P * sizeof(float) > kStreamBytes) hipLaunchKernelGGL((wino_grad_output_kernel<4, true>), grid, dim3(kWinoThreads), 0, hs, dy, K, H, W, tiles_of(H, m), tiles_of(W, m), P, dM);
+  else hipLaunchKernelGGL((wino_grad_output_kernel<4>), grid, dim3(kWinoThreads), 0, hs, dy, K, H, W, tiles_of(H, m), tiles_of(W, m), P, dM);
   return launch_status("fpsg_wino_grad_output_transform");
 }
 

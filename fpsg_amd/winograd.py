@@ -5,7 +5,8 @@ both arguments.  The 16 transform-domain GEMMs are fp32 batched matrix products 
 pipes (``torch.bmm`` = hipBLASLt); the input / output / filter transforms are the HIP kernels
 of ``csrc/winograd.hip`` through the C ABI.  2.25x (m=2) / 4x (m=4) fewer multiplications than the
 direct form; ``tile_size`` picks m = 4 where the image is a multiple of 4 and at least 28 wide
-(the 56x56 and 28x28 stages), m = 2 otherwise (14x14); ``FPSG_WINOGRAD_M=2`` forces m = 2.
+(the 112x112, 56x56 and 28x28 stages) and, with half-empty edge tiles, where its sides are even and at least 12
+(the 14x14 stage as a 4x4 grid of tiles: ``ragged_enabled``), m = 2 otherwise; ``FPSG_WINOGRAD_M=2`` forces m = 2.
 fp32 error against a float64 convolution: ~1e-6 of the output scale for m = 2, ~1e-5 for m = 4
 (the library's own kernels: ~1e-6), inside the 1e-4 budget of the path.  Measured on MI355X against MIOpen's own fp32 Winograd kernel (the solver it picks for these
 layers) this is faster from 64 channels up with 4x4 tiles, where the 4x larger transform-domain tensors are
@@ -47,11 +48,27 @@ def eligible(x: torch.Tensor, conv: torch.nn.Conv2d) -> bool:
             and _wide_enough(conv.in_channels, conv.out_channels, tile_size(x.shape[2], x.shape[3])))
 
 
+def ragged_enabled() -> bool:
+    """F(4x4,3x3) on images whose (even) sides are not multiples of 4 -- VGG's 14 x 14 stage as a 4 x 4 grid of tiles
+    whose last row and column are half empty: 16 tiles per image and 36 products instead of 49 tiles and 16 products,
+    1.36x fewer multiplications and smaller transform-domain tensors (the three 512-channel layers' products
+    145 -> 110 us each at 37 images).  ``FPSG_WINOGRAD_RAGGED=0``: F(2x2) there, as before (A/B)."""
+    return os.environ.get("FPSG_WINOGRAD_RAGGED", "1") != "0"
+
+
 def tile_size(H: int, W: int) -> int:
     forced = os.environ.get("FPSG_WINOGRAD_M")
     if forced:
         return int(forced)
-    return 4 if (H % 4 == 0 and W % 4 == 0 and min(H, W) >= 28) else 2
+    if H % 4 == 0 and W % 4 == 0 and min(H, W) >= 28:
+        return 4
+    if ragged_enabled() and H % 2 == 0 and W % 2 == 0 and min(H, W) >= 12 and (H % 4 or W % 4):
+        return 4                      # ceil(H/4) x ceil(W/4) tiles; from 12 up the half-empty edge tiles cost less than F(2x2)'s extra products
+    return 2
+
+
+def _tiles(H: int, W: int, m: int) -> int:
+    return -(-H // m) * -(-W // m)
 
 
 def fused_enabled() -> bool:
@@ -242,7 +259,7 @@ def _filter(m, w, flip):
 
 def _input(m, x):
     N, C, H, W = x.shape
-    V = torch.empty(((m + 2) ** 2, C, N * (H // m) * (W // m)), dtype=torch.float32, device=x.device)
+    V = torch.empty(((m + 2) ** 2, C, N * _tiles(H, W, m)), dtype=torch.float32, device=x.device)
     _call("fpsg_wino_input_transform", m, _hip.ptr(x), N, C, H, W, _hip.ptr(V), _hip.stream_of(x))
     return V
 
@@ -313,7 +330,7 @@ def _fused(x, U):
 
 def _grad_output(m, gy):
     N, K, H, W = gy.shape
-    dM = torch.empty(((m + 2) ** 2, K, N * (H // m) * (W // m)), dtype=torch.float32, device=gy.device)
+    dM = torch.empty(((m + 2) ** 2, K, N * _tiles(H, W, m)), dtype=torch.float32, device=gy.device)
     _call("fpsg_wino_grad_output_transform", m, _hip.ptr(gy), N, K, H, W, _hip.ptr(dM), _hip.stream_of(gy))
     return dM
 
@@ -385,7 +402,7 @@ class _Conv3x3(torch.autograd.Function):
 
 def _input_act(m, x, chan, pre_bias):
     N, C, H, W = x.shape
-    V = torch.empty(((m + 2) ** 2, C, N * (H // m) * (W // m)), dtype=torch.float32, device=x.device)
+    V = torch.empty(((m + 2) ** 2, C, N * _tiles(H, W, m)), dtype=torch.float32, device=x.device)
     _call("fpsg_wino_input_transform_act", m, _hip.ptr(x), _hip.ptr(chan), _hip.ptr(pre_bias) if pre_bias is not None else None,
           N, C, H, W, _hip.ptr(V), _hip.stream_of(x))
     return V
@@ -527,8 +544,8 @@ def conv3x3(x: torch.Tensor, weight: torch.Tensor, m: int | None = None, stats_b
         raise ValueError(f"conv3x3: x {tuple(x.shape)} / weight {tuple(weight.shape)}")
     if m is None:
         m = tile_size(x.shape[2], x.shape[3])
-    if m not in (2, 4) or x.shape[2] % m or x.shape[3] % m:
-        raise ValueError(f"conv3x3: H and W must be multiples of the tile size m={m} (2 or 4)")
+    if m not in (2, 4) or x.shape[2] % 2 or x.shape[3] % 2:
+        raise ValueError(f"conv3x3: m={m} must be 2 or 4 and H, W even (got {tuple(x.shape[2:])})")
     if want_parts:
         return _Conv3x3.apply(x, weight, m, stats_bias, True)
     return _Conv3x3.apply(x, weight, m)

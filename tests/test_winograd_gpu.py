@@ -14,6 +14,8 @@ SHAPES = [  # N, C, K, H, W, m
     (37, 40, 32, 14, 14, 2),
     (2, 8, 5, 4, 8, 4), (1, 3, 7, 4, 4, 4), (3, 16, 16, 12, 16, 4), (2, 32, 24, 28, 32, 4), (5, 64, 48, 56, 56, 4),
     (7, 256, 128, 28, 28, 4),
+    # m = 4 on sides that are even but not multiples of 4 (half-empty last tile row / column; VGG's 14 x 14 stage)
+    (3, 16, 16, 14, 14, 4), (2, 32, 24, 18, 12, 4), (5, 40, 32, 14, 20, 4), (37, 24, 16, 14, 14, 4), (1, 8, 8, 2, 6, 4),
 ]
 
 
@@ -70,10 +72,14 @@ def test_argument_checks(gpu):
     assert b"null" in lib.fpsg_last_error()
     x = torch.randn(1, 1, 3, 4, device=gpu)
     assert lib.fpsg_wino_input_transform(2, _hip.ptr(x), 1, 1, 3, 4, _hip.ptr(x), None) != 0              # odd H
-    assert lib.fpsg_wino_input_transform(4, _hip.ptr(x), 1, 1, 2, 4, _hip.ptr(x), None) != 0              # H % 4
+    assert lib.fpsg_wino_input_transform(4, _hip.ptr(x), 1, 1, 3, 4, _hip.ptr(x), None) != 0              # odd H, m = 4
+    assert lib.fpsg_wino_input_transform(4, _hip.ptr(x), 1, 1, 2, 3, _hip.ptr(x), None) != 0              # odd W
     assert lib.fpsg_wino_input_transform(3, _hip.ptr(x), 1, 1, 2, 4, _hip.ptr(x), None) != 0              # m
     with pytest.raises(ValueError):
-        conv3x3(torch.randn(1, 4, 6, 8, device=gpu), torch.randn(4, 4, 3, 3, device=gpu), 4)
+        conv3x3(torch.randn(1, 4, 6, 7, device=gpu), torch.randn(4, 4, 3, 3, device=gpu), 4)             # odd W
+    # m = 4 on an even side that is not a multiple of 4 is served (half-empty edge tiles), not refused
+    y = conv3x3(torch.randn(1, 4, 6, 8, device=gpu), torch.randn(4, 4, 3, 3, device=gpu), 4)
+    assert y.shape == (1, 4, 6, 8)
 
 
 @pytest.mark.parametrize("m", [2, 4])
@@ -92,7 +98,8 @@ def test_deterministic(gpu, m):
 
 def test_tile_size_rule():
     from fpsg_amd.winograd import tile_size
-    assert tile_size(56, 56) == 4 and tile_size(28, 28) == 4 and tile_size(14, 14) == 2 and tile_size(30, 28) == 2
+    assert tile_size(56, 56) == 4 and tile_size(28, 28) == 4 and tile_size(14, 14) == 4 and tile_size(30, 28) == 4
+    assert tile_size(6, 6) == 2 and tile_size(10, 14) == 2 and tile_size(24, 24) == 2 and tile_size(7, 8) == 2
 
 
 @pytest.mark.parametrize("shape", [(3, 64, 64, 32, 32), (2, 64, 128, 28, 36), (5, 64, 16, 8, 12), (1, 64, 64, 4, 4),
@@ -187,7 +194,7 @@ def test_full_size_layers_against_the_library_and_linearity(gpu, layer):
     assert float((lhs - rhs).abs().max()) <= 6e-5 * float(rhs.abs().max())
 
 
-@pytest.mark.parametrize("C,K,H,N", [(64, 64, 112, 6), (64, 128, 56, 6), (128, 128, 56, 6), (256, 256, 28, 24)])
+@pytest.mark.parametrize("C,K,H,N", [(64, 64, 112, 6), (64, 128, 56, 6), (128, 128, 56, 6), (256, 256, 28, 24), (128, 256, 14, 90)])
 @pytest.mark.parametrize("mode", ["train", "eval"])
 def test_bn_relu_folded_into_next_conv_equals_two_ops(gpu, monkeypatch, C, K, H, N, mode):
     """``bn_relu_conv3x3(y, pre_bias, bn, w)`` -- BatchNorm + ReLU applied by the convolution's own input
@@ -310,14 +317,14 @@ def test_trunk_with_batchnorm_statistics_from_the_convolutions(gpu, monkeypatch)
 
 
 @pytest.mark.parametrize("m,shape", [(4, (3, 8, 12, 20)), (2, (5, 16, 6, 10)), (4, (37, 32, 28, 28)), (2, (37, 24, 14, 14)),
-                                     (4, (2, 5, 112, 112))])
+                                     (4, (2, 5, 112, 112)), (4, (37, 24, 14, 14)), (4, (3, 8, 18, 12)), (4, (5, 6, 6, 10))])
 def test_output_transform_delivers_batchnorm_partial_sums(gpu, m, shape):
     """fpsg_wino_output_transform_stats: the same pixels as the plain output transform, and per channel the
     partial sums of (y + bias) and (y + bias)^2 over each workgroup's tiles (ragged last workgroup included)."""
     from fpsg_amd import winograd as wg
     N, K, H, W = shape
     torch.manual_seed(H + K)
-    P = N * (H // m) * (W // m)
+    P = N * -(-H // m) * -(-W // m)
     Mt = torch.randn((m + 2) ** 2, K, P, device=gpu)
     b = torch.randn(K, device=gpu)
     y_ref = wg._output(m, Mt, N, H, W)
@@ -526,7 +533,8 @@ def test_filter_bank_refreshes_every_registered_filter_in_one_launch(gpu, monkey
     assert calls["single"] == n0 + 2 and not winograd._bank.entries
 
 
-@pytest.mark.parametrize("m,shape", [(4, (6, 128, 56, 56)), (2, (5, 48, 50, 30)), (4, (37, 32, 28, 28)), (4, (3, 7, 8, 12))])
+@pytest.mark.parametrize("m,shape", [(4, (6, 128, 56, 56)), (2, (5, 48, 50, 30)), (4, (37, 32, 28, 28)), (4, (3, 7, 8, 12)),
+                                     (4, (37, 24, 14, 14)), (4, (3, 8, 18, 12))])
 def test_output_transform_delivers_batchnorm_backward_sums(gpu, m, shape):
     """fpsg_wino_output_transform_bwd_stats: y equals the plain output transform bit for bit, and the per-workgroup
     partial sums add up (float64) to sum(dz) and sum(dz * xhat) with dz = y * [bn(xpre + bias) > 0], as
@@ -536,7 +544,7 @@ def test_output_transform_delivers_batchnorm_backward_sums(gpu, m, shape):
     lib = _hip.load()
     N, K, H, W = shape
     torch.manual_seed(H + K)
-    P = N * (H // m) * (W // m)
+    P = N * -(-H // m) * -(-W // m)
     M = torch.randn((m + 2) ** 2, K, P, device=gpu)
     xpre = torch.randn(N, K, H, W, device=gpu)
     pb = torch.randn(K, device=gpu) * 0.1
