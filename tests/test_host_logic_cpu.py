@@ -10,7 +10,12 @@ import torch.nn as nn
 def test_winograd_tile_and_width_rules(monkeypatch):
     from fpsg_amd import winograd as wg
     monkeypatch.delenv("FPSG_WINOGRAD_M", raising=False)
-    assert [wg.tile_size(s, s) for s in (224, 112, 56, 28, 14, 24, 30)] == [4, 4, 4, 4, 2, 2, 2]
+    monkeypatch.delenv("FPSG_WINOGRAD_RAGGED", raising=False)
+    # 14 and 30 are even but not multiples of 4: F(4x4) with half-empty edge tiles (winograd.ragged_enabled)
+    assert [wg.tile_size(s, s) for s in (224, 112, 56, 28, 14, 24, 30, 10, 6)] == [4, 4, 4, 4, 4, 2, 4, 2, 2]
+    monkeypatch.setenv("FPSG_WINOGRAD_RAGGED", "0")
+    assert [wg.tile_size(s, s) for s in (224, 28, 14, 30)] == [4, 4, 2, 2]
+    monkeypatch.delenv("FPSG_WINOGRAD_RAGGED")
     monkeypatch.setenv("FPSG_WINOGRAD_M", "2")
     assert wg.tile_size(224, 224) == 2
     monkeypatch.delenv("FPSG_WINOGRAD_M")
