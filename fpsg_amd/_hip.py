@@ -89,6 +89,15 @@ SIGNATURES = {
                             _c_f32p, _c_stream],
     "fpsg_bn_act_max_bwd": [_c_f32p, _c_f32p, _c_f32p, _c_i32p, _c_f32p, _c_int, _c_int, _c_int, _c_int, _c_int,
                             ctypes.c_float, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_stream],
+    "fpsg_max_bwd_prep": [_c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_int, _c_int, _c_int, _c_int, _c_f32p, _c_f32p,
+                          _c_f32p, _c_f32p, _c_stream],
+    "fpsg_max_bwd_dw": [_c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_int, _c_int, _c_int, _c_f32p, _c_stream],
+    "fpsg_max_bwd_gather": [_c_f32p, _c_f32p, _c_i32p, _c_int, _c_int, _c_int, _c_int, _c_f32p, _c_stream],
+    "fpsg_max_bwd_scatter": [_c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_i32p, _c_f32p, _c_int, _c_int, _c_int, _c_int, _c_f32p,
+                             _c_stream],
+    "fpsg_max_bwd_scatter_workspace_floats": [_c_int, _c_int, _c_int],
+    "fpsg_bn_act_max_bwd_coef": [_c_f32p, _c_f32p, _c_f32p, _c_i32p, _c_f32p, _c_int, _c_int, _c_int, _c_int, _c_int,
+                                 ctypes.c_float, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_stream],
     "fpsg_wino_input_transform": [_c_int, _c_f32p, _c_int, _c_int, _c_int, _c_int, _c_f32p, _c_stream],
     "fpsg_wino_output_transform": [_c_int, _c_f32p, _c_int, _c_int, _c_int, _c_int, _c_f32p, _c_stream],
     "fpsg_wino_stats_parts": [_c_int, _c_int, _c_int, _c_int],
@@ -129,7 +138,7 @@ SIGNATURES = {
 _RESTYPES = {"fpsg_last_error": ctypes.c_char_p, "fpsg_chamfer_workspace_bytes": ctypes.c_size_t,
              "fpsg_sinkhorn_workspace_floats": ctypes.c_size_t,
              "fpsg_knn_workspace_floats": ctypes.c_size_t,
-             "fpsg_bn_workspace_floats": ctypes.c_size_t, "fpsg_bn_pool_workspace_floats": ctypes.c_size_t, "fpsg_bn_max_workspace_floats": ctypes.c_size_t, "fpsg_conv_first_dw_workspace_floats": ctypes.c_size_t, "fpsg_emd_workspace_floats": ctypes.c_size_t,
+             "fpsg_bn_workspace_floats": ctypes.c_size_t, "fpsg_bn_pool_workspace_floats": ctypes.c_size_t, "fpsg_bn_max_workspace_floats": ctypes.c_size_t, "fpsg_conv_first_dw_workspace_floats": ctypes.c_size_t, "fpsg_emd_workspace_floats": ctypes.c_size_t, "fpsg_max_bwd_scatter_workspace_floats": ctypes.c_size_t,
              "fpsg_wino_dw_fused_workspace_floats": ctypes.c_size_t}
 
 _lib = None

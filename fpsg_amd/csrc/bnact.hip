@@ -1268,6 +1268,29 @@ extern "C" int fpsg_bn_act_max_fwd(const float* x, const float* pre_bias, const 
   return launch_status("fpsg_bn_act_max_fwd(out)");
 }
 
+// The coefficient pass of fpsg_bn_act_max_bwd alone: dz [N,C] (left in the workspace at the offset that function uses: after
+// the channel partials and the dx partials), dgamma, dbeta and coef [3][C] = k1, k2, k3 of
+//   dx'[n,c,l] = k1_c dz[n,c] [l = idx[n,c]] + k2_c (x[n,c,l] + pre_bias_c) + k3_c .
+// For callers that do not form the dense dx: with x = W a the two products over it reduce to 128 x 128 Gram-matrix
+// algebra plus a gather and a scatter of N*C columns (fpsg_amd/fused_bn.py: _ConvBNActMax).
+extern "C" int fpsg_bn_act_max_bwd_coef(const float* x, const float* pre_bias, const float* gout, const int32_t* idx,
+                                        const float* chan, int N, int C, int L, int training, int act, float slope,
+                                        float* dgamma, float* dbeta, float* coef, float* ws, fpsg_stream_t stream) {
+  using namespace fpsg;
+  int rc = check_dims("fpsg_bn_act_max_bwd_coef", N, C, L, act);
+  if (rc) return rc;
+  FPSG_REQUIRE_PTR(x); FPSG_REQUIRE_PTR(gout); FPSG_REQUIRE_PTR(idx); FPSG_REQUIRE_PTR(chan);
+  FPSG_REQUIRE_PTR(dgamma); FPSG_REQUIRE_PTR(dbeta); FPSG_REQUIRE_PTR(coef); FPSG_REQUIRE_PTR(ws);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int segs = (L + kBnSeg - 1) / kBnSeg;
+  float* dz = ws + (size_t)C * kBnSlices * 2 + (size_t)N * C * segs * 4;
+#define FPSG_MAXB(A) hipLaunchKernelGGL(bn_max_bwd_coef_kernel<A>, dim3(C), dim3(64), 0, s, x, pre_bias, gout, idx, chan, \
+                                        N, C, L, training, slope, dz, dgamma, dbeta, coef)
+  if (act == kActRelu) FPSG_MAXB(kActRelu); else if (act == kActLeaky) FPSG_MAXB(kActLeaky); else FPSG_MAXB(kActNone);
+#undef FPSG_MAXB
+  return launch_status("fpsg_bn_act_max_bwd_coef");
+}
+
 extern "C" int fpsg_bn_act_max_bwd(const float* x, const float* pre_bias, const float* gout, const int32_t* idx,
                                    const float* chan, int N, int C, int L, int training, int act, float slope,
                                    float* dx, float* dgamma, float* dbeta, float* dpre_bias, float* coef, float* ws,

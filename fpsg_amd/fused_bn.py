@@ -198,6 +198,114 @@ class _BNActMax(torch.autograd.Function):
         return dx, (dgamma if has_w else None), (dbeta if has_b else None), None, None, None, None, None, None, dpb, None
 
 
+def W_is_plain(conv) -> bool:
+    return conv.weight.is_contiguous() and conv.weight.dim() == 3 and conv.weight.shape[2] == 1
+
+
+# Below this many points over the batch (8 clouds of 2048) the dense gradient's two GEMMs are small and the algebraic
+# form's dozen launches cost more than they save (1-shot episodes: 2 clouds; 287 vs 262 episodes/s).
+_MAX_ALGEBRA_MIN_POINTS = 16384
+
+
+def max_bwd_algebra_enabled() -> bool:
+    """The backward of conv1x1 -> BatchNorm (+ReLU) -> max over the points through K x K algebra instead of two GEMMs
+    over the dense [B,C,L] gradient (``_ConvBNActMax``).  ``FPSG_MAX_BWD_ALGEBRA=0``: the dense form (A/B)."""
+    return os.environ.get("FPSG_MAX_BWD_ALGEBRA", "1") != "0"
+
+
+class _ConvBNActMax(torch.autograd.Function):
+    """``act(BN(W a + conv_bias)).max(dim=2)[0]`` for ``a [B, K, L]``, ``weight [C, K, 1]`` as ONE op: the tail of
+    PointNet's shared MLPs (``pointnet/model.py:35-37, 222-224``).  Forward = the batched product + ``_BNActMax``'s
+    kernels.  Backward: the gradient of the pre-BatchNorm tensor is ``k1 dz [l = sel] + k2 x' + k3`` (sparse + affine
+    in ``x' = W a + b``), so the two products over it (``dW = dx' a^T``, ``da = W^T dx'``: 34 GFLOP each at B = 64,
+    C = 1024, L = 2048, plus a 537 MB write and two reads of ``dx'``) reduce to the K x K Gram matrix ``G = a a^T``, K x K
+    products, one [K x K].[K x B L] GEMM and a gather / scatter of B*C columns (``csrc/maxbwd.hip``): 8.6 GFLOP.
+    Same mathematics, sums reassociated (1e-6 of the gradients' scale); deterministic."""
+
+    @staticmethod
+    def forward(ctx, a, weight, conv_bias, gamma, beta, running_mean, running_var, training, eps, act_code, slope, momentum):
+        B, K, L = a.shape
+        C = weight.shape[0]
+        lib = _hip.load()
+        dev = a.device
+        W = weight.reshape(C, K)
+        x = torch.bmm(W.unsqueeze(0).expand(B, -1, -1), a)              # [B, C, L], bias-free
+        out = torch.empty((B, C), dtype=torch.float32, device=dev)
+        idx = torch.empty((B, C), dtype=torch.int32, device=dev)
+        chan = torch.empty((4, C), dtype=torch.float32, device=dev)
+        ws = torch.empty((lib.fpsg_bn_max_workspace_floats(B, C, L),), dtype=torch.float32, device=dev)
+        opt = lambda t: _hip.ptr(t) if t is not None else None
+        with torch.cuda.device(dev):
+            rc = lib.fpsg_bn_act_max_fwd(_hip.ptr(x), opt(conv_bias), opt(gamma), opt(beta), opt(running_mean),
+                                         opt(running_var), float(momentum), B, C, L, 1 if training else 0, float(eps),
+                                         act_code, float(slope), _hip.ptr(out), _hip.ptr(idx), _hip.ptr(chan), None,
+                                         None, _hip.ptr(ws), _hip.stream_of(a))
+        _hip.check(rc, "fpsg_bn_act_max_fwd")
+        ctx.save_for_backward(a, weight, x, chan, idx, conv_bias)
+        ctx.cfg = (B, K, C, L, bool(training), act_code, slope, gamma is not None, beta is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        a, weight, x, chan, idx, pb = ctx.saved_tensors
+        B, K, C, L, training, act_code, slope, has_g, has_b = ctx.cfg
+        lib = _hip.load()
+        dev = a.device
+        gout = gout.contiguous()
+        W = weight.reshape(C, K)
+        dgamma = torch.empty((C,), dtype=torch.float32, device=dev)
+        dbeta = torch.empty((C,), dtype=torch.float32, device=dev)
+        coef = torch.empty((3, C), dtype=torch.float32, device=dev)
+        ws = torch.empty((lib.fpsg_bn_max_workspace_floats(B, C, L),), dtype=torch.float32, device=dev)
+        segs = (L + 4095) // 4096
+        st = _hip.stream_of(a)
+        with torch.cuda.device(dev):
+            _hip.check(lib.fpsg_bn_act_max_bwd_coef(_hip.ptr(x), _hip.ptr(pb) if pb is not None else None, _hip.ptr(gout),
+                                                    _hip.ptr(idx), _hip.ptr(chan), B, C, L, 1 if training else 0, act_code,
+                                                    float(slope), _hip.ptr(dgamma), _hip.ptr(dbeta), _hip.ptr(coef),
+                                                    _hip.ptr(ws), st), "fpsg_bn_act_max_bwd_coef")
+            off = C * 128 + B * C * segs * 4
+            dz = ws[off: off + B * C].view(B, C)
+            opt = lambda t: _hip.ptr(t) if t is not None else None
+            da = dw = dpb = None
+            want_dpb = pb is not None and ctx.needs_input_grad[2]
+            # per-channel scalings of the K x K products: one launch (fpsg_max_bwd_prep)
+            Wk = torch.empty((C, K), dtype=torch.float32, device=dev)
+            u = torch.empty((C,), dtype=torch.float32, device=dev)
+            if want_dpb:
+                dpb = torch.empty((C,), dtype=torch.float32, device=dev)
+            spart = s = None
+            if training and ctx.needs_input_grad[1]:
+                spart = torch.mv(a.view(B * K, L), torch.ones((L,), dtype=torch.float32, device=dev))   # [B*K] row sums of a
+                s = torch.empty((K,), dtype=torch.float32, device=dev)
+            _hip.check(lib.fpsg_max_bwd_prep(_hip.ptr(W), _hip.ptr(coef), opt(pb), _hip.ptr(chan[2]), _hip.ptr(dz), opt(spart),
+                                             B, K, C, L, _hip.ptr(Wk), _hip.ptr(u), opt(dpb), opt(s), st), "fpsg_max_bwd_prep")
+            if ctx.needs_input_grad[1]:
+                S = torch.empty((C, K), dtype=torch.float32, device=dev)
+                _hip.check(lib.fpsg_max_bwd_gather(_hip.ptr(a), _hip.ptr(dz), _hip.ptr(idx), B, K, C, L, _hip.ptr(S), st),
+                           "fpsg_max_bwd_gather")
+                WG = None
+                if training:
+                    G = torch.bmm(a, a.transpose(1, 2)).sum(0)              # [K, K] Gram matrix
+                    WG = W @ G
+                dw = torch.empty((C, K), dtype=torch.float32, device=dev)
+                _hip.check(lib.fpsg_max_bwd_dw(_hip.ptr(S), opt(WG), _hip.ptr(coef), opt(pb), opt(s), B, K, C, _hip.ptr(dw),
+                                               st), "fpsg_max_bwd_dw")
+                dw = dw.reshape(weight.shape)
+            if ctx.needs_input_grad[0]:
+                if training:
+                    M = W.t() @ Wk                                          # [K, K] = W^T diag(k2) W
+                    v = torch.mv(W.t(), u)                                  # [K]   = W^T (k2 pb + k3)
+                    da = torch.bmm(M.unsqueeze(0).expand(B, -1, -1), a)
+                else:
+                    v = torch.zeros((K,), dtype=torch.float32, device=dev)
+                    da = torch.zeros_like(a)
+                sws = torch.empty((lib.fpsg_max_bwd_scatter_workspace_floats(B, C, L),), dtype=torch.float32, device=dev)
+                _hip.check(lib.fpsg_max_bwd_scatter(_hip.ptr(da), _hip.ptr(W), _hip.ptr(coef), _hip.ptr(dz), _hip.ptr(idx),
+                                                    _hip.ptr(v), B, K, C, L, _hip.ptr(sws), st), "fpsg_max_bwd_scatter")
+        return (da, dw, dpb, dgamma if has_g else None, dbeta if has_b else None, None, None, None, None, None, None, None)
+
+
 def _eligible(x: torch.Tensor) -> bool:
     if not (x.is_cuda and x.dtype == torch.float32 and x.dim() >= 3 and fused_enabled()):
         return False
@@ -371,6 +479,17 @@ def conv_bn_act_max(conv: nn.Conv1d, bn: nn.BatchNorm1d, x: torch.Tensor, act=No
     (``pointnet/model.py:35-37, 222-224``)."""
     fused = (conv.bias is not None and x.is_cuda and x.dtype == torch.float32 and fused_enabled()
              and bn.track_running_stats and conv.padding_mode == "zeros")
+    if (fused and max_bwd_algebra_enabled() and _is_pointwise(conv) and x.dim() == 3 and conv.in_channels <= 128
+            and x.shape[2] >= _MIN_ROW and x.shape[2] % 4 == 0 and conv.out_channels <= 65535 and x.is_contiguous()
+            and x.shape[2] <= 2048 and x.shape[0] * x.shape[2] >= _MAX_ALGEBRA_MIN_POINTS
+            and W_is_plain(conv)):
+        training = bn.training
+        if training:
+            count_batch(bn)
+        act_code, slope = _parse_act(act)
+        m = (0.1 if bn.momentum is None else float(bn.momentum)) if training else -1.0
+        return _ConvBNActMax.apply(x, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                                   bool(training), bn.eps, act_code, slope, m)
     if fused:
         y = _conv_without_bias(conv, x)
         fused = y.dim() == 3 and _eligible(y)

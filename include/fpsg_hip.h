@@ -337,6 +337,36 @@ int fpsg_bn_act_max_fwd(const float* x, const float* pre_bias, const float* gamm
 int fpsg_bn_act_max_bwd(const float* x, const float* pre_bias, const float* gout, const int32_t* idx,
                         const float* chan, int N, int C, int L, int training, int act, float slope, float* dx,
                         float* dgamma, float* dbeta, float* dpre_bias, float* coef, float* ws, fpsg_stream_t stream);
+/* The coefficient pass of fpsg_bn_act_max_bwd alone (no dense dx): dgamma, dbeta, coef [3][C] = k1, k2, k3 of
+ * dx'[n,c,l] = k1_c dz[n,c] [l = idx[n,c]] + k2_c (x[n,c,l] + pre_bias_c) + k3_c, and dz [N,C] left in ws at float offset
+ * C*128 + N*C*ceil(L/4096)*4.  ws: fpsg_bn_max_workspace_floats(N,C,L) floats. */
+int fpsg_bn_act_max_bwd_coef(const float* x, const float* pre_bias, const float* gout, const int32_t* idx,
+                             const float* chan, int N, int C, int L, int training, int act, float slope,
+                             float* dgamma, float* dbeta, float* coef, float* ws, fpsg_stream_t stream);
+
+/* ---- K5m: backward of conv1x1 -> BatchNorm (+ReLU) -> max over the points without the dense gradient ----------
+ * (PointNet's last shared layer, src/pointnet/model.py:35-37, 222-224).  With the coefficients of
+ * fpsg_bn_act_max_bwd_coef the two GEMMs over the [B,C,L] gradient reduce to K x K algebra (library GEMMs on the
+ * caller's side, fpsg_amd/fused_bn.py) plus these two passes.  a [B,K,L] the layer's input, W [C,K], idx [B,C] the
+ * selected point of every row, dz [B,C].
+ *   fpsg_max_bwd_gather : S[c,k] = sum_b dz[b,c] a[b,k,idx[b,c]]            (ascending b; L % 4 == 0, L <= 2048)
+ *   fpsg_max_bwd_scatter: da[b,k,l] += v[k] + sum_{c: idx[b,c] = l} (k1[c] dz[b,c]) W[c,k]   (ascending c; K <= 128,
+ *                         L < 65407; ws: fpsg_max_bwd_scatter_workspace_floats(B,C,L) floats of caller scratch)
+ * Deterministic (no float atomics). */
+int fpsg_max_bwd_gather(const float* a, const float* dz, const int32_t* idx, int B, int K, int C, int L, float* S,
+                        fpsg_stream_t stream);
+/*   fpsg_max_bwd_prep   : Wk = diag(k2) W, u = k2 pb + k3, dpre_bias = k1 sum_b dz + (k2 mean + k3) B L, and (spart, s
+ *                         given) s[k] = sum_b spart[b,k], spart [B,K] = the row sums of a                 (one launch)
+ *   fpsg_max_bwd_dw     : dw = k1 S + k2 (WG + pb s^T) + k3 s^T; WG = NULL (eval mode): dw = k1 S */
+int fpsg_max_bwd_prep(const float* W, const float* coef, const float* pre_bias, const float* mean, const float* dz,
+                      const float* spart, int B, int K, int C, int L, float* Wk, float* u, float* dpre_bias, float* s,
+                      fpsg_stream_t stream);
+int fpsg_max_bwd_dw(const float* S, const float* WG, const float* coef, const float* pre_bias, const float* s, int B,
+                    int K, int C, float* dw, fpsg_stream_t stream);
+size_t fpsg_max_bwd_scatter_workspace_floats(int B, int C, int L);
+int fpsg_max_bwd_scatter(float* da, const float* W, const float* k1, const float* dz, const int32_t* idx, const float* v,
+                         int B, int K, int C, int L, float* ws, fpsg_stream_t stream);
+
 
 /* ---- K6: Winograd F(m x m, 3x3) transforms (m = 2 or 4) for the deep 3x3 convolutions -------
  * Replaces, together with the caller's fp32 batched GEMM (hipBLASLt, MFMA), the library

@@ -296,3 +296,49 @@ def test_max_variant_selected_index(gpu):
             row = xc[n, c]
             want = int((row == (row.max() if gamma[c] >= 0 else row.min())).nonzero()[0])
             assert int(idx[n, c]) == want, (n, c)
+
+
+@pytest.mark.parametrize("shape,act", [((64, 128, 1024, 2048), None), ((8, 128, 1024, 2048), "relu"), ((5, 100, 1000, 300), "relu"),
+                                       ((3, 16, 70, 4096 + 640), ("leaky", 0.2)), ((2, 64, 2500, 512), None)])
+@pytest.mark.parametrize("mode", ["train", "eval"])
+def test_max_variant_backward_without_the_dense_gradient(gpu, monkeypatch, shape, act, mode):
+    """``_ConvBNActMax``: the backward of conv1x1 -> BatchNorm (+act) -> max over the points through the K x K Gram-matrix
+    algebra + gather / scatter of csrc/maxbwd.hip against the dense form it replaces (``FPSG_MAX_BWD_ALGEBRA=0``: dx'
+    materialised, two GEMMs over it): same forward bit for bit, every gradient to reassociation round-off, deterministic;
+    PointNet's shape (64 clouds, 128 -> 1024, 2048 points), channel / point counts that are not multiples of the tiles,
+    more than 1024 channels (two sorting passes), gamma of both signs."""
+    import copy
+    from fpsg_amd import fused_bn
+    from fpsg_amd.fused_bn import conv_bn_act_max
+    monkeypatch.setattr(fused_bn, "_MAX_ALGEBRA_MIN_POINTS", 0)      # small batches take the dense form by default
+    B, K, C, L = shape
+    torch.manual_seed(B + C + L)
+    conv = nn.Conv1d(K, C, 1).to(gpu)
+    bn = nn.BatchNorm1d(C).to(gpu)
+    with torch.no_grad():
+        conv.bias.copy_(torch.randn(C) * 0.3)
+        bn.weight.copy_(torch.randn(C))
+        bn.bias.copy_(torch.randn(C) * 0.3)
+    bn.train(mode == "train")
+    a = torch.relu(torch.randn(B, K, L, device=gpu))
+    g = torch.randn(B, C, device=gpu)
+    res = []
+    for flag in ("1", "0", "1"):
+        monkeypatch.setenv("FPSG_MAX_BWD_ALGEBRA", flag)
+        c2, b2 = copy.deepcopy(conv), copy.deepcopy(bn)
+        ai = a.clone().requires_grad_()
+        y = conv_bn_act_max(c2, b2, ai, act)
+        y.backward(g)
+        res.append((y.detach(), ai.grad, c2.weight.grad, c2.bias.grad, b2.weight.grad, b2.bias.grad, b2.running_mean.clone()))
+    new, old, again = res
+    assert torch.equal(new[0], old[0]) and torch.equal(new[6], old[6])
+    for i, name in ((1, "d input"), (2, "d weight"), (4, "d gamma"), (5, "d beta")):
+        scale = float(old[i].abs().max()) + 1e-30
+        assert float((new[i] - old[i]).abs().max()) <= 2e-5 * scale, (name, float((new[i] - old[i]).abs().max()) / scale)
+    # the bias in front of a training-mode BatchNorm has a mathematically zero gradient: both forms leave round-off
+    if mode == "train":
+        assert float(new[3].abs().max()) <= 1e-3 * float(old[2].abs().max())
+    else:
+        assert float((new[3] - old[3]).abs().max()) <= 2e-5 * (float(old[3].abs().max()) + 1e-30)
+    for x, y in zip(new, again):
+        assert torch.equal(x, y)

@@ -46,8 +46,15 @@ def _fused_path_taken(monkeypatch):
         seen["max"] += 1
         return m0(*a, **k)
 
+    c0 = fused_bn._ConvBNActMax.forward            # conv1x1 + BatchNorm + max as one op (K5m backward)
+
+    def c1(*a, **k):
+        seen["max"] += 1
+        return c0(*a, **k)
+
     monkeypatch.setattr(fused_bn._BNAct, "forward", staticmethod(f1))
     monkeypatch.setattr(fused_bn._BNActMax, "forward", staticmethod(m1))
+    monkeypatch.setattr(fused_bn._ConvBNActMax, "forward", staticmethod(c1))
     return seen
 
 
