@@ -207,16 +207,20 @@ __global__ __launch_bounds__(kMbThreads) void max_bwd_scatter_kernel(float* __re
     }
   }
   __syncthreads();
-  // da rows: wave w takes k = w, w + 4, ...; lanes l = lane, lane + 64; eight rows' loads in flight
+  // da rows: wave w takes k = w, w + 4, ...; a lane moves the two adjacent points 2 lane, 2 lane + 1 of a row as one
+  // 8-byte access (a row of the tile = 512 contiguous bytes per wave instruction); eight rows' loads in flight
+  const bool pair_ok = (L & 1) == 0;                        // rows 8-byte aligned (L even): the vector form
   for (int k0 = wave; k0 < K; k0 += 8 * (kMbThreads / 64)) {
-    float r[8][kTL / 64];
+    v2f r[8];
+    const int l = 2 * lane;
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const int k = k0 + u * (kMbThreads / 64);
-#pragma unroll
-      for (int h = 0; h < kTL / 64; ++h) {
-        const int l = lane + 64 * h;
-        r[u][h] = (k < K && l0 + l < L) ? da[((size_t)b * K + k) * L + l0 + l] : 0.0f;
+      r[u] = (v2f){0.0f, 0.0f};
+      if (k < K) {
+        const float* row = da + ((size_t)b * K + k) * L + l0;
+        if (pair_ok && l0 + l + 1 < L) r[u] = *reinterpret_cast<const v2f*>(row + l);
+        else { if (l0 + l < L) r[u][0] = row[l]; if (l0 + l + 1 < L) r[u][1] = row[l + 1]; }
       }
     }
 #pragma unroll
@@ -224,11 +228,10 @@ __global__ __launch_bounds__(kMbThreads) void max_bwd_scatter_kernel(float* __re
       const int k = k0 + u * (kMbThreads / 64);
       if (k >= K) continue;
       const float vk = v[k];
-#pragma unroll
-      for (int h = 0; h < kTL / 64; ++h) {
-        const int l = lane + 64 * h;
-        if (l0 + l < L) da[((size_t)b * K + k) * L + l0 + l] = r[u][h] + (vk + D[l * ld + k]);
-      }
+      float* row = da + ((size_t)b * K + k) * L + l0;
+      const v2f o = {r[u][0] + (vk + D[l * ld + k]), r[u][1] + (vk + D[(l + 1) * ld + k])};
+      if (pair_ok && l0 + l + 1 < L) *reinterpret_cast<v2f*>(row + l) = o;
+      else { if (l0 + l < L) row[l] = o[0]; if (l0 + l + 1 < L) row[l + 1] = o[1]; }
     }
   }
 }

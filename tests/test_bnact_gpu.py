@@ -319,6 +319,11 @@ def test_max_variant_backward_without_the_dense_gradient(gpu, monkeypatch, shape
         conv.bias.copy_(torch.randn(C) * 0.3)
         bn.weight.copy_(torch.randn(C))
         bn.bias.copy_(torch.randn(C) * 0.3)
+        # the weight as it sits in the flat parameter buffer of the optimizer: at a 4-byte, not a 16-byte, boundary
+        flat = torch.empty(C * K + 5, device=gpu)
+        flat[1:1 + C * K].copy_(conv.weight.reshape(-1))
+        conv.weight.data = flat[1:1 + C * K].view(C, K, 1)
+        assert conv.weight.data_ptr() % 16 == 4
     bn.train(mode == "train")
     a = torch.relu(torch.randn(B, K, L, device=gpu))
     g = torch.randn(B, C, device=gpu)
