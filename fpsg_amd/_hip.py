@@ -92,7 +92,7 @@ SIGNATURES = {
     "fpsg_max_bwd_prep": [_c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_int, _c_int, _c_int, _c_int, _c_f32p, _c_f32p,
                           _c_f32p, _c_f32p, _c_stream],
     "fpsg_max_bwd_dw": [_c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_int, _c_int, _c_int, _c_f32p, _c_stream],
-    "fpsg_max_bwd_gather": [_c_f32p, _c_f32p, _c_i32p, _c_int, _c_int, _c_int, _c_int, _c_f32p, _c_stream],
+    "fpsg_max_bwd_gather": [_c_f32p, _c_f32p, _c_i32p, _c_int, _c_int, _c_int, _c_int, _c_f32p, _c_f32p, _c_stream],
     "fpsg_max_bwd_scatter": [_c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_i32p, _c_f32p, _c_int, _c_int, _c_int, _c_int, _c_f32p,
                              _c_stream],
     "fpsg_max_bwd_scatter_workspace_floats": [_c_int, _c_int, _c_int],

@@ -32,7 +32,8 @@ constexpr int kGatherNB = 4;       // clouds per step
 
 __global__ __launch_bounds__(kMbThreads) void max_bwd_gather_kernel(const float* __restrict__ a, const float* __restrict__ dz,
                                                                    const int32_t* __restrict__ idx, int B, int K, int C,
-                                                                   int L, float* __restrict__ S) {
+                                                                   int L, float* __restrict__ S,
+                                                                   float* __restrict__ spart /*[B][K] or null*/) {
   extern __shared__ __attribute__((aligned(16))) float rows[];        // [2][kGatherNB][L]
   constexpr int kPre = kGatherNB * kGatherL / 4 / kMbThreads;         // 16-byte vectors a thread moves per step (8)
   const int k = blockIdx.x;
@@ -67,6 +68,15 @@ __global__ __launch_bounds__(kMbThreads) void max_bwd_gather_kernel(const float*
     float* nxt = rows + (size_t)((step + 1) & 1) * kGatherNB * L;
     const bool more = b0 + kGatherNB < B;
     if (more) fetch(b0 + kGatherNB, pre);                    // in flight during this step's gathers
+    if (spart && blockIdx.y == 0) {                          // the row sums of a (s = sum a): wave w sums cloud b0 + w's staged row
+      const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+      if (w < kGatherNB && b0 + w < B) {
+        float t = 0.0f;
+        for (int l = lane; l < L; l += 64) t += cur[w * L + l];
+        t = wave_sum(t);
+        if (lane == 0) spart[(size_t)(b0 + w) * K + k] = t;
+      }
+    }
     if (live) {
       float d[kGatherNB];
       int sel[kGatherNB];
@@ -305,7 +315,7 @@ __global__ __launch_bounds__(kMbThreads) void max_bwd_dw_kernel(const float* __r
 }  // namespace fpsg
 
 extern "C" int fpsg_max_bwd_gather(const float* a, const float* dz, const int32_t* idx, int B, int K, int C, int L,
-                                   float* S, fpsg_stream_t stream) {
+                                   float* S, float* spart, fpsg_stream_t stream) {
   using namespace fpsg;
   FPSG_REQUIRE(B > 0 && K > 0 && C > 0 && L > 0, FPSG_E_SHAPE, "fpsg_max_bwd_gather: B,K,C,L must be positive (got %d,%d,%d,%d)",
                B, K, C, L);
@@ -315,8 +325,9 @@ extern "C" int fpsg_max_bwd_gather(const float* a, const float* dz, const int32_
   FPSG_REQUIRE((reinterpret_cast<uintptr_t>(a) & 15) == 0, FPSG_E_ALIGN, "fpsg_max_bwd_gather: a must be 16-byte aligned");
   dim3 grid(K, (C + kMbThreads - 1) / kMbThreads);
   const size_t lds_bytes = (size_t)2 * kGatherNB * L * sizeof(float);
+  FPSG_REQUIRE(!misaligned4(spart), FPSG_E_ALIGN, "fpsg_max_bwd_gather: spart not 4-byte aligned");
   hipLaunchKernelGGL(max_bwd_gather_kernel, grid, dim3(kMbThreads), lds_bytes, static_cast<hipStream_t>(stream), a, dz, idx, B, K, C,
-                     L, S);
+                     L, S, spart);
   return launch_status("fpsg_max_bwd_gather");
 }
 

@@ -274,16 +274,17 @@ class _ConvBNActMax(torch.autograd.Function):
             u = torch.empty((C,), dtype=torch.float32, device=dev)
             if want_dpb:
                 dpb = torch.empty((C,), dtype=torch.float32, device=dev)
-            spart = s = None
-            if training and ctx.needs_input_grad[1]:
-                spart = torch.mv(a.view(B * K, L), torch.ones((L,), dtype=torch.float32, device=dev))   # [B*K] row sums of a
-                s = torch.empty((K,), dtype=torch.float32, device=dev)
+            spart = s = S = None
+            if ctx.needs_input_grad[1]:
+                S = torch.empty((C, K), dtype=torch.float32, device=dev)
+                if training:                                                # the gather pass also leaves the row sums of a
+                    spart = torch.empty((B, K), dtype=torch.float32, device=dev)
+                    s = torch.empty((K,), dtype=torch.float32, device=dev)
+                _hip.check(lib.fpsg_max_bwd_gather(_hip.ptr(a), _hip.ptr(dz), _hip.ptr(idx), B, K, C, L, _hip.ptr(S), opt(spart),
+                                                   st), "fpsg_max_bwd_gather")
             _hip.check(lib.fpsg_max_bwd_prep(_hip.ptr(W), _hip.ptr(coef), opt(pb), _hip.ptr(chan[2]), _hip.ptr(dz), opt(spart),
                                              B, K, C, L, _hip.ptr(Wk), _hip.ptr(u), opt(dpb), opt(s), st), "fpsg_max_bwd_prep")
             if ctx.needs_input_grad[1]:
-                S = torch.empty((C, K), dtype=torch.float32, device=dev)
-                _hip.check(lib.fpsg_max_bwd_gather(_hip.ptr(a), _hip.ptr(dz), _hip.ptr(idx), B, K, C, L, _hip.ptr(S), st),
-                           "fpsg_max_bwd_gather")
                 WG = None
                 if training:
                     G = torch.bmm(a, a.transpose(1, 2)).sum(0)              # [K, K] Gram matrix

@@ -354,7 +354,7 @@ int fpsg_bn_act_max_bwd_coef(const float* x, const float* pre_bias, const float*
  *                         L < 65407; ws: fpsg_max_bwd_scatter_workspace_floats(B,C,L) floats of caller scratch)
  * Deterministic (no float atomics). */
 int fpsg_max_bwd_gather(const float* a, const float* dz, const int32_t* idx, int B, int K, int C, int L, float* S,
-                        fpsg_stream_t stream);
+                        float* spart /* [B,K] row sums of a, or NULL */, fpsg_stream_t stream);
 /*   fpsg_max_bwd_prep   : Wk = diag(k2) W, u = k2 pb + k3, dpre_bias = k1 sum_b dz + (k2 mean + k3) B L, and (spart, s
  *                         given) s[k] = sum_b spart[b,k], spart [B,K] = the row sums of a                 (one launch)
  *   fpsg_max_bwd_dw     : dw = k1 S + k2 (WG + pb s^T) + k3 s^T; WG = NULL (eval mode): dw = k1 S */
