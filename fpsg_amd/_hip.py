@@ -30,6 +30,10 @@ SIGNATURES = {
                          _c_f32p, _c_i32p, _c_f32p, _c_i32p, _c_stream],
     "fpsg_chamfer_bwd": [_c_f32p, _c_f32p, _c_i32p, _c_i32p, _c_f32p, _c_f32p,
                          _c_int, _c_int, _c_int, _c_f32p, _c_f32p, _c_stream],
+    "fpsg_chamfer_losses": [_c_f32p, _c_f32p, _c_int, _c_int, _c_int, _c_int, ctypes.c_float, ctypes.c_float, _c_f32p,
+                            _c_stream],
+    "fpsg_chamfer_loss_grads": [_c_f32p, _c_f32p, _c_f32p, _c_int, _c_int, _c_int, _c_int, ctypes.c_float,
+                                ctypes.c_float, _c_f32p, _c_f32p, _c_stream],
     "fpsg_chamfer_fwd_variant": [_c_f32p, _c_f32p, _c_int, _c_int, _c_int,
                                  _c_f32p, _c_i32p, _c_f32p, _c_i32p, _c_int, _c_stream],
     "fpsg_chamfer_workspace_bytes": [_c_int, _c_int, _c_int, _c_int],

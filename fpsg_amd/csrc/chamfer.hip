@@ -349,6 +349,71 @@ __global__ __launch_bounds__(kBwdThreads) void chamfer_bwd_kernel(
   }
 }
 
+
+// ---- K1l: the episode's reconstruction losses straight from the nearest-neighbour distances ---------------------
+// few_shot.py:110-124 of the reference: chamfer_distance(...) = mean_i d1 + mean_j d2 per cloud pair, .sum() over the
+// query pairs and over the support pairs, then query_factor * q + support_factor * s.  As PyTorch operations that is
+// eight launches of a few microseconds forward and eleven backward; here one each.  One workgroup: wave w owns the pairs
+// b = w, w + 16, ...; a lane adds its share of a row in ascending order (four independent chains when the row length is
+// a multiple of four), wave_sum's fixed tree joins the lanes, thread 0 adds the pairs in ascending b.  Deterministic.
+constexpr int kLossThreads = 1024;
+constexpr int kLossPairs = 4096;
+
+__device__ __forceinline__ float row_sum(const float* __restrict__ row, int n, int lane) {
+  float s = 0.f;
+  if ((n & 3) == 0 && (reinterpret_cast<uintptr_t>(row) & 15u) == 0) {
+    const v4f* r4 = reinterpret_cast<const v4f*>(row);
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    for (int i = lane; i < n / 4; i += 64) {
+      const v4f v = r4[i];
+      a0 += v.x; a1 += v.y; a2 += v.z; a3 += v.w;
+    }
+    s = (a0 + a1) + (a2 + a3);
+  } else {
+    for (int i = lane; i < n; i += 64) s += row[i];
+  }
+  return wave_sum(s);
+}
+
+__global__ __launch_bounds__(kLossThreads) void chamfer_losses_kernel(
+    const float* __restrict__ d1, const float* __restrict__ d2, int B, int N, int M, int n_first, float w_first,
+    float w_rest, float* __restrict__ out) {
+  __shared__ float cd[kLossPairs];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int b = wave; b < B; b += kLossThreads / 64) {
+    const float s1 = row_sum(d1 + (size_t)b * N, N, lane);
+    const float s2 = row_sum(d2 + (size_t)b * M, M, lane);
+    if (lane == 0) cd[b] = s1 / (float)N + s2 / (float)M;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float q = 0.f, r = 0.f;
+    for (int b = 0; b < n_first; ++b) q += cd[b];
+    for (int b = n_first; b < B; ++b) r += cd[b];
+    out[0] = q;
+    out[1] = r;
+    out[2] = w_first * q + w_rest * r;
+  }
+}
+
+// The gradients of those three values with respect to d1 / d2: a constant per cloud pair,
+//   g1[b, :] = (g_total * w_b + g_own_b) / N,  g2[b, :] = (same) / M,   w_b / g_own_b: the pair's group (first / rest).
+// g_first, g_rest, g_total: device scalars, null = no gradient arrives through that value.
+__global__ __launch_bounds__(256) void chamfer_loss_grads_kernel(
+    const float* __restrict__ g_first, const float* __restrict__ g_rest, const float* __restrict__ g_total, int N, int M,
+    int n_first, float w_first, float w_rest, float* __restrict__ g1, float* __restrict__ g2) {
+  const int b = blockIdx.y;
+  const bool first = b < n_first;
+  float g = 0.f;
+  if (g_total) g = *g_total * (first ? w_first : w_rest);
+  const float* own = first ? g_first : g_rest;
+  if (own) g += *own;
+  const float v1 = g / (float)N, v2 = g / (float)M;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < N) g1[(size_t)b * N + i] = v1;
+  if (i < M) g2[(size_t)b * M + i] = v2;
+}
+
 }  // namespace
 }  // namespace fpsg
 
@@ -417,4 +482,30 @@ extern "C" int fpsg_chamfer_bwd(const float* xyz1, const float* xyz2, const int3
   if (N > 0 && M > 0 && N <= 4096 && M <= 4096)
     return fpsg_chamfer_bwd_sorted(xyz1, xyz2, idx1, idx2, g1, g2, B, N, M, gxyz1, gxyz2, stream);
   return fpsg_chamfer_bwd_scan(xyz1, xyz2, idx1, idx2, g1, g2, B, N, M, gxyz1, gxyz2, stream);
+}
+
+extern "C" int fpsg_chamfer_losses(const float* dist1, const float* dist2, int B, int N, int M, int n_first,
+                                   float w_first, float w_rest, float* out3, fpsg_stream_t stream) {
+  using namespace fpsg;
+  FPSG_REQUIRE(B > 0 && N > 0 && M > 0, FPSG_E_SHAPE, "fpsg_chamfer_losses: B,N,M must be positive (got %d,%d,%d)", B, N, M);
+  FPSG_REQUIRE(B <= kLossPairs, FPSG_E_LIMIT, "fpsg_chamfer_losses: B=%d exceeds %d", B, kLossPairs);
+  FPSG_REQUIRE(n_first >= 0 && n_first <= B, FPSG_E_SHAPE, "fpsg_chamfer_losses: n_first=%d outside [0,%d]", n_first, B);
+  FPSG_REQUIRE_PTR(dist1); FPSG_REQUIRE_PTR(dist2); FPSG_REQUIRE_PTR(out3);
+  hipLaunchKernelGGL(chamfer_losses_kernel, dim3(1), dim3(kLossThreads), 0, static_cast<hipStream_t>(stream), dist1, dist2,
+                     B, N, M, n_first, w_first, w_rest, out3);
+  return launch_status("fpsg_chamfer_losses");
+}
+
+extern "C" int fpsg_chamfer_loss_grads(const float* g_first, const float* g_rest, const float* g_total, int B, int N, int M,
+                                       int n_first, float w_first, float w_rest, float* g1, float* g2,
+                                       fpsg_stream_t stream) {
+  using namespace fpsg;
+  FPSG_REQUIRE(B > 0 && N > 0 && M > 0, FPSG_E_SHAPE, "fpsg_chamfer_loss_grads: B,N,M must be positive (got %d,%d,%d)", B, N, M);
+  FPSG_REQUIRE(B <= 65535, FPSG_E_LIMIT, "fpsg_chamfer_loss_grads: B=%d exceeds 65535", B);
+  FPSG_REQUIRE(n_first >= 0 && n_first <= B, FPSG_E_SHAPE, "fpsg_chamfer_loss_grads: n_first=%d outside [0,%d]", n_first, B);
+  FPSG_REQUIRE_PTR(g1); FPSG_REQUIRE_PTR(g2);
+  const int nmax = N > M ? N : M;
+  hipLaunchKernelGGL(chamfer_loss_grads_kernel, dim3((unsigned)((nmax + 255) / 256), (unsigned)B), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), g_first, g_rest, g_total, N, M, n_first, w_first, w_rest, g1, g2);
+  return launch_status("fpsg_chamfer_loss_grads");
 }

@@ -76,6 +76,11 @@ def to_device(sample: dict, device) -> dict:
     return sample
 
 
+def _total(loss):
+    """The scalar to differentiate: the loss itself when it already is one (no reduction launch)."""
+    return loss if loss.dim() == 0 else loss.sum()
+
+
 class TrainStep:
     """One optimizer step over the local share of a global step's episodes.
 
@@ -109,7 +114,7 @@ class TrainStep:
         self.buckets.detach()
         with bn_counters.deferred():        # the ~20 num_batches_tracked increments as multi-tensor adds
             out = self.model.loss(sample)
-        out["ttl_loss"].sum().backward()
+        _total(out["ttl_loss"]).backward()
         if absorb:
             self.buckets.absorb(first)
         return {n: v.detach() for n, v in out.items()}
@@ -122,7 +127,7 @@ class TrainStep:
         self.buckets.arm(first)
         with bn_counters.deferred():
             out = self.model.loss(sample)
-        out["ttl_loss"].sum().backward()
+        _total(out["ttl_loss"]).backward()
         return {n: v.detach() for n, v in out.items()}
 
     def _capture(self, sample, first, absorb):

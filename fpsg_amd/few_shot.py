@@ -19,10 +19,15 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from .metrics import chamfer_distance, emd_loss
+from .metrics import chamfer_distance, emd_loss, episode_chamfer_losses
 from .utils import emd_wrapper
 
 _AGGREGATOR = ["single", "multi", "mask_single", "mask_multi"]
+
+
+def _fused_losses_enabled() -> bool:
+    """``FPSG_FUSED_LOSSES=0``: the loss sums as separate PyTorch operations (A/B measurements)."""
+    return os.environ.get("FPSG_FUSED_LOSSES", "1") != "0"
 
 
 class ImgPCProtoNet(nn.Module):
@@ -119,7 +124,14 @@ class ImgPCProtoNet(nn.Module):
                 # Q + S cloud pairs: per-pair results are independent, and a larger batch fills
                 # the chip better (K1 is 6 us + 0.9 us per pair)
                 n_q = syn_q.size(0)
-                cd = self.pc_metric(torch.cat([syn_q, syn_s]), torch.cat([ref_q, ref_s]))
+                syn, ref = torch.cat([syn_q, syn_s]), torch.cat([ref_q, ref_s])
+                if syn.is_cuda and _fused_losses_enabled():
+                    # K1l: the two sums and the weighted total in one launch behind K1 (and one in the backward)
+                    loss_rec_q, loss_rec_s, loss_recon = episode_chamfer_losses(syn, ref, n_q, self.query_factor,
+                                                                                self.support_factor)
+                    return {"ttl_loss": loss_recon, "recon_loss": loss_recon, "query_rec_loss": loss_rec_q,
+                            "support_rec_loss": loss_rec_s}
+                cd = self.pc_metric(syn, ref)
                 loss_rec_q, loss_rec_s = cd[:n_q].sum(), cd[n_q:].sum()
             else:
                 loss_rec_q = self.pc_metric(syn_q, ref_q).sum()

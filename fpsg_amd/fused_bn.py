@@ -48,11 +48,14 @@ class _BNAct(torch.autograd.Function):
         L = x.numel() // (N * C)
         lib = _hip.load()
         dev = x.device
+        ctx.set_materialize_grads(False)        # no zero tensors for the (non-differentiable) statistics outputs
         y = torch.empty_like(x)
         chan = torch.empty((4, C), dtype=torch.float32, device=dev)
         ws = torch.empty((lib.fpsg_bn_workspace_floats(N, C, L),), dtype=torch.float32, device=dev)
-        bmean = torch.empty((C,), dtype=torch.float32, device=dev) if (training and want_stats) else None
-        bvar = torch.empty((C,), dtype=torch.float32, device=dev) if (training and want_stats) else None
+        bmean = bvar = None
+        if training and want_stats:
+            # the two rows of one tensor: callers that post-process both (point_cloud_net._update_running) do it in one op
+            bmean, bvar = torch.empty((2, C), dtype=torch.float32, device=dev).unbind(0)
         with torch.cuda.device(dev):
             rc = lib.fpsg_bn_act_fwd(
                 _hip.ptr(x), _hip.ptr(pre_bias) if pre_bias is not None else None,
@@ -73,6 +76,8 @@ class _BNAct(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gy, _gm, _gv):
+        if gy is None:
+            return (None,) * 12
         x, chan, pre_bias = ctx.saved_tensors
         N, C, L, training, act_code, slope, has_w, has_b = ctx.cfg
         want_dpb = pre_bias is not None and ctx.needs_input_grad[10]

@@ -54,39 +54,63 @@ def _check_clouds(p1: torch.Tensor, p2: torch.Tensor):
     _hip.dev_tensor(p2, torch.float32, "p2")
 
 
+def _sided_forward(p1, p2):
+    """K1 forward through the C ABI: ``(dist1 [B,N], dist2 [B,M], idx1, idx2)``, idx int32."""
+    _check_clouds(p1, p2)
+    B, N, _ = p1.shape
+    M = p2.size(1)
+    lib = _hip.load()
+    dist1 = torch.empty((B, N), dtype=torch.float32, device=p1.device)
+    dist2 = torch.empty((B, M), dtype=torch.float32, device=p1.device)
+    idx1 = torch.empty((B, N), dtype=torch.int32, device=p1.device)
+    idx2 = torch.empty((B, M), dtype=torch.int32, device=p1.device)
+    # one-pass tiled form (every d(i,j) evaluated once) for clouds of at most 4096 points; the
+    # two-pass kernel (no workspace) otherwise.  Bit-identical results.
+    ws_bytes = lib.fpsg_chamfer_workspace_bytes(B, N, M, -1) if _tiled_enabled() else 0
+    with torch.cuda.device(p1.device), _probe("chamfer_fwd", B, N, M):
+        if ws_bytes:
+            ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=p1.device)
+            rc = lib.fpsg_chamfer_fwd_tiled(_hip.ptr(p1), _hip.ptr(p2), B, N, M, _hip.ptr(dist1),
+                                            _hip.ptr(idx1), _hip.ptr(dist2), _hip.ptr(idx2),
+                                            _hip.ptr(ws), ws_bytes, -1, _hip.stream_of(p1))
+        else:
+            rc = lib.fpsg_chamfer_fwd(_hip.ptr(p1), _hip.ptr(p2), B, N, M, _hip.ptr(dist1),
+                                      _hip.ptr(idx1), _hip.ptr(dist2), _hip.ptr(idx2),
+                                      _hip.stream_of(p1))
+    _hip.check(rc, "fpsg_chamfer_fwd")
+    return dist1, dist2, idx1, idx2
+
+
+def _sided_backward(p1, p2, idx1, idx2, g1, g2):
+    """K1 backward: ``g1 [B,N]``, ``g2 [B,M]`` contiguous fp32 -> gradients of the two clouds."""
+    B, N, _ = p1.shape
+    M = p2.size(1)
+    gx1 = torch.empty_like(p1)
+    gx2 = torch.empty_like(p2)
+    with torch.cuda.device(p1.device), _probe("chamfer_bwd", B, N, M):
+        rc = _hip.load().fpsg_chamfer_bwd(_hip.ptr(p1), _hip.ptr(p2), _hip.ptr(idx1),
+                                          _hip.ptr(idx2), _hip.ptr(g1), _hip.ptr(g2), B, N,
+                                          M, _hip.ptr(gx1), _hip.ptr(gx2),
+                                          _hip.stream_of(p1))
+    _hip.check(rc, "fpsg_chamfer_bwd")
+    return gx1, gx2
+
+
 class _SidedPair(torch.autograd.Function):
     """(dist1, dist2, idx1, idx2) of two clouds in ONE launch; idx are int32, no grad."""
 
     @staticmethod
     def forward(ctx, p1, p2):
-        _check_clouds(p1, p2)
-        B, N, _ = p1.shape
-        M = p2.size(1)
-        lib = _hip.load()
-        dist1 = torch.empty((B, N), dtype=torch.float32, device=p1.device)
-        dist2 = torch.empty((B, M), dtype=torch.float32, device=p1.device)
-        idx1 = torch.empty((B, N), dtype=torch.int32, device=p1.device)
-        idx2 = torch.empty((B, M), dtype=torch.int32, device=p1.device)
-        # one-pass tiled form (every d(i,j) evaluated once) for clouds of at most 4096 points; the
-        # two-pass kernel (no workspace) otherwise.  Bit-identical results.
-        ws_bytes = lib.fpsg_chamfer_workspace_bytes(B, N, M, -1) if _tiled_enabled() else 0
-        with torch.cuda.device(p1.device), _probe("chamfer_fwd", B, N, M):
-            if ws_bytes:
-                ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=p1.device)
-                rc = lib.fpsg_chamfer_fwd_tiled(_hip.ptr(p1), _hip.ptr(p2), B, N, M, _hip.ptr(dist1),
-                                                _hip.ptr(idx1), _hip.ptr(dist2), _hip.ptr(idx2),
-                                                _hip.ptr(ws), ws_bytes, -1, _hip.stream_of(p1))
-            else:
-                rc = lib.fpsg_chamfer_fwd(_hip.ptr(p1), _hip.ptr(p2), B, N, M, _hip.ptr(dist1),
-                                          _hip.ptr(idx1), _hip.ptr(dist2), _hip.ptr(idx2),
-                                          _hip.stream_of(p1))
-        _hip.check(rc, "fpsg_chamfer_fwd")
+        ctx.set_materialize_grads(False)        # no zero tensors for the index outputs (or an unused direction)
+        dist1, dist2, idx1, idx2 = _sided_forward(p1, p2)
         ctx.save_for_backward(p1, p2, idx1, idx2)
         ctx.mark_non_differentiable(idx1, idx2)
         return dist1, dist2, idx1, idx2
 
     @staticmethod
     def backward(ctx, g1, g2, _gi1, _gi2):
+        if g1 is None and g2 is None:
+            return None, None
         p1, p2, idx1, idx2 = ctx.saved_tensors
         B, N, _ = p1.shape
         M = p2.size(1)
@@ -94,15 +118,54 @@ class _SidedPair(torch.autograd.Function):
             else g1.contiguous().float()
         g2 = torch.zeros((B, M), dtype=torch.float32, device=p1.device) if g2 is None \
             else g2.contiguous().float()
-        gx1 = torch.empty_like(p1)
-        gx2 = torch.empty_like(p2)
-        with torch.cuda.device(p1.device), _probe("chamfer_bwd", B, N, M):
-            rc = _hip.load().fpsg_chamfer_bwd(_hip.ptr(p1), _hip.ptr(p2), _hip.ptr(idx1),
-                                              _hip.ptr(idx2), _hip.ptr(g1), _hip.ptr(g2), B, N,
-                                              M, _hip.ptr(gx1), _hip.ptr(gx2),
-                                              _hip.stream_of(p1))
-        _hip.check(rc, "fpsg_chamfer_bwd")
-        return gx1, gx2
+        return _sided_backward(p1, p2, idx1, idx2, g1, g2)
+
+
+class _EpisodeChamfer(torch.autograd.Function):
+    """K1 + K1l: the Chamfer distances of B cloud pairs and, in one more launch, the sums over the first ``n_first``
+    pairs, over the rest, and their weighted total (``fpsg_chamfer_losses``); the backward builds the per-pair constant
+    gradients in one launch (``fpsg_chamfer_loss_grads``) and hands them to the K1 backward."""
+
+    @staticmethod
+    def forward(ctx, p1, p2, n_first, w_first, w_rest):
+        ctx.set_materialize_grads(False)
+        dist1, dist2, idx1, idx2 = _sided_forward(p1, p2)
+        B, N = dist1.shape
+        M = dist2.size(1)
+        out = torch.empty((3,), dtype=torch.float32, device=p1.device)
+        with torch.cuda.device(p1.device):
+            rc = _hip.load().fpsg_chamfer_losses(_hip.ptr(dist1), _hip.ptr(dist2), B, N, M, int(n_first), float(w_first),
+                                                 float(w_rest), _hip.ptr(out), _hip.stream_of(p1))
+        _hip.check(rc, "fpsg_chamfer_losses")
+        ctx.save_for_backward(p1, p2, idx1, idx2)
+        ctx.cfg = (int(n_first), float(w_first), float(w_rest))
+        return out[0], out[1], out[2]
+
+    @staticmethod
+    def backward(ctx, g_first, g_rest, g_total):
+        if g_first is None and g_rest is None and g_total is None:
+            return None, None, None, None, None
+        p1, p2, idx1, idx2 = ctx.saved_tensors
+        n_first, w_first, w_rest = ctx.cfg
+        B, N, _ = p1.shape
+        M = p2.size(1)
+        keep = [None if g is None else g.reshape(1).contiguous().float() for g in (g_first, g_rest, g_total)]
+        g1 = torch.empty((B, N), dtype=torch.float32, device=p1.device)
+        g2 = torch.empty((B, M), dtype=torch.float32, device=p1.device)
+        with torch.cuda.device(p1.device):
+            rc = _hip.load().fpsg_chamfer_loss_grads(*(None if g is None else _hip.ptr(g) for g in keep), B, N, M,
+                                                     n_first, w_first, w_rest, _hip.ptr(g1), _hip.ptr(g2),
+                                                     _hip.stream_of(p1))
+        _hip.check(rc, "fpsg_chamfer_loss_grads")
+        gx1, gx2 = _sided_backward(p1, p2, idx1, idx2, g1, g2)
+        return gx1, gx2, None, None, None
+
+
+def episode_chamfer_losses(p1: torch.Tensor, p2: torch.Tensor, n_first: int, w_first: float, w_rest: float):
+    """``cd = chamfer_distance(p1, p2)`` over B pairs -> ``(cd[:n_first].sum(), cd[n_first:].sum(),
+    w_first * first + w_rest * rest)`` as 0-dim tensors: the reconstruction losses of an episode whose query and
+    support pairs were batched into one K1 call (reference few_shot.py:110-124), two launches instead of ten."""
+    return _EpisodeChamfer.apply(p1, p2, n_first, w_first, w_rest)
 
 
 def sided_distances(p1: torch.Tensor, p2: torch.Tensor):

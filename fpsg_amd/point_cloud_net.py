@@ -204,6 +204,16 @@ def _momentum_weights(r, m, device):
     return w
 
 
+def _adjacent_rows(a, b):
+    """``a`` and ``b`` as one ``[2, n]`` tensor when they are consecutive contiguous rows of the same storage, else None."""
+    n = a.numel()
+    if (a.dim() == 1 and b.shape == a.shape and a.dtype == b.dtype and a.is_contiguous() and b.is_contiguous()
+            and a.untyped_storage().data_ptr() == b.untyped_storage().data_ptr()
+            and b.storage_offset() == a.storage_offset() + n):
+        return torch.as_strided(a, (2, n), (n, 1), a.storage_offset())
+    return None
+
+
 def _update_running(bns, r, mean, var):
     """``r`` sequential momentum updates per module of ``bns`` from the per-call statistics ``mean`` /
     ``var`` ``[len(bns)*r*C]`` (var unbiased, as torch), in closed form and as multi-tensor ops:
@@ -218,7 +228,11 @@ def _update_running(bns, r, mean, var):
         # one weighted sum over the r calls (the weights live on the device, built once per (r, m): the step stays
         # capturable) instead of 2r - 1 elementwise launches per statistic
         coef = _momentum_weights(r, m, mean.device)
-        new_mean, new_var = (mean3 * coef).sum(1), (var3 * coef).sum(1)
+        both = _adjacent_rows(mean, var)
+        if both is not None:                                        # K5 delivers them as the rows of one tensor
+            new_mean, new_var = (both.view(2, len(bns), r, C) * coef).sum(2).unbind(0)
+        else:
+            new_mean, new_var = (mean3 * coef).sum(1), (var3 * coef).sum(1)
     # (inside the train step's bn_counters.deferred() block these are batched with the other layers' updates)
     bn_counters.update_running([b.running_mean for b in bns] + [b.running_var for b in bns], (1 - m) ** r,
                                list(new_mean.unbind(0)) + list(new_var.unbind(0)), alpha)
@@ -248,6 +262,7 @@ class _DecoderLayer1(torch.autograd.Function):
         G, D, K = w1.shape
         B, L = x.shape
         BP = B * P
+        ctx.set_materialize_grads(False)        # no zero tensors for the (non-differentiable) statistics outputs
         w1 = w1.contiguous()
         pts = pts.contiguous()
         hlat = torch.baddbmm(b1, w1[..., :L], x.t().unsqueeze(0).expand(G, L, B))          # [G,D,B]
@@ -270,6 +285,8 @@ class _DecoderLayer1(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout, _gm, _gv):
+        if dout is None:
+            return (None,) * 11
         from . import _hip
         lib = _hip.load()
         w1, x, pts, hlat, chan = ctx.saved_tensors

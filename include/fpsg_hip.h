@@ -102,6 +102,17 @@ int fpsg_chamfer_bwd_scan(const float* xyz1, const float* xyz2,
                           int B, int N, int M,
                           float* gxyz1, float* gxyz2, fpsg_stream_t stream);
 
+/* K1l: the episode's reconstruction losses from the distances of one fpsg_chamfer_fwd* call over B cloud pairs of which
+ * the first n_first are the query pairs (src/models/few_shot.py:110-124: chamfer_distance(...).sum() per group, then
+ * query_factor * q + support_factor * s).  out3 = { sum_{b < n_first} cd_b, sum_{b >= n_first} cd_b,
+ * w_first * out3[0] + w_rest * out3[1] },  cd_b = mean_i dist1[b,i] + mean_j dist2[b,j].  B <= 4096.  Deterministic. */
+int fpsg_chamfer_losses(const float* dist1, const float* dist2, int B, int N, int M, int n_first,
+                        float w_first, float w_rest, float* out3, fpsg_stream_t stream);
+/* Its backward: g1 [B,N], g2 [B,M] (fully overwritten) = the gradients of the three values with respect to dist1 /
+ * dist2 given the upstream gradients g_first, g_rest, g_total (device scalars; null = none), ready for fpsg_chamfer_bwd. */
+int fpsg_chamfer_loss_grads(const float* g_first, const float* g_rest, const float* g_total, int B, int N, int M,
+                            int n_first, float w_first, float w_rest, float* g1, float* g2, fpsg_stream_t stream);
+
 /* ---- K3: kNN graph ----------------------------------------------------------------
  * Replaces `knn(x, k)` of src/dgcnn/model.py:13-20 (torch.matmul into a [B,N,N] matrix +
  * torch.topk).  x [B,C,N] fp32 channel-major (the reference's layout); idx [B,N,k] int32: for every point the k

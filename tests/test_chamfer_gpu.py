@@ -253,6 +253,44 @@ def test_chamfer_value_and_grad_vs_float64(gpu):
     np.testing.assert_allclose(t2.grad.cpu().numpy(), b.grad.numpy(), rtol=1e-4, atol=1e-9)
 
 
+@pytest.mark.parametrize("B,N,M,n_first", [(37, 2048, 2048, 5), (7, 301, 258, 3), (3, 64, 128, 0), (4, 100, 100, 4)])
+def test_episode_losses_equal_the_separate_operations(gpu, oracle, B, N, M, n_first):
+    """K1l (fpsg_chamfer_losses / fpsg_chamfer_loss_grads): the query sum, the support sum and the weighted total of
+    few_shot.py:110-124 from one launch -- values within fp32 summation-order noise of the PyTorch operation chain
+    and of the float64 sums over the oracle's distances; the cloud gradients bit-identical to the chain's for the
+    total (same per-pair constants), also when the gradient arrives through one of the partial sums."""
+    from fpsg_amd.metrics import chamfer_distance, episode_chamfer_losses
+    rng = np.random.default_rng(B * 1000 + N)
+    p1 = unit_ball_clouds(rng, B, N)
+    p2 = np.tanh(rng.standard_normal((B, M, 3))).astype(np.float32)
+    wq, ws = 1.0, 0.75
+    a1 = torch.from_numpy(p1).to(gpu).requires_grad_()
+    a2 = torch.from_numpy(p2).to(gpu).requires_grad_()
+    q, s, total = episode_chamfer_losses(a1, a2, n_first, wq, ws)
+    assert q.dim() == 0 and s.dim() == 0 and total.dim() == 0
+    b1 = torch.from_numpy(p1).to(gpu).requires_grad_()
+    b2 = torch.from_numpy(p2).to(gpu).requires_grad_()
+    cd = chamfer_distance(b1, b2)
+    rq, rs = cd[:n_first].sum(), cd[n_first:].sum()
+    rtotal = wq * rq + ws * rs
+    for got, want in ((q, rq), (s, rs), (total, rtotal)):
+        assert abs(got.item() - want.item()) <= 2e-6 * max(1.0, abs(want.item()))
+    od1, _, od2, _ = oracle.chamfer_fwd(p1, p2)
+    ocd = od1.astype(np.float64).mean(1) + od2.astype(np.float64).mean(1)
+    assert abs(q.item() - ocd[:n_first].sum()) <= 2e-6 * max(1.0, ocd[:n_first].sum())
+    assert abs(total.item() - (wq * ocd[:n_first].sum() + ws * ocd[n_first:].sum())) <= 2e-6 * max(1.0, ocd.sum())
+    total.backward()
+    rtotal.backward()
+    assert torch.equal(a1.grad, b1.grad) and torch.equal(a2.grad, b2.grad)
+    # a gradient through the partial sums only
+    a1.grad = a2.grad = b1.grad = b2.grad = None
+    q, s, total = episode_chamfer_losses(a1, a2, n_first, wq, ws)
+    (2.0 * q + 3.0 * s).backward()
+    cd = chamfer_distance(b1, b2)
+    (2.0 * cd[:n_first].sum() + 3.0 * cd[n_first:].sum()).backward()
+    assert torch.equal(a1.grad, b1.grad) and torch.equal(a2.grad, b2.grad)
+
+
 def test_full_size_properties(gpu):
     """BASELINE.json sizes (B=37 = 32-shot + 5-query clouds of 2048 points), checked
     through properties that need no oracle: self-distance is exactly zero with identity
