@@ -73,6 +73,17 @@ SIGNATURES = {
                       _c_int, _c_int, _c_int, ctypes.c_float, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_stream],
     "fpsg_dec1_bwd": [_c_f32p, _c_f32p, _c_f32p, _c_int, _c_int, _c_f32p, _c_f32p, _c_int, _c_int, _c_int, _c_int,
                       _c_int, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_stream],
+    "fpsg_dec1_fwd_ld": [_c_f32p, _c_int, _c_f32p, _c_int, _c_int, _c_f32p, _c_int, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_int,
+                         _c_int, _c_int, _c_int, _c_int, ctypes.c_float, _c_f32p, _c_int, _c_f32p, _c_f32p, _c_f32p,
+                         _c_stream],
+    "fpsg_dec1_bwd_ld": [_c_f32p, _c_int, _c_f32p, _c_int, _c_f32p, _c_int, _c_int, _c_f32p, _c_int, _c_f32p, _c_int, _c_int,
+                         _c_int, _c_int, _c_int, _c_int, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_stream],
+    "fpsg_bn_act_rows_fwd": [_c_f32p, _c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), _c_int,
+                             _c_f32p, _c_f32p, _c_f32p, _c_int, ctypes.c_float, _c_int, ctypes.c_float, _c_f32p,
+                             _c_f32p, _c_f32p, _c_stream],
+    "fpsg_bn_act_rows_bwd": [_c_f32p, _c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), _c_int,
+                             _c_f32p, _c_f32p, _c_f32p, _c_int, _c_int, ctypes.c_float, _c_f32p, _c_f32p, _c_f32p,
+                             _c_f32p, _c_stream],
     "fpsg_bn_workspace_floats": [_c_int, _c_int, _c_int],
     "fpsg_bn_act_fwd": [_c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, ctypes.c_float, _c_int, _c_int, _c_int, _c_int,
                         ctypes.c_float, _c_int, ctypes.c_float, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p,

@@ -22,6 +22,8 @@
 // All loops are 16-byte (float4) streams over contiguous row segments; work is split so that a
 // 64-channel, 37x224x224 tensor still fills the chip (the per-channel workgroup of the library
 // kernel cannot).  Deterministic: fixed partial layout, no atomics.
+#include <algorithm>
+
 #include "fpsg_common.h"
 
 namespace fpsg {
@@ -319,15 +321,39 @@ __global__ __launch_bounds__(64) void bn_dxsum_kernel(const float* __restrict__ 
 // MODE 0 forward, MODE 1 backward.
 constexpr int kBnSmallMax = 16384;
 
+// Column segments of the rows (blockIdx.y): segment s covers the elements off[s] .. off[s] + len[s] - 1 of every row and
+// is a BatchNorm call of its own -- its statistics and backward sums go to the s-th block of the per-channel outputs
+// (chan [4][C], batch_mean / batch_var [C] each, dgamma / dbeta / dpb [C] each).  The ordinary call is one segment
+// that is the whole row (ld == len[0]).  The decoder's two decodes of an episode share their GEMMs this way.
+constexpr int kBnMaxSegs = 4;
+struct BnSegs {
+  int ld;                  // distance between consecutive rows, in elements
+  int off[kBnMaxSegs], len[kBnMaxSegs];
+  int staged[kBnMaxSegs];  // the first sweep's values are kept in LDS (dynamic: N*L floats forward, 2*N*L backward)
+  int tpr_log2[kBnMaxSegs];  // threads per row: the smallest power of two >= the row's vectors (elements), at most the workgroup
+  int stat_stride;         // distance between the segments' blocks of batch_mean / batch_var_unbiased, in elements
+};
+
 template <int MODE, int ACT>
 __global__ __launch_bounds__(kBnThreads) void bn_small_kernel(
     const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ gamma,
-    const float* __restrict__ beta, const float* __restrict__ pb, int N, int C, int L, int training, float eps,
+    const float* __restrict__ beta, const float* __restrict__ pb, int N, int C, BnSegs segs, int training, float eps,
     float slope, float* __restrict__ out, float* __restrict__ chan, float* __restrict__ batch_mean,
     float* __restrict__ batch_var_unbiased, float* __restrict__ dgamma, float* __restrict__ dbeta,
-    float* __restrict__ dpb, float* __restrict__ run_mean, float* __restrict__ run_var, float momentum,
-    int staged /* the first sweep's values are kept in LDS (dynamic: N*L floats forward, 2*N*L backward) */,
-    int tpr_log2 /* threads per row: the smallest power of two >= the row's vectors (elements), at most the workgroup */) {
+    float* __restrict__ dpb, float* __restrict__ run_mean, float* __restrict__ run_var, float momentum) {
+  const int sgi = blockIdx.y;
+  const int L = segs.len[sgi], ld = segs.ld, staged = segs.staged[sgi], tpr_log2 = segs.tpr_log2[sgi];
+  x += segs.off[sgi];
+  out += segs.off[sgi];
+  if (MODE == 1) dy += segs.off[sgi];
+  chan += (size_t)sgi * 4 * C;
+  if (batch_mean) batch_mean += (size_t)sgi * segs.stat_stride;
+  if (batch_var_unbiased) batch_var_unbiased += (size_t)sgi * segs.stat_stride;
+  if (MODE == 1) {
+    dgamma += (size_t)sgi * C;
+    dbeta += (size_t)sgi * C;
+    if (dpb) dpb += (size_t)sgi * C;
+  }
   // The second sweep re-reads what the first one read.  With tens of thousands of 16-64 KB channels
   // in flight (the decoder's grouped BatchNorm: 24,624 channels) the 4 MB L2 of an XCD does not hold
   // them -- PMC: 3.7 reads per write in the backward instead of 2 -- so each thread parks its own
@@ -364,7 +390,7 @@ __global__ __launch_bounds__(kBnThreads) void bn_small_kernel(
         for (int j = 0; j < kBnU; ++j) {
           xq[j] = gq[j] = (v4f){0.0f, 0.0f, 0.0f, 0.0f};
           if (has) {
-            const size_t base = ((size_t)(n_first + j * rpi) * C + c) * L;
+            const size_t base = ((size_t)(n_first + j * rpi) * C + c) * ld;
             xq[j] = reinterpret_cast<const v4f*>(x + base)[e0];
             if (MODE == 1) gq[j] = reinterpret_cast<const v4f*>(dy + base)[e0];
           }
@@ -395,7 +421,7 @@ __global__ __launch_bounds__(kBnThreads) void bn_small_kernel(
       }
     }
     for (int n = n_first; n < N; n += rpi) {
-      const size_t base = ((size_t)n * C + c) * L;
+      const size_t base = ((size_t)n * C + c) * ld;
       if (vec) {
         const v4f* __restrict__ xp = reinterpret_cast<const v4f*>(x + base);
         const v4f* __restrict__ gp = reinterpret_cast<const v4f*>(MODE == 1 ? dy + base : x + base);
@@ -464,7 +490,7 @@ __global__ __launch_bounds__(kBnThreads) void bn_small_kernel(
   const float k1 = bc[0], k2 = bc[1], k3 = bc[2];
   float acc = 0.0f, unused = 0.0f;
   for (int n = n0; n < N; n += rpi) {
-    const size_t base = ((size_t)n * C + c) * L;
+    const size_t base = ((size_t)n * C + c) * ld;
     if (vec) {
       const v4f* __restrict__ xp = reinterpret_cast<const v4f*>(x + base);
       const v4f* __restrict__ gp = reinterpret_cast<const v4f*>(MODE == 1 ? dy + base : x + base);
@@ -518,26 +544,46 @@ __global__ __launch_bounds__(kBnThreads) void bn_small_kernel(
   }
 }
 
+inline void small_segment(BnSegs& g, int i, int N, int off, int L, int training, bool backward) {
+  g.off[i] = off;
+  g.len[i] = L;
+  // first-sweep values parked in LDS when they fit the default 64 KB of dynamic LDS
+  const size_t need = (size_t)N * L * sizeof(float) * (backward ? 2 : 1);
+  g.staged[i] = ((L & 3) == 0 && need <= 64 * 1024 && (backward || training)) ? 1 : 0;
+  const int row_items = (L & 3) == 0 ? L / 4 : L;
+  int t = 0;
+  while ((1 << t) < row_items && (1 << t) < kBnThreads) ++t;
+  g.tpr_log2[i] = t;
+}
+
+template <int MODE>
+void launch_small_segs(int act, const float* x, const float* dy, const float* gamma, const float* beta, const float* pb,
+                       int N, int C, const BnSegs& g, int nseg, int training, float eps, float slope, float* out,
+                       float* chan, float* bm, float* bv, float* dgamma, float* dbeta, float* dpb, float* rmean,
+                       float* rvar, float momentum, hipStream_t s) {
+  dim3 grid(C, nseg);
+  size_t lds = 0;
+  for (int i = 0; i < nseg; ++i)
+    if (g.staged[i]) lds = std::max(lds, (size_t)N * g.len[i] * sizeof(float) * (MODE == 1 ? 2 : 1));
+#define FPSG_SMALL(A) hipLaunchKernelGGL((bn_small_kernel<MODE, A>), grid, dim3(kBnThreads), lds, s, x, dy, gamma, beta, \
+                                         pb, N, C, g, training, eps, slope, out, chan, bm, bv, dgamma, dbeta, dpb, rmean, \
+                                         rvar, momentum)
+  if (act == kActRelu) FPSG_SMALL(kActRelu);
+  else if (act == kActLeaky) FPSG_SMALL(kActLeaky);
+  else FPSG_SMALL(kActNone);
+#undef FPSG_SMALL
+}
+
 template <int MODE>
 void launch_small(int act, const float* x, const float* dy, const float* gamma, const float* beta, const float* pb,
                   int N, int C, int L, int training, float eps, float slope, float* out, float* chan, float* bm,
                   float* bv, float* dgamma, float* dbeta, float* dpb, float* rmean, float* rvar, float momentum,
                   hipStream_t s) {
-  dim3 grid(C);
-  // first-sweep values parked in LDS when they fit the default 64 KB of dynamic LDS
-  const size_t need = (size_t)N * L * sizeof(float) * (MODE == 1 ? 2 : 1);
-  const int staged = ((L & 3) == 0 && need <= 64 * 1024 && (MODE == 1 || training)) ? 1 : 0;
-  const size_t lds = staged ? need : 0;
-  const int row_items = (L & 3) == 0 ? L / 4 : L;
-  int tpr_log2 = 0;
-  while ((1 << tpr_log2) < row_items && (1 << tpr_log2) < kBnThreads) ++tpr_log2;
-#define FPSG_SMALL(A) hipLaunchKernelGGL((bn_small_kernel<MODE, A>), grid, dim3(kBnThreads), lds, s, x, dy, gamma, beta, \
-                                         pb, N, C, L, training, eps, slope, out, chan, bm, bv, dgamma, dbeta, dpb, rmean, \
-                                         rvar, momentum, staged, tpr_log2)
-  if (act == kActRelu) FPSG_SMALL(kActRelu);
-  else if (act == kActLeaky) FPSG_SMALL(kActLeaky);
-  else FPSG_SMALL(kActNone);
-#undef FPSG_SMALL
+  BnSegs g{};
+  g.ld = L;
+  small_segment(g, 0, N, 0, L, training, MODE == 1);
+  launch_small_segs<MODE>(act, x, dy, gamma, beta, pb, N, C, g, 1, training, eps, slope, out, chan, bm, bv, dgamma,
+                          dbeta, dpb, rmean, rvar, momentum, s);
 }
 
 int slices_for(int N, int L) {
@@ -1054,6 +1100,68 @@ extern "C" int fpsg_bn_act_fwd(const float* x, const float* pre_bias, const floa
   }
   launch_apply<0>(act, x, nullptr, chan, nullptr, pre_bias, N, C, L, slope, y, nullptr, s);
   return launch_status("fpsg_bn_act_fwd(apply)");
+}
+
+namespace fpsg {
+namespace {
+int rows_segments(const char* fn, int ld, const int* seg_off, const int* seg_len, int nseg, int C, int act, bool backward,
+                  BnSegs& g) {
+  FPSG_REQUIRE(C > 0 && C <= 65535 * 64 && ld > 0, FPSG_E_SHAPE, "%s: C, ld must be positive (got %d, %d)", fn, C, ld);
+  FPSG_REQUIRE(act >= kActNone && act <= kActLeaky, FPSG_E_SHAPE, "%s: unknown activation %d", fn, act);
+  FPSG_REQUIRE(nseg >= 1 && nseg <= kBnMaxSegs, FPSG_E_LIMIT, "%s: %d segments (1..%d)", fn, nseg, kBnMaxSegs);
+  FPSG_REQUIRE_PTR(seg_off); FPSG_REQUIRE_PTR(seg_len);
+  FPSG_REQUIRE((ld & 3) == 0, FPSG_E_ALIGN, "%s: ld = %d must be a multiple of 4", fn, ld);
+  g = BnSegs{};
+  g.ld = ld;
+  for (int i = 0; i < nseg; ++i) {
+    FPSG_REQUIRE(seg_len[i] > 0 && seg_len[i] <= kBnSmallMax && seg_off[i] >= 0 && seg_off[i] + seg_len[i] <= ld,
+                 FPSG_E_SHAPE, "%s: segment %d = [%d, +%d) does not fit a row of %d (a segment holds at most %d)", fn, i,
+                 seg_off[i], seg_len[i], ld, kBnSmallMax);
+    FPSG_REQUIRE((seg_off[i] & 3) == 0, FPSG_E_ALIGN, "%s: segment offset %d must be a multiple of 4", fn, seg_off[i]);
+    for (int j = 0; j < i; ++j)
+      FPSG_REQUIRE(seg_off[i] >= seg_off[j] + seg_len[j] || seg_off[j] >= seg_off[i] + seg_len[i], FPSG_E_SHAPE,
+                   "%s: segments %d and %d overlap", fn, j, i);
+    small_segment(g, i, 1, seg_off[i], seg_len[i], 1, backward);
+  }
+  return 0;
+}
+}  // namespace
+}  // namespace fpsg
+
+extern "C" int fpsg_bn_act_rows_fwd(const float* x, int ld, const int* seg_off, const int* seg_len, int nseg,
+                                    const float* pre_bias, const float* gamma, const float* beta, int C, float eps,
+                                    int act, float slope, float* y, float* chan, float* stats,
+                                    fpsg_stream_t stream) {
+  using namespace fpsg;
+  BnSegs g;
+  int rc = rows_segments("fpsg_bn_act_rows_fwd", ld, seg_off, seg_len, nseg, C, act, false, g);
+  if (rc) return rc;
+  FPSG_REQUIRE_PTR(x); FPSG_REQUIRE_PTR(y); FPSG_REQUIRE_PTR(chan);
+  FPSG_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0, FPSG_E_ALIGN,
+               "fpsg_bn_act_rows_fwd: x and y must be 16-byte aligned");
+  g.stat_stride = 2 * C;
+  launch_small_segs<0>(act, x, nullptr, gamma, beta, pre_bias, 1, C, g, nseg, 1, eps, slope, y, chan, stats,
+                       stats ? stats + C : nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, -1.0f,
+                       static_cast<hipStream_t>(stream));
+  return launch_status("fpsg_bn_act_rows_fwd");
+}
+
+extern "C" int fpsg_bn_act_rows_bwd(const float* x, int ld, const int* seg_off, const int* seg_len, int nseg,
+                                    const float* pre_bias, const float* dy, const float* chan, int C, int act,
+                                    float slope, float* dx, float* dgamma, float* dbeta, float* dpre_bias,
+                                    fpsg_stream_t stream) {
+  using namespace fpsg;
+  BnSegs g;
+  int rc = rows_segments("fpsg_bn_act_rows_bwd", ld, seg_off, seg_len, nseg, C, act, true, g);
+  if (rc) return rc;
+  FPSG_REQUIRE_PTR(x); FPSG_REQUIRE_PTR(dy); FPSG_REQUIRE_PTR(chan); FPSG_REQUIRE_PTR(dx);
+  FPSG_REQUIRE_PTR(dgamma); FPSG_REQUIRE_PTR(dbeta);
+  FPSG_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(dx)) & 15) == 0,
+               FPSG_E_ALIGN, "fpsg_bn_act_rows_bwd: x, dy and dx must be 16-byte aligned");
+  launch_small_segs<1>(act, x, dy, nullptr, nullptr, pre_bias, 1, C, g, nseg, 1, 0.0f, slope, dx,
+                       const_cast<float*>(chan), nullptr, nullptr, dgamma, dbeta, dpre_bias, nullptr, nullptr, -1.0f,
+                       static_cast<hipStream_t>(stream));
+  return launch_status("fpsg_bn_act_rows_bwd");
 }
 
 extern "C" int fpsg_bn_stats(const float* x, const float* pre_bias, const float* gamma, const float* beta,

@@ -67,6 +67,10 @@ struct Dec1Args {
   const float* rvar;
   int G, D, B, P, ldw, wofs, training;
   float eps;
+  int ld_pts;           // distance between the rows of pts, in elements (B*P when the call owns the whole rows)
+  int ld_out;           // the same for out (forward) / dout (backward)
+  int accumulate;       // backward: dw's point columns, dgamma and dbeta are added to what the buffers hold
+  int ld_hlat;          // distance between the rows of hlat / dhlat (B when the call owns them)
 };
 
 // LDS: pts [3][BP] | hl [kD1Tile][B]
@@ -83,12 +87,14 @@ __global__ __launch_bounds__(kD1Threads) void dec1_fwd_kernel(Dec1Args a, float*
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   {
-    const v4f* src = reinterpret_cast<const v4f*>(a.pts + (size_t)g * 3 * BP);
     v4f* dst = reinterpret_cast<v4f*>(sp);
-    for (int e = tid; e < (3 * BP) / 4; e += kD1Threads) dst[e] = src[e];
+    for (int r = 0; r < 3; ++r) {
+      const v4f* src = reinterpret_cast<const v4f*>(a.pts + ((size_t)g * 3 + r) * a.ld_pts);
+      for (int e = tid; e < BP / 4; e += kD1Threads) dst[r * (BP / 4) + e] = src[e];
+    }
     for (int e = tid; e < kD1Tile * a.B; e += kD1Threads) {
       const int c = e / a.B, b = e - c * a.B;
-      hl[e] = (d0 + c < a.D) ? a.hlat[((size_t)g * a.D + d0 + c) * a.B + b] : 0.0f;
+      hl[e] = (d0 + c < a.D) ? a.hlat[((size_t)g * a.D + d0 + c) * a.ld_hlat + b] : 0.0f;
     }
   }
   __syncthreads();
@@ -135,7 +141,7 @@ __global__ __launch_bounds__(kD1Threads) void dec1_fwd_kernel(Dec1Args a, float*
       const size_t C = (size_t)a.G * a.D;
       chan[gd] = scale; chan[C + gd] = shift; chan[2 * C + gd] = mean; chan[3 * C + gd] = rstd;
     }
-    v4f* orow = reinterpret_cast<v4f*>(out + gd * BP);
+    v4f* orow = reinterpret_cast<v4f*>(out + gd * a.ld_out);
     for (int e4 = lane; e4 < BP / 4; e4 += 64) {
       const v4f X = reinterpret_cast<const v4f*>(sp)[e4], Y = reinterpret_cast<const v4f*>(sp + BP)[e4],
                 Z = reinterpret_cast<const v4f*>(sp + 2 * BP)[e4];
@@ -169,12 +175,14 @@ __global__ __launch_bounds__(kD1Threads) void dec1_bwd_kernel(Dec1Args a, const 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   {
-    const v4f* src = reinterpret_cast<const v4f*>(a.pts + (size_t)g * 3 * BP);
     v4f* dst = reinterpret_cast<v4f*>(sp);
-    for (int e = tid; e < (3 * BP) / 4; e += kD1Threads) dst[e] = src[e];
+    for (int r = 0; r < 3; ++r) {
+      const v4f* src = reinterpret_cast<const v4f*>(a.pts + ((size_t)g * 3 + r) * a.ld_pts);
+      for (int e = tid; e < BP / 4; e += kD1Threads) dst[r * (BP / 4) + e] = src[e];
+    }
     for (int e = tid; e < kD1Tile * a.B; e += kD1Threads) {
       const int c = e / a.B, b = e - c * a.B;
-      hl[e] = (d0 + c < a.D) ? a.hlat[((size_t)g * a.D + d0 + c) * a.B + b] : 0.0f;
+      hl[e] = (d0 + c < a.D) ? a.hlat[((size_t)g * a.D + d0 + c) * a.ld_hlat + b] : 0.0f;
     }
   }
   __syncthreads();
@@ -205,7 +213,7 @@ __global__ __launch_bounds__(kD1Threads) void dec1_bwd_kernel(Dec1Args a, const 
 #pragma unroll
     for (int cc = 0; cc < kD1ChPerWave; ++cc) {
       const size_t gd = (size_t)g * a.D + (live[cc] ? d0 + wave * kD1ChPerWave + cc : a.D - 1);
-      drow[cc] = reinterpret_cast<const v4f*>(dout + gd * BP);
+      drow[cc] = reinterpret_cast<const v4f*>(dout + gd * a.ld_out);
       hc[cc] = hl + (wave * kD1ChPerWave + cc) * a.B;
       s[cc] = 0.0f; sh[cc] = 0.0f;
     }
@@ -247,8 +255,8 @@ __global__ __launch_bounds__(kD1Threads) void dec1_bwd_kernel(Dec1Args a, const 
       const size_t gd = (size_t)g * a.D + d0 + wave * kD1ChPerWave + cc;
       const double S = wave_sum_f64((double)s[cc]), SH = wave_sum_f64((double)sh[cc]);
       if (lane == 0) {
-        dbeta[gd] = (float)S;
-        dgamma[gd] = (float)SH;
+        dbeta[gd] = a.accumulate ? dbeta[gd] + (float)S : (float)S;
+        dgamma[gd] = a.accumulate ? dgamma[gd] + (float)SH : (float)SH;
       }
       if (a.training) { c1[cc] = (float)(S / BP); c2[cc] = (float)(SH / BP); }
     }
@@ -265,7 +273,7 @@ __global__ __launch_bounds__(kD1Threads) void dec1_bwd_kernel(Dec1Args a, const 
 #pragma unroll
   for (int cc = 0; cc < kD1ChPerWave; ++cc) {
     const size_t gd = (size_t)g * a.D + (live[cc] ? d0 + wave * kD1ChPerWave + cc : a.D - 1);
-    drow2[cc] = reinterpret_cast<const v4f*>(dout + gd * BP);
+    drow2[cc] = reinterpret_cast<const v4f*>(dout + gd * a.ld_out);
     dyn[cc] = (v4f){0.0f, 0.0f, 0.0f, 0.0f};
     if (lane < BP / 4) dyn[cc] = ld_stream<NT>(drow2[cc] + lane);
   }
@@ -309,7 +317,7 @@ __global__ __launch_bounds__(kD1Threads) void dec1_bwd_kernel(Dec1Args a, const 
       }
       // gradient of hlat[d, b]: sum over the P points of cloud b = P/4 consecutive lanes of this block
       const float tot = group_sum(part, pshift4);
-      if (in && (lane & (pshift4 - 1)) == 0) dhlat[gd * a.B + b] = tot;
+      if (in && (lane & (pshift4 - 1)) == 0) dhlat[gd * a.ld_hlat + b] = tot;
     }
     // dpts of this element block: sum over the workgroup's channels, fixed wave order
 #pragma unroll
@@ -332,7 +340,8 @@ __global__ __launch_bounds__(kD1Threads) void dec1_bwd_kernel(Dec1Args a, const 
     const float t0 = wave_sum(aw0[cc]), t1 = wave_sum(aw1[cc]), t2 = wave_sum(aw2[cc]);
     if (lane == 0) {
       float* dst = dw + gd * a.ldw + a.wofs;
-      dst[0] = t0; dst[1] = t1; dst[2] = t2;
+      if (a.accumulate) { dst[0] += t0; dst[1] += t1; dst[2] += t2; }
+      else { dst[0] = t0; dst[1] = t1; dst[2] = t2; }
     }
   }
 }
@@ -357,11 +366,11 @@ inline int dec1_check(const char* fn, int G, int D, int B, int P, int ldw, int w
 
 extern "C" int fpsg_dec1_tiles(int D) { return (D + fpsg::kD1Tile - 1) / fpsg::kD1Tile; }
 
-extern "C" int fpsg_dec1_fwd(const float* hlat, const float* w, int ldw, int wofs, const float* pts,
-                             const float* gamma, const float* beta, const float* running_mean,
-                             const float* running_var, int G, int D, int B, int P, int training, float eps,
-                             float* out, float* chan, float* batch_mean, float* batch_var_unbiased,
-                             fpsg_stream_t stream) {
+extern "C" int fpsg_dec1_fwd_ld(const float* hlat, int ld_hlat, const float* w, int ldw, int wofs, const float* pts, int ld_pts,
+                                const float* gamma, const float* beta, const float* running_mean,
+                                const float* running_var, int G, int D, int B, int P, int training, float eps,
+                                float* out, int ld_out, float* chan, float* batch_mean, float* batch_var_unbiased,
+                                fpsg_stream_t stream) {
   using namespace fpsg;
   int rc = dec1_check("fpsg_dec1_fwd", G, D, B, P, ldw, wofs);
   if (rc) return rc;
@@ -371,7 +380,11 @@ extern "C" int fpsg_dec1_fwd(const float* hlat, const float* w, int ldw, int wof
                "fpsg_dec1_fwd: eval mode needs the running statistics");
   FPSG_REQUIRE((reinterpret_cast<uintptr_t>(pts) & 15) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0,
                FPSG_E_ALIGN, "fpsg_dec1_fwd: pts / out must be 16-byte aligned");
-  Dec1Args a{hlat, w, pts, gamma, beta, running_mean, running_var, G, D, B, P, ldw, wofs, training, eps};
+  FPSG_REQUIRE(ld_pts >= B * P && ld_out >= B * P && (ld_pts & 3) == 0 && (ld_out & 3) == 0 && ld_hlat >= B, FPSG_E_SHAPE,
+               "fpsg_dec1_fwd: row strides %d / %d must be multiples of 4, at least B*P = %d (hlat: %d >= %d)", ld_pts,
+               ld_out, B * P, ld_hlat, B);
+  Dec1Args a{hlat, w, pts, gamma, beta, running_mean, running_var, G, D, B, P, ldw, wofs, training, eps, ld_pts, ld_out, 0,
+             ld_hlat};
   const size_t lds_bytes = dec1_lds_bytes(B, P, false);
   // the output (403 MB at 32 clouds) is written once: past the Infinity Cache when it exceeds it
   auto kern = beyond_cache((size_t)G * D * B * P * sizeof(float)) ? dec1_fwd_kernel<true> : dec1_fwd_kernel<false>;
@@ -385,10 +398,19 @@ extern "C" int fpsg_dec1_fwd(const float* hlat, const float* w, int ldw, int wof
   return launch_status("fpsg_dec1_fwd");
 }
 
-extern "C" int fpsg_dec1_bwd(const float* dout, const float* hlat, const float* w, int ldw, int wofs,
-                             const float* pts, const float* chan, int G, int D, int B, int P, int training,
-                             float* dhlat, float* dw, float* dpts_part, float* dgamma, float* dbeta,
+extern "C" int fpsg_dec1_fwd(const float* hlat, const float* w, int ldw, int wofs, const float* pts,
+                             const float* gamma, const float* beta, const float* running_mean,
+                             const float* running_var, int G, int D, int B, int P, int training, float eps,
+                             float* out, float* chan, float* batch_mean, float* batch_var_unbiased,
                              fpsg_stream_t stream) {
+  return fpsg_dec1_fwd_ld(hlat, B, w, ldw, wofs, pts, B * P, gamma, beta, running_mean, running_var, G, D, B, P, training,
+                          eps, out, B * P, chan, batch_mean, batch_var_unbiased, stream);
+}
+
+extern "C" int fpsg_dec1_bwd_ld(const float* dout, int ld_dout, const float* hlat, int ld_hlat, const float* w, int ldw, int wofs,
+                                const float* pts, int ld_pts, const float* chan, int G, int D, int B, int P,
+                                int training, int accumulate, float* dhlat, float* dw, float* dpts_part, float* dgamma,
+                                float* dbeta, fpsg_stream_t stream) {
   using namespace fpsg;
   int rc = dec1_check("fpsg_dec1_bwd", G, D, B, P, ldw, wofs);
   if (rc) return rc;
@@ -396,7 +418,11 @@ extern "C" int fpsg_dec1_bwd(const float* dout, const float* hlat, const float* 
   FPSG_REQUIRE_PTR(dhlat); FPSG_REQUIRE_PTR(dw); FPSG_REQUIRE_PTR(dpts_part); FPSG_REQUIRE_PTR(dgamma); FPSG_REQUIRE_PTR(dbeta);
   FPSG_REQUIRE((reinterpret_cast<uintptr_t>(pts) & 15) == 0 && (reinterpret_cast<uintptr_t>(dout) & 15) == 0,
                FPSG_E_ALIGN, "fpsg_dec1_bwd: pts / dout must be 16-byte aligned");
-  Dec1Args a{hlat, w, pts, nullptr, nullptr, nullptr, nullptr, G, D, B, P, ldw, wofs, training, 0.0f};
+  FPSG_REQUIRE(ld_pts >= B * P && ld_dout >= B * P && (ld_pts & 3) == 0 && (ld_dout & 3) == 0 && ld_hlat >= B, FPSG_E_SHAPE,
+               "fpsg_dec1_bwd: row strides %d / %d must be multiples of 4, at least B*P = %d (hlat: %d >= %d)", ld_pts,
+               ld_dout, B * P, ld_hlat, B);
+  Dec1Args a{hlat, w, pts, nullptr, nullptr, nullptr, nullptr, G, D, B, P, ldw, wofs, training, 0.0f, ld_pts, ld_dout,
+             accumulate ? 1 : 0, ld_hlat};
   const size_t lds_bytes = dec1_lds_bytes(B, P, true);
   // the output gradient's second (last) read of a row
   auto kern = beyond_cache((size_t)G * D * B * P * sizeof(float)) ? dec1_bwd_kernel<true> : dec1_bwd_kernel<false>;
@@ -408,4 +434,12 @@ extern "C" int fpsg_dec1_bwd(const float* dout, const float* hlat, const float* 
   hipLaunchKernelGGL(kern, dim3((unsigned)fpsg_dec1_tiles(D), (unsigned)G), dim3(kD1Threads), lds_bytes,
                      static_cast<hipStream_t>(stream), a, dout, chan, dhlat, dw, dpts_part, dgamma, dbeta);
   return launch_status("fpsg_dec1_bwd");
+}
+
+extern "C" int fpsg_dec1_bwd(const float* dout, const float* hlat, const float* w, int ldw, int wofs,
+                             const float* pts, const float* chan, int G, int D, int B, int P, int training,
+                             float* dhlat, float* dw, float* dpts_part, float* dgamma, float* dbeta,
+                             fpsg_stream_t stream) {
+  return fpsg_dec1_bwd_ld(dout, B * P, hlat, B, w, ldw, wofs, pts, B * P, chan, G, D, B, P, training, 0, dhlat, dw,
+                          dpts_part, dgamma, dbeta, stream);
 }

@@ -113,18 +113,28 @@ class ImgPCProtoNet(nn.Module):
     def _loss_single_class(self, img_s, img_q, img_ad, pc_s, pc_q, pc_ad):
         img_zad, img_zq, pc_z_proto, pc_z_ad = self._encode(img_s, img_q, img_ad, pc_s, pc_ad)
         pack = self._decoder_pack() if self.intra_flag else None
-        syn_q = self._decode_queries(img_zq, pc_z_proto, pack)
         ref_q = pc_q.squeeze(0).contiguous()
         if self.intra_flag:
-            syn_s = self._decode(torch.cat([img_zad, pc_z_ad], dim=1), pack)
             ref_s = pc_ad.squeeze(0).contiguous()
+            n_q = img_zq.size(0)
+            pair = getattr(self.pc_decoder, "forward_pair", None)
+            if pair is not None and pack is not None:
+                # the two decodes (queries, then supports) side by side: every GEMM of the decoder once (PCDecoder.forward_pair)
+                proto = pc_z_proto.mean(0, keepdim=True).expand(n_q, -1)
+                syn = pair(torch.cat([img_zq, proto], dim=1), torch.cat([img_zad, pc_z_ad], dim=1), pack=pack)
+                syn_q, syn_s = syn[:n_q], syn[n_q:]
+            else:
+                syn_q = self._decode_queries(img_zq, pc_z_proto, pack)
+                syn_s = self._decode(torch.cat([img_zad, pc_z_ad], dim=1), pack)
+                syn = None
             if self.pc_metric is chamfer_distance and syn_q.shape[1:] == syn_s.shape[1:] \
                     and ref_q.shape[1:] == ref_s.shape[1:]:
                 # the two Chamfer calls of the reference (few_shot.py:110,117) as ONE launch over
                 # Q + S cloud pairs: per-pair results are independent, and a larger batch fills
                 # the chip better (K1 is 6 us + 0.9 us per pair)
-                n_q = syn_q.size(0)
-                syn, ref = torch.cat([syn_q, syn_s]), torch.cat([ref_q, ref_s])
+                if syn is None:
+                    syn = torch.cat([syn_q, syn_s])
+                ref = torch.cat([ref_q, ref_s])
                 if syn.is_cuda and _fused_losses_enabled():
                     # K1l: the two sums and the weighted total in one launch behind K1 (and one in the backward)
                     loss_rec_q, loss_rec_s, loss_recon = episode_chamfer_losses(syn, ref, n_q, self.query_factor,
@@ -137,6 +147,7 @@ class ImgPCProtoNet(nn.Module):
                 loss_rec_q = self.pc_metric(syn_q, ref_q).sum()
                 loss_rec_s = self.pc_metric(syn_s, ref_s).sum()
         else:
+            syn_q = self._decode_queries(img_zq, pc_z_proto, pack)
             loss_rec_q = self.pc_metric(syn_q, ref_q).sum()
             loss_rec_s = torch.zeros(1, dtype=loss_rec_q.dtype, device=loss_rec_q.device)
         loss_recon = self.query_factor * loss_rec_q + self.support_factor * loss_rec_s

@@ -101,6 +101,64 @@ class _BNAct(torch.autograd.Function):
                 None, dpb, None)
 
 
+class _BNActRows(torch.autograd.Function):
+    """Training-mode ``act(BN(x + pre_bias))`` over column segments of the rows of ``x [..., M]`` (contiguous): segment
+    ``i`` = the next ``seg_lens[i]`` columns is one BatchNorm call with its own statistics
+    (``fpsg_bn_act_rows_fwd/bwd``: one launch for all segments).  Returns ``(y, stats [nseg, 2, rows])`` -- batch mean
+    and unbiased batch variance per segment and row; the affine parameters' gradients are summed over the segments."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, pre_bias, seg_lens, eps, act_code, slope):
+        import ctypes
+        M = x.shape[-1]
+        rows = x.numel() // M
+        seg_lens = [int(n) for n in seg_lens]
+        if sum(seg_lens) != M or not x.is_contiguous():
+            raise ValueError(f"_BNActRows: segments {seg_lens} must tile the contiguous rows of {tuple(x.shape)}")
+        nseg = len(seg_lens)
+        offs = [sum(seg_lens[:i]) for i in range(nseg)]
+        c_off, c_len = (ctypes.c_int * nseg)(*offs), (ctypes.c_int * nseg)(*seg_lens)
+        lib = _hip.load()
+        dev = x.device
+        ctx.set_materialize_grads(False)
+        y = torch.empty_like(x)
+        chan = torch.empty((nseg, 4, rows), dtype=torch.float32, device=dev)
+        stats = torch.empty((nseg, 2, rows), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            rc = lib.fpsg_bn_act_rows_fwd(_hip.ptr(x), M, c_off, c_len, nseg,
+                                          _hip.ptr(pre_bias) if pre_bias is not None else None, _hip.ptr(weight),
+                                          _hip.ptr(bias), rows, float(eps), act_code, float(slope), _hip.ptr(y),
+                                          _hip.ptr(chan), _hip.ptr(stats), _hip.stream_of(x))
+        _hip.check(rc, "fpsg_bn_act_rows_fwd")
+        ctx.save_for_backward(x, chan, pre_bias)
+        ctx.cfg = (M, rows, offs, seg_lens, act_code, slope)
+        ctx.mark_non_differentiable(stats)
+        return y, stats
+
+    @staticmethod
+    def backward(ctx, gy, _gstats):
+        if gy is None:
+            return (None,) * 8
+        import ctypes
+        x, chan, pre_bias = ctx.saved_tensors
+        M, rows, offs, seg_lens, act_code, slope = ctx.cfg
+        nseg = len(seg_lens)
+        c_off, c_len = (ctypes.c_int * nseg)(*offs), (ctypes.c_int * nseg)(*seg_lens)
+        want_dpb = pre_bias is not None and ctx.needs_input_grad[3]
+        dev = x.device
+        gy = gy.contiguous()
+        dx = torch.empty_like(x)
+        grads = torch.empty((3 if want_dpb else 2, nseg, rows), dtype=torch.float32, device=dev)   # dgamma, dbeta, dpre_bias
+        with torch.cuda.device(dev):
+            rc = _hip.load().fpsg_bn_act_rows_bwd(
+                _hip.ptr(x), M, c_off, c_len, nseg, _hip.ptr(pre_bias) if pre_bias is not None else None, _hip.ptr(gy),
+                _hip.ptr(chan), rows, act_code, float(slope), _hip.ptr(dx), _hip.ptr(grads[0]), _hip.ptr(grads[1]),
+                _hip.ptr(grads[2]) if want_dpb else None, _hip.stream_of(x))
+        _hip.check(rc, "fpsg_bn_act_rows_bwd")
+        g = grads.sum(1) if nseg > 1 else grads[:, 0]          # the segments share the affine parameters and the bias
+        return dx, g[0], g[1], (g[2] if want_dpb else None), None, None, None, None
+
+
 class _BNActPool(torch.autograd.Function):
     """``max_pool2d(act(BN(x + pre_bias)), 2)`` as one op (K5 pooled variants): the forward writes
     only the pooled tensor, the backward re-derives the windows' arg-max from ``x``."""
@@ -352,6 +410,16 @@ def batch_norm_act(x, weight, bias, running_mean, running_var, training, momentu
         return _plain_act(y, act_code, slope), mean, var
     y = F.batch_norm(x, running_mean, running_var, weight, bias, training, 0.1 if momentum is None else momentum, eps)
     return _plain_act(y, act_code, slope)
+
+
+def batch_norm_act_rows(x, weight, bias, seg_lens, eps, act=None, pre_bias=None):
+    """Training-mode ``act(batch_norm(x + pre_bias))`` with independent batch statistics per column segment of the rows
+    of ``x [..., M]`` (K5, one launch): -> ``(y, stats [nseg, 2, rows])``, the batch mean and the unbiased batch variance
+    of every segment.  ROCm fp32 contiguous tensors only; the caller applies the running-statistics updates."""
+    act_code, slope = _parse_act(act)
+    if not _eligible(x):
+        raise RuntimeError("batch_norm_act_rows needs the HIP path (an fp32 tensor on the GPU)")
+    return _BNActRows.apply(x, weight, bias, pre_bias, tuple(seg_lens), eps, act_code, slope)
 
 
 def bn_act(bn: nn.modules.batchnorm._BatchNorm, x: torch.Tensor, act=None, pre_bias=None) -> torch.Tensor:

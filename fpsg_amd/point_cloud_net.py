@@ -27,7 +27,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import bn_counters
-from .fused_bn import batch_norm_act, bn_act
+from .fused_bn import batch_norm_act, batch_norm_act_rows, bn_act
 from .pointnet import PointNetfeat
 from .utils import get_template
 
@@ -240,6 +240,26 @@ def _update_running(bns, r, mean, var):
         bn_counters.count_batch(b, r)
 
 
+def _update_running_calls(bns, r, stats):
+    """``stats [n, 2, len(bns)*r*C]`` (batch mean, unbiased batch variance): the statistics of ``n`` consecutive forward
+    passes, each of which calls module ``i`` of ``bns`` ``r`` times -- ``n * r`` sequential momentum updates per module,
+    in closed form (see ``_update_running``)."""
+    n = stats.shape[0]
+    C, K = bns[0].num_features, len(bns)
+    m = 0.1 if bns[0].momentum is None else bns[0].momentum
+    runs = [b.running_mean for b in bns] + [b.running_var for b in bns]
+    if r == 1:
+        for i in range(n):          # views only: the updates are the multi-tensor ops of bn_counters
+            both = stats[i].view(2, K, C)
+            bn_counters.update_running(runs, 1 - m, list(both[0].unbind(0)) + list(both[1].unbind(0)), m)
+    else:
+        w = _momentum_weights(n * r, m, stats.device).view(n, 1, 1, r, 1)
+        new = (stats.view(n, 2, K, r, C) * w).sum((0, 3))                       # [2, K, C]
+        bn_counters.update_running(runs, (1 - m) ** (n * r), list(new[0].unbind(0)) + list(new[1].unbind(0)), 1.0)
+    for b in bns:
+        bn_counters.count_batch(b, n * r)
+
+
 def _layer1_fused_ok(x, pts, B, P, act) -> bool:
     """K9 applies: ROCm tensors, ReLU, patch sizes the kernel tiles (P = 4 x a power of two <= 256,
     B*P <= 8192).  ``FPSG_DEC1=0`` selects the library chain (A/B measurements)."""
@@ -310,6 +330,75 @@ class _DecoderLayer1(torch.autograd.Function):
         gx = torch.matmul(dhlat.reshape(G * D, B).t(), w1.reshape(G * D, K)[:, :L])          # [B,L]
         gpts = dpts_part.sum(dim=1)
         return gw, gb, gx, gpts, dgamma, dbeta, None, None, None, None, None
+
+
+class _DecoderLayer1Pair(torch.autograd.Function):
+    """``_DecoderLayer1`` for several decodes side by side (training mode): ``x [B, L]`` holds the latents of all decodes
+    in order, ``batches`` their sizes, ``pts`` / the result ``[G, ., B*P]`` their columns in the same order.  One latent
+    GEMM for all of them, one K9 launch per decode (its BatchNorm statistics are that decode's), every later layer then
+    runs once on the joint tensor.  Returns ``(out [G,D,B*P], stats [n, 2, G*D])``."""
+
+    @staticmethod
+    def forward(ctx, w1, b1, x, pts, gamma, beta, eps, P, batches):
+        from . import _hip
+        lib = _hip.load()
+        G, D, K = w1.shape
+        B, L = x.shape
+        M = B * P
+        ctx.set_materialize_grads(False)
+        w1 = w1.contiguous()
+        pts = pts.contiguous()
+        hlat = torch.baddbmm(b1, w1[..., :L], x.t().unsqueeze(0).expand(G, L, B))          # [G,D,B]
+        out = torch.empty((G, D, M), dtype=torch.float32, device=x.device)
+        chan = torch.empty((len(batches), 4, G * D), dtype=torch.float32, device=x.device)
+        stats = torch.empty((len(batches), 2, G * D), dtype=torch.float32, device=x.device)
+        b0 = 0
+        with torch.cuda.device(x.device):
+            for i, Bi in enumerate(batches):
+                rc = lib.fpsg_dec1_fwd_ld(_hip.ptr(hlat) + 4 * b0, B, _hip.ptr(w1), K, L, _hip.ptr(pts) + 4 * b0 * P, M,
+                                          _hip.ptr(gamma), _hip.ptr(beta), None, None, G, D, Bi, P, 1, float(eps),
+                                          _hip.ptr(out) + 4 * b0 * P, M, _hip.ptr(chan[i]), _hip.ptr(stats[i, 0]),
+                                          _hip.ptr(stats[i, 1]), _hip.stream_of(x))
+                _hip.check(rc, "fpsg_dec1_fwd_ld")
+                b0 += Bi
+        ctx.save_for_backward(w1, x, pts, hlat, chan)
+        ctx.cfg = (G, D, B, P, L, K, tuple(batches))
+        ctx.mark_non_differentiable(stats)
+        return out, stats
+
+    @staticmethod
+    def backward(ctx, dout, _gstats):
+        if dout is None:
+            return (None,) * 9
+        from . import _hip
+        lib = _hip.load()
+        w1, x, pts, hlat, chan = ctx.saved_tensors
+        G, D, B, P, L, K, batches = ctx.cfg
+        M = B * P
+        dev = x.device
+        dout = dout.contiguous()
+        T = lib.fpsg_dec1_tiles(D)
+        dhlat = torch.empty((G, D, B), dtype=torch.float32, device=dev)
+        gw = torch.empty((G, D, K), dtype=torch.float32, device=dev)       # latent columns by the GEMM below, point columns by K9
+        gpts = torch.empty((G, 3, M), dtype=torch.float32, device=dev)
+        dgamma = torch.empty((G * D,), dtype=torch.float32, device=dev)
+        dbeta = torch.empty((G * D,), dtype=torch.float32, device=dev)
+        b0 = 0
+        with torch.cuda.device(dev):
+            for i, Bi in enumerate(batches):
+                part = torch.empty((G, T, 3, Bi * P), dtype=torch.float32, device=dev)
+                rc = lib.fpsg_dec1_bwd_ld(_hip.ptr(dout) + 4 * b0 * P, M, _hip.ptr(hlat) + 4 * b0, B, _hip.ptr(w1), K, L,
+                                          _hip.ptr(pts) + 4 * b0 * P, M, _hip.ptr(chan[i]), G, D, Bi, P, 1,
+                                          1 if i else 0, _hip.ptr(dhlat) + 4 * b0, _hip.ptr(gw), _hip.ptr(part),
+                                          _hip.ptr(dgamma), _hip.ptr(dbeta), _hip.stream_of(x))
+                _hip.check(rc, "fpsg_dec1_bwd_ld")
+                torch.sum(part, dim=1, out=gpts[:, :, b0 * P:(b0 + Bi) * P])
+                b0 += Bi
+        # d/dW[:, :L] = dhlat x  written straight into the stacked gradient (ldc = L + 3): no split / concat copies
+        torch.bmm(dhlat, x.unsqueeze(0).expand(G, B, L), out=gw[..., :L])
+        gb = dhlat.sum(dim=2, keepdim=True)
+        gx = torch.matmul(dhlat.reshape(G * D, B).t(), w1.reshape(G * D, K)[:, :L])          # [B,L]
+        return gw, gb, gx, gpts, dgamma, dbeta, None, None, None
 
 
 class _StackFrozen(torch.autograd.Function):
@@ -433,6 +522,20 @@ def _group_batch_norm(h, bns, calls_per_bn, act, affine=None, pre_bias=None):
     return post(y.reshape(G, C, M))
 
 
+def _group_batch_norm_rows(h, bns, calls_per_bn, act, affine, pre_bias, seg_lens):
+    """``_group_batch_norm`` (training mode) for several forward passes side by side: the column segments
+    ``seg_lens`` of ``h [G, C, M]`` are consecutive passes, each normalised with its own batch statistics (K5, one
+    launch) and followed by its own running-statistics updates, in order."""
+    G, C, M = h.shape
+    gamma, beta = affine
+    fuse = "relu" if act is F.relu else None
+    post = (lambda t: t) if act is F.relu else act
+    y, stats = batch_norm_act_rows(h, gamma, beta, seg_lens, bns[0].eps, fuse, pre_bias=pre_bias)
+    with torch.no_grad():
+        _update_running_calls(bns, calls_per_bn, stats)
+    return post(y)
+
+
 class PCDecoder(nn.Module):
     """AtlasNet-style decoder: ``num_clusters`` clusters x ``num_nodes`` patches;
     ``forward(hidden[B, bottleneck]) -> [B, num_pts, 3]`` (contiguous).
@@ -483,6 +586,77 @@ class PCDecoder(nn.Module):
         if self.batched:
             return self._forward_batched(hidden_feat, grid, generator, pack)
         return self._forward_looped(hidden_feat, grid, generator)
+
+    def pair_ready(self, hidden_a, hidden_b) -> bool:
+        """``forward_pair`` has its joint form for these inputs: the batched decoder in training mode on the GPU, ReLU
+        patch MLPs, K9's patch sizes.  ``FPSG_DECODE_PAIR=0`` keeps the two separate passes (A/B measurements)."""
+        import os
+        c0 = self.cluster_pool[0]
+        P = c0.pts_per_node
+        return (self.batched and self.training and hidden_a.is_cuda and hidden_a.dtype == torch.float32
+                and hidden_a.dim() == 2 and hidden_b.dim() == 2 and hidden_a.shape[1] == hidden_b.shape[1]
+                and os.environ.get("FPSG_DECODE_PAIR", "1") != "0" and self.conf.raw_dim == 3
+                and c0.deformer.activation is F.relu and c0.node_pool[0].activation is F.relu
+                and _layer1_fused_ok(hidden_a, hidden_a, max(hidden_a.shape[0], hidden_b.shape[0]), P, F.relu))
+
+    def forward_pair(self, hidden_a, hidden_b, generator=None, pack=None, grids=None):
+        """``forward(hidden_a)`` then ``forward(hidden_b)`` -- the two decodes of an episode with intra-reconstruction
+        (queries, then supports) -- returned as ONE tensor ``[Ba + Bb, num_pts, 3]`` (a's clouds first).  Where
+        ``pair_ready``: every GEMM runs once on the two decodes' columns side by side, while each BatchNorm call keeps
+        its own batch statistics and its own running-statistics update, in the order of two separate passes (K5 over
+        column segments, K9 per decode); the shared parameters receive one gradient instead of two to be added.
+        ``grids`` (optional): ``(grid_a, grid_b)``, each as ``forward``'s ``grid``."""
+        if not self.pair_ready(hidden_a, hidden_b):
+            ga, gb = grids if grids is not None else (None, None)
+            return torch.cat([self.forward(hidden_a, ga, generator, pack), self.forward(hidden_b, gb, generator, pack)])
+        if pack is None:
+            pack = self.pack_parameters()
+        clusters = list(self.cluster_pool)
+        K, R = len(clusters), self.num_nodes
+        G = K * R
+        P = clusters[0].pts_per_node
+        act = clusters[0].deformer.activation
+        batches = (hidden_a.shape[0], hidden_b.shape[0])
+        B = sum(batches)
+        seg_lens = tuple(b * P for b in batches)
+        x = torch.cat([hidden_a, hidden_b])
+        L = x.shape[1]
+        dim = clusters[0].template[0].dim
+        square = type(clusters[0].template[0]).__name__ == "SquareTemplate"
+        cols = []
+        for i, b in enumerate(batches):   # drawn per decode, in the order of two separate passes
+            if grids is not None and grids[i] is not None:
+                g = torch.stack([t for per_cluster in grids[i] for t in per_cluster])  # [G,b,dim,P]
+            else:
+                g = torch.empty((G, b, dim, P), dtype=torch.float32, device=x.device)
+                g = g.uniform_(0, 1, generator=generator) if square else g.normal_(0, 1, generator=generator)
+            cols.append(g.permute(0, 2, 1, 3).reshape(G, g.size(2), b * P))
+        h = torch.cat(cols, dim=2)                                                      # [G,dim,B*P]
+
+        defs = [c.deformer for c in clusters]
+        w, b = pack["d1"]
+        h = _group_batch_norm_rows(torch.bmm(w, h), [d.bn1 for d in defs], R, act, pack["dbn1"], b.reshape(-1), seg_lens)
+        w, b = pack["d2"]
+        h = _group_batch_norm_rows(torch.bmm(w, h), [d.bn2 for d in defs], R, act, pack["dbn2"], b.reshape(-1), seg_lens)
+        w, b = pack["d3"]
+        pts = torch.tanh(torch.baddbmm(b, w, h))                                        # [G,raw,B*P]
+
+        nodes = [n for c in clusters for n in c.node_pool]
+        w1, b1 = pack["n1"]
+        if w1.size(2) - self.conf.raw_dim != L:
+            raise ValueError(f"PCDecoder: hidden size {L} does not match the first layer ({w1.size(2) - self.conf.raw_dim} latent columns)")
+        bn1s = [n.bn1 for n in nodes]
+        gamma, beta = pack["nbn1"]
+        h, stats = _DecoderLayer1Pair.apply(w1, b1, x, pts, gamma, beta, bn1s[0].eps, P, batches)
+        with torch.no_grad():
+            _update_running_calls(bn1s, 1, stats)
+        w, b = pack["n2"]
+        h = _group_batch_norm_rows(torch.bmm(w, h), [n.bn2 for n in nodes], 1, act, pack["nbn2"], b.reshape(-1), seg_lens)
+        w, b = pack["n3"]
+        h = _group_batch_norm_rows(torch.bmm(w, h), [n.bn3 for n in nodes], 1, act, pack["nbn3"], b.reshape(-1), seg_lens)
+        w, b = pack["n4"]
+        out = torch.tanh(torch.baddbmm(b, w, h))                                        # [G,3,B*P]
+        return out.view(G, 3, B, P).permute(2, 0, 3, 1).reshape(B, G * P, 3).contiguous()
 
     def pack_parameters(self):
         """The per-patch weights / biases / BatchNorm affine parameters stacked for the batched

@@ -269,6 +269,20 @@ int fpsg_dec1_bwd(const float* dout, const float* hlat, const float* w, int ldw,
                   const float* chan, int G, int D, int B, int P, int training, float* dhlat, float* dw,
                   float* dpts_part, float* dgamma, float* dbeta, fpsg_stream_t stream);
 
+/* The same with row strides: pts rows ld_pts apart, out / dout rows ld_out / ld_dout apart (multiples of 4, >= B*P),
+ * hlat / dhlat rows ld_hlat apart (>= B) --
+ * a call then owns a column range of tensors that hold several decodes side by side (an episode's query and support
+ * decodes share every GEMM after this layer).  accumulate != 0: dw's point columns, dgamma and dbeta are added to the
+ * buffers' contents (the second call of a pair) instead of overwriting them. */
+int fpsg_dec1_fwd_ld(const float* hlat, int ld_hlat, const float* w, int ldw, int wofs, const float* pts, int ld_pts,
+                     const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                     int G, int D, int B, int P, int training, float eps, float* out, int ld_out, float* chan,
+                     float* batch_mean, float* batch_var_unbiased, fpsg_stream_t stream);
+int fpsg_dec1_bwd_ld(const float* dout, int ld_dout, const float* hlat, int ld_hlat, const float* w, int ldw, int wofs,
+                     const float* pts, int ld_pts, const float* chan, int G, int D, int B, int P, int training,
+                     int accumulate, float* dhlat, float* dw, float* dpts_part, float* dgamma, float* dbeta,
+                     fpsg_stream_t stream);
+
 /* ---- K5: BatchNorm fused with its activation (training and eval mode) -------------------
  * Replaces the BatchNorm{1,2}d + ReLU / LeakyReLU module pairs of the reference networks
  * (src/models/image_net.py:14 VGG16-BN trunk; src/pointnet/model.py:30-44,220-233;
@@ -305,6 +319,19 @@ int fpsg_bn_stats(const float* x, const float* pre_bias, const float* gamma, con
 int fpsg_bn_act_bwd(const float* x, const float* pre_bias, const float* dy, const float* chan, int N, int C,
                     int L, int training, int act, float slope, float* dx, float* dgamma, float* dbeta,
                     float* dpre_bias, float* coef, float* ws, fpsg_stream_t stream);
+/* Training-mode K5 over column segments of C rows that lie ld elements apart (x, y, dy, dx share the layout): segment i
+ * = the elements seg_off[i] .. seg_off[i] + seg_len[i] - 1 of every row is one BatchNorm call (one reference
+ * BatchNorm1d call per patch and decode, src/models/point_cloud_net.py:76-80): own statistics, one launch for all
+ * segments.  nseg <= 4, seg_len <= 16384, ld and seg_off multiples of 4 (host arrays), segments disjoint.
+ *   fwd: y = act(BN(x + pre_bias)); chan [nseg][4][C]; stats [nseg][2][C] (optional): batch mean, unbiased batch variance.
+ *   bwd: dx; dgamma, dbeta, dpre_bias (optional) [nseg][C] -- the caller adds the segments (the affine parameters are
+ *        shared).  Columns outside every segment are neither read nor written. */
+int fpsg_bn_act_rows_fwd(const float* x, int ld, const int* seg_off, const int* seg_len, int nseg,
+                         const float* pre_bias, const float* gamma, const float* beta, int C, float eps, int act,
+                         float slope, float* y, float* chan, float* stats, fpsg_stream_t stream);
+int fpsg_bn_act_rows_bwd(const float* x, int ld, const int* seg_off, const int* seg_len, int nseg,
+                         const float* pre_bias, const float* dy, const float* chan, int C, int act, float slope,
+                         float* dx, float* dgamma, float* dbeta, float* dpre_bias, fpsg_stream_t stream);
 /* fpsg_bn_act_bwd with the two sums per channel delivered by the kernel that produced dy
  * (fpsg_wino_output_transform_bwd_stats): parts [C][n_parts][2].  ws may be NULL unless dpre_bias is wanted. */
 int fpsg_bn_act_bwd_parts(const float* x, const float* pre_bias, const float* dy, const float* chan, int N,

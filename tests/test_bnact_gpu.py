@@ -347,3 +347,67 @@ def test_max_variant_backward_without_the_dense_gradient(gpu, monkeypatch, shape
         assert float((new[3] - old[3]).abs().max()) <= 2e-5 * (float(old[3].abs().max()) + 1e-30)
     for x, y in zip(new, again):
         assert torch.equal(x, y)
+
+
+@pytest.mark.parametrize("rows,seg_lens,act,with_bias", [(48, (640, 4096), "relu", True), (7, (128, 256, 64), None, False),
+                                                         (130, (68, 100, 64), "relu", True)])
+def test_column_segments_equal_separate_calls(gpu, rows, seg_lens, act, with_bias):
+    """fpsg_bn_act_rows_fwd/bwd: BatchNorm over column segments of the rows in one launch = one K5 call per segment on
+    its own contiguous copy, bit for bit (output, batch statistics, input gradient); the affine / bias gradients are the
+    sums over the segments."""
+    from fpsg_amd.fused_bn import batch_norm_act, batch_norm_act_rows
+    gen = torch.Generator().manual_seed(rows)
+    M = sum(seg_lens)
+    x = torch.randn((1, rows, M), generator=gen).to(gpu)
+    gamma = (torch.randn(rows, generator=gen) * 0.5 + 1).to(gpu)
+    beta = (torch.randn(rows, generator=gen) * 0.1).to(gpu)
+    pb = (torch.randn(rows, generator=gen) * 0.3).to(gpu) if with_bias else None
+    gy = torch.randn((1, rows, M), generator=gen).to(gpu)
+
+    xr = x.clone().requires_grad_()
+    pr = [t.clone().requires_grad_() if t is not None else None for t in (gamma, beta, pb)]
+    y, stats = batch_norm_act_rows(xr, pr[0], pr[1], seg_lens, 1e-5, act, pre_bias=pr[2])
+    y.backward(gy)
+    assert stats.shape == (len(seg_lens), 2, rows)
+
+    off = 0
+    sums = [torch.zeros_like(gamma), torch.zeros_like(beta), torch.zeros_like(gamma)]
+    for i, n in enumerate(seg_lens):
+        xs = x[:, :, off:off + n].contiguous().requires_grad_()
+        ps = [t.clone().requires_grad_() if t is not None else None for t in (gamma, beta, pb)]
+        ys, mean, var = batch_norm_act(xs, ps[0], ps[1], None, None, True, 1.0, 1e-5, act, return_stats=True, pre_bias=ps[2])
+        ys.backward(gy[:, :, off:off + n].contiguous())
+        assert torch.equal(y[:, :, off:off + n], ys), i
+        assert torch.equal(stats[i, 0], mean) and torch.equal(stats[i, 1], var), i
+        assert torch.equal(xr.grad[:, :, off:off + n], xs.grad), i
+        for k in range(3):
+            if ps[k] is not None:
+                sums[k] += ps[k].grad
+        off += n
+    for k in range(3):
+        if pr[k] is not None:
+            scale = float(sums[k].abs().max()) + 1e-12
+            assert float((pr[k].grad - sums[k]).abs().max()) <= 1e-6 * scale, k
+
+
+def test_column_segments_reject_bad_layouts(gpu):
+    from fpsg_amd import _hip
+    import ctypes
+    lib = _hip.load()
+    x = torch.zeros((4, 64), device=gpu)
+    ch = torch.zeros((2, 4, 4), device=gpu)
+    g = torch.ones(4, device=gpu)
+
+    def call(ld, offs, lens):
+        n = len(offs)
+        return lib.fpsg_bn_act_rows_fwd(_hip.ptr(x), ld, (ctypes.c_int * n)(*offs), (ctypes.c_int * n)(*lens), n, None,
+                                        _hip.ptr(g), _hip.ptr(g), 4, 1e-5, 1, 0.0, _hip.ptr(x), _hip.ptr(ch), None,
+                                        _hip.stream_of(x))
+
+    assert call(64, [0, 32], [32, 32]) == 0
+    assert call(64, [0, 32], [32, 40]) != 0          # past the row
+    assert call(64, [0, 16], [32, 32]) != 0          # overlap
+    assert call(64, [0, 30], [28, 32]) != 0          # offset not a multiple of 4
+    assert call(62, [0], [32]) != 0                  # ld not a multiple of 4
+    assert call(64, [0] * 5, [4] * 5) != 0           # too many segments
+    torch.cuda.synchronize()

@@ -357,6 +357,9 @@ def test_graph_replay_equals_eager_step(gpu):
         fixed = {b: m.pc_decoder.sample_grids(b, gpu, torch.Generator(device=gpu).manual_seed(5 + b)) for b in (4, 2)}
         orig = m.pc_decoder.forward
         m.pc_decoder.forward = lambda h, grid=None, generator=None, pack=None, orig=orig, fixed=fixed: orig(h, grid=fixed[h.size(0)], pack=pack)
+        pair = m.pc_decoder.forward_pair
+        m.pc_decoder.forward_pair = lambda a, b, generator=None, pack=None, pair=pair, fixed=fixed: pair(
+            a, b, pack=pack, grids=(fixed[a.size(0)], fixed[b.size(0)]))
         for _ in range(4):                       # graph mode: 2 eager uses, capture, replay
             out = step([eps[0], eps[1]])
         if mode == "graph":

@@ -117,6 +117,98 @@ def test_pack_shared_by_two_decodes_sums_gradients(gpu):
         assert float((a[n] - b[n]).abs().max()) <= 1e-4 * s + 1e-7, n
 
 
+def test_pair_of_decodes_vs_literal_float64(gpu):
+    """PCDecoder.forward_pair (an episode's query and support decodes side by side: joint GEMMs, K5 over column
+    segments, K9 per decode with row strides) against the LITERAL formulation evaluated twice in float64, queries
+    first: outputs, every running statistic and call counter after BOTH passes, the gradients of both latents and of
+    every parameter (one gradient = the sum of the two passes')."""
+    Ba, Bb = 3, 6
+    dec, hidden, grids_a = _make(Ba, 23)
+    hidden_b = torch.randn(Bb, 1536, generator=torch.Generator().manual_seed(5))
+    grids_b = dec.sample_grids(Bb, "cpu", torch.Generator().manual_seed(6))
+    dec.train()
+    ref = copy.deepcopy(dec).double()
+    ref.batched = False
+    dev = copy.deepcopy(dec).to(gpu)
+    w = torch.randn((Ba + Bb, 2048, 3), generator=torch.Generator().manual_seed(3))
+
+    def literal(model, ha, hb, cast):
+        out = torch.cat([_literal(model, ha, [[cast(g) for g in c] for c in grids_a]),
+                         _literal(model, hb, [[cast(g) for g in c] for c in grids_b])])
+        (out * cast(w)).sum().backward()
+        return out
+
+    a64, b64 = hidden.double().requires_grad_(), hidden_b.double().requires_grad_()
+    out64 = literal(ref, a64, b64, lambda t: t.double())
+
+    ag, bg = hidden.to(gpu).requires_grad_(), hidden_b.to(gpu).requires_grad_()
+    assert dev.pair_ready(ag, bg)
+    out = dev.forward_pair(ag, bg, grids=([[g.to(gpu) for g in c] for c in grids_a],
+                                          [[g.to(gpu) for g in c] for c in grids_b]))
+    assert out.shape == (Ba + Bb, 2048, 3) and out.is_contiguous()
+    (out * w.to(gpu)).sum().backward()
+    err_out = float((out.detach().cpu().double() - out64.detach()).abs().max())
+    print(f"decoder pair ({Ba}, {Bb}): max |out - float64 literal| = {err_out:.3e}")
+    assert err_out <= 2e-4
+    dev_sd, ref_sd = dev.state_dict(), ref.state_dict()
+    for key in ref_sd:                  # (fp32 means of O(1) values: 2e-6 of absolute noise after eight updates)
+        if "running" in key or "num_batches" in key:
+            assert torch.allclose(dev_sd[key].cpu().double(), ref_sd[key].double(), rtol=1e-4, atol=4e-6), key
+
+    lit = copy.deepcopy(dec)
+    lit.batched = False
+    a32, b32 = hidden.clone().requires_grad_(), hidden_b.clone().requires_grad_()
+    literal(lit, a32, b32, lambda t: t)
+    truth = {"latent.a.grad": a64.grad, "latent.b.grad": b64.grad, **{n: q.grad for n, q in ref.named_parameters()}}
+    yard = {"latent.a.grad": a32.grad, "latent.b.grad": b32.grad, **{n: q.grad for n, q in lit.named_parameters()}}
+    got = {"latent.a.grad": ag.grad, "latent.b.grad": bg.grad, **{n: q.grad for n, q in dev.named_parameters()}}
+    assert_like_yardstick(got, yard, truth, f"decoder pair ({Ba}, {Bb})", factor=10.0)
+
+
+def test_pair_of_decodes_equals_two_passes_at_episode_size(gpu, monkeypatch):
+    """5 query + 32 support clouds: forward_pair against two forward calls sharing one parameter pack (the path
+    FPSG_DECODE_PAIR=0 keeps) -- same outputs, statistics and gradients up to the GEMMs' summation order."""
+    dec, hidden, _ = _make(5, 29)
+    dev = dec.to(gpu).train()
+    ha = hidden.to(gpu)
+    hb = torch.randn(32, 1536, generator=torch.Generator().manual_seed(8)).to(gpu)
+    ga = dev.sample_grids(5, gpu, torch.Generator(device=gpu).manual_seed(1))
+    gb = dev.sample_grids(32, gpu, torch.Generator(device=gpu).manual_seed(2))
+    w = torch.randn((37, 2048, 3), generator=torch.Generator().manual_seed(3)).to(gpu)
+
+    def run(pair):
+        monkeypatch.setenv("FPSG_DECODE_PAIR", "1" if pair else "0")
+        dev.zero_grad()
+        state = copy.deepcopy(dev.state_dict())
+        a, b = ha.clone().requires_grad_(), hb.clone().requires_grad_()
+        assert dev.pair_ready(a, b) == pair
+        out = dev.forward_pair(a, b, grids=(ga, gb), pack=dev.pack_parameters())
+        (out * w).sum().backward()
+        after = {k: v.clone() for k, v in dev.state_dict().items() if "running" in k or "num_batches" in k}
+        grads = {"a": a.grad, "b": b.grad, **{n: p.grad.clone() for n, p in dev.named_parameters()}}
+        dev.load_state_dict(state)
+        return out.detach(), after, grads
+
+    o1, s1, g1 = run(True)
+    o2, s2, g2 = run(False)
+    assert float((o1 - o2).abs().max()) <= 2e-5
+    for k in s1:
+        assert torch.allclose(s1[k].float(), s2[k].float(), rtol=1e-5, atol=1e-7), k
+    # a bias in front of a training-mode BatchNorm has an exactly cancelled gradient (round-off on both sides): every
+    # tensor is measured against the largest gradient of its module family (deformer / node of its cluster)
+    scale = {}
+    for n in g2:
+        fam = n.rsplit(".", 2)[0]
+        scale[fam] = max(scale.get(fam, 0.0), float(g2[n].abs().max()))
+    worst, where = 0.0, ""
+    for n in g1:
+        d = float((g1[n] - g2[n]).abs().max()) / (scale[n.rsplit(".", 2)[0]] + 1e-12)
+        if d > worst:
+            worst, where = d, n
+    print(f"decoder pair (5, 32) vs two passes: worst gradient difference {worst:.2e} of its module's scale ({where})")
+    assert worst <= 2e-2          # ReLU-kink flips under a changed summation order (see _gradcheck); typical 1e-5
+
+
 def test_stacked_weights_are_copied_once_per_step(gpu, monkeypatch):
     """Inside ``winograd.weights_frozen()`` (the episodes of one optimizer step) the 16 patch MLPs' weights are
     stacked once: later packs take the cached values; outputs and every parameter gradient of each episode are

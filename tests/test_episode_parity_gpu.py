@@ -21,6 +21,9 @@ def _fixed_grids(model, sizes, device):
 def _pin_grids(model, grids):
     orig = model.pc_decoder.forward
     model.pc_decoder.forward = lambda h, grid=None, generator=None, pack=None: orig(h, grid=grids[h.size(0)], pack=pack)
+    pair = model.pc_decoder.forward_pair        # the episode's two decodes side by side (its fallback calls .forward)
+    model.pc_decoder.forward_pair = lambda a, b, generator=None, pack=None, grids_=None: pair(
+        a, b, pack=pack, grids=(grids[a.size(0)], grids[b.size(0)]))
 
 
 def _record(name, payload):
