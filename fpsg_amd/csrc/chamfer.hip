@@ -363,10 +363,18 @@ __device__ __forceinline__ float row_sum(const float* __restrict__ row, int n, i
   float s = 0.f;
   if ((n & 3) == 0 && (reinterpret_cast<uintptr_t>(row) & 15u) == 0) {
     const v4f* r4 = reinterpret_cast<const v4f*>(row);
+    const int n4 = n >> 2;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    for (int i = lane; i < n / 4; i += 64) {
-      const v4f v = r4[i];
-      a0 += v.x; a1 += v.y; a2 += v.z; a3 += v.w;
+    // eight vectors of a lane requested together (a 2048-element row is one trip), added in ascending order
+    for (int i0 = lane; i0 < n4; i0 += 64 * 8) {
+      v4f v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int i = i0 + 64 * j;
+        v[j] = i < n4 ? r4[i] : (v4f){0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { a0 += v[j].x; a1 += v[j].y; a2 += v[j].z; a3 += v[j].w; }
     }
     s = (a0 + a1) + (a2 + a3);
   } else {
