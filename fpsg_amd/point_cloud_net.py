@@ -425,6 +425,38 @@ class _StackFrozen(torch.autograd.Function):
         return (None,) + tuple(g.unbind(0))
 
 
+class _RepeatFrozen(torch.autograd.Function):
+    """``t.repeat_interleave(r, dim=0)`` whose VALUES come from the step-scoped cache of ``winograd.weights_frozen`` when
+    the same tensor was repeated earlier in the step (a deformer's parameters serve its cluster's ``r`` patches: ten small
+    copies per episode otherwise); the gradient is the sum over the ``r`` copies, as ``repeat_interleave``'s is."""
+
+    @staticmethod
+    def forward(ctx, t, r):
+        from . import winograd
+        ctx.r = r
+        cache = winograd.frozen_cache()
+        key = ("repeat", t.data_ptr(), tuple(t.shape), r)
+        if cache is not None and key in cache:
+            return cache[key].detach()
+        out = t.detach().repeat_interleave(r, dim=0)
+        if cache is not None:
+            cache[key] = out
+            return out.detach()
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.reshape(g.shape[0] // ctx.r, ctx.r, *g.shape[1:]).sum(1), None
+
+
+def _repeat_rows(t, r):
+    if r == 1:
+        return t
+    if t.is_cuda and torch.is_grad_enabled() and t.requires_grad:
+        return _RepeatFrozen.apply(t, r)
+    return t.repeat_interleave(r, dim=0)
+
+
 class _StackView(torch.autograd.Function):
     """``torch.stack(tensors)`` of tensors that ARE the consecutive rows of one contiguous block (a stack group of
     ``fpsg_amd.optim.layout_order`` inside the optimizer's flat parameter buffer): a view of that block, no copy; the
@@ -489,8 +521,7 @@ class _LazySplit:
 def _stack_affine(bns, calls_per_bn):
     """gamma / beta of ``bns`` stacked to ``[G*C]`` for ``_group_batch_norm``."""
     gamma, beta = _stack("bn.weight", [b.weight for b in bns]), _stack("bn.bias", [b.bias for b in bns])
-    if calls_per_bn > 1:
-        gamma, beta = gamma.repeat_interleave(calls_per_bn, dim=0), beta.repeat_interleave(calls_per_bn, dim=0)
+    gamma, beta = _repeat_rows(gamma, calls_per_bn), _repeat_rows(beta, calls_per_bn)
     return gamma.reshape(-1), beta.reshape(-1)
 
 
@@ -674,9 +705,7 @@ class PCDecoder(nn.Module):
         def stack_w(mods, name, repeat=1):
             w = _stack(name + ".w", [getattr(m, name).weight.squeeze(-1) for m in mods])   # [n,out,in]
             b = _stack(name + ".b", [getattr(m, name).bias for m in mods])                 # [n,out]
-            if repeat > 1:
-                w = w.repeat_interleave(repeat, dim=0)
-                b = b.repeat_interleave(repeat, dim=0)
+            w, b = _repeat_rows(w, repeat), _repeat_rows(b, repeat)
             return w, b.unsqueeze(-1)
 
         pack = {f"d{i}": stack_w(defs, f"conv{i}", R) for i in (1, 2, 3)}
