@@ -143,6 +143,8 @@ SIGNATURES = {
     "fpsg_adam_step": [_c_f32p, _c_f32p, _c_f32p, _c_f32p, ctypes.c_size_t, ctypes.c_float, ctypes.c_float,
                        ctypes.c_float, ctypes.c_float, _c_int, ctypes.c_float, _c_stream],
     "fpsg_flat_accumulate_segments": [_c_f32p, ctypes.c_void_p, ctypes.c_void_p, _c_int, ctypes.c_size_t, _c_int, _c_stream],
+    "fpsg_flat_accumulate_tables": [_c_f32p, ctypes.c_void_p, ctypes.c_void_p, _c_int, _c_int, ctypes.c_size_t, _c_int,
+                                    _c_stream],
     "fpsg_adam_step_segments": [_c_f32p, ctypes.c_void_p, ctypes.c_void_p, _c_int, _c_f32p, _c_f32p, ctypes.c_size_t,
                                 ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, _c_int, ctypes.c_float,
                                 _c_stream],

@@ -227,6 +227,105 @@ __global__ __launch_bounds__(kAdamThreads) void flat_accumulate_kernel(float* __
   }
 }
 
+// The same for up to kAccTables gradient tables at once: flat (+)= g_0 + g_1 + ... added in table order, i.e. the
+// fp32 sums of that many consecutive flat_accumulate_kernel launches, bit for bit -- but flat is read and written once
+// instead of once per table (8 episodes of a step: 2.8 GB of traffic instead of 7.4).  gtabs [ntab][nseg].
+constexpr int kAccTables = 8;
+
+__global__ __launch_bounds__(kAdamThreads) void flat_accumulate_tables_kernel(float* __restrict__ flat,
+                                                                              const float* const* __restrict__ gtabs,
+                                                                              const long long* __restrict__ seg_off,
+                                                                              int nseg, int ntab, size_t n4, size_t n,
+                                                                              int accumulate) {
+  __shared__ long long soff[kSegLds];
+  const long long* so = seg_off;
+  if (nseg + 1 <= kSegLds) {
+    for (int e = threadIdx.x; e <= nseg; e += kAdamThreads) soff[e] = seg_off[e];
+    __syncthreads();
+    so = soff;
+  }
+  const size_t stride = (size_t)gridDim.x * kAdamThreads;
+  size_t j = (size_t)blockIdx.x * kAdamThreads + threadIdx.x;
+  // whole vectors, two per trip: the flat loads, one table search per vector (the tables share the layout), then the
+  // vectors of all tables in flight together; the adds run in table order
+  constexpr int kU = 2;
+  for (; j + (kU - 1) * stride < n4; j += kU * stride) {
+    v4f f[kU];
+    int sg[kU];
+    bool fast[kU];
+    long long base[kU];
+#pragma unroll
+    for (int u = 0; u < kU; ++u) {
+      f[u] = (v4f){0.0f, 0.0f, 0.0f, 0.0f};
+      if (accumulate) f[u] = reinterpret_cast<const v4f*>(flat)[j + u * stride];
+    }
+#pragma unroll
+    for (int u = 0; u < kU; ++u) {
+      const long long i = (long long)(4 * (j + u * stride));
+      sg[u] = segment_of(so, nseg, i);
+      fast[u] = i + 4 <= so[sg[u] + 1];
+      base[u] = i - so[sg[u]];
+    }
+    v4f g[kU][kAccTables];
+    bool any[kU];
+#pragma unroll
+    for (int u = 0; u < kU; ++u) {
+      any[u] = false;
+#pragma unroll
+      for (int t = 0; t < kAccTables; ++t) {
+        g[u][t] = (v4f){0.0f, 0.0f, 0.0f, 0.0f};
+        if (t >= ntab) continue;
+        const float* const* tab = gtabs + (size_t)t * nseg;
+        if (fast[u]) {
+          const float* gp = tab[sg[u]];
+          if (gp) {
+            any[u] = true;
+            if ((reinterpret_cast<uintptr_t>(gp + base[u]) & 15) == 0) {
+              g[u][t] = *reinterpret_cast<const v4f*>(gp + base[u]);
+            } else {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) g[u][t][e] = gp[base[u] + e];
+            }
+          }
+        } else {
+          float gg[4];
+          any[u] = gather_grad4(tab, so, nseg, (long long)(4 * (j + u * stride)), 4, gg) || any[u];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) g[u][t][e] = gg[e];
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < kU; ++u) {
+      if (accumulate && !any[u]) continue;
+#pragma unroll
+      for (int t = 0; t < kAccTables; ++t) {
+        if (t >= ntab) continue;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) f[u][e] += g[u][t][e];
+      }
+      reinterpret_cast<v4f*>(flat)[j + u * stride] = f[u];
+    }
+  }
+  for (; j < n4 + 1; j += stride) {
+    const long long i = (long long)(4 * j);
+    const int cnt = j < n4 ? 4 : (int)(n - 4 * n4);
+    if (cnt == 0) break;
+    float f[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (accumulate) {
+      for (int u = 0; u < cnt; ++u) f[u] = flat[(size_t)i + u];
+    }
+    bool any = false;
+    for (int t = 0; t < ntab; ++t) {
+      float gg[4];
+      any = gather_grad4(gtabs + (size_t)t * nseg, so, nseg, i, cnt, gg) || any;
+      for (int u = 0; u < cnt; ++u) f[u] += gg[u];
+    }
+    if (accumulate && !any) continue;
+    for (int u = 0; u < cnt; ++u) flat[(size_t)i + u] = f[u];
+  }
+}
+
 __global__ __launch_bounds__(kAdamThreads) void adam_ptr_kernel(float* __restrict__ p, const float* const* __restrict__ gtab,
                                                                 const long long* __restrict__ seg_off, int nseg,
                                                                 float* __restrict__ m, float* __restrict__ v, size_t n4,
@@ -369,4 +468,20 @@ extern "C" int fpsg_flat_accumulate_segments(float* flat, const float* const* gr
   hipLaunchKernelGGL(flat_accumulate_kernel, dim3((unsigned)blocks), dim3(kAdamThreads), 0, static_cast<hipStream_t>(stream),
                      flat, grad_ptrs, seg_off, nseg, n4, n, accumulate);
   return launch_status("fpsg_flat_accumulate_segments");
+}
+
+extern "C" int fpsg_flat_accumulate_tables(float* flat, const float* const* grad_ptrs, const long long* seg_off, int nseg,
+                                           int ntab, size_t n, int accumulate, fpsg_stream_t stream) {
+  using namespace fpsg;
+  FPSG_REQUIRE(n > 0 && nseg > 0, FPSG_E_SHAPE, "fpsg_flat_accumulate_tables: n, nseg must be positive (got %zu, %d)", n, nseg);
+  FPSG_REQUIRE(ntab >= 1 && ntab <= kAccTables, FPSG_E_LIMIT, "fpsg_flat_accumulate_tables: %d tables (1..%d)", ntab, kAccTables);
+  FPSG_REQUIRE_PTR(flat);
+  FPSG_REQUIRE(grad_ptrs != nullptr && seg_off != nullptr, FPSG_E_NULL, "fpsg_flat_accumulate_tables: null table");
+  FPSG_REQUIRE((reinterpret_cast<uintptr_t>(flat) & 15) == 0, FPSG_E_ALIGN, "fpsg_flat_accumulate_tables: flat must be 16-byte aligned");
+  const size_t n4 = n / 4;
+  size_t blocks = (n4 + 1 + kAdamThreads - 1) / kAdamThreads;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  hipLaunchKernelGGL(flat_accumulate_tables_kernel, dim3((unsigned)blocks), dim3(kAdamThreads), 0,
+                     static_cast<hipStream_t>(stream), flat, grad_ptrs, seg_off, nseg, ntab, n4, n, accumulate);
+  return launch_status("fpsg_flat_accumulate_tables");
 }

@@ -72,6 +72,8 @@ def shutdown() -> None:
 class FlatGradBuckets:
     """Flat gradient storage + bucketed, overlapped all-reduce for ``model``."""
 
+    _MAX_STASH = 8          # fpsg_flat_accumulate_tables' limit
+
     def __init__(self, model: nn.Module, bucket_mb: float = 80.0, group=None):
         params = [p for p in model.parameters() if p.requires_grad]
         if not params:
@@ -125,6 +127,12 @@ class FlatGradBuckets:
                 o += p.numel()
             self._seg_off = torch.tensor(offs + [o], dtype=torch.int64, device=dev)
             self._gtab = torch.zeros(len(self._layout_params), dtype=torch.int64, device=dev)
+            self._gtabs = torch.zeros(self._MAX_STASH * len(self._layout_params), dtype=torch.int64, device=dev)
+        # absorb() keeps an episode's gradient tensors and adds up to _MAX_STASH episodes in one launch (flush()): the
+        # flat buffer is read and written once per flush instead of once per episode; same sums in the same order
+        self.lazy = True
+        self._stash: list = []
+        self._stash_first = False
         self.attach()
 
     # -- bookkeeping ---------------------------------------------------------------
@@ -138,6 +146,7 @@ class FlatGradBuckets:
 
     def zero(self) -> None:
         """Replaces ``optimizer.zero_grad()``: the flat buffer is the step's gradient."""
+        self._stash, self._stash_first = [], False
         self.flat.zero_()
 
     def attach(self) -> None:
@@ -155,6 +164,9 @@ class FlatGradBuckets:
         """Adds the gradients a backward left in ``p.grad`` into the flat buffer with
         multi-tensor launches; ``first`` overwrites instead (no ``zero()`` needed).  The sums
         are the same fp32 adds, in the same order over episodes, as in-place accumulation."""
+        if self.lazy and self._stash_episode(first):
+            return
+        self.flush()
         if self._absorb_segments(first):
             return
         dst, src, missing = [], [], []
@@ -173,12 +185,9 @@ class FlatGradBuckets:
             elif dst:
                 torch._foreach_add_(dst, src)
 
-    def _absorb_segments(self, first: bool) -> bool:
-        """``absorb`` as ONE launch (``fpsg_flat_accumulate_segments``: the gradient tensors read through a pointer
-        table, the flat buffer updated at HBM rate) when every gradient is a dense fp32 tensor laid out like its
-        parameter; False -> the multi-tensor path.  Not under stream capture (the table upload is a host copy)."""
-        if self._gtab is None or os.environ.get("FPSG_ABSORB_SEGMENTS", "1") == "0" or torch.cuda.is_current_stream_capturing():
-            return False
+    def _segment_pointers(self):
+        """The gradient tensors' addresses in layout order (0: no gradient) when every gradient is a dense fp32 tensor
+        laid out like its parameter, else None."""
         dev = self.flat.device
         ptrs = []
         for p in self._layout_params:
@@ -189,7 +198,54 @@ class FlatGradBuckets:
                   and g.data_ptr() != self.views[id(p)].data_ptr()):
                 ptrs.append(g.data_ptr())
             else:
-                return False
+                return None
+        return ptrs
+
+    def _stash_episode(self, first: bool) -> bool:
+        """``absorb`` deferred: the episode's gradient tensors are kept (``detach()`` drops the parameters' references,
+        not these) and added by ``flush()`` together with the following episodes'.  False -> not applicable here."""
+        if (self._gtab is None or os.environ.get("FPSG_ABSORB_SEGMENTS", "1") == "0"
+                or os.environ.get("FPSG_ABSORB_LAZY", "1") == "0" or torch.cuda.is_current_stream_capturing()):
+            return False
+        ptrs = self._segment_pointers()
+        if ptrs is None:
+            return False
+        if first and self._stash:
+            self.flush()
+        if not self._stash:
+            self._stash_first = bool(first)
+        self._stash.append((ptrs, [p.grad for p in self._layout_params]))
+        if len(self._stash) == self._MAX_STASH:
+            self.flush()
+        return True
+
+    def flush(self) -> None:
+        """Adds the kept episodes' gradients into the flat buffer, in episode order, in ONE launch
+        (``fpsg_flat_accumulate_tables``); called before anything reads or adds to the flat buffer."""
+        if not self._stash:
+            return
+        from . import _hip
+        stash, first = self._stash, self._stash_first
+        self._stash, self._stash_first = [], False
+        n = len(self._layout_params)
+        table = torch.tensor([q for ptrs, _ in stash for q in ptrs], dtype=torch.int64).pin_memory()
+        self._gtabs[:len(stash) * n].copy_(table, non_blocking=True)
+        with torch.cuda.device(self.flat.device):
+            rc = _hip.load().fpsg_flat_accumulate_tables(_hip.ptr(self.flat), _hip.ptr(self._gtabs), _hip.ptr(self._seg_off),
+                                                         n, len(stash), self.flat.numel(), 0 if first else 1,
+                                                         _hip.stream_of(self.flat))
+        _hip.check(rc, "fpsg_flat_accumulate_tables")
+
+    def _absorb_segments(self, first: bool) -> bool:
+        """``absorb`` as ONE launch (``fpsg_flat_accumulate_segments``: the gradient tensors read through a pointer
+        table, the flat buffer updated at HBM rate) when every gradient is a dense fp32 tensor laid out like its
+        parameter; False -> the multi-tensor path.  Not under stream capture (the table upload is a host copy)."""
+        if self._gtab is None or os.environ.get("FPSG_ABSORB_SEGMENTS", "1") == "0" or torch.cuda.is_current_stream_capturing():
+            return False
+        dev = self.flat.device
+        ptrs = self._segment_pointers()
+        if ptrs is None:
+            return False
         from . import _hip
         # a fresh pinned tensor per call: the caching host allocator keeps it until the copy ran
         self._gtab.copy_(torch.tensor(ptrs, dtype=torch.int64).pin_memory(), non_blocking=True)
@@ -204,6 +260,7 @@ class FlatGradBuckets:
         """Call (after ``detach()``) before the backward of the LAST local episode of a step:
         each bucket is absorbed into the flat buffer (copied if ``first``: the step's only local
         episode) and all-reduced as soon as its gradients are complete during that backward."""
+        self.flush()            # the hooks add to the flat buffer during the backward
         self._armed = dist.is_initialized()
         self._armed_first = bool(first)
         self._pending = list(self._bucket_size)
@@ -264,6 +321,7 @@ class FlatGradBuckets:
     def finish(self, n_episodes_global: int) -> None:
         """Waits for the in-flight buckets, reduces any bucket whose parameters received no
         gradient in the armed backward, and turns the sum into the mean over episodes."""
+        self.flush()
         if self._armed:
             cur = torch.cuda.current_stream(self.flat.device) if self.flat.is_cuda else None
             late = len(self.buckets) - self._next_launch

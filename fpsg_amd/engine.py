@@ -98,6 +98,8 @@ class TrainStep:
         if isinstance(optimizer, FlatAdam):
             optimizer.bind_gradients(self.buckets.flat)      # same layout: the step reads it in place
         self.use_graph = bool(graph) and next(model.parameters()).is_cuda
+        if self.use_graph:
+            self.buckets.lazy = False       # a captured episode ends with its own adds into the flat buffer, in order
         self._graphs = {}
         self._eager_runs = {}
 

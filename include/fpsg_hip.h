@@ -539,6 +539,11 @@ int fpsg_adam_step_segments(float* param, const float* const* grad_ptrs, const l
  */
 int fpsg_flat_accumulate_segments(float* flat, const float* const* grad_ptrs, const long long* seg_off, int nseg,
                                   size_t n, int accumulate, fpsg_stream_t stream);
+/* The same for ntab (<= 8) tables at once, grad_ptrs [ntab][nseg]: flat (+)= g_0 + g_1 + ... added in table order -- the
+ * fp32 sums of ntab consecutive fpsg_flat_accumulate_segments calls bit for bit, with flat read and written once (the
+ * episodes of a step keep their gradient tensors until the step's last backward). */
+int fpsg_flat_accumulate_tables(float* flat, const float* const* grad_ptrs, const long long* seg_off, int nseg, int ntab,
+                                size_t n, int accumulate, fpsg_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -211,15 +211,16 @@ def test_gradient_accumulation_over_episodes_in_one_launch(gpu, monkeypatch):
             self.unused = nn.Parameter(torch.randn(11))
             self.d = nn.Parameter(torch.randn(2, 2))
 
-    def run(flag, channels_last=False):
+    def run(flag, channels_last=False, lazy=False, episodes=3):
         monkeypatch.setenv("FPSG_ABSORB_SEGMENTS", flag)
         torch.manual_seed(7)
         net = Net().to(gpu)
         if channels_last:
             net.e = nn.Parameter(torch.randn(4, 6, 3, 3, device=gpu).contiguous(memory_format=torch.channels_last))
         fb = FlatGradBuckets(net, bucket_mb=0.001)
+        fb.lazy = lazy
         snaps = []
-        for ep in range(3):
+        for ep in range(episodes):
             fb.detach()
             big = torch.randn(5000, device=gpu)
             for n_, p in net.named_parameters():
@@ -230,6 +231,12 @@ def test_gradient_accumulation_over_episodes_in_one_launch(gpu, monkeypatch):
                 else:
                     p.grad = torch.randn_like(p)
             fb.absorb(first=(ep == 0))
+            if not lazy:
+                snaps.append(fb.flat.clone())
+        if lazy:
+            assert len(fb._stash) == episodes % 8
+            fb.flush()
+            assert not fb._stash
             snaps.append(fb.flat.clone())
         return snaps
 
@@ -237,6 +244,11 @@ def test_gradient_accumulation_over_episodes_in_one_launch(gpu, monkeypatch):
         seg, ref = run("1", cl), run("0", cl)
         for s_, r_ in zip(seg, ref):
             assert torch.equal(s_, r_)
+    # the deferred form (FlatGradBuckets.lazy, the default): the episodes' gradient tensors are kept and added by ONE
+    # launch of fpsg_flat_accumulate_tables per 8 episodes -- the same sums in the same order, bit for bit
+    for episodes, cl in ((3, False), (8, False), (11, False), (3, True)):
+        lazy, ref = run("1", cl, lazy=True, episodes=episodes), run("0", cl, episodes=episodes)
+        assert torch.equal(lazy[-1], ref[-1]), (episodes, cl)
     # the one-launch form is really taken for the plain model
     calls = {"n": 0}
     orig = FlatGradBuckets._absorb_segments
