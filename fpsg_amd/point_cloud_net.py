@@ -692,15 +692,21 @@ class PCDecoder(nn.Module):
         L = x.shape[1]
         dim = clusters[0].template[0].dim
         square = type(clusters[0].template[0]).__name__ == "SquareTemplate"
-        cols = []
-        for i, b in enumerate(batches):   # drawn per decode, in the order of two separate passes
-            if grids is not None and grids[i] is not None:
-                g = torch.stack([t for per_cluster in grids[i] for t in per_cluster])  # [G,b,dim,P]
-            else:
-                g = torch.empty((G, b, dim, P), dtype=torch.float32, device=x.device)
-                g = g.uniform_(0, 1, generator=generator) if square else g.normal_(0, 1, generator=generator)
-            cols.append(g.permute(0, 2, 1, 3).reshape(G, g.size(2), b * P))
-        h = torch.cat(cols, dim=2)                                                      # [G,dim,B*P]
+        if grids is None or (grids[0] is None and grids[1] is None):
+            # both decodes' patch samples from one draw (i.i.d. either way): one generator launch, one permuting copy
+            g = torch.empty((G, B, dim, P), dtype=torch.float32, device=x.device)
+            g = g.uniform_(0, 1, generator=generator) if square else g.normal_(0, 1, generator=generator)
+            h = g.permute(0, 2, 1, 3).reshape(G, dim, B * P)                            # [G,dim,B*P]
+        else:
+            cols = []
+            for i, b in enumerate(batches):
+                if grids[i] is not None:
+                    g = torch.stack([t for per_cluster in grids[i] for t in per_cluster])  # [G,b,dim,P]
+                else:
+                    g = torch.empty((G, b, dim, P), dtype=torch.float32, device=x.device)
+                    g = g.uniform_(0, 1, generator=generator) if square else g.normal_(0, 1, generator=generator)
+                cols.append(g.permute(0, 2, 1, 3).reshape(G, g.size(2), b * P))
+            h = torch.cat(cols, dim=2)                                                  # [G,dim,B*P]
 
         defs = [c.deformer for c in clusters]
         w, b = pack["d1"]

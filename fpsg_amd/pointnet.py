@@ -32,6 +32,20 @@ class _PointTrunk(nn.Module):
         self.bn3 = nn.BatchNorm1d(1024)
 
 
+_EYE9: dict = {}
+
+
+def _identity9(like: torch.Tensor) -> torch.Tensor:
+    """The flattened 3x3 identity on ``like``'s device (built once per device and dtype: two launches per call otherwise)."""
+    key = (like.device, like.dtype)
+    eye = _EYE9.get(key)
+    if eye is None:
+        eye = torch.eye(3, dtype=like.dtype, device=like.device).reshape(1, 9)
+        if not (like.is_cuda and torch.cuda.is_current_stream_capturing()):      # a capture's allocations belong to its graph
+            _EYE9[key] = eye
+    return eye
+
+
 class STN3d(_PointTrunk):
     """Predicts a 3x3 alignment matrix per cloud (identity + learned residual)."""
 
@@ -52,8 +66,7 @@ class STN3d(_PointTrunk):
         h = F.relu(self.bn4(self.fc1(h)))
         h = F.relu(self.bn5(self.fc2(h)))
         h = self.fc3(h)
-        eye = torch.eye(3, dtype=h.dtype, device=h.device).reshape(1, 9)
-        return (h + eye).view(-1, 3, 3)
+        return (h + _identity9(h)).view(-1, 3, 3)
 
 
 class PointNetfeat(_PointTrunk):
