@@ -1,0 +1,62 @@
+"""The optimizer step with this round's host-side fusions against the same step with each of them switched off: the
+episode's two decodes side by side (FPSG_DECODE_PAIR), the loss chain behind K1 (FPSG_FUSED_LOSSES), the step's gradient
+tables added in one launch (FPSG_ABSORB_LAZY).  Same weights, episodes and patch grids; the yardstick for "equal" is a
+second run of the default step (library GEMMs are not bit-reproducible across shapes, and six-image training-mode
+BatchNorm amplifies the last bits)."""
+import copy
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+SWITCHES = ("FPSG_DECODE_PAIR", "FPSG_FUSED_LOSSES", "FPSG_ABSORB_LAZY")
+
+
+def _run(gpu, monkeypatch, base, eps, off):
+    from fpsg_amd.engine import TrainStep, build_optimizer, default_options
+    for name in SWITCHES:
+        monkeypatch.delenv(name, raising=False)
+    for name in off:
+        monkeypatch.setenv(name, "0")
+    opt = default_options(device="cuda", intra_recon=True, lr=0.0)
+    m = copy.deepcopy(base)
+    optimizer, _ = build_optimizer(m, opt)
+    step = TrainStep(m, optimizer)
+    fixed = {b: m.pc_decoder.sample_grids(b, gpu, torch.Generator(device=gpu).manual_seed(5 + b)) for b in (4, 2)}
+    orig, pair = m.pc_decoder.forward, m.pc_decoder.forward_pair
+    m.pc_decoder.forward = lambda h, grid=None, generator=None, pack=None: orig(h, grid=fixed[h.size(0)], pack=pack)
+    m.pc_decoder.forward_pair = lambda a, b, generator=None, pack=None: pair(
+        a, b, pack=pack, grids=(fixed[a.size(0)], fixed[b.size(0)]))
+    out = step(eps)
+    losses = [float(o["ttl_loss"].sum()) for o in out] + [float(out[-1]["query_rec_loss"].sum()),
+                                                           float(out[-1]["support_rec_loss"].sum())]
+    stats = m.pc_decoder.cluster_pool[0].node_pool[0].bn2.running_mean.clone()
+    return step.buckets.flat.clone(), losses, stats
+
+
+def test_step_equals_the_step_with_each_fusion_off(gpu, monkeypatch):
+    from fpsg_amd.engine import build_model, default_options
+    from fpsg_amd.episodes import synthetic_episode
+    torch.manual_seed(0)
+    base = build_model(default_options(device="cuda", intra_recon=True, lr=0.0)).to(gpu).train()
+    eps = [synthetic_episode(4, 2, n_pts=2048, img_size=96, seed=s, device=gpu) for s in (1, 2, 3)]
+    cos = torch.nn.functional.cosine_similarity
+    g0, l0, s0 = _run(gpu, monkeypatch, base, eps, ())
+    g1, l1, s1 = _run(gpu, monkeypatch, base, eps, ())
+    noise = 1 - float(cos(g0, g1, dim=0))
+    lnoise = max(abs(a - b) / abs(a) for a, b in zip(l0, l1))
+    for off in [(s,) for s in SWITCHES] + [SWITCHES]:
+        g, losses, s = _run(gpu, monkeypatch, base, eps, off)
+        diff = 1 - float(cos(g0, g, dim=0))
+        ldiff = max(abs(a - b) / abs(a) for a, b in zip(l0, losses))
+        print(f"switched off {off}: gradient 1 - cos = {diff:.2e} (two default runs: {noise:.2e}), losses {ldiff:.2e} ({lnoise:.2e})")
+        assert ldiff <= max(3 * lnoise, 1e-4), (off, l0, losses)
+        assert diff <= max(3 * noise, 2e-3), (off, diff, noise)
+        assert abs(float(g.norm() / g0.norm()) - 1) <= max(3 * abs(float(g1.norm() / g0.norm()) - 1), 1e-2), off
+        assert torch.allclose(s, s0, rtol=1e-4, atol=1e-6), off
+    # with the gradient accumulation deferred or not the sums are the same bit for bit
+    ga, _, _ = _run(gpu, monkeypatch, base, eps, ("FPSG_DECODE_PAIR", "FPSG_FUSED_LOSSES"))
+    gb, _, _ = _run(gpu, monkeypatch, base, eps, SWITCHES)
+    print(f"deferred vs per-episode accumulation: max |difference| = {float((ga - gb).abs().max()):.2e}")
+    assert torch.equal(ga, gb)
