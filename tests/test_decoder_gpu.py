@@ -313,3 +313,68 @@ def test_stacked_weights_are_views_of_the_flat_parameters(gpu, monkeypatch):
     assert a.cluster_pool[1].node_pool[2].conv1.weight.data_ptr() == ptr
     w, _ = a.pack_parameters()["n1"]
     assert torch.equal(w[6], sd["cluster_pool.1.node_pool.2.conv1.weight"].squeeze(-1).to(gpu))
+
+
+def test_k9_row_strides_equal_contiguous_calls(gpu):
+    """fpsg_dec1_fwd_ld / _bwd_ld: two decodes side by side in joint tensors (row strides, hlat stride, the second
+    backward call accumulating) = one fpsg_dec1_fwd / _bwd call per decode on contiguous copies, bit for bit."""
+    from fpsg_amd import _hip
+    lib = _hip.load()
+    torch.manual_seed(3)
+    G, D, L, P = 3, 70, 24, 32
+    batches = (2, 5)
+    B = sum(batches)
+    K, M = L + 3, B * P
+    w = torch.randn(G, D, K, device=gpu)
+    hlat = torch.randn(G, D, B, device=gpu)
+    pts = torch.tanh(torch.randn(G, 3, M, device=gpu))
+    gamma, beta = torch.randn(G * D, device=gpu) * 0.5 + 1, torch.randn(G * D, device=gpu) * 0.1
+    dout = torch.randn(G, D, M, device=gpu)
+    st = _hip.stream_of(w)
+    T = lib.fpsg_dec1_tiles(D)
+
+    out = torch.zeros(G, D, M, device=gpu)
+    chan = torch.zeros(2, 4, G * D, device=gpu)
+    stats = torch.zeros(2, 2, G * D, device=gpu)
+    dhlat = torch.zeros(G, D, B, device=gpu)
+    gw = torch.zeros(G, D, K, device=gpu)
+    dgamma, dbeta = torch.zeros(G * D, device=gpu), torch.zeros(G * D, device=gpu)
+    parts, ref = [], []
+    b0 = 0
+    for i, Bi in enumerate(batches):
+        rc = lib.fpsg_dec1_fwd_ld(_hip.ptr(hlat) + 4 * b0, B, _hip.ptr(w), K, L, _hip.ptr(pts) + 4 * b0 * P, M, _hip.ptr(gamma),
+                                  _hip.ptr(beta), None, None, G, D, Bi, P, 1, 1e-5, _hip.ptr(out) + 4 * b0 * P, M,
+                                  _hip.ptr(chan[i]), _hip.ptr(stats[i, 0]), _hip.ptr(stats[i, 1]), st)
+        _hip.check(rc, "dec1")
+        part = torch.zeros(G, T, 3, Bi * P, device=gpu)
+        rc = lib.fpsg_dec1_bwd_ld(_hip.ptr(dout) + 4 * b0 * P, M, _hip.ptr(hlat) + 4 * b0, B, _hip.ptr(w), K, L,
+                                  _hip.ptr(pts) + 4 * b0 * P, M, _hip.ptr(chan[i]), G, D, Bi, P, 1, 1 if i else 0,
+                                  _hip.ptr(dhlat) + 4 * b0, _hip.ptr(gw), _hip.ptr(part), _hip.ptr(dgamma), _hip.ptr(dbeta), st)
+        _hip.check(rc, "dec1")
+        parts.append(part)
+        # the same decode alone, on contiguous copies
+        cols = slice(b0 * P, (b0 + Bi) * P)
+        h_c, p_c, d_c = hlat[:, :, b0:b0 + Bi].contiguous(), pts[:, :, cols].contiguous(), dout[:, :, cols].contiguous()
+        o_c = torch.zeros(G, D, Bi * P, device=gpu)
+        ch_c, m_c, v_c = torch.zeros(4, G * D, device=gpu), torch.zeros(G * D, device=gpu), torch.zeros(G * D, device=gpu)
+        rc = lib.fpsg_dec1_fwd(_hip.ptr(h_c), _hip.ptr(w), K, L, _hip.ptr(p_c), _hip.ptr(gamma), _hip.ptr(beta), None, None,
+                               G, D, Bi, P, 1, 1e-5, _hip.ptr(o_c), _hip.ptr(ch_c), _hip.ptr(m_c), _hip.ptr(v_c), st)
+        _hip.check(rc, "dec1")
+        dh_c, gw_c = torch.zeros(G, D, Bi, device=gpu), torch.zeros(G, D, K, device=gpu)
+        pa_c, dg_c, db_c = torch.zeros(G, T, 3, Bi * P, device=gpu), torch.zeros(G * D, device=gpu), torch.zeros(G * D, device=gpu)
+        rc = lib.fpsg_dec1_bwd(_hip.ptr(d_c), _hip.ptr(h_c), _hip.ptr(w), K, L, _hip.ptr(p_c), _hip.ptr(ch_c), G, D, Bi, P, 1,
+                               _hip.ptr(dh_c), _hip.ptr(gw_c), _hip.ptr(pa_c), _hip.ptr(dg_c), _hip.ptr(db_c), st)
+        _hip.check(rc, "dec1")
+        assert torch.equal(out[:, :, cols], o_c) and torch.equal(chan[i], ch_c)
+        assert torch.equal(stats[i, 0], m_c) and torch.equal(stats[i, 1], v_c)
+        assert torch.equal(dhlat[:, :, b0:b0 + Bi], dh_c) and torch.equal(part, pa_c)
+        ref.append((gw_c[..., L:], dg_c, db_c))
+        b0 += Bi
+    assert torch.equal(gw[..., L:], ref[0][0] + ref[1][0])
+    assert torch.equal(dgamma, ref[0][1] + ref[1][1]) and torch.equal(dbeta, ref[0][2] + ref[1][2])
+    # strides that do not fit the call are refused
+    assert lib.fpsg_dec1_fwd_ld(_hip.ptr(hlat), B, _hip.ptr(w), K, L, _hip.ptr(pts), M - 2, _hip.ptr(gamma), _hip.ptr(beta), None,
+                                None, G, D, 2, P, 1, 1e-5, _hip.ptr(out), M, _hip.ptr(chan[0]), None, None, st) != 0
+    assert lib.fpsg_dec1_fwd_ld(_hip.ptr(hlat), 1, _hip.ptr(w), K, L, _hip.ptr(pts), M, _hip.ptr(gamma), _hip.ptr(beta), None,
+                                None, G, D, 2, P, 1, 1e-5, _hip.ptr(out), M, _hip.ptr(chan[0]), None, None, st) != 0
+    torch.cuda.synchronize()
