@@ -1,8 +1,10 @@
 #!/usr/bin/env python3
 """bench.py -- episodes/sec of the FPSG hot path + Chamfer-kernel roofline on MI355X.
 
-Contract: ``python bench.py --gpus N --steps K --warmup W`` (for N>1 launched by
-``python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...``).
+Contract: ``python bench.py --gpus N --steps K --warmup W``.  For N>1 either launched by
+``python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py
+--gpus N ...`` or typed as is: without a torchrun environment (no WORLD_SIZE) bench.py starts that launcher itself
+as a child process, before any GPU call, and relays rank 0's line and the exit code.
 A *step* is one optimizer step: every rank runs ``--episodes-per-rank`` independent
 few-shot episodes (forward, Chamfer loss, backward), gradients are all-reduced over RCCL,
 Adam updates the 77 M parameters.  Weak scaling: per-rank work is fixed.
@@ -471,6 +473,25 @@ def run_workload(wl, args, rank, world, device, steps, warmup, probe=None, graph
                             "and the decoder's split first layer do the same arithmetic with 4x / ~100x fewer multiplies"}}
 
 
+def self_launch(n_gpus):
+    """``python bench.py --gpus N`` (N > 1) without a torchrun environment: runs
+    ``python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free>
+    bench.py <the same arguments>`` as a child process, passes its stdout / stderr through (rank 0 prints the one
+    JSON line) and returns its exit code.  Called before anything touches the GPU."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL's intra-node transport needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n_gpus) // n_gpus)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print("[bench] no torchrun environment: launching " + " ".join(cmd), file=sys.stderr, flush=True)
+    return subprocess.run(cmd, env=env, cwd=ROOT).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -504,11 +525,16 @@ def main():
     steps = args.steps if args.steps is not None else (5 if epr > 1 else 20)
     warmup = args.warmup if args.warmup is not None else (2 if epr > 1 else 5)
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # typed as `python bench.py --gpus N` with no launcher around it: start one rank per GPU as CHILD processes of
+        # torch.distributed.run and relay rank 0's line.  This process has made no HIP call up to here and makes none
+        # afterwards (it never replaces itself either: an exec from a GPU-initialised process is what the pool forbids).
+        raise SystemExit(self_launch(args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU (the hot path has no CPU fallback)")
     rank, world, device = fdist.init_distributed("cuda")
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's --nproc-per-node and --gpus differ")
     torch.backends.cudnn.benchmark = bool(args.miopen_benchmark)
     if args.gemm_tuning is not None:
         os.environ["FPSG_GEMM_TUNING"] = {"off": "0"}.get(args.gemm_tuning, args.gemm_tuning)

@@ -248,3 +248,23 @@ def test_sharded_evaluation_reports_what_one_process_reports(tmp_path):
     for rank in (0, 1):
         got = torch.load(os.path.join(tmp_path, f"eval{rank}.pt"), weights_only=True)
         assert got["every"] == every and got["lines"] == lines
+
+
+def test_bench_gpus_n_without_a_launcher_starts_one_as_a_child():
+    """`python bench.py --gpus 2` with no torchrun variables: bench.py must start torch.distributed.run itself (a child
+    process, before any GPU call) and hand back the child's exit code.  There is no GPU here, so each of the two ranks
+    stops at the loud 'needs a ROCm GPU' line -- which shows that two ranks were started with a rendezvous environment
+    and that the parent relays their failure instead of the old 'launch with torch.distributed.run' exit."""
+    import subprocess
+    import sys
+    if torch.cuda.is_available():
+        pytest.skip("on a GPU box tests/test_dist_gpu.py runs the same command to completion")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "1", "--warmup", "0"], cwd=root, env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert "launching" in r.stderr and "--nproc-per-node 2" in r.stderr and "--master-addr 127.0.0.1" in r.stderr
+    assert r.returncode != 0
+    assert r.stderr.count("bench.py needs a ROCm GPU") >= 2, r.stderr[-3000:]
+    assert "launch with torch.distributed.run" not in r.stderr

@@ -54,3 +54,20 @@ def test_two_ranks_share_the_gpu_over_gloo(gpu):
     assert d["value"] > 0 and d["final_loss"] == d["final_loss"]
     assert "cpu_baseline" not in d and "configs" not in d    # N = 1 legs only
     assert len(d["allreduce"]["buckets"]) == 4
+
+
+def test_bench_typed_with_gpus_2_launches_itself(gpu):
+    """`python3 bench.py --gpus 2` as the driver types it for N = 1 -- no launcher, no torchrun variables: bench.py starts
+    torch.distributed.run as a child process before it touches the GPU and relays rank 0's one line and the exit code."""
+    env = dict(os.environ, FPSG_DIST_BACKEND="gloo", FPSG_LOCAL_DEVICE="0", PYTHONPATH=ROOT)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--workload", "c3", "--steps", "2", "--warmup", "1"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert "launching" in r.stderr and "torch.distributed.run" in r.stderr
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["distributed"]["world_size"] == 2 and d["distributed"]["ranks_that_reported"] == 2
+    assert d["config"]["episodes_per_step_global"] == 2 and d["value"] > 0
