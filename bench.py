@@ -60,7 +60,7 @@ WORKLOADS = {
 }
 
 # one two-sided Chamfer forward on a 2048-point cloud pair = 81,920 algorithmic
-# bytes (2*2048*12 B read + 2*2048*(4+4) B written) and 2*N*M pair evaluations x 8 flop
+# bytes (2*2048*12 B read + 2*2048*(4+4) B written) and N*M distances x 8 flop when one pass serves both sides
 HBM_PEAK = 8.0e12                                # B/s  (MI355X_MICROARCH.md)
 F32_PEAK = 157.3e12                              # FLOP/s, fp32 vector == fp32-input MFMA
 
@@ -120,7 +120,7 @@ class EventProbe:
             sec += e0.elapsed_time(e1) * 1e-3
             pairs += B
             nbytes += B * ((N + M) * 12 + (N + M) * 8)   # read both clouds; write dist+idx
-            flops += B * 2.0 * N * M * 8.0                # 2*N*M pair evaluations x 8 flop
+            flops += B * 1.0 * N * M * 8.0                # N*M distances EVALUATED (each serves both directions) x 8 flop
         return n, sec, pairs, nbytes, flops
 
 
@@ -578,16 +578,20 @@ def main():
         if n_l:
             achieved_flops = flops / sec
             res["roofline"] = {
-                "kernel": "K1 Chamfer forward (chamfer_tile_kernel + chamfer_finalize_kernel: two-sided nearest "
-                          "neighbour + argmin, every pair distance evaluated once), the launches of the timed steps",
+                "kernel": "K1 Chamfer forward of the timed steps: chamfer_tile_kernel + chamfer_finalize_kernel (two-sided "
+                          "nearest neighbour + argmin, every pair distance evaluated once) + the loss sums' last stage "
+                          "(chamfer_loss_reduce_kernel), one C call bracketed by HIP events",
                 "bound": "valu",   # fp32 vector-ALU bound (no MFMA instruction in it); same 157.3 TFLOP/s peak
                 "achieved": achieved_flops / 1e12, "peak": F32_PEAK / 1e12, "unit": "TFLOP/s",
                 "frac": achieved_flops / F32_PEAK,
-                "flop_convention": "SURVEY.md 8(d): 2*N*M directed pair evaluations x 8 flop per cloud pair "
-                                   "(the one-pass kernel evaluates N*M distances; by that count the rate is half)",
-                "achieved_one_pass_convention": achieved_flops / 2e12,
+                "flop_convention": "EXECUTED work: N*M distances per cloud pair x 8 flop (one evaluation serves both "
+                                   "directions; SURVEY.md 8(d)'s 4,194,304 pair evaluations 'if one fused pass yields "
+                                   "both sides')",
+                "frac_directed_pair_convention": 2.0 * achieved_flops / F32_PEAK,
+                "directed_pair_convention": "SURVEY.md 8(d)'s other count, 2*N*M directed pair evaluations x 8 flop, which "
+                                            "a two-pass kernel executes and this one does not",
                 "traffic": pmc_traffic(probe, "chamfer_fwd"),
-                "traffic_unit": "HBM bytes per op (tiles + finalize), rocprofv3 PMC (2*FETCH_SIZE+WRITE_SIZE)*1024, "
+                "traffic_unit": "HBM bytes per op (tiles + finalize + sums), rocprofv3 PMC (2*FETCH_SIZE+WRITE_SIZE)*1024, "
                                 "profiles/k1_traffic.json",
                 "algorithmic_bytes_per_launch": nbytes / n_l,
                 "launches": n_l, "avg_launch_us": sec / n_l * 1e6,
@@ -595,19 +599,21 @@ def main():
                 "hbm": {"achieved": nbytes / sec / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                         "frac": nbytes / sec / HBM_PEAK,
                         "note": "algorithmic bytes (81,920 B per 2048x2048 cloud pair); the kernel "
-                                "is fp32-VALU bound: arithmetic intensity ~820 flop/B vs ridge ~20"},
+                                "is fp32-VALU bound: arithmetic intensity ~410 flop/B vs ridge ~20"},
             }
             if nb_l:
                 res["roofline"]["bwd_avg_launch_us"] = bsec / nb_l * 1e6
         kernels = {}
         if nb_l:
-            # K1 backward in the step: 131,072 algorithmic bytes per 2048x2048 cloud pair; the
-            # kernel is a latency chain (sort + runs), not a stream
-            bb = bpairs * 131072.0
+            # K1 backward in the step (fpsg_chamfer_bwd_losses): SURVEY.md 8(d)'s 131,072 algorithmic bytes per 2048x2048
+            # cloud pair less the two upstream-gradient rows (16,384 B) that the per-pair constants replace; the kernel
+            # is a latency chain (sort + runs), not a stream
+            bb = bpairs * (131072.0 - 16384.0)
             kernels["K1_chamfer_bwd_in_step"] = {
                 "bound": "hbm", "achieved": bb / bsec / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                 "frac": bb / bsec / HBM_PEAK, "us": bsec / nb_l * 1e6, "shape": f"B={bpairs / nb_l:.0f} N=M=2048",
-                "work": "131,072 algorithmic bytes per cloud pair; one workgroup per (pair, side): LDS sort of the "
+                "work": "114,688 algorithmic bytes per cloud pair (idx + clouds read, gradients written; the loss sums' per-pair "
+                        "constants are formed in the kernel); one workgroup per (pair, side): LDS sort of the "
                         "argmin list + blocked ascending sums, time independent of the in-degree distribution"}
         if world == 1 and not args.no_extra:
             del main_run["step"]

@@ -40,6 +40,12 @@ SIGNATURES = {
     "fpsg_chamfer_fwd_tiled": [_c_f32p, _c_f32p, _c_int, _c_int, _c_int,
                                _c_f32p, _c_i32p, _c_f32p, _c_i32p, ctypes.c_void_p, ctypes.c_size_t, _c_int,
                                _c_stream],
+    "fpsg_chamfer_fwd_tiled_losses": [_c_f32p, _c_f32p, _c_int, _c_int, _c_int,
+                                      _c_f32p, _c_i32p, _c_f32p, _c_i32p, ctypes.c_void_p, ctypes.c_size_t, _c_int,
+                                      _c_int, ctypes.c_float, ctypes.c_float, _c_f32p, _c_stream],
+    "fpsg_chamfer_bwd_losses": [_c_f32p, _c_f32p, _c_i32p, _c_i32p, _c_f32p, _c_f32p, _c_f32p,
+                                _c_int, _c_int, _c_int, _c_int, ctypes.c_float, ctypes.c_float, _c_f32p, _c_f32p,
+                                _c_stream],
     "fpsg_chamfer_bwd_sorted": [_c_f32p, _c_f32p, _c_i32p, _c_i32p, _c_f32p, _c_f32p,
                                 _c_int, _c_int, _c_int, _c_f32p, _c_f32p, _c_stream],
     "fpsg_chamfer_bwd_scan": [_c_f32p, _c_f32p, _c_i32p, _c_i32p, _c_f32p, _c_f32p,

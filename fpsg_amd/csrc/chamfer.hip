@@ -353,59 +353,67 @@ __global__ __launch_bounds__(kBwdThreads) void chamfer_bwd_kernel(
 // ---- K1l: the episode's reconstruction losses straight from the nearest-neighbour distances ---------------------
 // few_shot.py:110-124 of the reference: chamfer_distance(...) = mean_i d1 + mean_j d2 per cloud pair, .sum() over the
 // query pairs and over the support pairs, then query_factor * q + support_factor * s.  As PyTorch operations that is
-// eight launches of a few microseconds forward and eleven backward; here one each.  One workgroup: wave w owns the pairs
-// b = w, w + 16, ...; a lane adds its share of a row in ascending order (four independent chains when the row length is
-// a multiple of four), wave_sum's fixed tree joins the lanes, thread 0 adds the pairs in ascending b.  Deterministic.
+// eight launches of a few microseconds forward and eleven backward; here one each.
+// Summation order (one order for this kernel, for the sums fused into the one-pass forward -- chamfer_finalize_kernel<true>
+// + chamfer_loss_reduce_kernel -- and for the oracle's chamfer_losses):
+//   a row is cut into blocks of 256 consecutive values (past the end: +0); inside a block the four groups of 64 are each
+//   summed by the balanced tree over the lane index (wave_sum), block = ((T0 + T1) + T2) + T3; the row's sum adds its
+//   blocks in ascending order from +0; cd_b = s1 * (1/N) + s2 * (1/M); a group's sum (pairs below n_first / the rest, a pair outside
+//   the group as +0): 64 partial sums p_l = cd_l + cd_(l+64) + ... (ascending), then the balanced tree over l.
+// This kernel: ONE workgroup (the stand-alone form serves the few-pair launches that take the two-pass forward; from ~7
+// pairs up the sums ride in the one-pass forward's finalize kernel), wave w owns the rows w, w + 16, ... of the 2 B.
 constexpr int kLossThreads = 1024;
 constexpr int kLossPairs = 4096;
+constexpr int kLossBlock = 256;          // = chamfer_tiled.hip's kFinThreads
 
 __device__ __forceinline__ float row_sum(const float* __restrict__ row, int n, int lane) {
   float s = 0.f;
-  if ((n & 3) == 0 && (reinterpret_cast<uintptr_t>(row) & 15u) == 0) {
-    const v4f* r4 = reinterpret_cast<const v4f*>(row);
-    const int n4 = n >> 2;
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    // eight vectors of a lane requested together (a 2048-element row is one trip), added in ascending order
-    for (int i0 = lane; i0 < n4; i0 += 64 * 8) {
-      v4f v[8];
+  for (int c0 = 0; c0 < n; c0 += 2 * kLossBlock) {       // two blocks' eight loads requested together
+    float v[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int i = i0 + 64 * j;
-        v[j] = i < n4 ? r4[i] : (v4f){0.f, 0.f, 0.f, 0.f};
-      }
-#pragma unroll
-      for (int j = 0; j < 8; ++j) { a0 += v[j].x; a1 += v[j].y; a2 += v[j].z; a3 += v[j].w; }
+    for (int g = 0; g < 8; ++g) {
+      const int i = c0 + 64 * g + lane;
+      v[g] = i < n ? row[i] : 0.f;
     }
-    s = (a0 + a1) + (a2 + a3);
-  } else {
-    for (int i = lane; i < n; i += 64) s += row[i];
+#pragma unroll
+    for (int g = 0; g < 8; ++g) v[g] = wave_sum(v[g]);
+    s += ((v[0] + v[1]) + v[2]) + v[3];
+    if (c0 + kLossBlock < n) s += ((v[4] + v[5]) + v[6]) + v[7];
   }
-  return wave_sum(s);
+  return s;
 }
 
 __global__ __launch_bounds__(kLossThreads) void chamfer_losses_kernel(
     const float* __restrict__ d1, const float* __restrict__ d2, int B, int N, int M, int n_first, float w_first,
     float w_rest, float* __restrict__ out) {
-  __shared__ float cd[kLossPairs];
+  __shared__ float sums[2 * kLossPairs];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int b = wave; b < B; b += kLossThreads / 64) {
-    const float s1 = row_sum(d1 + (size_t)b * N, N, lane);
-    const float s2 = row_sum(d2 + (size_t)b * M, M, lane);
-    if (lane == 0) cd[b] = s1 / (float)N + s2 / (float)M;
+  for (int u = wave; u < 2 * B; u += kLossThreads / 64) {
+    const int b = u >> 1;
+    const float s = (u & 1) ? row_sum(d2 + (size_t)b * M, M, lane) : row_sum(d1 + (size_t)b * N, N, lane);
+    if (lane == 0) sums[u] = s;
   }
   __syncthreads();
-  if (threadIdx.x == 0) {
+  if (wave == 0) {
     float q = 0.f, r = 0.f;
-    for (int b = 0; b < n_first; ++b) q += cd[b];
-    for (int b = n_first; b < B; ++b) r += cd[b];
-    out[0] = q;
-    out[1] = r;
-    out[2] = w_first * q + w_rest * r;
+    for (int b = lane; b < B; b += 64) {
+      const float v = sums[2 * b] * (1.0f / (float)N) + sums[2 * b + 1] * (1.0f / (float)M);
+      if (b < n_first) q += v; else r += v;
+    }
+    q = wave_sum(q);
+    r = wave_sum(r);
+    if (lane == 0) {
+      out[0] = q;
+      out[1] = r;
+      out[2] = w_first * q + w_rest * r;
+    }
   }
 }
 
 // The gradients of those three values with respect to d1 / d2: a constant per cloud pair,
-//   g1[b, :] = (g_total * w_b + g_own_b) / N,  g2[b, :] = (same) / M,   w_b / g_own_b: the pair's group (first / rest).
+//   g1[b, :] = (g_total * w_b + g_own_b) * (1/N),  g2[b, :] = (same) * (1/M),   w_b / g_own_b: the pair's group (first /
+// rest); fp32 reciprocals: PyTorch's GPU kernels divide by a host scalar that way, so these are the bits of autograd's
+// own mean backward for any N, not only powers of two.
 // g_first, g_rest, g_total: device scalars, null = no gradient arrives through that value.
 __global__ __launch_bounds__(256) void chamfer_loss_grads_kernel(
     const float* __restrict__ g_first, const float* __restrict__ g_rest, const float* __restrict__ g_total, int N, int M,
@@ -416,7 +424,7 @@ __global__ __launch_bounds__(256) void chamfer_loss_grads_kernel(
   if (g_total) g = *g_total * (first ? w_first : w_rest);
   const float* own = first ? g_first : g_rest;
   if (own) g += *own;
-  const float v1 = g / (float)N, v2 = g / (float)M;
+  const float v1 = g * (1.0f / (float)N), v2 = g * (1.0f / (float)M);
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i < N) g1[(size_t)b * N + i] = v1;
   if (i < M) g2[(size_t)b * M + i] = v2;

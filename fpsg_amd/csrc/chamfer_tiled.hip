@@ -17,13 +17,16 @@
 //     then reduced across the 64 lanes through a wave-private LDS transpose: lane (s,c) reads the 16
 //     partials of candidate c from the lanes of segment s, keeps the minimum and the first lane that
 //     holds it; two butterfly steps merge the four segments (lower lane on ties).  Partial results are
-//     64-bit keys
-//       rows:    dist_bits << 32 | candidate chunk        -> row_keys[b][cs][i]
-//       columns: dist_bits << 32 | row segment (16*R rows) -> col_keys[b][rt][j]
-//     (unsigned min = smallest distance, then lowest index range = Kaolin's first-minimum rule).
-//   chamfer_finalize_kernel: merges the partial keys of a point (min over tiles) and recovers the exact
-//     index inside the winning range by re-evaluating it with the identical arithmetic, strict '<',
-//     ascending index (16 candidates for a row; R rows for a column).
+//     32-bit keys (round 4; 64-bit before: the partial keys were 6.6x the op's algorithmic HBM bytes)
+//       rows:    dist_bits & ~63 | candidate chunk inside the tile (< 64) -> row_keys[b][cs][i]
+//       columns: dist_bits & ~63 | lane = group of R rows inside the tile -> col_keys[b][rt][j]
+//     i.e. the tile's exact minimum with its six lowest mantissa bits replaced by where it was found.
+//   chamfer_finalize_kernel<LOSS>: the truncation is monotone, so the tile that holds a point's true minimum is
+//     among those whose truncated distance equals the smallest truncated distance (nearly always exactly one);
+//     the kernel re-evaluates the named range of every such tile with the identical arithmetic, strict '<',
+//     ascending tile and index (16 candidates for a row; R rows for a column) = Kaolin's first-minimum rule,
+//     bit for bit.  LOSS: it also leaves the sum of each block's 256 distances (fixed tree) for the episode's
+//     loss sums (chamfer_loss_reduce_kernel; fpsg_chamfer_fwd_tiled_losses).
 //
 // Instruction count: ~4.7 per d(i,j) = 2.35 per directed pair evaluation against 3.7 for the two-pass
 // kernel.
@@ -100,7 +103,7 @@ __device__ __forceinline__ int xcd_work_index() {
 template <int R, int W>
 __global__ __launch_bounds__(64 * W) void chamfer_tile_kernel(
     const float* __restrict__ xyz1, const float* __restrict__ xyz2, int N, int M, int RT, int CS,
-    int cpw, unsigned long long* __restrict__ row_keys, unsigned long long* __restrict__ col_keys) {
+    int cpw, unsigned* __restrict__ row_keys, unsigned* __restrict__ col_keys) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int CW = W * cpw * kChunk;
   const int work = xcd_work_index();
@@ -180,7 +183,7 @@ __global__ __launch_bounds__(64 * W) void chamfer_tile_kernel(
   float best[R];
   int bestc[R];
 #pragma unroll
-  for (int r = 0; r < R; ++r) { best[r] = __builtin_inff(); bestc[r] = 0; }
+  for (int r = 0; r < R; ++r) { best[r] = __builtin_inff(); bestc[r] = c0 / kChunk; }
 
   const int seg = lane >> 4;          // 16-lane segment = 16*R consecutive rows
   const int cl = lane & 15;           // candidate of the chunk this lane reduces
@@ -256,15 +259,14 @@ __global__ __launch_bounds__(64 * W) void chamfer_tile_kernel(
       }
       const int cand = c0 + cbase + cl;
       if (lane < 16 && cand < M) {
-        // low word: the group of R consecutive rows (one lane's) that holds the column minimum
-        const unsigned long long key =
-            ((unsigned long long)__float_as_uint(v) << 32) | (unsigned)(rt * 64 + ln);
-        col_keys[((size_t)b * RT + rt) * M + cand] = key;
+        // low six bits: the lane whose R consecutive rows hold the column minimum
+        col_keys[((size_t)b * RT + rt) * M + cand] = (__float_as_uint(v) & ~63u) | (unsigned)ln;
       }
     }
   }
 
-  // ---- rows: merge the W waves' partial minima, store the tile's row keys
+  // ---- rows: merge the W waves' partial minima (exact 64-bit keys in LDS), store the tile's 32-bit row keys
+  const unsigned chunk0 = (unsigned)(c0 / kChunk);       // bestc - chunk0 < W * cpw <= 36
   if (W > 1) {
     unsigned long long* keys = reinterpret_cast<unsigned long long*>(lds + 3 * CW + W * 64 * kTStride);
 #pragma unroll
@@ -281,7 +283,8 @@ __global__ __launch_bounds__(64 * W) void chamfer_tile_kernel(
         const unsigned long long k2 = keys[w * (64 * R) + ql];
         key = k2 < key ? k2 : key;
       }
-      row_keys[((size_t)b * CS + cs) * N + i] = key;
+      row_keys[((size_t)b * CS + cs) * N + i] =
+          ((unsigned)(key >> 32) & ~63u) | (((unsigned)key - chunk0) & 63u);
     }
   } else {
 #pragma unroll
@@ -289,7 +292,7 @@ __global__ __launch_bounds__(64 * W) void chamfer_tile_kernel(
       const int i = row0 + r;
       if (i < N)
         row_keys[((size_t)b * CS + cs) * N + i] =
-            ((unsigned long long)__float_as_uint(best[r]) << 32) | (unsigned)bestc[r];
+            (__float_as_uint(best[r]) & ~63u) | (((unsigned)bestc[r] - chunk0) & 63u);
     }
   }
 }
@@ -297,12 +300,18 @@ __global__ __launch_bounds__(64 * W) void chamfer_tile_kernel(
 constexpr int kFinThreads = 256;
 
 // One thread per output point.  Blocks [0, nb1) of a cloud pair serve xyz1's points (rows), the
-// others xyz2's points (columns).
+// others xyz2's points (columns).  A point's partial keys are scanned once (smallest truncated distance, the
+// first tile that has it, how many have it); the first such tile's range is re-evaluated by every lane together,
+// further ones (two tiles whose minima agree in all but the six lowest mantissa bits: rare) in a second loop.
+// LOSS: block_sums[b * (nb1 + nb2) + blk] = the sum of the block's distances, points past the end as +0:
+//   wave w = tree sum over its 64 lanes (wave_sum), block = ((w0 + w1) + w2) + w3.
+template <bool LOSS>
 __global__ __launch_bounds__(kFinThreads) void chamfer_finalize_kernel(
     const float* __restrict__ xyz1, const float* __restrict__ xyz2, int N, int M, int RT, int CS,
-    int grp_rows, const unsigned long long* __restrict__ row_keys,
-    const unsigned long long* __restrict__ col_keys, float* __restrict__ dist1,
-    int32_t* __restrict__ idx1, float* __restrict__ dist2, int32_t* __restrict__ idx2) {
+    int grp_rows, int tile_chunks, const unsigned* __restrict__ row_keys,
+    const unsigned* __restrict__ col_keys, float* __restrict__ dist1,
+    int32_t* __restrict__ idx1, float* __restrict__ dist2, int32_t* __restrict__ idx2,
+    float* __restrict__ block_sums) {
   const int nb1 = (N + kFinThreads - 1) / kFinThreads;
   const int nb2 = (M + kFinThreads - 1) / kFinThreads;
   const int work = xcd_work_index();
@@ -311,99 +320,180 @@ __global__ __launch_bounds__(kFinThreads) void chamfer_finalize_kernel(
   const int tid = threadIdx.x;
   const float* __restrict__ P1 = xyz1 + (size_t)b * N * 3;
   const float* __restrict__ P2 = xyz2 + (size_t)b * M * 3;
+  float mine = 0.f;                                      // this thread's distance (LOSS)
 
   if (blk < nb1) {
-    // ---- a point of xyz1: best candidate chunk, then its 16 candidates in ascending order
+    // ---- a point of xyz1: best candidate chunk(s), 16 candidates each in ascending order
     const int i = blk * kFinThreads + tid;
-    if (i >= N) return;
-    const unsigned long long* kp = row_keys + ((size_t)b * CS) * N + i;
-    unsigned long long key = ~0ull;
-    int s = 0;
-    for (; s + 4 <= CS; s += 4) {                      // four independent loads in flight
-      const unsigned long long k0 = kp[(size_t)s * N], k1 = kp[(size_t)(s + 1) * N];
-      const unsigned long long k2 = kp[(size_t)(s + 2) * N], k3 = kp[(size_t)(s + 3) * N];
-      const unsigned long long m01 = k0 < k1 ? k0 : k1, m23 = k2 < k3 ? k2 : k3;
-      const unsigned long long m = m01 < m23 ? m01 : m23;
-      key = m < key ? m : key;
-    }
-    for (; s < CS; ++s) {
-      const unsigned long long k2 = kp[(size_t)s * N];
-      key = k2 < key ? k2 : key;
-    }
-    const int j0 = (int)(unsigned)(key & 0xffffffffull) * kChunk;
-    const float x = P1[3 * i + 0], y = P1[3 * i + 1], z = P1[3 * i + 2];
-    float cx[kChunk], cy[kChunk], cz[kChunk];
-    if (((reinterpret_cast<uintptr_t>(P2) & 15) == 0) && j0 + kChunk <= M) {
-      // a chunk is 192 contiguous, 16-byte aligned bytes: twelve 16-byte loads instead of 48 scalar ones
-      float f[3 * kChunk];
-      const v4f* c4 = reinterpret_cast<const v4f*>(P2 + 3 * j0);
-#pragma unroll
-      for (int u = 0; u < (3 * kChunk) / 4; ++u) {
-        const v4f v = c4[u];
-        f[4 * u] = v.x; f[4 * u + 1] = v.y; f[4 * u + 2] = v.z; f[4 * u + 3] = v.w;
+    if (i < N) {
+      const unsigned* kp = row_keys + ((size_t)b * CS) * N + i;
+      unsigned tmin = 0xffffffffu, kfirst = 0;
+      int sfirst = 0, same = 0;
+      auto take = [&](unsigned k, int s) {
+        const unsigned t = k & ~63u;
+        same = t < tmin ? 1 : same + (t == tmin ? 1 : 0);
+        sfirst = t < tmin ? s : sfirst;
+        kfirst = t < tmin ? k : kfirst;
+        tmin = t < tmin ? t : tmin;
+      };
+      int s = 0;
+      for (; s + 4 <= CS; s += 4) {                      // four independent loads in flight
+        const unsigned k0 = kp[(size_t)s * N], k1 = kp[(size_t)(s + 1) * N];
+        const unsigned k2 = kp[(size_t)(s + 2) * N], k3 = kp[(size_t)(s + 3) * N];
+        take(k0, s); take(k1, s + 1); take(k2, s + 2); take(k3, s + 3);
       }
+      for (; s < CS; ++s) take(kp[(size_t)s * N], s);
+      const float x = P1[3 * i + 0], y = P1[3 * i + 1], z = P1[3 * i + 2];
+      float bd = __builtin_inff();
+      int bi = 0;
+      auto chunk = [&](int j0) {
+        float cx[kChunk], cy[kChunk], cz[kChunk];
+        if (((reinterpret_cast<uintptr_t>(P2) & 15) == 0) && j0 + kChunk <= M) {
+          // a chunk is 192 contiguous, 16-byte aligned bytes: twelve 16-byte loads instead of 48 scalar ones
+          float f[3 * kChunk];
+          const v4f* c4 = reinterpret_cast<const v4f*>(P2 + 3 * j0);
 #pragma unroll
-      for (int u = 0; u < kChunk; ++u) { cx[u] = f[3 * u]; cy[u] = f[3 * u + 1]; cz[u] = f[3 * u + 2]; }
-    } else {
+          for (int u = 0; u < (3 * kChunk) / 4; ++u) {
+            const v4f v = c4[u];
+            f[4 * u] = v.x; f[4 * u + 1] = v.y; f[4 * u + 2] = v.z; f[4 * u + 3] = v.w;
+          }
 #pragma unroll
-      for (int u = 0; u < kChunk; ++u) {               // all loads first; candidates past M read the last one
-        const int j = (j0 + u) < M ? (j0 + u) : (M - 1);
-        cx[u] = P2[3 * j + 0]; cy[u] = P2[3 * j + 1]; cz[u] = P2[3 * j + 2];
+          for (int u = 0; u < kChunk; ++u) { cx[u] = f[3 * u]; cy[u] = f[3 * u + 1]; cz[u] = f[3 * u + 2]; }
+        } else {
+#pragma unroll
+          for (int u = 0; u < kChunk; ++u) {             // all loads first; candidates past M read the last one
+            const int j = (j0 + u) < M ? (j0 + u) : (M - 1);
+            cx[u] = P2[3 * j + 0]; cy[u] = P2[3 * j + 1]; cz[u] = P2[3 * j + 2];
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < kChunk; ++u) {
+          const float d = (j0 + u) < M ? sq_dist(x, y, z, cx[u], cy[u], cz[u]) : __builtin_inff();
+          const bool lt = d < bd;
+          bi = lt ? j0 + u : bi;
+          bd = lt ? d : bd;
+        }
+      };
+      chunk((sfirst * tile_chunks + (int)(kfirst & 63u)) * kChunk);
+      if (same > 1) {
+        for (s = sfirst + 1; s < CS; ++s) {
+          const unsigned k = kp[(size_t)s * N];
+          if ((k & ~63u) == tmin) chunk((s * tile_chunks + (int)(k & 63u)) * kChunk);
+        }
       }
+      dist1[(size_t)b * N + i] = bd;
+      idx1[(size_t)b * N + i] = bi;
+      mine = bd;
     }
-    float bd = __builtin_inff();
-    int bi = 0;
+  } else {
+    // ---- a point of xyz2: best group(s) of grp_rows consecutive rows (one lane's rows of a tile)
+    const int j = (blk - nb1) * kFinThreads + tid;
+    if (j < M) {
+      const unsigned* kp = col_keys + ((size_t)b * RT) * M + j;
+      unsigned tmin = 0xffffffffu, kfirst = 0;
+      int tfirst = 0, same = 0;
+      auto take = [&](unsigned k, int t_) {
+        const unsigned t = k & ~63u;
+        same = t < tmin ? 1 : same + (t == tmin ? 1 : 0);
+        tfirst = t < tmin ? t_ : tfirst;
+        kfirst = t < tmin ? k : kfirst;
+        tmin = t < tmin ? t : tmin;
+      };
+      int t = 0;
+      for (; t + 4 <= RT; t += 4) {
+        const unsigned k0 = kp[(size_t)t * M], k1 = kp[(size_t)(t + 1) * M];
+        const unsigned k2 = kp[(size_t)(t + 2) * M], k3 = kp[(size_t)(t + 3) * M];
+        take(k0, t); take(k1, t + 1); take(k2, t + 2); take(k3, t + 3);
+      }
+      for (; t < RT; ++t) take(kp[(size_t)t * M], t);
+      const float x = P2[3 * j + 0], y = P2[3 * j + 1], z = P2[3 * j + 2];
+      float bd = __builtin_inff();
+      int bi = 0;
+      // the reference's second direction evaluates d(q = xyz2[j], c = xyz1[i]); same bits either way
+      auto group = [&](int i0) {
+        for (int u0 = 0; u0 < grp_rows; u0 += 4) {       // grp_rows is 4 or 8
+          float rx[4], ry[4], rz[4];
 #pragma unroll
-    for (int u = 0; u < kChunk; ++u) {
-      const float d = (j0 + u) < M ? sq_dist(x, y, z, cx[u], cy[u], cz[u]) : __builtin_inff();
-      const bool lt = d < bd;
-      bi = lt ? j0 + u : bi;
-      bd = lt ? d : bd;
+          for (int u = 0; u < 4; ++u) {
+            const int i = (i0 + u0 + u) < N ? (i0 + u0 + u) : (N - 1);
+            rx[u] = P1[3 * i + 0]; ry[u] = P1[3 * i + 1]; rz[u] = P1[3 * i + 2];
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const float d = (i0 + u0 + u) < N ? sq_dist(x, y, z, rx[u], ry[u], rz[u]) : __builtin_inff();
+            const bool lt = d < bd;
+            bi = lt ? i0 + u0 + u : bi;
+            bd = lt ? d : bd;
+          }
+        }
+      };
+      group((tfirst * 64 + (int)(kfirst & 63u)) * grp_rows);
+      if (same > 1) {
+        for (t = tfirst + 1; t < RT; ++t) {
+          const unsigned k = kp[(size_t)t * M];
+          if ((k & ~63u) == tmin) group((t * 64 + (int)(k & 63u)) * grp_rows);
+        }
+      }
+      dist2[(size_t)b * M + j] = bd;
+      idx2[(size_t)b * M + j] = bi;
+      mine = bd;
     }
-    dist1[(size_t)b * N + i] = bd;
-    idx1[(size_t)b * N + i] = bi;
-    return;
   }
 
-  // ---- a point of xyz2: best group of grp_rows consecutive rows (one lane's rows), then those rows
-  const int j = (blk - nb1) * kFinThreads + tid;
-  if (j >= M) return;
-  const unsigned long long* kp = col_keys + ((size_t)b * RT) * M + j;
-  unsigned long long key = ~0ull;
-  int t = 0;
-  for (; t + 4 <= RT; t += 4) {
-    const unsigned long long k0 = kp[(size_t)t * M], k1 = kp[(size_t)(t + 1) * M];
-    const unsigned long long k2 = kp[(size_t)(t + 2) * M], k3 = kp[(size_t)(t + 3) * M];
-    const unsigned long long m01 = k0 < k1 ? k0 : k1, m23 = k2 < k3 ? k2 : k3;
-    const unsigned long long m = m01 < m23 ? m01 : m23;
-    key = m < key ? m : key;
+  if (LOSS) {
+    __shared__ float wsum[kFinThreads / 64];
+    const float w = wave_sum(mine);
+    if ((tid & 63) == 0) wsum[tid >> 6] = w;
+    __syncthreads();
+    if (tid == 0) block_sums[(size_t)b * (nb1 + nb2) + blk] = ((wsum[0] + wsum[1]) + wsum[2]) + wsum[3];
   }
-  for (; t < RT; ++t) {
-    const unsigned long long k2 = kp[(size_t)t * M];
-    key = k2 < key ? k2 : key;
-  }
-  const int i0 = (int)(unsigned)(key & 0xffffffffull) * grp_rows;
-  const float x = P2[3 * j + 0], y = P2[3 * j + 1], z = P2[3 * j + 2];
-  float bd = __builtin_inff();
-  int bi = 0;
-  // the reference's second direction evaluates d(q = xyz2[j], c = xyz1[i]); same bits either way
-  for (int u0 = 0; u0 < grp_rows; u0 += 4) {             // grp_rows is 4 or 8
-    float rx[4], ry[4], rz[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int i = (i0 + u0 + u) < N ? (i0 + u0 + u) : (N - 1);
-      rx[u] = P1[3 * i + 0]; ry[u] = P1[3 * i + 1]; rz[u] = P1[3 * i + 2];
+}
+
+// The last stage of the episode's loss sums (few_shot.py:110-124), one workgroup.  Thread (b, side) adds that row's
+// block sums in ascending block order from +0; cd_b = s1 / N + s2 / M; the two group sums (pairs below n_first / the
+// rest; a pair outside the group counts as +0): lane l of wave 0 adds cd_b for b = l, l + 64, ... in ascending order,
+// then the balanced tree over the lanes (wave_sum).  out3 = { q, r, w_first * q + w_rest * r }.
+constexpr int kLossPairsMax = 4096;
+constexpr int kRedThreads = 256;
+__global__ __launch_bounds__(kRedThreads) void chamfer_loss_reduce_kernel(
+    const float* __restrict__ block_sums, int B, int N, int M, int n_first, float w_first, float w_rest,
+    float* __restrict__ out) {
+  __shared__ float cd[kLossPairsMax];
+  __shared__ float stage[2048];                          // block sums of up to kRedThreads / 2 pairs at a time
+  const int nb1 = (N + kFinThreads - 1) / kFinThreads;   // <= 16 each (N, M <= 4096)
+  const int nb2 = (M + kFinThreads - 1) / kFinThreads;
+  const int nb = nb1 + nb2;
+  const int tid = threadIdx.x;
+  const int per = 2048 / nb < kRedThreads / 2 ? 2048 / nb : kRedThreads / 2;   // pairs per round
+  for (int b0 = 0; b0 < B; b0 += per) {
+    const int cnt = (B - b0 < per ? B - b0 : per) * nb;
+    for (int e = tid; e < cnt; e += kRedThreads) stage[e] = block_sums[(size_t)b0 * nb + e];   // independent, coalesced
+    __syncthreads();
+    const int bl = tid >> 1, side = tid & 1;
+    float sum = 0.f;
+    if (bl < per && b0 + bl < B) {
+      const float* p = stage + bl * nb + (side ? nb1 : 0);
+      const int n = side ? nb2 : nb1;
+      for (int k = 0; k < n; ++k) sum += p[k];
     }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const float d = (i0 + u0 + u) < N ? sq_dist(x, y, z, rx[u], ry[u], rz[u]) : __builtin_inff();
-      const bool lt = d < bd;
-      bi = lt ? i0 + u0 + u : bi;
-      bd = lt ? d : bd;
+    const float other = __uint_as_float(lane_xor<1>(__float_as_uint(sum)));
+    if (side == 0 && bl < per && b0 + bl < B) cd[b0 + bl] = sum * (1.0f / (float)N) + other * (1.0f / (float)M);
+    __syncthreads();
+  }
+  if (tid < 64) {
+    float q = 0.f, r = 0.f;
+    for (int b = tid; b < B; b += 64) {
+      const float v = cd[b];
+      if (b < n_first) q += v; else r += v;
+    }
+    q = wave_sum(q);
+    r = wave_sum(r);
+    if (tid == 0) {
+      out[0] = q;
+      out[1] = r;
+      out[2] = w_first * q + w_rest * r;
     }
   }
-  dist2[(size_t)b * M + j] = bd;
-  idx2[(size_t)b * M + j] = bi;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -440,7 +530,7 @@ inline bool tile_cfg(int B, int N, int M, int variant, TileCfg* c) {
 
 template <int R, int W>
 int launch_tiles(const float* xyz1, const float* xyz2, int B, int N, int M, const TileCfg& c,
-                 unsigned long long* row_keys, unsigned long long* col_keys, hipStream_t s) {
+                 unsigned* row_keys, unsigned* col_keys, hipStream_t s) {
   const int CW = W * c.cpw * kChunk;
   const size_t lds_bytes = (size_t)3 * CW * 4 + (size_t)W * 64 * kTStride * 4 + (W > 1 ? (size_t)W * 64 * R * 8 : 0);
   dim3 grid((unsigned)((size_t)B * c.RT * c.CS));
@@ -500,11 +590,21 @@ __device__ __forceinline__ void sort2048_regs(unsigned& a, unsigned& b, unsigned
   }
 }
 
-template <bool REG_SORT>
+// PAIR: the upstream gradient of a distance is one value per cloud pair and side -- the episode's loss sums
+// (fpsg_chamfer_bwd_losses): g = g_total * (b < n_first ? w_first : w_rest) + (b < n_first ? g_first : g_rest),
+// dist1's gradient g * (1/N), dist2's g * (1/M), formed here exactly as chamfer_loss_grads_kernel forms them (g1 = g_first,
+// g2 = g_rest then point at device scalars, null = none) instead of being read from two constant [B,N] arrays.
+struct PairGrad {
+  const float* g_total;
+  int n_first;
+  float w_first, w_rest;
+};
+
+template <bool REG_SORT, bool PAIR>
 __global__ __launch_bounds__(kSortThreads) void chamfer_bwd_sorted_kernel(
     const float* __restrict__ xyz1, const float* __restrict__ xyz2,
     const int32_t* __restrict__ idx1, const int32_t* __restrict__ idx2,
-    const float* __restrict__ g1, const float* __restrict__ g2, int N, int M, int NBP_max,
+    const float* __restrict__ g1, const float* __restrict__ g2, PairGrad pg, int N, int M, int NBP_max,
     float* __restrict__ gxyz1, float* __restrict__ gxyz2) {
   extern __shared__ __attribute__((aligned(16))) unsigned smem[];
   __shared__ int n_blocks;
@@ -517,8 +617,19 @@ __global__ __launch_bounds__(kSortThreads) void chamfer_bwd_sorted_kernel(
   const float* __restrict__ Bc = (side ? xyz1 : xyz2) + (size_t)b * nb * 3;
   const int32_t* __restrict__ ia = (side ? idx2 : idx1) + (size_t)b * na;
   const int32_t* __restrict__ ib = (side ? idx1 : idx2) + (size_t)b * nb;
-  const float* __restrict__ ga_up = (side ? g2 : g1) + (size_t)b * na;
-  const float* __restrict__ gb_up = (side ? g1 : g2) + (size_t)b * nb;
+  const float* __restrict__ ga_up = PAIR ? nullptr : (side ? g2 : g1) + (size_t)b * na;
+  const float* __restrict__ gb_up = PAIR ? nullptr : (side ? g1 : g2) + (size_t)b * nb;
+  float ga_pair = 0.f, gb_pair = 0.f;                    // PAIR: the constants of this pair's two sides
+  if (PAIR) {
+    const bool first = b < pg.n_first;
+    float g = 0.f;
+    if (pg.g_total) g = *pg.g_total * (first ? pg.w_first : pg.w_rest);
+    const float* own = first ? g1 : g2;
+    if (own) g += *own;
+    const float v1 = g * (1.0f / (float)N), v2 = g * (1.0f / (float)M);
+    ga_pair = side ? v2 : v1;
+    gb_pair = side ? v1 : v2;
+  }
   float* __restrict__ out = (side ? gxyz2 : gxyz1) + (size_t)b * na * 3;
 
   // LDS (NBP_max = power of two >= max(N, M), >= 2048):
@@ -532,7 +643,8 @@ __global__ __launch_bounds__(kSortThreads) void chamfer_bwd_sorted_kernel(
   const int tid = threadIdx.x;
 
   for (int e = tid; e < 3 * nb; e += kSortThreads) sb[e] = Bc[e];
-  for (int j = tid; j < nb; j += kSortThreads) sg[j] = gb_up[j];
+  if (!PAIR)
+    for (int j = tid; j < nb; j += kSortThreads) sg[j] = gb_up[j];
   if (tid == 0) n_blocks = 0;
 
   auto make_key = [&](int j) -> unsigned {
@@ -551,7 +663,7 @@ __global__ __launch_bounds__(kSortThreads) void chamfer_bwd_sorted_kernel(
     const int i = tid + r * kSortThreads;
     const int ic = i < na ? i : na - 1;
     apx[r] = A[3 * ic + 0]; apy[r] = A[3 * ic + 1]; apz[r] = A[3 * ic + 2];
-    aup[r] = ga_up[ic];
+    aup[r] = PAIR ? ga_pair : ga_up[ic];
     aidx[r] = ia[ic];
   }
 
@@ -608,7 +720,7 @@ __global__ __launch_bounds__(kSortThreads) void chamfer_bwd_sorted_kernel(
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        tt[u] = 2.0f * sg[jj[u]];
+        tt[u] = 2.0f * (PAIR ? gb_pair : sg[jj[u]]);
         bx[u] = sb[3 * jj[u] + 0]; by[u] = sb[3 * jj[u] + 1]; bz[u] = sb[3 * jj[u] + 2];
       }
 #pragma unroll
@@ -693,34 +805,40 @@ __global__ __launch_bounds__(kSortThreads) void chamfer_bwd_sorted_kernel(
 }  // namespace
 }  // namespace fpsg
 
-extern "C" size_t fpsg_chamfer_workspace_bytes(int B, int N, int M, int variant) {
-  fpsg::TileCfg c;
-  if (B <= 0 || N <= 0 || M <= 0 || !fpsg::tile_cfg(B, N, M, variant, &c)) return 0;
-  return ((size_t)B * c.CS * N + (size_t)B * c.RT * M) * sizeof(unsigned long long);
+namespace fpsg {
+namespace {
+
+inline size_t tile_ws_bytes(int B, int N, int M, const TileCfg& c) {
+  const size_t nblk = (size_t)((N + kFinThreads - 1) / kFinThreads + (M + kFinThreads - 1) / kFinThreads);
+  // 32-bit partial keys of both sides, then the finalize blocks' distance sums (fpsg_chamfer_fwd_tiled_losses)
+  return ((size_t)B * c.CS * N + (size_t)B * c.RT * M) * sizeof(unsigned) + (size_t)B * nblk * sizeof(float);
 }
 
-extern "C" int fpsg_chamfer_fwd_tiled(const float* xyz1, const float* xyz2, int B, int N, int M,
-                                      float* dist1, int32_t* idx1, float* dist2, int32_t* idx2,
-                                      void* ws, size_t ws_bytes, int variant, fpsg_stream_t stream) {
-  using namespace fpsg;
-  FPSG_REQUIRE(B > 0 && N > 0 && M > 0, FPSG_E_SHAPE,
-               "fpsg_chamfer_fwd_tiled: B,N,M must be positive (got %d,%d,%d)", B, N, M);
+// tiles + finalize (+ the loss sums' last stage when out3 is given)
+int tiled_forward(const char* who, const float* xyz1, const float* xyz2, int B, int N, int M, float* dist1,
+                  int32_t* idx1, float* dist2, int32_t* idx2, void* ws, size_t ws_bytes, int variant,
+                  bool loss, int n_first, float w_first, float w_rest, float* out3, fpsg_stream_t stream) {
+  FPSG_REQUIRE(B > 0 && N > 0 && M > 0, FPSG_E_SHAPE, "%s: B,N,M must be positive (got %d,%d,%d)", who, B, N, M);
   FPSG_REQUIRE_PTR(xyz1); FPSG_REQUIRE_PTR(xyz2);
   FPSG_REQUIRE_PTR(dist1); FPSG_REQUIRE_PTR(idx1);
   FPSG_REQUIRE_PTR(dist2); FPSG_REQUIRE_PTR(idx2);
   TileCfg c;
   FPSG_REQUIRE(tile_cfg(B, N, M, variant, &c), FPSG_E_LIMIT,
-               "fpsg_chamfer_fwd_tiled: N=%d, M=%d (limit 4096 each) or variant %d unsupported; use fpsg_chamfer_fwd",
-               N, M, variant);
-  const size_t need = ((size_t)B * c.CS * N + (size_t)B * c.RT * M) * sizeof(unsigned long long);
+               "%s: N=%d, M=%d (limit 4096 each) or variant %d unsupported; use fpsg_chamfer_fwd", who, N, M, variant);
+  const size_t need = tile_ws_bytes(B, N, M, c);
   FPSG_REQUIRE(ws != nullptr && (reinterpret_cast<uintptr_t>(ws) & 7) == 0, FPSG_E_NULL,
-               "fpsg_chamfer_fwd_tiled: workspace missing or not 8-byte aligned");
-  FPSG_REQUIRE(ws_bytes >= need, FPSG_E_LIMIT, "fpsg_chamfer_fwd_tiled: workspace of %zu bytes, %zu needed",
-               ws_bytes, need);
-  FPSG_REQUIRE((size_t)B * c.RT * c.CS < (1u << 31), FPSG_E_LIMIT, "fpsg_chamfer_fwd_tiled: grid too large");
+               "%s: workspace missing or not 8-byte aligned", who);
+  FPSG_REQUIRE(ws_bytes >= need, FPSG_E_LIMIT, "%s: workspace of %zu bytes, %zu needed", who, ws_bytes, need);
+  FPSG_REQUIRE((size_t)B * c.RT * c.CS < (1u << 31), FPSG_E_LIMIT, "%s: grid too large", who);
+  if (loss) {
+    FPSG_REQUIRE_PTR(out3);
+    FPSG_REQUIRE(B <= kLossPairsMax, FPSG_E_LIMIT, "%s: B=%d exceeds %d", who, B, kLossPairsMax);
+    FPSG_REQUIRE(n_first >= 0 && n_first <= B, FPSG_E_SHAPE, "%s: n_first=%d outside [0,%d]", who, n_first, B);
+  }
   hipStream_t s = static_cast<hipStream_t>(stream);
-  unsigned long long* row_keys = static_cast<unsigned long long*>(ws);
-  unsigned long long* col_keys = row_keys + (size_t)B * c.CS * N;
+  unsigned* row_keys = static_cast<unsigned*>(ws);
+  unsigned* col_keys = row_keys + (size_t)B * c.CS * N;
+  float* block_sums = reinterpret_cast<float*>(col_keys + (size_t)B * c.RT * M);
   int rc;
   if (c.R == 8) {
     rc = c.W == 4 ? launch_tiles<8, 4>(xyz1, xyz2, B, N, M, c, row_keys, col_keys, s)
@@ -733,37 +851,89 @@ extern "C" int fpsg_chamfer_fwd_tiled(const float* xyz1, const float* xyz2, int 
   }
   if (rc != 0) return rc;
   const int nblk = (N + kFinThreads - 1) / kFinThreads + (M + kFinThreads - 1) / kFinThreads;
-  hipLaunchKernelGGL(chamfer_finalize_kernel, dim3((unsigned)((size_t)B * nblk)), dim3(kFinThreads), 0,
-                     s, xyz1, xyz2, N, M, c.RT, c.CS, c.R, row_keys, col_keys, dist1, idx1, dist2, idx2);
-  return launch_status("fpsg_chamfer_fwd_tiled (finalize)");
+  const dim3 grid((unsigned)((size_t)B * nblk));
+  if (loss)
+    hipLaunchKernelGGL(chamfer_finalize_kernel<true>, grid, dim3(kFinThreads), 0, s, xyz1, xyz2, N, M, c.RT, c.CS, c.R,
+                       c.W * c.cpw, row_keys, col_keys, dist1, idx1, dist2, idx2, block_sums);
+  else
+    hipLaunchKernelGGL(chamfer_finalize_kernel<false>, grid, dim3(kFinThreads), 0, s, xyz1, xyz2, N, M, c.RT, c.CS, c.R,
+                       c.W * c.cpw, row_keys, col_keys, dist1, idx1, dist2, idx2, block_sums);
+  rc = launch_status("fpsg_chamfer_fwd_tiled (finalize)");
+  if (rc != 0 || !loss) return rc;
+  hipLaunchKernelGGL(chamfer_loss_reduce_kernel, dim3(1), dim3(kRedThreads), 0, s, block_sums, B, N, M, n_first, w_first,
+                     w_rest, out3);
+  return launch_status("fpsg_chamfer_fwd_tiled_losses (sums)");
+}
+
+int sorted_backward(const char* who, bool pair, const float* xyz1, const float* xyz2, const int32_t* idx1,
+                    const int32_t* idx2, const float* g1, const float* g2, PairGrad pg, int B, int N, int M,
+                    float* gxyz1, float* gxyz2, fpsg_stream_t stream) {
+  FPSG_REQUIRE(B > 0 && N > 0 && M > 0, FPSG_E_SHAPE, "%s: B,N,M must be positive (got %d,%d,%d)", who, B, N, M);
+  FPSG_REQUIRE(N <= kSortMax && M <= kSortMax, FPSG_E_LIMIT, "%s: N=%d, M=%d beyond %d; use fpsg_chamfer_bwd", who, N,
+               M, kSortMax);
+  FPSG_REQUIRE(B < (1 << 30), FPSG_E_LIMIT, "%s: B=%d too large", who, B);
+  FPSG_REQUIRE_PTR(xyz1); FPSG_REQUIRE_PTR(xyz2); FPSG_REQUIRE_PTR(idx1); FPSG_REQUIRE_PTR(idx2);
+  FPSG_REQUIRE_PTR(gxyz1); FPSG_REQUIRE_PTR(gxyz2);
+  const int nmax = N > M ? N : M;
+  const int NBP = nmax <= 2048 ? 2048 : 4096;
+  const size_t lds_bytes = (size_t)NBP * 4 * 7 + (size_t)(NBP / 16) * 4 * 5;   // keys, start, count, 3 coordinates, gradient; block table
+  const void* fn = NBP == 2048
+      ? (pair ? reinterpret_cast<const void*>(chamfer_bwd_sorted_kernel<true, true>)
+              : reinterpret_cast<const void*>(chamfer_bwd_sorted_kernel<true, false>))
+      : (pair ? reinterpret_cast<const void*>(chamfer_bwd_sorted_kernel<false, true>)
+              : reinterpret_cast<const void*>(chamfer_bwd_sorted_kernel<false, false>));
+  if (lds_bytes > 65536) {                              // dynamic LDS beyond 64 KiB has to be requested (no state kept)
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) { set_error("%s: %s", who, hipGetErrorString(e)); return (int)e; }
+  }
+  const dim3 grid((unsigned)(2 * B)), block(kSortThreads);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+#define FPSG_BWD_LAUNCH(RS, PR)                                                                                  \
+  hipLaunchKernelGGL((chamfer_bwd_sorted_kernel<RS, PR>), grid, block, lds_bytes, s, xyz1, xyz2, idx1, idx2, g1, \
+                     g2, pg, N, M, NBP, gxyz1, gxyz2)
+  if (NBP == 2048) { if (pair) FPSG_BWD_LAUNCH(true, true); else FPSG_BWD_LAUNCH(true, false); }
+  else             { if (pair) FPSG_BWD_LAUNCH(false, true); else FPSG_BWD_LAUNCH(false, false); }
+#undef FPSG_BWD_LAUNCH
+  return launch_status(who);
+}
+
+}  // namespace
+}  // namespace fpsg
+
+extern "C" size_t fpsg_chamfer_workspace_bytes(int B, int N, int M, int variant) {
+  fpsg::TileCfg c;
+  if (B <= 0 || N <= 0 || M <= 0 || !fpsg::tile_cfg(B, N, M, variant, &c)) return 0;
+  return fpsg::tile_ws_bytes(B, N, M, c);
+}
+
+extern "C" int fpsg_chamfer_fwd_tiled(const float* xyz1, const float* xyz2, int B, int N, int M,
+                                      float* dist1, int32_t* idx1, float* dist2, int32_t* idx2,
+                                      void* ws, size_t ws_bytes, int variant, fpsg_stream_t stream) {
+  return fpsg::tiled_forward("fpsg_chamfer_fwd_tiled", xyz1, xyz2, B, N, M, dist1, idx1, dist2, idx2, ws, ws_bytes,
+                             variant, false, 0, 0.f, 0.f, nullptr, stream);
+}
+
+extern "C" int fpsg_chamfer_fwd_tiled_losses(const float* xyz1, const float* xyz2, int B, int N, int M,
+                                             float* dist1, int32_t* idx1, float* dist2, int32_t* idx2,
+                                             void* ws, size_t ws_bytes, int variant, int n_first, float w_first,
+                                             float w_rest, float* out3, fpsg_stream_t stream) {
+  return fpsg::tiled_forward("fpsg_chamfer_fwd_tiled_losses", xyz1, xyz2, B, N, M, dist1, idx1, dist2, idx2, ws,
+                             ws_bytes, variant, true, n_first, w_first, w_rest, out3, stream);
 }
 
 extern "C" int fpsg_chamfer_bwd_sorted(const float* xyz1, const float* xyz2, const int32_t* idx1,
                                        const int32_t* idx2, const float* g1, const float* g2, int B,
                                        int N, int M, float* gxyz1, float* gxyz2, fpsg_stream_t stream) {
-  using namespace fpsg;
-  FPSG_REQUIRE(B > 0 && N > 0 && M > 0, FPSG_E_SHAPE,
-               "fpsg_chamfer_bwd_sorted: B,N,M must be positive (got %d,%d,%d)", B, N, M);
-  FPSG_REQUIRE(N <= kSortMax && M <= kSortMax, FPSG_E_LIMIT,
-               "fpsg_chamfer_bwd_sorted: N=%d, M=%d beyond %d; use fpsg_chamfer_bwd", N, M, kSortMax);
-  FPSG_REQUIRE(B < (1 << 30), FPSG_E_LIMIT, "fpsg_chamfer_bwd_sorted: B=%d too large", B);
-  FPSG_REQUIRE_PTR(xyz1); FPSG_REQUIRE_PTR(xyz2); FPSG_REQUIRE_PTR(idx1); FPSG_REQUIRE_PTR(idx2);
-  FPSG_REQUIRE_PTR(g1); FPSG_REQUIRE_PTR(g2); FPSG_REQUIRE_PTR(gxyz1); FPSG_REQUIRE_PTR(gxyz2);
-  const int nmax = N > M ? N : M;
-  const int NBP = nmax <= 2048 ? 2048 : 4096;
-  const size_t lds_bytes = (size_t)NBP * 4 * 7 + (size_t)(NBP / 16) * 4 * 5;   // keys, start, count, 3 coordinates, gradient; block table
-  if (lds_bytes > 65536) {                              // dynamic LDS beyond 64 KiB has to be requested (no state kept)
-    hipError_t e = hipFuncSetAttribute(
-        NBP == 2048 ? reinterpret_cast<const void*>(chamfer_bwd_sorted_kernel<true>)
-                    : reinterpret_cast<const void*>(chamfer_bwd_sorted_kernel<false>),
-        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    if (e != hipSuccess) { set_error("fpsg_chamfer_bwd_sorted: %s", hipGetErrorString(e)); return (int)e; }
-  }
-  if (NBP == 2048)
-    hipLaunchKernelGGL(chamfer_bwd_sorted_kernel<true>, dim3((unsigned)(2 * B)), dim3(kSortThreads), lds_bytes,
-                       static_cast<hipStream_t>(stream), xyz1, xyz2, idx1, idx2, g1, g2, N, M, NBP, gxyz1, gxyz2);
-  else
-    hipLaunchKernelGGL(chamfer_bwd_sorted_kernel<false>, dim3((unsigned)(2 * B)), dim3(kSortThreads), lds_bytes,
-                       static_cast<hipStream_t>(stream), xyz1, xyz2, idx1, idx2, g1, g2, N, M, NBP, gxyz1, gxyz2);
-  return launch_status("fpsg_chamfer_bwd_sorted");
+  FPSG_REQUIRE_PTR(g1); FPSG_REQUIRE_PTR(g2);
+  return fpsg::sorted_backward("fpsg_chamfer_bwd_sorted", false, xyz1, xyz2, idx1, idx2, g1, g2,
+                               fpsg::PairGrad{nullptr, 0, 0.f, 0.f}, B, N, M, gxyz1, gxyz2, stream);
+}
+
+extern "C" int fpsg_chamfer_bwd_losses(const float* xyz1, const float* xyz2, const int32_t* idx1,
+                                       const int32_t* idx2, const float* g_first, const float* g_rest,
+                                       const float* g_total, int B, int N, int M, int n_first, float w_first,
+                                       float w_rest, float* gxyz1, float* gxyz2, fpsg_stream_t stream) {
+  FPSG_REQUIRE(n_first >= 0 && n_first <= B, FPSG_E_SHAPE, "fpsg_chamfer_bwd_losses: n_first=%d outside [0,%d]", n_first, B);
+  return fpsg::sorted_backward("fpsg_chamfer_bwd_losses", true, xyz1, xyz2, idx1, idx2, g_first, g_rest,
+                               fpsg::PairGrad{g_total, n_first, w_first, w_rest}, B, N, M, gxyz1, gxyz2, stream);
 }

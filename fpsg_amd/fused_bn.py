@@ -28,6 +28,7 @@ from . import _hip, conv_first, winograd
 
 _ACT_CODES = {None: 0, "none": 0, "relu": 1, "leaky": 2}
 _MIN_ROW = 64
+ROWS_SEGMENT_MAX = 16384       # bnact.hip's kBnSmallMax: the longest column segment of fpsg_bn_act_rows_*
 
 
 def fused_enabled() -> bool:

@@ -54,8 +54,10 @@ def _check_clouds(p1: torch.Tensor, p2: torch.Tensor):
     _hip.dev_tensor(p2, torch.float32, "p2")
 
 
-def _sided_forward(p1, p2):
-    """K1 forward through the C ABI: ``(dist1 [B,N], dist2 [B,M], idx1, idx2)``, idx int32."""
+def _sided_forward(p1, p2, losses=None):
+    """K1 forward through the C ABI: ``(dist1 [B,N], dist2 [B,M], idx1, idx2)``, idx int32.
+    ``losses = (n_first, w_first, w_rest)``: also K1l's three sums (``out3``, a fifth result) -- fused into the
+    one-pass forward's second launch where that form serves, one more launch over the distances otherwise."""
     _check_clouds(p1, p2)
     B, N, _ = p1.shape
     M = p2.size(1)
@@ -64,21 +66,35 @@ def _sided_forward(p1, p2):
     dist2 = torch.empty((B, M), dtype=torch.float32, device=p1.device)
     idx1 = torch.empty((B, N), dtype=torch.int32, device=p1.device)
     idx2 = torch.empty((B, M), dtype=torch.int32, device=p1.device)
+    out3 = torch.empty((3,), dtype=torch.float32, device=p1.device) if losses is not None else None
     # one-pass tiled form (every d(i,j) evaluated once) for clouds of at most 4096 points; the
     # two-pass kernel (no workspace) otherwise.  Bit-identical results.
     ws_bytes = lib.fpsg_chamfer_workspace_bytes(B, N, M, -1) if _tiled_enabled() else 0
     with torch.cuda.device(p1.device), _probe("chamfer_fwd", B, N, M):
         if ws_bytes:
             ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=p1.device)
-            rc = lib.fpsg_chamfer_fwd_tiled(_hip.ptr(p1), _hip.ptr(p2), B, N, M, _hip.ptr(dist1),
-                                            _hip.ptr(idx1), _hip.ptr(dist2), _hip.ptr(idx2),
-                                            _hip.ptr(ws), ws_bytes, -1, _hip.stream_of(p1))
+            if losses is not None:
+                rc = lib.fpsg_chamfer_fwd_tiled_losses(_hip.ptr(p1), _hip.ptr(p2), B, N, M, _hip.ptr(dist1),
+                                                       _hip.ptr(idx1), _hip.ptr(dist2), _hip.ptr(idx2),
+                                                       _hip.ptr(ws), ws_bytes, -1, int(losses[0]), float(losses[1]),
+                                                       float(losses[2]), _hip.ptr(out3), _hip.stream_of(p1))
+            else:
+                rc = lib.fpsg_chamfer_fwd_tiled(_hip.ptr(p1), _hip.ptr(p2), B, N, M, _hip.ptr(dist1),
+                                                _hip.ptr(idx1), _hip.ptr(dist2), _hip.ptr(idx2),
+                                                _hip.ptr(ws), ws_bytes, -1, _hip.stream_of(p1))
         else:
             rc = lib.fpsg_chamfer_fwd(_hip.ptr(p1), _hip.ptr(p2), B, N, M, _hip.ptr(dist1),
                                       _hip.ptr(idx1), _hip.ptr(dist2), _hip.ptr(idx2),
                                       _hip.stream_of(p1))
     _hip.check(rc, "fpsg_chamfer_fwd")
-    return dist1, dist2, idx1, idx2
+    if losses is None:
+        return dist1, dist2, idx1, idx2
+    if not ws_bytes:
+        with torch.cuda.device(p1.device):
+            rc = lib.fpsg_chamfer_losses(_hip.ptr(dist1), _hip.ptr(dist2), B, N, M, int(losses[0]), float(losses[1]),
+                                         float(losses[2]), _hip.ptr(out3), _hip.stream_of(p1))
+        _hip.check(rc, "fpsg_chamfer_losses")
+    return dist1, dist2, idx1, idx2, out3
 
 
 def _sided_backward(p1, p2, idx1, idx2, g1, g2):
@@ -122,21 +138,15 @@ class _SidedPair(torch.autograd.Function):
 
 
 class _EpisodeChamfer(torch.autograd.Function):
-    """K1 + K1l: the Chamfer distances of B cloud pairs and, in one more launch, the sums over the first ``n_first``
-    pairs, over the rest, and their weighted total (``fpsg_chamfer_losses``); the backward builds the per-pair constant
-    gradients in one launch (``fpsg_chamfer_loss_grads``) and hands them to the K1 backward."""
+    """K1 + K1l: the Chamfer distances of B cloud pairs and the sums over the first ``n_first`` pairs, over the rest,
+    and their weighted total -- inside the one-pass forward (``fpsg_chamfer_fwd_tiled_losses``) or one launch behind the
+    two-pass one (``fpsg_chamfer_losses``); the backward forms the per-pair constant gradients inside the K1 backward
+    kernel (``fpsg_chamfer_bwd_losses``; clouds beyond 4096 points: ``fpsg_chamfer_loss_grads`` + the scanning kernel)."""
 
     @staticmethod
     def forward(ctx, p1, p2, n_first, w_first, w_rest):
         ctx.set_materialize_grads(False)
-        dist1, dist2, idx1, idx2 = _sided_forward(p1, p2)
-        B, N = dist1.shape
-        M = dist2.size(1)
-        out = torch.empty((3,), dtype=torch.float32, device=p1.device)
-        with torch.cuda.device(p1.device):
-            rc = _hip.load().fpsg_chamfer_losses(_hip.ptr(dist1), _hip.ptr(dist2), B, N, M, int(n_first), float(w_first),
-                                                 float(w_rest), _hip.ptr(out), _hip.stream_of(p1))
-        _hip.check(rc, "fpsg_chamfer_losses")
+        _, _, idx1, idx2, out = _sided_forward(p1, p2, losses=(n_first, w_first, w_rest))
         ctx.save_for_backward(p1, p2, idx1, idx2)
         ctx.cfg = (int(n_first), float(w_first), float(w_rest))
         return out[0], out[1], out[2]
@@ -150,6 +160,16 @@ class _EpisodeChamfer(torch.autograd.Function):
         B, N, _ = p1.shape
         M = p2.size(1)
         keep = [None if g is None else g.reshape(1).contiguous().float() for g in (g_first, g_rest, g_total)]
+        if N <= 4096 and M <= 4096:
+            gx1 = torch.empty_like(p1)
+            gx2 = torch.empty_like(p2)
+            with torch.cuda.device(p1.device), _probe("chamfer_bwd", B, N, M):
+                rc = _hip.load().fpsg_chamfer_bwd_losses(_hip.ptr(p1), _hip.ptr(p2), _hip.ptr(idx1), _hip.ptr(idx2),
+                                                         *(None if g is None else _hip.ptr(g) for g in keep), B, N, M,
+                                                         n_first, w_first, w_rest, _hip.ptr(gx1), _hip.ptr(gx2),
+                                                         _hip.stream_of(p1))
+            _hip.check(rc, "fpsg_chamfer_bwd_losses")
+            return gx1, gx2, None, None, None
         g1 = torch.empty((B, N), dtype=torch.float32, device=p1.device)
         g2 = torch.empty((B, M), dtype=torch.float32, device=p1.device)
         with torch.cuda.device(p1.device):

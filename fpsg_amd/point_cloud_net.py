@@ -660,9 +660,16 @@ class PCDecoder(nn.Module):
         """``forward_pair`` has its joint form for these inputs: the batched decoder in training mode on the GPU, ReLU
         patch MLPs, K9's patch sizes.  ``FPSG_DECODE_PAIR=0`` keeps the two separate passes (A/B measurements)."""
         import os
+        from . import fused_bn
         c0 = self.cluster_pool[0]
         P = c0.pts_per_node
-        return (self.batched and self.training and hidden_a.is_cuda and hidden_a.dtype == torch.float32
+        Ba, Bb = hidden_a.shape[0], hidden_b.shape[0]
+        # K5's row form (batch_norm_act_rows) has no library fallback: it needs the fused BatchNorm switched on
+        # (FPSG_FUSED_BN), a joint row of at least 64 columns in multiples of 4, segment starts on multiples of 4 and
+        # segments within the kernel's row limit -- otherwise the two decodes run as two passes
+        rows_ok = (fused_bn.fused_enabled() and (Ba + Bb) * P >= fused_bn._MIN_ROW and (Ba * P) % 4 == 0
+                   and (Bb * P) % 4 == 0 and max(Ba, Bb) * P <= fused_bn.ROWS_SEGMENT_MAX)
+        return (rows_ok and self.batched and self.training and hidden_a.is_cuda and hidden_a.dtype == torch.float32
                 and hidden_a.dim() == 2 and hidden_b.dim() == 2 and hidden_a.shape[1] == hidden_b.shape[1]
                 and os.environ.get("FPSG_DECODE_PAIR", "1") != "0" and self.conf.raw_dim == 3
                 and c0.deformer.activation is F.relu and c0.node_pool[0].activation is F.relu

@@ -62,16 +62,25 @@ int fpsg_chamfer_fwd_variant(const float* xyz1, const float* xyz2, int B, int N,
 
 /* One-pass form of the same op (the default of the Python mirror for clouds of at most 4096 points):
  * every d(i,j) is evaluated once and serves both directions (d is bit-symmetric); 2-D tiles of
- * 64*R rows x W*cpw*16 candidates leave 64-bit partial keys in the caller's workspace, a second
- * launch merges them and recovers the exact indices.  Bit-identical results to fpsg_chamfer_fwd.
+ * 64*R rows x W*cpw*16 candidates leave 32-bit partial keys in the caller's workspace (a tile's exact minimum with
+ * its six lowest mantissa bits replaced by where inside the tile it was found), a second launch re-evaluates the
+ * named range of every tile whose truncated minimum equals the smallest one and so recovers the exact distances and
+ * first-minimum indices.  Bit-identical results to fpsg_chamfer_fwd.
  * ws: fpsg_chamfer_workspace_bytes(B,N,M,variant) bytes, 8-byte aligned.  variant: -1 automatic,
  * else (R==8 ? 100 : 0) + 10*W + cpw with R in {4,8}, W in {1,2,4}, cpw in 1..9.  The workspace size
  * is 0 when this form does not apply: N or M > 4096, or (variant -1) fewer than ~7 pairs of
- * 2048-point clouds, where fpsg_chamfer_fwd's small workgroups fill the chip better. */
+ * 2048-point clouds, where fpsg_chamfer_fwd's small workgroups fill the chip better.
+ * fpsg_chamfer_fwd_tiled_losses: the same op plus K1l's three loss sums (fpsg_chamfer_losses below: same values, bit
+ * for bit) -- the second launch also leaves every 256-point block's distance sum in the workspace, a one-workgroup
+ * third launch adds them up; no separate pass over dist1 / dist2.  B <= 4096. */
 size_t fpsg_chamfer_workspace_bytes(int B, int N, int M, int variant);
 int fpsg_chamfer_fwd_tiled(const float* xyz1, const float* xyz2, int B, int N, int M,
                            float* dist1, int32_t* idx1, float* dist2, int32_t* idx2,
                            void* ws, size_t ws_bytes, int variant, fpsg_stream_t stream);
+int fpsg_chamfer_fwd_tiled_losses(const float* xyz1, const float* xyz2, int B, int N, int M,
+                                  float* dist1, int32_t* idx1, float* dist2, int32_t* idx2,
+                                  void* ws, size_t ws_bytes, int variant, int n_first, float w_first,
+                                  float w_rest, float* out3, fpsg_stream_t stream);
 
 /* Backward of the two sided distances w.r.t. both clouds (Kaolin's
  * sided_distance backward, reached through autograd from
@@ -105,13 +114,30 @@ int fpsg_chamfer_bwd_scan(const float* xyz1, const float* xyz2,
 /* K1l: the episode's reconstruction losses from the distances of one fpsg_chamfer_fwd* call over B cloud pairs of which
  * the first n_first are the query pairs (src/models/few_shot.py:110-124: chamfer_distance(...).sum() per group, then
  * query_factor * q + support_factor * s).  out3 = { sum_{b < n_first} cd_b, sum_{b >= n_first} cd_b,
- * w_first * out3[0] + w_rest * out3[1] },  cd_b = mean_i dist1[b,i] + mean_j dist2[b,j].  B <= 4096.  Deterministic. */
+ * w_first * out3[0] + w_rest * out3[1] },  cd_b = mean_i dist1[b,i] + mean_j dist2[b,j].  B <= 4096.  Deterministic;
+ * the summation order (also fpsg_chamfer_fwd_tiled_losses's and the oracle's oracle_chamfer_losses):
+ *   a row (dist1[b,:] or dist2[b,:]) is cut into blocks of 256 consecutive values, values past the end count as +0;
+ *   inside a block each of the four groups of 64 consecutive values is summed by the balanced binary tree over the
+ *   position in the group (pairs at distance 1, then 2, 4, ... 32), block = ((T0 + T1) + T2) + T3;
+ *   the row's sum adds its blocks in ascending order starting from +0;  cd_b = s1 * (1/N) + s2 * (1/M) with the
+ *   reciprocals rounded to fp32 first (how PyTorch's GPU mean divides; equal to a division when N is a power of two);
+ *   a group's sum (the pairs below n_first / the rest; a pair outside the group counts as +0): 64 partial sums
+ *   p_l = cd_l + cd_(l+64) + ... in ascending order from +0, then the same balanced tree over l = 0..63;
+ *   the total is w_first * q + w_rest * r, unfused. */
 int fpsg_chamfer_losses(const float* dist1, const float* dist2, int B, int N, int M, int n_first,
                         float w_first, float w_rest, float* out3, fpsg_stream_t stream);
 /* Its backward: g1 [B,N], g2 [B,M] (fully overwritten) = the gradients of the three values with respect to dist1 /
- * dist2 given the upstream gradients g_first, g_rest, g_total (device scalars; null = none), ready for fpsg_chamfer_bwd. */
+ * dist2 given the upstream gradients g_first, g_rest, g_total (device scalars; null = none), ready for fpsg_chamfer_bwd:
+ *   g1[b,:] = g * (1/N), g2[b,:] = g * (1/M) (fp32 reciprocals, the bits of autograd's mean backward on the GPU),
+ *   g = g_total * (b < n_first ? w_first : w_rest) + (b < n_first ? g_first : g_rest). */
 int fpsg_chamfer_loss_grads(const float* g_first, const float* g_rest, const float* g_total, int B, int N, int M,
                             int n_first, float w_first, float w_rest, float* g1, float* g2, fpsg_stream_t stream);
+/* fpsg_chamfer_loss_grads + fpsg_chamfer_bwd_sorted in one launch (N, M <= 4096): the per-pair constants are formed
+ * inside the backward kernel, the two constant [B,N] / [B,M] arrays are never written or read.  Same bits. */
+int fpsg_chamfer_bwd_losses(const float* xyz1, const float* xyz2, const int32_t* idx1, const int32_t* idx2,
+                            const float* g_first, const float* g_rest, const float* g_total,
+                            int B, int N, int M, int n_first, float w_first, float w_rest,
+                            float* gxyz1, float* gxyz2, fpsg_stream_t stream);
 
 /* ---- K3: kNN graph ----------------------------------------------------------------
  * Replaces `knn(x, k)` of src/dgcnn/model.py:13-20 (torch.matmul into a [B,N,N] matrix +

@@ -102,6 +102,20 @@ def chamfer_bwd(xyz1, xyz2, idx1, idx2, g1, g2):
     return gx1, gx2
 
 
+def chamfer_losses(dist1, dist2, n_first, w_first, w_rest):
+    """K1l in the order include/fpsg_hip.h pins: -> float32 [3] = (sum over the first n_first pairs of cd_b, sum over
+    the rest, w_first * first + w_rest * rest), cd_b = mean_i dist1[b] + mean_j dist2[b]."""
+    dist1, dist2 = _f32(dist1), _f32(dist2)
+    B, N = dist1.shape
+    M = dist2.shape[1]
+    out = np.empty((3,), np.float32)
+    fn = lib().oracle_chamfer_losses
+    fn.argtypes = [_f32p, _f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float,
+                   ctypes.c_float, _f32p]
+    fn(_p(dist1), _p(dist2), B, N, M, int(n_first), float(w_first), float(w_rest), _p(out))
+    return out
+
+
 def chamfer_distance_np(p1, p2, w1=1.0, w2=1.0):
     """Kaolin 0.9.0 chamfer_distance: w1*mean_i(dist1) + w2*mean_j(dist2), shape [B].
     The means are taken in float32 by numpy (pairwise summation)."""

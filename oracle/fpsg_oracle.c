@@ -124,6 +124,53 @@ void oracle_chamfer_bwd(const float* xyz1, const float* xyz2, const int32_t* idx
   }
 }
 
+/* K1l: the episode's loss sums over the distances of B cloud pairs (reference src/models/few_shot.py:110-124:
+ * chamfer_distance(...).sum() over the query pairs and over the support pairs, then query_factor * q +
+ * support_factor * s; chamfer_distance = mean_i d1 + mean_j d2, Kaolin 0.9.0).  PyTorch's own summation order is
+ * unspecified (it differs between CPU and CUDA builds), so the order is the one include/fpsg_hip.h pins for
+ * fpsg_chamfer_losses / fpsg_chamfer_fwd_tiled_losses: blocks of 256 values, four balanced trees of 64 per block,
+ * ((T0 + T1) + T2) + T3, blocks ascending; a group's pairs in 64 interleaved partial sums joined by the same tree. */
+static float tree64(const float* v) {          /* balanced binary tree over 64 values: pairs at distance 1, 2, ... 32 */
+  float t[64];
+  memcpy(t, v, sizeof t);
+  for (int step = 1; step < 64; step <<= 1)
+    for (int i = 0; i < 64; i += 2 * step) t[i] = t[i] + t[i + step];
+  return t[0];
+}
+
+static float row_sum_blocks(const float* row, int n) {
+  float s = 0.0f;
+  for (int c0 = 0; c0 < n; c0 += 256) {
+    float T[4];
+    for (int g = 0; g < 4; ++g) {
+      float v[64];
+      for (int l = 0; l < 64; ++l) {
+        const int i = c0 + 64 * g + l;
+        v[l] = i < n ? row[i] : 0.0f;
+      }
+      T[g] = tree64(v);
+    }
+    s += ((T[0] + T[1]) + T[2]) + T[3];
+  }
+  return s;
+}
+
+void oracle_chamfer_losses(const float* dist1, const float* dist2, int B, int N, int M, int n_first, float w_first,
+                           float w_rest, float* out3) {
+  float pq[64], pr[64];                       /* 64 partial sums per group: pair b goes to slot b % 64, ascending b */
+  for (int l = 0; l < 64; ++l) pq[l] = pr[l] = 0.0f;
+  for (int b = 0; b < B; ++b) {
+    const float s1 = row_sum_blocks(dist1 + (size_t)b * N, N);
+    const float s2 = row_sum_blocks(dist2 + (size_t)b * M, M);
+    const float cd = s1 * (1.0f / (float)N) + s2 * (1.0f / (float)M);   /* torch's GPU mean: sum * fl(1/N) */
+    if (b < n_first) pq[b & 63] += cd; else pr[b & 63] += cd;
+  }
+  const float q = tree64(pq), r = tree64(pr);
+  out3[0] = q;
+  out3[1] = r;
+  out3[2] = w_first * q + w_rest * r;
+}
+
 /* ------------------------------------------------------------------------------------
  * kNN graph of DGCNN: src/dgcnn/model.py:13-20.
  *   inner = -2 * x^T x ; xx = sum_c x^2 ; pairwise = -xx - inner - xx^T ; topk(k) indices.

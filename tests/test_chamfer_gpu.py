@@ -107,6 +107,36 @@ def test_tiled_ties_and_duplicates(gpu, oracle):
         _assert_fwd_equal(_call_fwd(lib, "fpsg_chamfer_fwd_tiled", p1, p2, gpu, ws.data_ptr(), nbytes, variant), exp)
 
 
+def test_tiled_near_ties_across_tiles(gpu, oracle):
+    """The one-pass forward's partial keys are a tile's minimum with its six lowest mantissa bits replaced by a position;
+    the second launch must re-evaluate EVERY tile whose truncated minimum equals the smallest one.  Here every point has
+    two nearest candidates in different tiles whose distances differ by a few ulps (either way round, or not at all)."""
+    from fpsg_amd import _hip
+    lib = _hip.load()
+    rng = np.random.default_rng(23)
+    n = 600
+    # points on an exactly representable lattice, offsets of 14-bit multiples of 2^-23: p + delta is exact, so the two
+    # candidates p + (a,b,c) and p + (c,a,b) are at the same true distance and their fp32 distances -- rounded in a
+    # different order -- differ by an ulp or two, in either direction, for about a fifth of the points
+    lat = np.stack(np.meshgrid(np.arange(8) * 0.25 - 1.0, np.arange(8) * 0.25 - 1.0, np.arange(10) * 0.125 - 0.5,
+                               indexing="ij"), -1).reshape(-1, 3)[:n]
+    p1 = np.stack([lat[rng.permutation(n)] for _ in range(3)]).astype(np.float32)
+    delta = (rng.integers(-(1 << 14), 1 << 14, size=(3, n, 3)) * 2.0 ** -23).astype(np.float32)
+    p2 = np.concatenate([p1 + delta, p1 + np.roll(delta, 1, axis=-1)], axis=1).astype(np.float32)   # 1200 candidates
+    for a, b in ((p1, p2), (p2, p1)):
+        exp = oracle.chamfer_fwd(a, b)
+        for variant in (141, 144, 41, 11, 122, 148):
+            nbytes = lib.fpsg_chamfer_workspace_bytes(3, a.shape[1], b.shape[1], variant)
+            ws = torch.empty((nbytes,), dtype=torch.uint8, device=gpu)
+            _assert_fwd_equal(_call_fwd(lib, "fpsg_chamfer_fwd_tiled", a, b, gpu, ws.data_ptr(), nbytes, variant), exp)
+    # the construction does produce candidates in different tiles whose distances agree above the six lowest mantissa
+    # bits and differ below them, both ways round
+    da = oracle.chamfer_fwd(p1, p2[:, :n])[0].view(np.uint32)
+    db = oracle.chamfer_fwd(p1, p2[:, n:])[0].view(np.uint32)
+    assert ((da & ~np.uint32(63)) == (db & ~np.uint32(63))).mean() > 0.9
+    assert (da < db).mean() > 0.05 and (da > db).mean() > 0.05
+
+
 def test_tiled_refuses_what_it_cannot_do(gpu):
     from fpsg_amd import _hip
     lib = _hip.load()
@@ -253,12 +283,15 @@ def test_chamfer_value_and_grad_vs_float64(gpu):
     np.testing.assert_allclose(t2.grad.cpu().numpy(), b.grad.numpy(), rtol=1e-4, atol=1e-9)
 
 
-@pytest.mark.parametrize("B,N,M,n_first", [(37, 2048, 2048, 5), (7, 301, 258, 3), (3, 64, 128, 0), (4, 100, 100, 4)])
+@pytest.mark.parametrize("B,N,M,n_first", [(37, 2048, 2048, 5), (7, 301, 258, 3), (3, 64, 128, 0), (4, 100, 100, 4),
+                                           (64, 301, 258, 10), (9, 4096, 3000, 9), (2, 5000, 700, 1)])
 def test_episode_losses_equal_the_separate_operations(gpu, oracle, B, N, M, n_first):
-    """K1l (fpsg_chamfer_losses / fpsg_chamfer_loss_grads): the query sum, the support sum and the weighted total of
-    few_shot.py:110-124 from one launch -- values within fp32 summation-order noise of the PyTorch operation chain
-    and of the float64 sums over the oracle's distances; the cloud gradients bit-identical to the chain's for the
-    total (same per-pair constants), also when the gradient arrives through one of the partial sums."""
+    """K1l: the query sum, the support sum and the weighted total of few_shot.py:110-124 -- fused into the one-pass
+    forward (fpsg_chamfer_fwd_tiled_losses: from ~7 pairs of 2048 points up) or one launch behind the two-pass forward
+    (fpsg_chamfer_losses) -- bit for bit the oracle's sums in the order include/fpsg_hip.h pins, within fp32
+    summation-order noise of the PyTorch operation chain and of float64 sums; the cloud gradients
+    (fpsg_chamfer_bwd_losses: the per-pair constants formed inside the backward kernel) bit-identical to the chain's
+    for the total, also when the gradient arrives through one of the partial sums."""
     from fpsg_amd.metrics import chamfer_distance, episode_chamfer_losses
     rng = np.random.default_rng(B * 1000 + N)
     p1 = unit_ball_clouds(rng, B, N)
@@ -276,6 +309,9 @@ def test_episode_losses_equal_the_separate_operations(gpu, oracle, B, N, M, n_fi
     for got, want in ((q, rq), (s, rs), (total, rtotal)):
         assert abs(got.item() - want.item()) <= 2e-6 * max(1.0, abs(want.item()))
     od1, _, od2, _ = oracle.chamfer_fwd(p1, p2)
+    want3 = oracle.chamfer_losses(od1, od2, n_first, wq, ws)
+    got3 = np.array([q.item(), s.item(), total.item()], np.float32)
+    assert np.array_equal(got3.view(np.uint32), want3.view(np.uint32)), (got3, want3)
     ocd = od1.astype(np.float64).mean(1) + od2.astype(np.float64).mean(1)
     assert abs(q.item() - ocd[:n_first].sum()) <= 2e-6 * max(1.0, ocd[:n_first].sum())
     assert abs(total.item() - (wq * ocd[:n_first].sum() + ws * ocd[n_first:].sum())) <= 2e-6 * max(1.0, ocd.sum())

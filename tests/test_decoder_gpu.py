@@ -378,3 +378,34 @@ def test_k9_row_strides_equal_contiguous_calls(gpu):
     assert lib.fpsg_dec1_fwd_ld(_hip.ptr(hlat), 1, _hip.ptr(w), K, L, _hip.ptr(pts), M, _hip.ptr(gamma), _hip.ptr(beta), None,
                                 None, G, D, 2, P, 1, 1e-5, _hip.ptr(out), M, _hip.ptr(chan[0]), None, None, st) != 0
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("case", ["fused_bn_off", "tiny_patches"])
+def test_pair_of_decodes_falls_back_where_the_row_batchnorm_cannot_run(gpu, monkeypatch, case):
+    """forward_pair's joint form needs K5's row kernel, which has no library fallback: with FPSG_FUSED_BN=0 (the
+    documented A/B switch) and with patches so small that the joint row is under 64 columns (16 points per patch,
+    1-shot 1-query: 32) pair_ready must say no and forward_pair must run the two passes -- as before the joint form
+    existed -- instead of raising."""
+    from fpsg_amd.engine import default_options
+    from fpsg_amd.point_cloud_net import PCDecoder
+    torch.manual_seed(3)
+    if case == "fused_bn_off":
+        monkeypatch.setenv("FPSG_FUSED_BN", "0")
+        dec, Ba, Bb = PCDecoder(conf=default_options(device="cpu")), 2, 3
+    else:
+        dec, Ba, Bb = PCDecoder(conf=default_options(device="cpu"), num_pts=256), 1, 1
+    dev = dec.to(gpu).train()
+    P = dev.cluster_pool[0].pts_per_node
+    a = torch.randn(Ba, 1536, device=gpu, requires_grad=True)
+    b = torch.randn(Bb, 1536, device=gpu, requires_grad=True)
+    assert not dev.pair_ready(a, b)
+    ga = dev.sample_grids(Ba, gpu, torch.Generator(device=gpu).manual_seed(1))
+    gb = dev.sample_grids(Bb, gpu, torch.Generator(device=gpu).manual_seed(2))
+    state = copy.deepcopy(dev.state_dict())
+    out = dev.forward_pair(a, b, grids=(ga, gb))
+    assert out.shape == (Ba + Bb, 16 * P, 3) and torch.isfinite(out).all()
+    out.sum().backward()
+    assert a.grad is not None and b.grad is not None and torch.isfinite(a.grad).all()
+    dev.load_state_dict(state)
+    want = torch.cat([dev.forward(a.detach(), ga), dev.forward(b.detach(), gb)])
+    assert torch.allclose(out.detach(), want, rtol=1e-4, atol=1e-5)

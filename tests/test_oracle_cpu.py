@@ -120,3 +120,18 @@ def test_in_edge_lists_are_the_stable_grouping_of_the_edges():
     gx_lists = [list(rev[off[d]:off[d + 1]]) for d in range(50)]
     assert sorted(e for l in gx_lists for e in l) == sorted(np.nonzero(valid)[0].tolist())
     assert all(l == sorted(l) for l in gx_lists)
+
+
+def test_chamfer_losses_order_is_a_valid_sum(oracle):
+    """oracle_chamfer_losses (the summation order include/fpsg_hip.h pins for K1l) against float64 sums, ragged rows
+    (a last block of 45 values, a row shorter than one group of 64) included."""
+    rng = np.random.default_rng(3)
+    for B, N, M, n_first in ((5, 2048, 2048, 2), (3, 301, 40, 0), (4, 1, 700, 4)):
+        d1 = rng.random((B, N)).astype(np.float32)
+        d2 = rng.random((B, M)).astype(np.float32)
+        out = oracle.chamfer_losses(d1, d2, n_first, 1.0, 0.75)
+        cd = d1.astype(np.float64).mean(1) + d2.astype(np.float64).mean(1)
+        want = np.array([cd[:n_first].sum(), cd[n_first:].sum(), cd[:n_first].sum() + 0.75 * cd[n_first:].sum()])
+        np.testing.assert_allclose(out, want, rtol=3e-6, atol=1e-7)
+    ones = np.ones((2, 1024), np.float32)
+    assert np.array_equal(oracle.chamfer_losses(ones, ones, 1, 2.0, 3.0), np.array([2.0, 2.0, 10.0], np.float32))

@@ -7,7 +7,8 @@ HBM bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: on gfx950 FETCH_SIZE tallies t
 requests of a coalesced stream at 64 B (MI355X_MICROARCH.md, HBM section); WRITE_SIZE is exact.
 FETCH_SIZE and WRITE_SIZE need separate passes (TCC counter slots).
 
-One K1 forward op is the tile kernel followed by the finalize kernel (fpsg_chamfer_fwd_tiled), or
+One K1 forward op is the tile kernel followed by the finalize kernel (fpsg_chamfer_fwd_tiled) and, in the step, the
+loss sums' one-workgroup last stage (fpsg_chamfer_fwd_tiled_losses), or
 one two-pass kernel (fpsg_chamfer_fwd) for few pairs; the backward op is one kernel.  Dispatches
 are grouped into ops in dispatch order; the number of cloud pairs of an op comes from the grid of
 its LAST kernel at N = M = 2048 (finalize: 4096 threads per pair; sorted backward: 2048 per pair;
@@ -37,13 +38,17 @@ def dispatches(d, counter):
 def ops(rows):
     """-> {(op, cloud_pairs): [KiB per op, ...]}"""
     out = collections.defaultdict(list)
-    pending = None
+    pending = last_fwd = None
     for _, name, tmpl, grid, val in rows:
         if name == "chamfer_tile_kernel":
             pending = val
         elif name == "chamfer_finalize_kernel":
             out[("chamfer_fwd", grid // 4096)].append(val + (pending or 0.0))
             pending = None
+            last_fwd = ("chamfer_fwd", grid // 4096)
+        elif name == "chamfer_loss_reduce_kernel" and last_fwd is not None:
+            out[last_fwd][-1] += val            # the loss sums' last stage belongs to the forward op before it
+            last_fwd = None
         elif name == "chamfer_fwd_kernel":
             R, W = (int(v) for v in re.findall(r"\d+", tmpl))
             out[("chamfer_fwd", grid * R // (4096 * W))].append(val)
