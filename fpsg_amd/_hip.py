@@ -105,6 +105,7 @@ SIGNATURES = {
     "fpsg_bn_act_pool_bwd": [_c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
                              ctypes.c_float, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_stream],
     "fpsg_bn_max_workspace_floats": [_c_int, _c_int, _c_int],
+    "fpsg_bn_max_dz_offset": [_c_int, _c_int, _c_int],
     "fpsg_bn_act_max_fwd": [_c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, ctypes.c_float, _c_int, _c_int, _c_int, _c_int,
                             ctypes.c_float, _c_int, ctypes.c_float, _c_f32p, _c_i32p, _c_f32p, _c_f32p, _c_f32p,
                             _c_f32p, _c_stream],
@@ -161,7 +162,7 @@ SIGNATURES = {
 _RESTYPES = {"fpsg_last_error": ctypes.c_char_p, "fpsg_chamfer_workspace_bytes": ctypes.c_size_t,
              "fpsg_sinkhorn_workspace_floats": ctypes.c_size_t,
              "fpsg_knn_workspace_floats": ctypes.c_size_t,
-             "fpsg_bn_workspace_floats": ctypes.c_size_t, "fpsg_bn_pool_workspace_floats": ctypes.c_size_t, "fpsg_bn_max_workspace_floats": ctypes.c_size_t, "fpsg_conv_first_dw_workspace_floats": ctypes.c_size_t, "fpsg_emd_workspace_floats": ctypes.c_size_t, "fpsg_max_bwd_scatter_workspace_floats": ctypes.c_size_t,
+             "fpsg_bn_workspace_floats": ctypes.c_size_t, "fpsg_bn_pool_workspace_floats": ctypes.c_size_t, "fpsg_bn_max_workspace_floats": ctypes.c_size_t, "fpsg_bn_max_dz_offset": ctypes.c_size_t, "fpsg_conv_first_dw_workspace_floats": ctypes.c_size_t, "fpsg_emd_workspace_floats": ctypes.c_size_t, "fpsg_max_bwd_scatter_workspace_floats": ctypes.c_size_t,
              "fpsg_wino_dw_fused_workspace_floats": ctypes.c_size_t}
 
 _lib = None

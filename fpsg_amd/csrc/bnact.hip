@@ -1336,6 +1336,12 @@ extern "C" size_t fpsg_bn_max_workspace_floats(int N, int C, int L) {
   return (size_t)C * fpsg::kBnSlices * 2 + (size_t)N * C * segs * 4 + (size_t)N * C;
 }
 
+extern "C" size_t fpsg_bn_max_dz_offset(int N, int C, int L) {
+  if (N <= 0 || C <= 0 || L <= 0) return 0;
+  const size_t segs = ((size_t)L + fpsg::kBnSeg - 1) / fpsg::kBnSeg;
+  return (size_t)C * fpsg::kBnSlices * 2 + (size_t)N * C * segs * 4;     // dz [N*C] is the workspace's last block
+}
+
 extern "C" int fpsg_bn_act_max_fwd(const float* x, const float* pre_bias, const float* gamma, const float* beta,
                                    float* running_mean, float* running_var, float momentum, int N, int C, int L,
                                    int training, float eps, int act, float slope, float* out, int32_t* idx,

@@ -133,6 +133,16 @@ class FlatGradBuckets:
         self.lazy = True
         self._stash: list = []
         self._stash_first = False
+        # the stash keeps whole gradient sets alive (310 MB each for the full model): at most _MAX_STASH of them, at most
+        # FPSG_STASH_MB megabytes [4096], and never more than an eighth of the memory that was free when the buckets
+        # were built -- a nearly full device flushes after every episode or two instead of failing an allocation
+        budget = float(os.environ.get("FPSG_STASH_MB", "4096")) * (1 << 20)
+        if dev.type == "cuda":
+            try:
+                budget = min(budget, torch.cuda.mem_get_info(dev)[0] / 8)
+            except RuntimeError:
+                pass
+        self._stash_cap = max(1, min(self._MAX_STASH, int(budget // max(1, self.flat.numel() * self.flat.element_size()))))
         self.attach()
 
     # -- bookkeeping ---------------------------------------------------------------
@@ -215,7 +225,7 @@ class FlatGradBuckets:
         if not self._stash:
             self._stash_first = bool(first)
         self._stash.append((ptrs, [p.grad for p in self._layout_params]))
-        if len(self._stash) == self._MAX_STASH:
+        if len(self._stash) >= self._stash_cap:
             self.flush()
         return True
 
@@ -421,6 +431,21 @@ def broadcast_object(obj, src: int = 0, group=None):
     box = [obj]
     dist.broadcast_object_list(box, src=src, group=group)
     return box[0]
+
+
+def agree(error: str | None, what: str, group=None) -> None:
+    """Every rank reports how a rank-local step went (``None`` = fine, else a message); if ANY rank failed, EVERY rank
+    raises the same RuntimeError -- a rank that raised alone would leave the others waiting in the next collective
+    (file reads at resume: a checkpoint that one node cannot see)."""
+    if not dist.is_initialized():
+        if error is not None:
+            raise RuntimeError(f"{what}: {error}")
+        return
+    box = [None] * dist.get_world_size(group)
+    dist.all_gather_object(box, error, group=group)
+    bad = [(r, e) for r, e in enumerate(box) if e is not None]
+    if bad:
+        raise RuntimeError(f"{what} failed on " + "; ".join(f"rank {r}: {e}" for r, e in bad))
 
 
 def all_reduce_scalars(values: Iterable[float], device) -> list[float]:

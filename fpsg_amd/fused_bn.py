@@ -321,14 +321,13 @@ class _ConvBNActMax(torch.autograd.Function):
         dbeta = torch.empty((C,), dtype=torch.float32, device=dev)
         coef = torch.empty((3, C), dtype=torch.float32, device=dev)
         ws = torch.empty((lib.fpsg_bn_max_workspace_floats(B, C, L),), dtype=torch.float32, device=dev)
-        segs = (L + 4095) // 4096
         st = _hip.stream_of(a)
         with torch.cuda.device(dev):
             _hip.check(lib.fpsg_bn_act_max_bwd_coef(_hip.ptr(x), _hip.ptr(pb) if pb is not None else None, _hip.ptr(gout),
                                                     _hip.ptr(idx), _hip.ptr(chan), B, C, L, 1 if training else 0, act_code,
                                                     float(slope), _hip.ptr(dgamma), _hip.ptr(dbeta), _hip.ptr(coef),
                                                     _hip.ptr(ws), st), "fpsg_bn_act_max_bwd_coef")
-            off = C * 128 + B * C * segs * 4
+            off = lib.fpsg_bn_max_dz_offset(B, C, L)        # the workspace layout is bnact.hip's
             dz = ws[off: off + B * C].view(B, C)
             opt = lambda t: _hip.ptr(t) if t is not None else None
             da = dw = dpb = None

@@ -79,9 +79,12 @@ def fused_enabled() -> bool:
     return os.environ.get("FPSG_WINOGRAD_FUSED", "1") != "0"
 
 
-def _can_fuse(m: int, c_in: int, c_out: int, n_pixels: int) -> bool:
-    """``n_pixels`` = N*H*W of the tensor the kernel reads: K6f addresses it with 32-bit byte offsets (< 4 GiB)."""
-    return fused_enabled() and m == 4 and c_in == 64 and c_out % 16 == 0 and n_pixels * 64 * 4 < (1 << 32)
+def _can_fuse(m: int, c_in: int, c_out: int, n_pixels: int, H: int = 4, W: int = 4) -> bool:
+    """``n_pixels`` = N*H*W of the tensor the kernel reads: K6f addresses it with 32-bit byte offsets (< 4 GiB).  K6f tiles
+    whole 4x4 output blocks: planes whose sides are not multiples of 4 (F(4x4) with ragged edge tiles, e.g. 14x14) stay
+    on the three-kernel form."""
+    return (fused_enabled() and m == 4 and c_in == 64 and c_out % 16 == 0 and n_pixels * 64 * 4 < (1 << 32)
+            and H % 4 == 0 and W % 4 == 0)
 
 
 MIN_DW_TILES = 16384      # below (2 images at 224x224: 6272 tiles) the per-range partial sums cost more than K6w saves
@@ -354,7 +357,7 @@ class _Conv3x3(torch.autograd.Function):
         K = w.shape[0]
         parts = None
         with torch.cuda.device(x.device):
-            if _can_fuse(m, C, K, N * H * W):
+            if _can_fuse(m, C, K, N * H * W, H, W):
                 if want_parts:
                     y, parts = _fused_stats(x, None, None, _filter(m, w, False), stats_bias)
                 else:
@@ -387,7 +390,7 @@ class _Conv3x3(torch.autograd.Function):
         gx = gw = None
         with torch.cuda.device(gy.device):
             if ctx.needs_input_grad[0]:
-                if _can_fuse(m, K, C, N * H * W):                     # the data gradient is a convolution K -> C
+                if _can_fuse(m, K, C, N * H * W, H, W):                     # the data gradient is a convolution K -> C
                     gx = _fused(gy, _filter(m, w, True))
                 else:
                     gx = _output(m, torch.bmm(_filter(m, w, True), _input(m, gy)), N, H, W)
@@ -452,7 +455,7 @@ class _BNReluConv3x3(torch.autograd.Function):
                   float(momentum), N, C, H * W, 1 if training else 0, float(eps), _hip.ptr(chan), None, None,
                   opt(ws), _hip.ptr(parts) if use_parts else None, parts.shape[1] if use_parts else 0,
                   _hip.stream_of(y))
-            if _can_fuse(m, C, K, N * H * W):
+            if _can_fuse(m, C, K, N * H * W, H, W):
                 if want_parts:
                     out, out_parts = _fused_stats(y, chan, pre_bias, _filter(m, w, False), stats_bias)
                 else:
@@ -487,7 +490,7 @@ class _BNReluConv3x3(torch.autograd.Function):
         with torch.cuda.device(dev):
             # convolution backward: gradient of the (never stored) activation, and of the filter
             bwd_parts = None
-            if _can_fuse(m, K, C, N * H * W):
+            if _can_fuse(m, K, C, N * H * W, H, W):
                 ga = _fused(gout, _filter(m, w, True))
             elif bwd_stats_enabled() and N * H * W > _BN_SMALL_MAX:
                 # the output transform that writes ga also delivers the sums K5's backward starts from

@@ -391,9 +391,12 @@ int fpsg_bn_act_pool_bwd(const float* x, const float* pre_bias, const float* dy_
  * is one read of x (no normalised tensor is written), idx [N,C] receives the selected position
  * (first arg-max of x where scale >= 0, first arg-min otherwise); the backward takes gout [N,C],
  * and is one read + one write (dx).  Other arguments as fpsg_bn_act_fwd / _bwd;
- * ws: fpsg_bn_max_workspace_floats(N,C,L).
+ * ws: fpsg_bn_max_workspace_floats(N,C,L).  fpsg_bn_max_dz_offset(N,C,L): where, in floats from the start of that
+ * workspace, fpsg_bn_act_max_bwd_coef leaves dz [N,C] (the gradient at the selected positions, in front of the
+ * BatchNorm) for fpsg_max_bwd_gather / _prep / _scatter -- the workspace layout is the library's, not the caller's.
  */
 size_t fpsg_bn_max_workspace_floats(int N, int C, int L);
+size_t fpsg_bn_max_dz_offset(int N, int C, int L);
 int fpsg_bn_act_max_fwd(const float* x, const float* pre_bias, const float* gamma, const float* beta,
                         float* running_mean, float* running_var, float momentum, int N, int C, int L, int training,
                         float eps, int act, float slope, float* out, int32_t* idx, float* chan, float* batch_mean,

@@ -253,7 +253,8 @@ def test_sharded_evaluation_reports_what_one_process_reports(tmp_path):
 def test_bench_gpus_n_without_a_launcher_starts_one_as_a_child():
     """`python bench.py --gpus 2` with no torchrun variables: bench.py must start torch.distributed.run itself (a child
     process, before any GPU call) and hand back the child's exit code.  There is no GPU here, so each of the two ranks
-    stops at the loud 'needs a ROCm GPU' line -- which shows that two ranks were started with a rendezvous environment
+    stops at the loud 'needs a ROCm GPU' line (the launcher's failure report names both ranks) -- which shows that two ranks
+    were started with a rendezvous environment
     and that the parent relays their failure instead of the old 'launch with torch.distributed.run' exit."""
     import subprocess
     import sys
@@ -266,5 +267,32 @@ def test_bench_gpus_n_without_a_launcher_starts_one_as_a_child():
                        capture_output=True, text=True, timeout=300)
     assert "launching" in r.stderr and "--nproc-per-node 2" in r.stderr and "--master-addr 127.0.0.1" in r.stderr
     assert r.returncode != 0
-    assert r.stderr.count("bench.py needs a ROCm GPU") >= 2, r.stderr[-3000:]
+    # the first rank to fail ends the launch (the launcher stops the other one, which may not have printed yet)
+    assert r.stderr.count("bench.py needs a ROCm GPU") >= 1 and "local_rank: 1" in r.stderr, r.stderr[-3000:]
     assert "launch with torch.distributed.run" not in r.stderr
+
+
+def _run_agree(rank, world, port, out_dir):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    fdist.init_distributed("cpu")
+    fdist.agree(None, "a step every rank managed")             # nobody failed: returns
+    try:
+        fdist.agree("FileNotFoundError: model_epoch_3.pt" if rank == 1 else None, "resume (weights)")
+        seen = "no error"
+    except RuntimeError as e:
+        seen = str(e)
+    dist.barrier()                                             # both ranks are still in step with each other
+    open(os.path.join(out_dir, f"agree{rank}.txt"), "w").write(seen)
+    fdist.shutdown()
+
+
+def test_a_rank_local_failure_is_raised_on_every_rank(tmp_path):
+    """at resume each rank reads the checkpoint itself; a rank that failed alone would leave the others
+    waiting in the next collective.  fdist.agree makes every rank raise the same error."""
+    mp.spawn(_run_agree, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    seen = [open(os.path.join(tmp_path, f"agree{r}.txt")).read() for r in (0, 1)]
+    assert seen[0] == seen[1] and "rank 1: FileNotFoundError: model_epoch_3.pt" in seen[0]
+    with pytest.raises(RuntimeError, match="resume"):
+        fdist.agree("boom", "resume (weights)")                # without a process group: a plain raise
+    fdist.agree(None, "fine")

@@ -46,6 +46,9 @@ def test_winograd_eligibility_needs_gpu_fp32_3x3(monkeypatch):
     assert wg._can_fuse(4, 64, 128, px) and not wg._can_fuse(4, 128, 64, px) and not wg._can_fuse(2, 64, 64, px)
     # K6f addresses its input with 32-bit byte offsets: 4 GiB and above takes the three-kernel form
     assert wg._can_fuse(4, 64, 64, (1 << 24) - 1) and not wg._can_fuse(4, 64, 64, 1 << 24)
+    # K6f tiles whole 4x4 blocks: F(4x4) with ragged edge tiles (14x14, 30x18) keeps the three-kernel form
+    assert wg._can_fuse(4, 64, 64, 3 * 16 * 16, 16, 16) and not wg._can_fuse(4, 64, 64, 3 * 14 * 14, 14, 14)
+    assert not wg._can_fuse(4, 64, 64, 2 * 30 * 16, 30, 16) and not wg._can_fuse(4, 64, 64, 2 * 16 * 18, 16, 18)
 
 
 def test_filter_cache_lives_only_inside_weights_frozen():

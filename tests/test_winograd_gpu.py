@@ -16,6 +16,8 @@ SHAPES = [  # N, C, K, H, W, m
     (7, 256, 128, 28, 28, 4),
     # m = 4 on sides that are even but not multiples of 4 (half-empty last tile row / column; VGG's 14 x 14 stage)
     (3, 16, 16, 14, 14, 4), (2, 32, 24, 18, 12, 4), (5, 40, 32, 14, 20, 4), (37, 24, 16, 14, 14, 4), (1, 8, 8, 2, 6, 4),
+    # 64 channels on ragged planes: K6f tiles whole 4x4 blocks only, so these take the three-kernel form
+    (3, 64, 64, 14, 14, 4), (2, 64, 32, 30, 18, 4), (2, 32, 64, 14, 22, 4),
 ]
 
 

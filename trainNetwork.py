@@ -86,9 +86,15 @@ def main(opt):
             print(f"Resume previous training, start from epoch {opt.resume}, loading previous model")   # reference :106
         start_epoch = opt.resume
         resume_path = os.path.join(checkpoint_path, f"model_epoch_{start_epoch}.pt")
-        if not os.path.exists(resume_path):
-            raise RuntimeError(f"{resume_path} does not exist, loading failed")
-        model.load_state_dict(torch.load(resume_path, map_location="cpu", weights_only=True))
+        # every rank reads the weights itself; all ranks learn whether all succeeded before anyone enters a collective
+        err = None
+        try:
+            if not os.path.exists(resume_path):
+                raise FileNotFoundError(f"{resume_path} does not exist, loading failed")
+            model.load_state_dict(torch.load(resume_path, map_location="cpu", weights_only=True))
+        except Exception as e:          # noqa: BLE001 -- reported on every rank by agree()
+            err = f"{type(e).__name__}: {e}"
+        fdist.agree(err, "resume (weights)")
         # Extension: the reference saves weights only, so a resumed run restarts
         # Adam's moments and the LR schedule.  A sidecar file keeps them; the weights file keeps
         # the reference's format and name.  Rank 0 decides whether the sidecar is used (ranks that saw different
@@ -101,13 +107,18 @@ def main(opt):
 
     optimizer, scheduler = build_optimizer(model, opt)
     if state_path is not None:
-        state = torch.load(state_path, map_location=device, weights_only=True)
-        optimizer.load_state_dict(state["optimizer"])
-        scheduler.load_state_dict(state["scheduler"])
-        # the sidecar holds the state AFTER epoch N's scheduler.step(): training continues with epoch
-        # N+1 (the weights-only resume of the reference re-runs epoch N from fresh moments; doing that
-        # here would step the LR schedule twice for epoch N and reuse post-epoch-N moments)
-        start_epoch = int(state.get("epoch", start_epoch)) + 1
+        err = None
+        try:
+            state = torch.load(state_path, map_location=device, weights_only=True)
+            optimizer.load_state_dict(state["optimizer"])
+            scheduler.load_state_dict(state["scheduler"])
+            # the sidecar holds the state AFTER epoch N's scheduler.step(): training continues with epoch
+            # N+1 (the weights-only resume of the reference re-runs epoch N from fresh moments; doing that
+            # here would step the LR schedule twice for epoch N and reuse post-epoch-N moments)
+            start_epoch = int(state.get("epoch", start_epoch)) + 1
+        except Exception as e:          # noqa: BLE001
+            err = f"{type(e).__name__}: {e}"
+        fdist.agree(err, "resume (optimizer / scheduler state)")
     start_epoch = int(fdist.broadcast_object(start_epoch))
     if opt.resume > 0 and is_main:
         how = (f"optimizer / scheduler state restored from {state_path}" if state_path is not None
