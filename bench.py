@@ -19,7 +19,9 @@ Workloads (BASELINE.json ``configs``; synthetic data, random-init weights, fp32)
 Rank 0 prints ONE JSON line with ``roofline`` (the K1 Chamfer forward launches of the timed
 region, bracketed with HIP events on the launch stream) and ``cpu_baseline`` (the same
 episode step on the host cores through the CPU oracle; N=1 only).  At N=1 the line also carries
-  ``configs``   short legs of the other BASELINE workloads (c2, c3, c4: episodes/s each),
+  ``configs``   short legs of the other BASELINE workloads (c2, c3, c4: episodes/s each) and ``eval``: items/s of the
+                evaluation loop (``_return_reconstruction``: forward + Chamfer + Sinkhorn-form EMD) on the configs[2]
+                episode with K1's and K2b's event-timed shares,
   ``kernels``   event-timed rooflines of the other hand-written distance / graph kernels at the
                 BASELINE shapes (K1 backward in-step; K2, K2b, K3, K4b as micro-legs), each with its
                 bound (valu / mfma / hbm), algorithmic work and fraction of peak,
@@ -372,6 +374,47 @@ def trunk_kernel_rooflines(device, entry):
     return out
 
 
+def eval_leg(device, probe, items=20, warmup=3):
+    """The evaluation hot loop (reference src/evaluate_Network.py:107-118 around few_shot.py:131-176) on the configs[2]
+    episode: eval mode, no_grad, per item ``_return_reconstruction`` (image + point encoders, query decode, K1 Chamfer,
+    K2b Sinkhorn-form EMD = what ``emd_wrapper`` calls) and the loop's two ``.item()`` reads.  items/s is wall clock over
+    the loop; K1's and K2b's shares come from HIP events around their C calls."""
+    S, Q = 32, 5
+    opt = default_options(device="cuda", intra_recon=True, pc_encoder="pointnet", n_shot=S, n_query=Q)
+    torch.manual_seed(0)
+    model = build_model(opt).to(device).eval()
+    eps = make_episodes(S, Q, 4, seed=77, device=device)
+    keep, keep_enabled = list(probe.records), probe.enabled
+    probe.records, probe.enabled = [], False
+    with torch.no_grad():
+        for i in range(warmup):
+            out = model._return_reconstruction(eps[i % len(eps)])
+            out["cd_loss"].item(), out["emd_loss"].item()
+        torch.cuda.synchronize()
+        probe.enabled = True
+        t0 = time.perf_counter()
+        for i in range(items):
+            out = model._return_reconstruction(eps[i % len(eps)])
+            cd, emd = out["cd_loss"].item() / Q, out["emd_loss"].item() / Q
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+    probe.enabled = False
+    sec = {}
+    for (k, B, N, M), e0, e1 in probe.records:
+        sec[k] = sec.get(k, 0.0) + e0.elapsed_time(e1) * 1e-3
+    probe.records, probe.enabled = keep, keep_enabled
+    del model
+    torch.cuda.empty_cache()
+    return {"items_per_s": items / el, "ms_per_item": el / items * 1e3, "items": items,
+            "workload": "evaluation loop, configs[2] episode: 32-shot 5-query PointNet, eval mode, no_grad; per item "
+                        "_return_reconstruction (37 images + 64 clouds encoded, 5 query clouds decoded, Chamfer K1 + "
+                        "Sinkhorn-form EMD K2b on B=5 x 2048 x 2048) + two .item() reads",
+            "k1_chamfer_us_per_item": sec.get("chamfer_fwd", 0.0) / items * 1e6,
+            "k2b_sinkhorn_us_per_item": sec.get("sinkhorn", 0.0) / items * 1e6,
+            "k2b_share_of_item": sec.get("sinkhorn", 0.0) / el,
+            "last_cd_per_query": cd, "last_emd_per_query": emd}
+
+
 def allreduce_probe(step, world):
     """Per-bucket all-reduce of the flat gradient buffer, one collective at a time (event-timed on the
     current stream after a barrier): bucket bytes, time, algorithmic and bus bandwidth."""
@@ -632,6 +675,10 @@ def main():
                     torch.cuda.empty_cache()
                 except Exception as e:      # the headline numbers stay valid without a leg
                     configs[wl] = {"error": repr(e)}
+            try:
+                configs["eval"] = eval_leg(device, probe)
+            except Exception as e:
+                configs["eval"] = {"error": repr(e)}
             res["configs"] = configs
             try:
                 kernels.update(kernel_rooflines(device))
