@@ -109,11 +109,18 @@ __global__ __launch_bounds__(kD1Threads) void dec1_fwd_kernel(Dec1Args a, float*
     const float* hc = hl + c * a.B;
     float mean, rstd;
     if (a.training) {
+      // The sums run over h - K, K = the mean of the latent part over the clouds: the variance does not depend on K, and
+      // E[h^2] - E[h]^2 on the raw values cancels when h is a constant plus a small variation -- with ONE cloud (1-shot
+      // episodes, BASELINE configs[1]) h = hlat[d] + w.p with |hlat| ~ 60 sigma: 2e-4 relative in the variance, 3.5e-4
+      // in the episode's loss against the reference arithmetic (profiles/r04/episode_parity_deviation.jsonl).
+      float ksum = 0.0f;
+      for (int b = lane; b < a.B; b += 64) ksum += hc[b];
+      const float K = wave_sum(ksum) / (float)a.B;
       float s = 0.0f, ss = 0.0f;
       for (int e4 = lane; e4 < BP / 4; e4 += 64) {
         const v4f X = reinterpret_cast<const v4f*>(sp)[e4], Y = reinterpret_cast<const v4f*>(sp + BP)[e4],
                   Z = reinterpret_cast<const v4f*>(sp + 2 * BP)[e4];
-        const float hb = hc[e4 / pshift4];
+        const float hb = hc[e4 / pshift4] - K;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           const float h = fma_rn(w2, Z[u], fma_rn(w1, Y[u], w0 * X[u])) + hb;
@@ -122,9 +129,10 @@ __global__ __launch_bounds__(kD1Threads) void dec1_fwd_kernel(Dec1Args a, float*
         }
       }
       const double S = wave_sum_f64((double)s), SS = wave_sum_f64((double)ss);
-      const double mu = S / BP;
-      double var = SS / BP - mu * mu;
+      const double mk = S / BP;
+      double var = SS / BP - mk * mk;
       var = var < 0.0 ? 0.0 : var;
+      const double mu = (double)K + mk;
       mean = (float)mu;
       rstd = (float)(1.0 / sqrt(var + (double)a.eps));
       if (lane == 0) {

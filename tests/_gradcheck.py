@@ -64,10 +64,22 @@ def summarize(dev: dict) -> dict:
 
 
 def assert_like_yardstick(got: dict, yard: dict, truth64: dict, what: str, factor: float = 4.0,
-                          hard_max: float = 0.15, cancelled_max: float = 2e-2):
-    """`got` (HIP path, fp32), `yard` (reference arithmetic, fp32, CPU), `truth64` (float64)."""
+                          hard_max: float = 0.15, cancelled_max: float = 2e-2, ill_conditioned_ok: bool = False):
+    """`got` (HIP path, fp32), `yard` (reference arithmetic, fp32, CPU), `truth64` (float64).
+    `ill_conditioned_ok`: tensors on which the REFERENCE arithmetic itself misses the float64 gradient by more than
+    `hard_max` are set aside -- with a BatchNorm over a batch of two (1-shot episodes) the normalised values are +-1
+    whatever the input, the true gradient behind it is O(eps) and fp32 holds round-off there on every side; for those the
+    HIP path's values must stay on the scale of the reference arithmetic's."""
     dg, cg = deviations(got, truth64)
     dy, _ = deviations(yard, truth64)
+    if ill_conditioned_ok:
+        ill = sorted(k for k in dy if dy[k] > hard_max)
+        for k in ill:
+            a, b = float(np.abs(_np(got[k])).max()), float(np.abs(_np(yard[k])).max())
+            assert a <= 10.0 * b + 1e-30, (what, "ill-conditioned tensor off the reference arithmetic's scale", k, a, b)
+            dg.pop(k, None)
+            dy.pop(k, None)
+        print(f"{what}: {len(ill)} tensors set aside (the reference fp32 arithmetic itself is > {hard_max} from float64 on them)")
     sg, sy = summarize(dg), summarize(dy)
     print(f"{what}: gradient deviation from float64 -- HIP path {sg} | reference fp32 arithmetic {sy}")
     assert sg["median"] <= factor * sy["median"] + 2e-6, (what, sg, sy)

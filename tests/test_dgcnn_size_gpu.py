@@ -127,9 +127,13 @@ def test_training_gradients_match_reference_module(gpu):
         with open(os.path.join(out, "parity_deviation.jsonl"), "a") as f:
             f.write(json.dumps({"test": "dgcnn_gradient_goldens", "max": max(worst.values()),
                                 "median": float(np.median(list(worst.values()))), "per_tensor": worst}) + "\n")
-    # fp32 near-tie neighbour swaps between torch.matmul's and the kernel's inner products move single edges
-    assert max(worst.values()) <= 2e-2, worst
-    assert np.median(list(worst.values())) <= 5e-3, worst
+    # Measured on MI355X (profiles/r04/episode_parity_deviation.jsonl, "dgcnn_gradient_goldens"): worst tensor 2.7e-6,
+    # median 1.4e-6 of the reference module's largest component -- on this golden input the kernel's neighbour lists
+    # are the reference's, so only summation order differs.  Bounds = 3x the measurement (rounds 1-3 carried 2e-2 /
+    # 5e-3 for near-tie neighbour swaps between torch.matmul's and the kernel's inner products; none occurs here: a
+    # swap would move single tensors by ~1e-3 and trip this bound -- then look at the graph, not at the bound).
+    assert max(worst.values()) <= 8.1e-6, worst
+    assert np.median(list(worst.values())) <= 4.3e-6, worst
 
 
 def test_b64_shape_determinism_and_batch_independence(gpu):
