@@ -158,6 +158,8 @@ SIGNATURES = {
     "fpsg_emd_workspace_floats": [_c_int, _c_int, _c_int],
     "fpsg_emd_approx": [_c_f32p, _c_f32p, _c_int, _c_int, _c_int, _c_f32p, _c_f32p, _c_f32p, _c_f32p,
                         _c_stream],
+    "fpsg_emd_approx_variant": [_c_f32p, _c_f32p, _c_int, _c_int, _c_int, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_int,
+                                _c_stream],
 }
 _RESTYPES = {"fpsg_last_error": ctypes.c_char_p, "fpsg_chamfer_workspace_bytes": ctypes.c_size_t,
              "fpsg_sinkhorn_workspace_floats": ctypes.c_size_t,

@@ -11,17 +11,26 @@
 //     column consumption, assignment); each sweep is ONE launch of small workgroups: a wave owns
 //     two points and its lanes stride over the other cloud (see emd_sweep_kernel);
 //   * the per-pair work is packed FP32 VALU + one v_exp_f32 (and v_sqrt/v_rcp in the assignment
-//     sweep); distances use the same fma form as K1.
+//     sweep); distances use the same fma form as K1;
+//   * round 4, forward-only calls (evaluation): a level's assignment sweep and the NEXT level's row-normaliser sweep
+//     have the same owners and sweep the same cloud, so they are ONE launch (kMatchRatio*: 21 sweeps instead of 30
+//     per call, the distance evaluated once for both); the levels are a factor 4 apart, so the assignment's
+//     exp(4 l d^2) is the square of the square of the normaliser's exp(l d^2) -- two packed multiplications instead of
+//     a second quarter-rate v_exp_f32 (relative difference ~4e-7 per weight; the cost is checked against the CPU
+//     restatement, which calls expf per level, to 1e-5); a wave owns FOUR points (half the vector-memory instructions
+//     per pair: the sweeps were close to the CU's 64 B/clk load path).
 #include "fpsg_common.h"
 
 namespace fpsg {
 namespace {
 
 constexpr int kEmdWaves = 4;     // waves per workgroup
-constexpr int kEmdOwners = 2;    // owner points per wave
+constexpr int kEmdOwners = 2;    // owner points per wave (gradient sweeps; the forward-only sweeps take 4)
 constexpr int kEmdThreads = 64 * kEmdWaves;
 
-enum EmdMode { kRatioL = 0, kRatioR = 1, kMatch = 2, kGradOther = 3 };
+enum EmdMode { kRatioL = 0, kRatioR = 1, kMatch = 2, kGradOther = 3,
+               kMatchRatioQ = 4,    // kMatch at `level` + the next level's kRatioL at `level2` = level / 4
+               kMatchRatioZ = 5 };  // the same with level2 = 0 (the last level: exp(0 d^2) = 1)
 
 inline int emd_pad4(int n) { return (n + 3) & ~3; }
 
@@ -35,6 +44,8 @@ struct EmdArgs {
   float* own_grad;       // [B, No, 3] or null: kMatch / kGradOther gradient accumulators (the caller's layout)
   int No, Nt;            // points; the workspace rows are padded to multiples of 4 (Nop, Ntp)
   float level;
+  const float* oth_w2;   // kMatchRatio*: [B, Ntp] the swept points' weights of the normaliser half (remainR)
+  float level2;          // kMatchRatioQ: level / 4
 };
 
 // One wave = kEmdOwners owner points against the whole swept cloud.  The clouds are read from coordinate-major copies
@@ -45,8 +56,12 @@ struct EmdArgs {
 // sums are folded over the 64 lanes by the row_shr / row_bcast DPP tree (deterministic, no float atomics, no LDS).
 // A sweep of one 2048-point pair is 256 workgroups of 4 waves, so even a single pair fills the chip; per pair: distance
 // (3 packed-half instructions) + v_exp_f32 + weights (+ v_sqrt / v_rcp and 4 FMAs in the assignment sweeps).
-template <int MODE, bool GRAD>
+template <int MODE, bool GRAD, int OWN>
 __global__ __launch_bounds__(kEmdThreads) void emd_sweep_kernel(EmdArgs a) {
+  constexpr int kEmdOwners = OWN;                       // (shadows the default: this instance's owners per wave)
+  constexpr bool kMerged = MODE == kMatchRatioQ || MODE == kMatchRatioZ;
+  constexpr bool kAssign = MODE == kMatch || MODE == kGradOther || kMerged;
+  static_assert(!(GRAD && kMerged), "the merged sweeps are forward-only");
   const int b = blockIdx.y;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -58,6 +73,7 @@ __global__ __launch_bounds__(kEmdThreads) void emd_sweep_kernel(EmdArgs a) {
   const float* __restrict__ othy = othx + Ntp;
   const float* __restrict__ othz = othy + Ntp;
   const float* __restrict__ ow = a.oth_w + (size_t)b * Ntp;
+  const float* __restrict__ ow2 = kMerged ? a.oth_w2 + (size_t)b * Ntp : ow;
   v2f px[kEmdOwners], py[kEmdOwners], pz[kEmdOwners];
   float fac[kEmdOwners];
 #pragma unroll
@@ -66,45 +82,65 @@ __global__ __launch_bounds__(kEmdThreads) void emd_sweep_kernel(EmdArgs a) {
     const float x = own[oc], y = own[Nop + oc], z = own[2 * Nop + oc];
     px[r] = v2f{x, x}; py[r] = v2f{y, y}; pz[r] = v2f{z, z};
     // factor applied to every pair weight of this owner (assignment sweeps only)
-    fac[r] = (MODE == kMatch || MODE == kGradOther) ? a.own_ratio[(size_t)b * Nop + oc] : 1.0f;
+    fac[r] = kAssign ? a.own_ratio[(size_t)b * Nop + oc] : 1.0f;
   }
-  v2f s[kEmdOwners], c[kEmdOwners], gx[kEmdOwners], gy[kEmdOwners], gz[kEmdOwners];
+  v2f s[kEmdOwners], c[kEmdOwners], gx[kEmdOwners], gy[kEmdOwners], gz[kEmdOwners], s2[kEmdOwners];
 #pragma unroll
-  for (int r = 0; r < kEmdOwners; ++r) { s[r] = v2f{0, 0}; c[r] = v2f{0, 0}; gx[r] = v2f{0, 0}; gy[r] = v2f{0, 0}; gz[r] = v2f{0, 0}; }
-  const v2f lvl = {a.level, a.level};
+  for (int r = 0; r < kEmdOwners; ++r) {
+    s[r] = v2f{0, 0}; c[r] = v2f{0, 0}; gx[r] = v2f{0, 0}; gy[r] = v2f{0, 0}; gz[r] = v2f{0, 0}; s2[r] = v2f{0, 0};
+  }
+  // exp(level d^2) = 2^((level log2 e) d^2): v_exp_f32 itself (base 2), no range / denormal scaffolding around it -- with
+  // -fno-fast-math __expf and sqrtf expand to ~15 compare / select / refine instructions per call, 120 of the merged
+  // sweep's 250 loop instructions; a weight below 2^-126 or a distance below 1e-19 is nothing this sum can see
+  constexpr float kLog2e = 1.44269504088896340736f;
+  const v2f lvl = {a.level * kLog2e, a.level * kLog2e};
+  const v2f lvl2 = {a.level2 * kLog2e, a.level2 * kLog2e};
 
   const int ngroups = Ntp >> 2;                         // groups of four candidates
-  auto fetch = [&](int g, v4f& X, v4f& Y, v4f& Z, v4f& Wt) {
+  auto fetch = [&](int g, v4f& X, v4f& Y, v4f& Z, v4f& Wt, v4f& W2) {
     const bool in = g < ngroups;
     const int gc = in ? g : 0;                          // a lane beyond the cloud re-reads group 0 with weight 0
     X = reinterpret_cast<const v4f*>(othx)[gc];
     Y = reinterpret_cast<const v4f*>(othy)[gc];
     Z = reinterpret_cast<const v4f*>(othz)[gc];
     Wt = reinterpret_cast<const v4f*>(ow)[gc];
-    if (!in) Wt = (v4f){0.0f, 0.0f, 0.0f, 0.0f};
+    if (kMerged) W2 = reinterpret_cast<const v4f*>(ow2)[gc];
+    if (!in) { Wt = (v4f){0.0f, 0.0f, 0.0f, 0.0f}; W2 = Wt; }
   };
-  v4f X, Y, Z, Wt;
-  fetch(lane, X, Y, Z, Wt);
+  v4f X, Y, Z, Wt, W2 = {0.0f, 0.0f, 0.0f, 0.0f};
+  fetch(lane, X, Y, Z, Wt, W2);
   for (int g = lane; g < ngroups; g += 64) {
-    v4f Xn, Yn, Zn, Wn;
-    fetch(g + 64, Xn, Yn, Zn, Wn);                      // (past the end: group 0, weight 0, never used)
+    v4f Xn, Yn, Zn, Wn, W2n = {0.0f, 0.0f, 0.0f, 0.0f};
+    fetch(g + 64, Xn, Yn, Zn, Wn, W2n);                 // (past the end: group 0, weight 0, never used)
 #pragma unroll
     for (int h = 0; h < 2; ++h) {                       // candidates (4g, 4g+1) and (4g+2, 4g+3) as packed pairs
       const v2f cx = h ? v2f{X[2], X[3]} : v2f{X[0], X[1]};
       const v2f cy = h ? v2f{Y[2], Y[3]} : v2f{Y[0], Y[1]};
       const v2f cz = h ? v2f{Z[2], Z[3]} : v2f{Z[0], Z[1]};
       const v2f cw = h ? v2f{Wt[2], Wt[3]} : v2f{Wt[0], Wt[1]};
+      const v2f cw2 = h ? v2f{W2[2], W2[3]} : v2f{W2[0], W2[1]};
 #pragma unroll
       for (int r = 0; r < kEmdOwners; ++r) {
         const v2f dx = cx - px[r], dy = cy - py[r], dz = cz - pz[r];
         const v2f d2 = fma_rn(dz, dz, fma_rn(dy, dy, dx * dx));
-        const v2f e = lvl * d2;
         const v2f f2 = {fac[r], fac[r]};
-        const v2f w = v2f{__expf(e.x), __expf(e.y)} * cw * f2;
+        v2f ex;                                        // exp(level d^2)
+        if (MODE == kMatchRatioQ) {
+          const v2f e2 = lvl2 * d2;
+          const v2f x1 = {__builtin_amdgcn_exp2f(e2.x), __builtin_amdgcn_exp2f(e2.y)};  // the next level's exp(level/4 d^2) ...
+          s2[r] = fma_rn(x1, cw2, s2[r]);
+          const v2f x2 = x1 * x1;
+          ex = x2 * x2;                                 // ... and its fourth power: this level's
+        } else {
+          const v2f e = lvl * d2;
+          ex = v2f{__builtin_amdgcn_exp2f(e.x), __builtin_amdgcn_exp2f(e.y)};
+          if (MODE == kMatchRatioZ) s2[r] += cw2;       // exp(0 d^2) = 1
+        }
+        const v2f w = ex * cw * f2;
         s[r] += w;
-        if (MODE == kMatch || MODE == kGradOther) {
-          const v2f dist = {__builtin_sqrtf(d2.x), __builtin_sqrtf(d2.y)};
-          if (MODE == kMatch) c[r] = fma_rn(w, dist, c[r]);
+        if (kAssign) {
+          const v2f dist = {__builtin_amdgcn_sqrtf(d2.x), __builtin_amdgcn_sqrtf(d2.y)};
+          if (MODE == kMatch || kMerged) c[r] = fma_rn(w, dist, c[r]);
           if (GRAD) {
             const v2f f = {w.x / __builtin_fmaxf(dist.x, 1e-20f), w.y / __builtin_fmaxf(dist.y, 1e-20f)};
             gx[r] = fma_rn(f, -dx, gx[r]);   // owner - other
@@ -114,14 +150,22 @@ __global__ __launch_bounds__(kEmdThreads) void emd_sweep_kernel(EmdArgs a) {
         }
       }
     }
-    X = Xn; Y = Yn; Z = Zn; Wt = Wn;
+    X = Xn; Y = Yn; Z = Zn; Wt = Wn; W2 = W2n;
   }
-  static_assert(kEmdOwners == 2, "the reductions below fold two owners' sums per DPP tree");
-  float st[2] = {s[0].x + s[0].y, s[1].x + s[1].y};
-  float ct[2] = {c[0].x + c[0].y, c[1].x + c[1].y};
-  wave_sum4_to_last(st[0], st[1], ct[0], ct[1]);
+  static_assert(kEmdOwners == 2 || (kEmdOwners == 4 && !GRAD), "the reductions below fold four sums per DPP tree");
+  float st[kEmdOwners], ct[kEmdOwners], s2t[kEmdOwners];
+#pragma unroll
+  for (int r = 0; r < kEmdOwners; ++r) { st[r] = s[r].x + s[r].y; ct[r] = c[r].x + c[r].y; s2t[r] = s2[r].x + s2[r].y; }
+  if constexpr (kEmdOwners == 2) {
+    wave_sum4_to_last(st[0], st[1], ct[0], ct[1]);
+    if (kMerged) { float p0 = 0.0f, p1 = 0.0f; wave_sum4_to_last(s2t[0], s2t[1], p0, p1); }
+  } else {
+    wave_sum4_to_last(st[0], st[1], st[2], st[3]);
+    if (MODE == kMatch || kMerged) wave_sum4_to_last(ct[0], ct[1], ct[2], ct[3]);
+    if (kMerged) wave_sum4_to_last(s2t[0], s2t[1], s2t[2], s2t[3]);
+  }
   float gt[2][3] = {{0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f}};
-  if (GRAD) {
+  if constexpr (GRAD) {
 #pragma unroll
     for (int r = 0; r < 2; ++r) { gt[r][0] = gx[r].x + gx[r].y; gt[r][1] = gy[r].x + gy[r].y; gt[r][2] = gz[r].x + gz[r].y; }
     float pad = 0.0f, pad2 = 0.0f;
@@ -145,8 +189,13 @@ __global__ __launch_bounds__(kEmdThreads) void emd_sweep_kernel(EmdArgs a) {
     } else if (MODE == kMatch) {
       a.own_cost[oi] += ct[r];
       a.own_remain[oi] = __builtin_fmaxf(0.0f, a.own_remain[oi] - st[r]);
+    } else if (kMerged) {
+      a.own_cost[oi] += ct[r];
+      const float rem = __builtin_fmaxf(0.0f, a.own_remain[oi] - st[r]);
+      a.own_remain[oi] = rem;
+      a.own_ratio[oi] = rem / (s2t[r] + 1e-9f);         // the next level's row normaliser (kRatioL's epilogue)
     }
-    if (GRAD && (MODE == kMatch || MODE == kGradOther)) {
+    if constexpr (GRAD) if (MODE == kMatch || MODE == kGradOther) {
       const size_t gi = ((size_t)b * a.No + o) * 3;
       a.own_grad[gi] += gt[r][0];
       a.own_grad[gi + 1] += gt[r][1];
@@ -198,10 +247,10 @@ __global__ __launch_bounds__(256) void emd_cost_kernel(const float* __restrict__
   if (threadIdx.x == 0) cost[blockIdx.x] = red[0];
 }
 
-template <int MODE, bool GRAD>
+template <int MODE, bool GRAD, int OWN = kEmdOwners>
 int sweep(const EmdArgs& a, int B, hipStream_t s, const char* what) {
-  dim3 grid((a.No + kEmdWaves * kEmdOwners - 1) / (kEmdWaves * kEmdOwners), B);
-  hipLaunchKernelGGL((emd_sweep_kernel<MODE, GRAD>), grid, dim3(kEmdThreads), 0, s, a);
+  dim3 grid((a.No + kEmdWaves * OWN - 1) / (kEmdWaves * OWN), B);
+  hipLaunchKernelGGL((emd_sweep_kernel<MODE, GRAD, OWN>), grid, dim3(kEmdThreads), 0, s, a);
   return launch_status(what);
 }
 
@@ -214,13 +263,27 @@ extern "C" size_t fpsg_emd_workspace_floats(int B, int N, int M) {
   return (size_t)B * (6 * Np + 5 * Mp);      // remainL, ratioL, costrow, x1/y1/z1 | remainR, ratioR, x2/y2/z2
 }
 
-extern "C" int fpsg_emd_approx(const float* xyz1, const float* xyz2, int B, int N, int M,
-                               float* cost, float* gxyz1, float* gxyz2, float* ws,
-                               fpsg_stream_t stream) {
+namespace fpsg {
+namespace {
+float emd_level(int j) {                      // -4^j for j = 7 .. -1, then 0
+  if (j == -2) return 0.0f;
+  float level = -1.0f;
+  for (int p = 0; p < (j < 0 ? -j : j); ++p) level = (j < 0) ? level * 0.25f : level * 4.0f;
+  return level;
+}
+}  // namespace
+}  // namespace fpsg
+
+// variant: -1 automatic; else bit 0 = a level's assignment sweep and the next level's row-normaliser sweep as one launch
+// (forward-only calls), bit 1 = four owner points per wave in the forward-only sweeps (two otherwise).
+extern "C" int fpsg_emd_approx_variant(const float* xyz1, const float* xyz2, int B, int N, int M,
+                                       float* cost, float* gxyz1, float* gxyz2, float* ws, int variant,
+                                       fpsg_stream_t stream) {
   using namespace fpsg;
   FPSG_REQUIRE(B > 0 && N > 0 && M > 0, FPSG_E_SHAPE,
                "fpsg_emd_approx: B,N,M must be positive (got %d,%d,%d)", B, N, M);
   FPSG_REQUIRE(B <= 65535, FPSG_E_LIMIT, "fpsg_emd_approx: B=%d exceeds 65535", B);
+  FPSG_REQUIRE(variant >= -1 && variant <= 3, FPSG_E_SHAPE, "fpsg_emd_approx_variant: variant %d not in [-1, 3]", variant);
   FPSG_REQUIRE_PTR(xyz1); FPSG_REQUIRE_PTR(xyz2); FPSG_REQUIRE_PTR(cost); FPSG_REQUIRE_PTR(ws);
   FPSG_REQUIRE(!misaligned4(gxyz1) && !misaligned4(gxyz2), FPSG_E_ALIGN,
                "fpsg_emd_approx: gradient buffers must be 4-byte aligned");
@@ -243,26 +306,51 @@ extern "C" int fpsg_emd_approx(const float* xyz1, const float* xyz2, int B, int 
     int rc = launch_status("fpsg_emd_approx(init)");
     if (rc) return rc;
   }
+  const bool forward_only = gxyz1 == nullptr && gxyz2 == nullptr;
+  // measured on MI355X (profiles/r04/k2_variants.txt): the merged sweeps win at every size (B = 5: 372 -> 297 us); four
+  // owners per wave only once the grid has waves to spare (B = 37: 1630 -> 1565 us; B = 5: 297 -> 348: 2.5 waves per SIMD)
+  if (variant < 0) variant = 1 | ((long)B * (N > M ? N : M) >= 32768 ? 2 : 0);
+  const bool merged = forward_only && (variant & 1);
+  const bool own4 = forward_only && (variant & 2);
+  int rc;
+  auto rows = [&](EmdArgs& a) {               // owners = cloud 1, sweeping cloud 2
+    a.own = soa1; a.oth = soa2; a.own_remain = remainL; a.own_ratio = ratioL; a.No = N; a.Nt = M;
+  };
+  auto cols = [&](EmdArgs& a) {               // owners = cloud 2, sweeping cloud 1
+    a.own = soa2; a.oth = soa1; a.own_remain = remainR; a.own_ratio = ratioR; a.No = M; a.Nt = N;
+  };
   for (int j = 7; j >= -2; --j) {
-    float level = -1.0f;
-    for (int p = 0; p < (j < 0 ? -j : j); ++p) level = (j < 0) ? level * 0.25f : level * 4.0f;
-    if (j == -2) level = 0.0f;   // -4^j for j = 7..-1, then 0
     EmdArgs a{};
-    a.level = level;
-    int rc;
-    // row normalisers: owners = cloud 1, sweep cloud 2 weighted by remainR
-    a.own = soa1; a.oth = soa2; a.oth_w = remainR; a.own_remain = remainL; a.own_ratio = ratioL;
-    a.own_cost = nullptr; a.own_grad = nullptr; a.No = N; a.Nt = M;
-    if ((rc = sweep<kRatioL, false>(a, B, s, "fpsg_emd_approx(ratioL)"))) return rc;
-    // column consumption: owners = cloud 2, sweep cloud 1 weighted by ratioL
-    a.own = soa2; a.oth = soa1; a.oth_w = ratioL; a.own_remain = remainR; a.own_ratio = ratioR;
-    a.No = M; a.Nt = N;
-    if ((rc = sweep<kRatioR, false>(a, B, s, "fpsg_emd_approx(ratioR)"))) return rc;
+    a.level = emd_level(j);
+    // row normalisers: sweep cloud 2 weighted by remainR (merged: done by the previous level's assignment launch)
+    if (!merged || j == 7) {
+      rows(a); a.oth_w = remainR;
+      rc = own4 ? sweep<kRatioL, false, 4>(a, B, s, "fpsg_emd_approx(ratioL)")
+                : sweep<kRatioL, false>(a, B, s, "fpsg_emd_approx(ratioL)");
+      if (rc) return rc;
+    }
+    // column consumption: sweep cloud 1 weighted by ratioL
+    cols(a); a.oth_w = ratioL;
+    rc = own4 ? sweep<kRatioR, false, 4>(a, B, s, "fpsg_emd_approx(ratioR)")
+              : sweep<kRatioR, false>(a, B, s, "fpsg_emd_approx(ratioR)");
+    if (rc) return rc;
     // assignment: owners = cloud 1 (factor ratioL), sweep cloud 2 weighted by ratioR
-    a.own = soa1; a.oth = soa2; a.oth_w = ratioR; a.own_remain = remainL; a.own_ratio = ratioL;
-    a.own_cost = costrow; a.own_grad = gxyz1; a.No = N; a.Nt = M;
-    rc = gxyz1 ? sweep<kMatch, true>(a, B, s, "fpsg_emd_approx(match+grad)")
-               : sweep<kMatch, false>(a, B, s, "fpsg_emd_approx(match)");
+    rows(a); a.oth_w = ratioR; a.own_cost = costrow; a.own_grad = gxyz1;
+    if (merged && j > -2) {                   // + the next level's row normalisers (weights remainR)
+      a.oth_w2 = remainR;
+      a.level2 = emd_level(j - 1);
+      if (j - 1 == -2)
+        rc = own4 ? sweep<kMatchRatioZ, false, 4>(a, B, s, "fpsg_emd_approx(match+ratioL)")
+                  : sweep<kMatchRatioZ, false>(a, B, s, "fpsg_emd_approx(match+ratioL)");
+      else
+        rc = own4 ? sweep<kMatchRatioQ, false, 4>(a, B, s, "fpsg_emd_approx(match+ratioL)")
+                  : sweep<kMatchRatioQ, false>(a, B, s, "fpsg_emd_approx(match+ratioL)");
+    } else if (gxyz1) {
+      rc = sweep<kMatch, true>(a, B, s, "fpsg_emd_approx(match+grad)");
+    } else {
+      rc = own4 ? sweep<kMatch, false, 4>(a, B, s, "fpsg_emd_approx(match)")
+                : sweep<kMatch, false>(a, B, s, "fpsg_emd_approx(match)");
+    }
     if (rc) return rc;
     if (gxyz2) {  // same weights seen from cloud 2
       a.own = soa2; a.oth = soa1; a.oth_w = ratioL; a.own_remain = nullptr; a.own_ratio = ratioR;
@@ -272,4 +360,10 @@ extern "C" int fpsg_emd_approx(const float* xyz1, const float* xyz2, int B, int 
   }
   hipLaunchKernelGGL(emd_cost_kernel, dim3(B), dim3(256), 0, s, costrow, N, Np, cost);
   return launch_status("fpsg_emd_approx(cost)");
+}
+
+extern "C" int fpsg_emd_approx(const float* xyz1, const float* xyz2, int B, int N, int M,
+                               float* cost, float* gxyz1, float* gxyz2, float* ws,
+                               fpsg_stream_t stream) {
+  return fpsg_emd_approx_variant(xyz1, xyz2, B, N, M, cost, gxyz1, gxyz2, ws, -1, stream);
 }

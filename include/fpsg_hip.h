@@ -190,10 +190,17 @@ int fpsg_edge_feature_bwd(const float* gout, const int32_t* idx, int B, int C, i
  * fpsg_emd_workspace_floats(B,N,M) floats, 16-byte aligned (per-point state and
  * coordinate-major copies of both clouds, rows padded to multiples of 4 points).
  * Deterministic (no float atomics).
+ * fpsg_emd_approx_variant: `variant` -1 = automatic (what fpsg_emd_approx passes), else two bits that only act on
+ * forward-only calls (both gradients NULL: the evaluation path): bit 0 = a level's assignment sweep and the next
+ * level's row-normaliser sweep as ONE launch (same owners, same swept cloud; 21 sweeps per call instead of 30; the
+ * assignment's exp(level d^2) is formed as the fourth power of the normaliser's exp(level/4 d^2)), bit 1 = four owner
+ * points per wave instead of two.  Same values up to fp32 rounding of the exponentials (~4e-7 per weight).
  */
 size_t fpsg_emd_workspace_floats(int B, int N, int M);
 int fpsg_emd_approx(const float* xyz1, const float* xyz2, int B, int N, int M, float* cost,
                     float* gxyz1, float* gxyz2, float* ws, fpsg_stream_t stream);
+int fpsg_emd_approx_variant(const float* xyz1, const float* xyz2, int B, int N, int M, float* cost,
+                            float* gxyz1, float* gxyz2, float* ws, int variant, fpsg_stream_t stream);
 
 /* ---- K4b: fused EdgeConv (gather + BatchNorm statistics + max over k) -----------------
  * Replaces the chain get_graph_feature -> Conv2d 1x1 -> BatchNorm2d -> LeakyReLU -> max_k of
