@@ -96,6 +96,8 @@ SIGNATURES = {
                         _c_stream],
     "fpsg_bn_act_bwd": [_c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_int, _c_int, _c_int, _c_int, _c_int,
                         ctypes.c_float, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_stream],
+    "fpsg_bn_act_bwd_coef": [_c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_int, _c_int, _c_int, _c_int, _c_int, ctypes.c_float,
+                             _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_stream],
     "fpsg_bn_act_bwd_parts": [_c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_int, _c_int, _c_int, _c_int, _c_int,
                         ctypes.c_float, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_int, _c_stream],
     "fpsg_bn_pool_workspace_floats": [_c_int, _c_int, _c_int, _c_int],
@@ -147,6 +149,8 @@ SIGNATURES = {
     "fpsg_conv_first_parts": [_c_int, _c_int, _c_int],
     "fpsg_conv_first_fwd": [_c_f32p, _c_f32p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_f32p, _c_f32p, _c_f32p, _c_stream],
     "fpsg_conv_first_dw": [_c_f32p, _c_f32p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_f32p, _c_f32p, _c_stream],
+    "fpsg_conv_first_dw_fold": [_c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_int, _c_int, _c_int, _c_int, _c_int,
+                                _c_f32p, _c_f32p, _c_stream],
     "fpsg_adam_step": [_c_f32p, _c_f32p, _c_f32p, _c_f32p, ctypes.c_size_t, ctypes.c_float, ctypes.c_float,
                        ctypes.c_float, ctypes.c_float, _c_int, ctypes.c_float, _c_stream],
     "fpsg_flat_accumulate_segments": [_c_f32p, ctypes.c_void_p, ctypes.c_void_p, _c_int, ctypes.c_size_t, _c_int, _c_stream],

@@ -1227,6 +1227,30 @@ extern "C" int fpsg_bn_act_bwd(const float* x, const float* pre_bias, const floa
   return 0;
 }
 
+// The sums + coefficient half of fpsg_bn_act_bwd alone (no dx pass): dgamma, dbeta and coef [3,C] of
+// dx = k1 dz + k2 (x + pre_bias) + k3 for a consumer that forms dx itself while it reads x and dy
+// (fpsg_conv_first_dw_fold).  The tensors of the large path only (N * L > the small-tensor limit).
+extern "C" int fpsg_bn_act_bwd_coef(const float* x, const float* pre_bias, const float* dy, const float* chan, int N,
+                                    int C, int L, int training, int act, float slope, float* dgamma, float* dbeta,
+                                    float* coef, float* ws, fpsg_stream_t stream) {
+  using namespace fpsg;
+  int rc = check_dims("fpsg_bn_act_bwd_coef", N, C, L, act);
+  if (rc) return rc;
+  FPSG_REQUIRE_PTR(x); FPSG_REQUIRE_PTR(dy); FPSG_REQUIRE_PTR(chan);
+  FPSG_REQUIRE_PTR(dgamma); FPSG_REQUIRE_PTR(dbeta); FPSG_REQUIRE_PTR(coef); FPSG_REQUIRE_PTR(ws);
+  FPSG_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy)) & 15) == 0, FPSG_E_ALIGN,
+               "fpsg_bn_act_bwd_coef: x and dy must be 16-byte aligned");
+  FPSG_REQUIRE((long)N * L > kBnSmallMax, FPSG_E_LIMIT, "fpsg_bn_act_bwd_coef: N*L = %ld is a small tensor (<= %d): use fpsg_bn_act_bwd",
+               (long)N * L, kBnSmallMax);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int S = slices_for(N, L);
+  launch_reduce<1>(act, x, dy, chan, pre_bias, N, C, L, S, slope, ws, s);
+  if ((rc = launch_status("fpsg_bn_act_bwd_coef(reduce)"))) return rc;
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, s, ws, chan, C, S,
+                     (double)N * (double)L, training, dgamma, dbeta, coef);
+  return launch_status("fpsg_bn_act_bwd_coef(finalize)");
+}
+
 extern "C" int fpsg_bn_act_bwd_parts(const float* x, const float* pre_bias, const float* dy, const float* chan, int N,
                                      int C, int L, int training, int act, float slope, float* dx, float* dgamma,
                                      float* dbeta, float* dpre_bias, float* coef, float* ws, const float* parts,

@@ -23,9 +23,21 @@ constexpr int kFirstThreads = 256;
 // PX = pixels per segment: 112 when the rows are whole multiples of it (VGG's 224: two 448-byte runs per channel row,
 // no idle pixels), 64 otherwise.  The NEXT segment's dy vectors and patch elements are fetched into registers before
 // the current segment's MFMAs start, so the HBM latency runs beside the matrix work instead of in front of it.
-template <int PX>
+// FOLD (round 4): dy is not given -- it is the BatchNorm + ReLU backward of the layer behind this convolution,
+//   dy = k1 dz + k2 (y + b) + k3,  dz = ga * [ (y + b) scale + shift > 0 ],
+// formed while the tile is written to LDS from the convolution's own output y, the gradient ga of the (never stored)
+// activation and seven per-channel constants (K5's dx pass, bn_apply_kernel<1>, same arithmetic bit for bit): the 475 MB
+// of dy are neither written by K5 nor read here (fpsg_conv_first_dw_fold).
+struct FoldArgs {
+  const float* y;        // [N,64,H,W] the convolution's output (pre-BatchNorm)
+  const float* chan;     // [4][64] scale, shift, mean, rstd
+  const float* coef;     // [3][64] k1, k2, k3
+  const float* pre_bias; // [64] or null
+};
+
+template <int PX, bool FOLD>
 __global__ __launch_bounds__(kFirstThreads) void conv_first_dw_kernel(const float* __restrict__ x,
-                                                                      const float* __restrict__ dy, int H, int W,
+                                                                      const float* __restrict__ dy, FoldArgs fa, int H, int W,
                                                                       int segs_per_row, int n_segs,
                                                                       float* __restrict__ part /*[grid][64][32]*/) {
   constexpr int LD = PX + 4;                      // LDS row stride: 2 lanes per bank for the A reads, the minimum
@@ -64,7 +76,19 @@ __global__ __launch_bounds__(kFirstThreads) void conv_first_dw_kernel(const floa
     pj[it] = e - (e / (PX + 2)) * (PX + 2);
   }
   v4f rv[NV];
+  v4f ry[FOLD ? NV : 1];
   float rp[NP];
+  // FOLD: the constants of this thread's channels (a slot's channel does not change from segment to segment)
+  float fsc[FOLD ? NV : 1], fsh[FOLD ? NV : 1], fk1[FOLD ? NV : 1], fk2[FOLD ? NV : 1], fk3[FOLD ? NV : 1], fb[FOLD ? NV : 1];
+  if constexpr (FOLD) {
+#pragma unroll
+    for (int it = 0; it < NV; ++it) {
+      const int c = vch[it];
+      fsc[it] = fa.chan[c]; fsh[it] = fa.chan[64 + c];
+      fk1[it] = fa.coef[c]; fk2[it] = fa.coef[64 + c]; fk3[it] = fa.coef[128 + c];
+      fb[it] = fa.pre_bias ? fa.pre_bias[c] : 0.0f;
+    }
+  }
   auto fetch = [&](int seg) {
     const int row = seg / segs_per_row;             // (n, h)
     const int w0 = (seg - row * segs_per_row) * PX;
@@ -73,8 +97,14 @@ __global__ __launch_bounds__(kFirstThreads) void conv_first_dw_kernel(const floa
 #pragma unroll
     for (int it = 0; it < NV; ++it) {
       rv[it] = (v4f){0.0f, 0.0f, 0.0f, 0.0f};       // W % 4 == 0: a vector is inside or outside as a whole
-      if (w0 + vq4[it] < W)
-        rv[it] = *reinterpret_cast<const v4f*>(dy + (((size_t)n * 64 + vch[it]) * H + h) * W + w0 + vq4[it]);
+      if constexpr (FOLD) ry[it] = rv[it];
+      if (w0 + vq4[it] < W) {
+        const size_t o = (((size_t)n * 64 + vch[it]) * H + h) * W + w0 + vq4[it];
+        rv[it] = *reinterpret_cast<const v4f*>(dy + o);
+        if constexpr (FOLD) ry[it] = *reinterpret_cast<const v4f*>(fa.y + o);
+      } else if constexpr (FOLD) {
+        ry[it] = (v4f){-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f};     // outside the row: flagged below, enters as 0
+      }
     }
 #pragma unroll
     for (int it = 0; it < NP; ++it) {
@@ -90,7 +120,19 @@ __global__ __launch_bounds__(kFirstThreads) void conv_first_dw_kernel(const floa
   for (; seg < n_segs; seg += gridDim.x) {
     __syncthreads();                                // the previous segment's tiles are consumed
 #pragma unroll
-    for (int it = 0; it < NV; ++it) *reinterpret_cast<v4f*>(dyt + vch[it] * LD + vq4[it]) = rv[it];
+    for (int it = 0; it < NV; ++it) {
+      v4f v = rv[it];
+      if constexpr (FOLD) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const float xv = ry[it][u] + fb[it];
+          const float dz = rv[it][u] * (fma_rn(xv, fsc[it], fsh[it]) > 0.0f ? 1.0f : 0.0f);
+          const float dx = fma_rn(fk1[it], dz, fma_rn(fk2[it], xv, fk3[it]));
+          v[u] = ry[it][u] == -3.0e38f ? 0.0f : dx;                 // pixels beyond the row contribute nothing
+        }
+      }
+      *reinterpret_cast<v4f*>(dyt + vch[it] * LD + vq4[it]) = v;
+    }
 #pragma unroll
     for (int it = 0; it < NP; ++it)
       if (pcr[it] >= 0) xt[pcr[it] * LD + pj[it]] = rp[it];
@@ -300,14 +342,16 @@ extern "C" size_t fpsg_conv_first_dw_workspace_floats(int N, int H, int W) {
   return (size_t)2048 * 64 * 32;
 }
 
-extern "C" int fpsg_conv_first_dw(const float* x, const float* dy, int N, int C, int K, int H, int W, float* dw,
-                                  float* ws, fpsg_stream_t stream) {
+static int conv_first_dw_launch(const char* fn, const float* x, const float* dy, fpsg::FoldArgs fa, int N, int C, int K,
+                                int H, int W, float* dw, float* ws, fpsg_stream_t stream) {
   using namespace fpsg;
-  FPSG_REQUIRE(C == 3 && K == 64, FPSG_E_SHAPE, "fpsg_conv_first_dw: the 3 -> 64 channel layer only (got %d -> %d)", C, K);
+  const bool fold = fa.y != nullptr;
+  FPSG_REQUIRE(C == 3 && K == 64, FPSG_E_SHAPE, "%s: the 3 -> 64 channel layer only (got %d -> %d)", fn, C, K);
   FPSG_REQUIRE(N > 0 && H > 0 && W > 0 && W % 4 == 0, FPSG_E_SHAPE,
-               "fpsg_conv_first_dw: N, H positive and W a positive multiple of 4 (got %d,%d,%d)", N, H, W);
+               "%s: N, H positive and W a positive multiple of 4 (got %d,%d,%d)", fn, N, H, W);
   FPSG_REQUIRE_PTR(x); FPSG_REQUIRE_PTR(dy); FPSG_REQUIRE_PTR(dw); FPSG_REQUIRE_PTR(ws);
-  FPSG_REQUIRE((reinterpret_cast<uintptr_t>(dy) & 15) == 0, FPSG_E_ALIGN, "fpsg_conv_first_dw: dy must be 16-byte aligned");
+  FPSG_REQUIRE((reinterpret_cast<uintptr_t>(dy) & 15) == 0 && (reinterpret_cast<uintptr_t>(fa.y) & 15) == 0, FPSG_E_ALIGN,
+               "%s: dy / y / ga must be 16-byte aligned", fn);
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int px = W % 112 == 0 ? 112 : 64;
   const int segs_per_row = (W + px - 1) / px;
@@ -318,14 +362,34 @@ extern "C" int fpsg_conv_first_dw(const float* x, const float* dy, int N, int C,
   // over its share of the segments.  (Non-temporal loads of dy were measured here: 144 -> 185 us; plain loads.)
   const int resident = px == 112 ? 1024 : 2048;
   const int blocks = n_segs < resident ? n_segs : resident;
-  if (px == 112)
-    hipLaunchKernelGGL(conv_first_dw_kernel<112>, dim3(blocks), dim3(kFirstThreads), 0, s, x, dy, H, W, segs_per_row, n_segs, ws);
+  if (px == 112 && fold)
+    hipLaunchKernelGGL((conv_first_dw_kernel<112, true>), dim3(blocks), dim3(kFirstThreads), 0, s, x, dy, fa, H, W, segs_per_row, n_segs, ws);
+  else if (px == 112)
+    hipLaunchKernelGGL((conv_first_dw_kernel<112, false>), dim3(blocks), dim3(kFirstThreads), 0, s, x, dy, fa, H, W, segs_per_row, n_segs, ws);
+  else if (fold)
+    hipLaunchKernelGGL((conv_first_dw_kernel<64, true>), dim3(blocks), dim3(kFirstThreads), 0, s, x, dy, fa, H, W, segs_per_row, n_segs, ws);
   else
-    hipLaunchKernelGGL(conv_first_dw_kernel<64>, dim3(blocks), dim3(kFirstThreads), 0, s, x, dy, H, W, segs_per_row, n_segs, ws);
-  int rc = launch_status("fpsg_conv_first_dw(partials)");
+    hipLaunchKernelGGL((conv_first_dw_kernel<64, false>), dim3(blocks), dim3(kFirstThreads), 0, s, x, dy, fa, H, W, segs_per_row, n_segs, ws);
+  int rc = launch_status(fn);
   if (rc) return rc;
   hipLaunchKernelGGL(conv_first_dw_reduce_kernel, dim3(64), dim3(1024), 0, s, ws, blocks, dw);
-  return launch_status("fpsg_conv_first_dw(reduce)");
+  return launch_status(fn);
+}
+
+extern "C" int fpsg_conv_first_dw(const float* x, const float* dy, int N, int C, int K, int H, int W, float* dw,
+                                  float* ws, fpsg_stream_t stream) {
+  return conv_first_dw_launch("fpsg_conv_first_dw", x, dy, fpsg::FoldArgs{nullptr, nullptr, nullptr, nullptr}, N, C, K, H, W,
+                              dw, ws, stream);
+}
+
+extern "C" int fpsg_conv_first_dw_fold(const float* x, const float* y, const float* ga, const float* chan,
+                                       const float* coef, const float* pre_bias, int N, int C, int K, int H, int W,
+                                       float* dw, float* ws, fpsg_stream_t stream) {
+  using namespace fpsg;
+  FPSG_REQUIRE_PTR(y); FPSG_REQUIRE_PTR(chan); FPSG_REQUIRE_PTR(coef);
+  FPSG_REQUIRE(!misaligned4(pre_bias), FPSG_E_ALIGN, "fpsg_conv_first_dw_fold: pre_bias not 4-byte aligned");
+  return conv_first_dw_launch("fpsg_conv_first_dw_fold", x, ga, FoldArgs{y, chan, coef, pre_bias}, N, C, K, H, W, dw, ws,
+                              stream);
 }
 
 extern "C" int fpsg_conv_first_parts(int N, int H, int W) {

@@ -90,7 +90,18 @@ class ImageEncoderWarpper(nn.Module):
                 # follows takes its statistics from those partial sums instead of reading y again
                 want = wants_conv_stats(layer, bn, x)
                 parts = None
-                if pending is not None:
+                nxt3 = layers[i + 3] if i + 5 < len(layers) else None
+                if (pending is None and i == 0 and isinstance(nxt3, nn.Conv2d) and isinstance(layers[i + 4], nn.BatchNorm2d)
+                        and isinstance(layers[i + 5], nn.ReLU) and fusable_conv(nxt3, layers[i + 4], x)
+                        and winograd.stem_applies(x, layer, bn, nxt3)):
+                    # the trunk's first two convolutions as one autograd function: conv1_1's BatchNorm backward stops
+                    # after its sums, K8 forms dy itself (winograd._StemConvBNReluConv); from here on the loop is at
+                    # conv1_2's output
+                    i += 3
+                    layer, bn = nxt3, layers[i + 1]
+                    want = bn.training and winograd.stats_enabled()      # (what wants_conv_stats answers for conv1_2 here)
+                    y = winograd.stem_conv_bn_relu_conv(x, layers[0], layers[1], layer, want_parts=want)
+                elif pending is not None:
                     py, pconv, pbn, pparts = pending
                     y = winograd.bn_relu_conv3x3(py, pconv.bias, pbn, layer.weight, parts=pparts,
                                                  stats_bias=layer.bias, want_parts=want)

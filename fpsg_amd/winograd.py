@@ -38,14 +38,16 @@ def enabled() -> bool:
     return os.environ.get("FPSG_WINOGRAD", "1") != "0"
 
 
-def eligible(x: torch.Tensor, conv: torch.nn.Conv2d) -> bool:
+def _eligible_layer(conv: torch.nn.Conv2d, H: int, W: int) -> bool:
     def is_(v, want):
         return v == want or v == (want, want)
-    return (enabled() and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4
-            and is_(conv.kernel_size, 3) and is_(conv.stride, 1) and is_(conv.padding, 1) and is_(conv.dilation, 1)
-            and conv.groups == 1 and conv.padding_mode == "zeros"
-            and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0
-            and _wide_enough(conv.in_channels, conv.out_channels, tile_size(x.shape[2], x.shape[3])))
+    return (enabled() and is_(conv.kernel_size, 3) and is_(conv.stride, 1) and is_(conv.padding, 1) and is_(conv.dilation, 1)
+            and conv.groups == 1 and conv.padding_mode == "zeros" and H % 2 == 0 and W % 2 == 0
+            and _wide_enough(conv.in_channels, conv.out_channels, tile_size(H, W)))
+
+
+def eligible(x: torch.Tensor, conv: torch.nn.Conv2d) -> bool:
+    return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and _eligible_layer(conv, x.shape[2], x.shape[3]))
 
 
 def ragged_enabled() -> bool:
@@ -523,6 +525,128 @@ class _BNReluConv3x3(torch.autograd.Function):
                       _hip.ptr(dbeta), _hip.ptr(dpb) if want_dpb else None, _hip.ptr(coef), _hip.ptr(ws), _hip.stream_of(y))
         return (dy, dpb, dgamma if has_g else None, dbeta if has_b else None, None, None, None, None, None, gw, None,
                 None, None, None)
+
+
+def stem_fold_enabled() -> bool:
+    """``FPSG_STEM_FOLD=0``: conv1_1 and the fused BatchNorm + ReLU + conv1_2 stay two autograd functions, the
+    BatchNorm's dx pass writes dy for K8 (A/B measurements)."""
+    return os.environ.get("FPSG_STEM_FOLD", "1") != "0"
+
+
+class _StemConvBNReluConv(torch.autograd.Function):
+    """The trunk's first two convolutions as ONE autograd function (training mode):
+    ``conv3x3(relu(BN(conv3x3_first(x, w1) + b1)), w2)`` = ``vgg16_bn.features[0:4]`` without conv1_2's bias
+    (reference ``src/models/image_net.py:14``).  Forward: K8f, K5's statistics from its epilogue sums, the activating
+    K6f / K6 -- the kernels ``conv3x3_first`` + ``_BNReluConv3x3`` launch.  What the fusion buys is the BACKWARD: the
+    gradient of conv1_1's output is consumed by exactly one kernel, K8's weight gradient (images carry no gradient), so
+    the BatchNorm backward stops after its sums (``fpsg_bn_act_bwd_coef``) and K8 forms ``dy`` tile by tile from ``y1``,
+    the activation gradient and the coefficients (``fpsg_conv_first_dw_fold``): the 475 MB ``dy`` of a 37-image episode
+    is neither written nor read.  Same values as the two functions, bit for bit, except the gradient of conv1_1's bias:
+    in front of a training-mode BatchNorm it is zero in exact arithmetic (sum(dx) = (k1 - scale) sum(dz), k1 = scale);
+    the two-function form returns K5's round-off for it, this one returns 0."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, gamma, beta, running_mean, running_var, momentum, eps, w2, m, stats_bias=None,
+                want_parts=False):
+        from . import conv_first
+        ctx.set_materialize_grads(False)
+        y1, parts1 = conv_first._forward(x, w1, b1, True)
+        N, C, H, W = y1.shape
+        K = w2.shape[0]
+        lib = _hip.load()
+        dev = y1.device
+        chan = torch.empty((4, C), dtype=torch.float32, device=dev)
+        opt = lambda t: _hip.ptr(t) if t is not None else None
+        out_parts = None
+        w2c = w2.contiguous()
+        with torch.cuda.device(dev):
+            _call("fpsg_bn_stats", _hip.ptr(y1), opt(b1), opt(gamma), opt(beta), opt(running_mean), opt(running_var),
+                  float(momentum), N, C, H * W, 1, float(eps), _hip.ptr(chan), None, None, None, _hip.ptr(parts1),
+                  parts1.shape[1], _hip.stream_of(y1))
+            if _can_fuse(m, C, K, N * H * W, H, W):
+                if want_parts:
+                    out, out_parts = _fused_stats(y1, chan, b1, _filter(m, w2c, False), stats_bias)
+                else:
+                    out = _fused_act(y1, chan, b1, _filter(m, w2c, False))
+                V = None
+            else:
+                V = _input_act(m, y1, chan, b1)
+                Mt = torch.bmm(_filter(m, w2c, False), V)
+                if want_parts:
+                    out, out_parts = _output(m, Mt, N, H, W, stats_bias, True)
+                else:
+                    out = _output(m, Mt, N, H, W)
+        ctx.save_for_backward(x, w1, y1, chan, b1, w2c, V if ctx.needs_input_grad[9] else None)
+        ctx.cfg = (N, C, H, W, m, gamma is not None, beta is not None)
+        if not want_parts:
+            return out
+        if out_parts is not None:
+            ctx.mark_non_differentiable(out_parts)
+        return out, out_parts
+
+    @staticmethod
+    def backward(ctx, gout, _gparts=None):
+        if gout is None:
+            return (None,) * 13
+        x, w1, y1, chan, b1, w2, V = ctx.saved_tensors
+        N, C, H, W, m, has_g, has_b = ctx.cfg
+        K = w2.shape[0]
+        lib = _hip.load()
+        dev = y1.device
+        gout = gout.contiguous()
+        gw1 = gw2 = db1 = None
+        with torch.cuda.device(dev):
+            if _can_fuse(m, K, C, N * H * W, H, W):
+                ga = _fused(gout, _filter(m, w2, True))
+            else:
+                ga = _output(m, torch.bmm(_filter(m, w2, True), _input(m, gout)), N, H, W)
+            if ctx.needs_input_grad[9]:
+                if V is None and _can_fuse_dw(m, C, K, N, H, W):
+                    gw2 = _filter_grad(m, _fused_dw(y1, chan, b1, gout), w2)
+                else:
+                    if V is None:
+                        V = _input_act(m, y1, chan, b1)
+                    gw2 = _filter_grad(m, torch.bmm(_grad_output(m, gout), V.transpose(1, 2)), w2)
+            dgamma = torch.empty((C,), dtype=torch.float32, device=dev)
+            dbeta = torch.empty((C,), dtype=torch.float32, device=dev)
+            coef = torch.empty((3, C), dtype=torch.float32, device=dev)
+            ws = torch.empty((lib.fpsg_bn_workspace_floats(N, C, H * W),), dtype=torch.float32, device=dev)
+            _call("fpsg_bn_act_bwd_coef", _hip.ptr(y1), _hip.ptr(b1), _hip.ptr(ga), _hip.ptr(chan), N, C, H * W, 1, 1, 0.0,
+                  _hip.ptr(dgamma), _hip.ptr(dbeta), _hip.ptr(coef), _hip.ptr(ws), _hip.stream_of(y1))
+            if ctx.needs_input_grad[1]:
+                gw1 = torch.empty_like(w1, memory_format=torch.contiguous_format)
+                ws1 = torch.empty((lib.fpsg_conv_first_dw_workspace_floats(N, H, W),), dtype=torch.float32, device=dev)
+                xc = x.contiguous()
+                _call("fpsg_conv_first_dw_fold", _hip.ptr(xc), _hip.ptr(y1), _hip.ptr(ga), _hip.ptr(chan), _hip.ptr(coef),
+                      _hip.ptr(b1), N, 3, 64, H, W, _hip.ptr(gw1), _hip.ptr(ws1), _hip.stream_of(y1))
+            if ctx.needs_input_grad[2]:
+                db1 = torch.zeros((C,), dtype=torch.float32, device=dev)
+        return (None, gw1, db1, dgamma if has_g else None, dbeta if has_b else None, None, None, None, None, gw2, None,
+                None, None)
+
+
+def stem_applies(x, conv1, bn1, conv2) -> bool:
+    """``stem_conv_bn_relu_conv`` serves: training mode, the 3 -> 64 first layer on K8f, images without a gradient, planes
+    beyond K5's small-tensor limit, a Winograd-eligible 64-channel second layer."""
+    from . import conv_first
+    if not (stem_fold_enabled() and fold_enabled() and bn1.training and bn1.track_running_stats and stats_enabled()):
+        return False
+    if x.requires_grad or not conv_first.eligible(x, conv1) or os.environ.get("FPSG_CONV_FIRST_FWD", "1") == "0":
+        return False
+    if conv1.bias is None or conv2.bias is None or x.shape[0] * x.shape[2] * x.shape[3] <= _BN_SMALL_MAX:
+        return False
+    return (isinstance(conv2, torch.nn.Conv2d) and conv2.in_channels == 64
+            and _eligible_layer(conv2, x.shape[2], x.shape[3]))
+
+
+def stem_conv_bn_relu_conv(x, conv1, bn1, conv2, want_parts=False):
+    """``conv2`` (bias-free) of ``relu(bn1(conv1(x)))`` -> the pre-BatchNorm output of conv1_2 (and, with ``want_parts``,
+    the statistics partial sums of ``y + conv2.bias``); updates ``bn1``'s running statistics as the module would."""
+    count_batch(bn1)
+    mom = 0.1 if bn1.momentum is None else float(bn1.momentum)
+    m = tile_size(x.shape[2], x.shape[3])
+    return _StemConvBNReluConv.apply(x.contiguous(), conv1.weight, conv1.bias, bn1.weight, bn1.bias, bn1.running_mean,
+                                     bn1.running_var, mom, bn1.eps, conv2.weight, m, conv2.bias, bool(want_parts))
 
 
 def bn_relu_conv3x3(y, pre_bias, bn, weight, m=None, parts=None, stats_bias=None, want_parts=False):

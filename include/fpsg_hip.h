@@ -352,6 +352,12 @@ int fpsg_bn_stats(const float* x, const float* pre_bias, const float* gamma, con
 int fpsg_bn_act_bwd(const float* x, const float* pre_bias, const float* dy, const float* chan, int N, int C,
                     int L, int training, int act, float slope, float* dx, float* dgamma, float* dbeta,
                     float* dpre_bias, float* coef, float* ws, fpsg_stream_t stream);
+/* The sums + coefficient half of fpsg_bn_act_bwd alone: dgamma, dbeta, coef [3,C] = (k1, k2, k3) of
+ * dx = k1 dz + k2 (x + pre_bias) + k3 -- for a consumer that forms dx itself while reading x and dy
+ * (fpsg_conv_first_dw_fold).  N * L above the small-tensor limit (16384) only; ws as fpsg_bn_act_bwd. */
+int fpsg_bn_act_bwd_coef(const float* x, const float* pre_bias, const float* dy, const float* chan, int N, int C,
+                         int L, int training, int act, float slope, float* dgamma, float* dbeta, float* coef,
+                         float* ws, fpsg_stream_t stream);
 /* Training-mode K5 over column segments of C rows that lie ld elements apart (x, y, dy, dx share the layout): segment i
  * = the elements seg_off[i] .. seg_off[i] + seg_len[i] - 1 of every row is one BatchNorm call (one reference
  * BatchNorm1d call per patch and decode, src/models/point_cloud_net.py:76-80): own statistics, one launch for all
@@ -538,6 +544,16 @@ int fpsg_wino_conv_fused_act(const float* x, const float* chan, const float* pre
 size_t fpsg_conv_first_dw_workspace_floats(int N, int H, int W);
 int fpsg_conv_first_dw(const float* x, const float* dy, int N, int C, int K, int H, int W, float* dw, float* ws,
                        fpsg_stream_t stream);
+/* The same weight gradient when dy is the BatchNorm + ReLU backward of the layer behind this convolution
+ * (conv1_1 -> bn -> relu -> conv1_2 of src/models/image_net.py:14 in loss.backward()): instead of dy the call takes
+ * the convolution's own output y [N,64,H,W], the gradient ga [N,64,H,W] of the activation relu(bn(y + pre_bias)), K5's
+ * chan [4,64] (scale, shift, ..) and coef [3,64] (fpsg_bn_act_bwd_coef), and forms
+ *   dy = k1 dz + k2 (y + pre_bias) + k3,  dz = ga * [(y + pre_bias) scale + shift > 0]
+ * while it stages a tile (fpsg_bn_act_bwd's dx pass, bit for bit): K5's dx pass and its 475 MB dy (37 images at
+ * 224 x 224) never exist.  Same result as fpsg_bn_act_bwd + fpsg_conv_first_dw, bit for bit. */
+int fpsg_conv_first_dw_fold(const float* x, const float* y, const float* ga, const float* chan, const float* coef,
+                            const float* pre_bias, int N, int C, int K, int H, int W, float* dw, float* ws,
+                            fpsg_stream_t stream);
 /* K8f: the forward of the same layer, y [N,64,H,W] = conv(x [N,3,H,W], w [64,3,3,3]), zero padding, no bias
  * (nn.Conv2d(3, 64, 3, padding=1) of vgg16_bn.features[0]; K5 adds the bias inside the BatchNorm).  Bound by the
  * write of y; per output the 27 taps are added in (c, a, b) order by an fma chain from 0.  parts (optional):

@@ -639,3 +639,93 @@ def test_graph_replay_reads_refreshed_filters_and_refuses_a_stale_bank(gpu, monk
             got = static_y.double()
         assert float((got - ref1).abs().max()) < 1e-3 * float(ref1.abs().max())
         assert float((got - ref0).abs().max()) > 0.1 * float(ref0.abs().max())       # and it is not the old result
+
+
+@pytest.mark.parametrize("shape", [(3, 224, 224), (5, 96, 128), (2, 100, 136)])
+def test_first_layer_weight_gradient_with_the_batchnorm_backward_folded_in(gpu, shape):
+    """fpsg_bn_act_bwd_coef + fpsg_conv_first_dw_fold (K8 forms dy from the convolution's output, the activation gradient
+    and K5's coefficients while it stages a tile) against fpsg_bn_act_bwd + fpsg_conv_first_dw: the same dw, dgamma,
+    dbeta bit for bit -- 112-pixel and 64-pixel segments, rows that are not whole segments."""
+    from fpsg_amd import _hip
+    lib = _hip.load()
+    N, H, W = shape
+    g = torch.Generator().manual_seed(N * H)
+    x = torch.randn(N, 3, H, W, generator=g).to(gpu)
+    y = torch.randn(N, 64, H, W, generator=g).to(gpu)
+    ga = torch.randn(N, 64, H, W, generator=g).to(gpu)
+    pb = (torch.randn(64, generator=g) * 0.1).to(gpu)
+    gamma = (torch.randn(64, generator=g) * 0.5 + 1).to(gpu)
+    beta = (torch.randn(64, generator=g) * 0.1).to(gpu)
+    st = torch.cuda.current_stream().cuda_stream
+    chan = torch.empty(4, 64, device=gpu)
+    ws = torch.empty(lib.fpsg_bn_workspace_floats(N, 64, H * W), device=gpu)
+    assert lib.fpsg_bn_stats(y.data_ptr(), pb.data_ptr(), gamma.data_ptr(), beta.data_ptr(), None, None, -1.0, N, 64, H * W,
+                             1, 1e-5, chan.data_ptr(), None, None, ws.data_ptr(), None, 0, st) == 0, lib.fpsg_last_error()
+    # the two-kernel chain
+    dy = torch.empty_like(y)
+    dg0, db0, coef0 = torch.empty(64, device=gpu), torch.empty(64, device=gpu), torch.empty(3, 64, device=gpu)
+    assert lib.fpsg_bn_act_bwd(y.data_ptr(), pb.data_ptr(), ga.data_ptr(), chan.data_ptr(), N, 64, H * W, 1, 1, 0.0,
+                               dy.data_ptr(), dg0.data_ptr(), db0.data_ptr(), None, coef0.data_ptr(), ws.data_ptr(), st) == 0
+    dw0 = torch.empty(64, 3, 3, 3, device=gpu)
+    ws1 = torch.empty(lib.fpsg_conv_first_dw_workspace_floats(N, H, W), device=gpu)
+    assert lib.fpsg_conv_first_dw(x.data_ptr(), dy.data_ptr(), N, 3, 64, H, W, dw0.data_ptr(), ws1.data_ptr(), st) == 0
+    # the folded form
+    dg1, db1, coef1 = torch.empty(64, device=gpu), torch.empty(64, device=gpu), torch.empty(3, 64, device=gpu)
+    assert lib.fpsg_bn_act_bwd_coef(y.data_ptr(), pb.data_ptr(), ga.data_ptr(), chan.data_ptr(), N, 64, H * W, 1, 1, 0.0,
+                                    dg1.data_ptr(), db1.data_ptr(), coef1.data_ptr(), ws.data_ptr(), st) == 0, lib.fpsg_last_error()
+    dw1 = torch.empty(64, 3, 3, 3, device=gpu)
+    assert lib.fpsg_conv_first_dw_fold(x.data_ptr(), y.data_ptr(), ga.data_ptr(), chan.data_ptr(), coef1.data_ptr(),
+                                       pb.data_ptr(), N, 3, 64, H, W, dw1.data_ptr(), ws1.data_ptr(), st) == 0, lib.fpsg_last_error()
+    assert torch.equal(dg0, dg1) and torch.equal(db0, db1) and torch.equal(coef0, coef1)
+    assert torch.equal(dw0, dw1)
+    # and against float64 autograd of the chain conv -> (+bias) -> BN -> relu, with ga as the upstream gradient
+    w = torch.randn(64, 3, 3, 3, generator=g, dtype=torch.float64, requires_grad=True)
+    x64 = x.double().cpu()
+    yc = F.conv2d(x64, w, None, 1, 1)
+    # (the kernels were given an arbitrary y; the float64 check uses the matching one)
+    y32 = yc.detach().float().to(gpu).contiguous()
+    assert lib.fpsg_bn_stats(y32.data_ptr(), pb.data_ptr(), gamma.data_ptr(), beta.data_ptr(), None, None, -1.0, N, 64, H * W,
+                             1, 1e-5, chan.data_ptr(), None, None, ws.data_ptr(), None, 0, st) == 0
+    assert lib.fpsg_bn_act_bwd_coef(y32.data_ptr(), pb.data_ptr(), ga.data_ptr(), chan.data_ptr(), N, 64, H * W, 1, 1, 0.0,
+                                    dg1.data_ptr(), db1.data_ptr(), coef1.data_ptr(), ws.data_ptr(), st) == 0
+    assert lib.fpsg_conv_first_dw_fold(x.data_ptr(), y32.data_ptr(), ga.data_ptr(), chan.data_ptr(), coef1.data_ptr(),
+                                       pb.data_ptr(), N, 3, 64, H, W, dw1.data_ptr(), ws1.data_ptr(), st) == 0
+    act = F.relu(F.batch_norm(yc + pb.double().cpu().view(1, -1, 1, 1), None, None, gamma.double().cpu(), beta.double().cpu(),
+                              True, 0.0, 1e-5))
+    act.backward(ga.double().cpu())
+    assert _errs(dw1, w.grad) <= 2e-4, _errs(dw1, w.grad)
+
+
+def test_trunk_with_the_stem_as_one_function_equals_two_functions(gpu, monkeypatch):
+    """ImageEncoderWarpper in training mode with conv1_1 + BatchNorm + ReLU + conv1_2 as ONE autograd function
+    (winograd._StemConvBNReluConv: no dy of conv1_1's output) against FPSG_STEM_FOLD=0 (conv3x3_first + _BNReluConv3x3):
+    outputs, running statistics and every parameter's gradient bit for bit, except conv1_1's bias gradient (round-off
+    of an exactly cancelled sum in the two-function form, 0 in the fused one)."""
+    import copy
+    from fpsg_amd.image_net import ImageEncoderWarpper
+    from fpsg_amd import winograd
+    torch.manual_seed(4)
+    base = ImageEncoderWarpper().to(gpu).train()
+    x = torch.rand(3, 3, 224, 224, device=gpu) * 2 - 1
+    gfeat = torch.randn(3, 512, device=gpu)
+    res = {}
+    for fold in ("1", "0"):
+        monkeypatch.setenv("FPSG_STEM_FOLD", fold)
+        net = copy.deepcopy(base)
+        assert winograd.stem_applies(x, net.img_feature_extractor[0], net.img_feature_extractor[1],
+                                     net.img_feature_extractor[3]) == (fold == "1")
+        out = net(x)
+        out.backward(gfeat)
+        res[fold] = (out.detach(), {n: p.grad.clone() for n, p in net.named_parameters()},
+                     {n: b.clone() for n, b in net.named_buffers()})
+    o1, g1, b1 = res["1"]
+    o0, g0, b0 = res["0"]
+    assert torch.equal(o1, o0)
+    for n in b0:
+        assert torch.equal(b1[n], b0[n]), n
+    for n in g0:
+        if n == "img_feature_extractor.0.bias":
+            assert float(g1[n].abs().max()) == 0.0
+            assert float(g0[n].abs().max()) <= 1e-4 * float(g0["img_feature_extractor.0.weight"].abs().max())
+            continue
+        assert torch.equal(g1[n], g0[n]), n
