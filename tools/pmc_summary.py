@@ -35,10 +35,14 @@ def dispatches(d, counter):
     return rows
 
 
+pair_bwd = set()     # cloud-pair counts whose backward formed the per-pair constants itself (no upstream-gradient rows read)
+
+
 def ops(rows):
     """-> {(op, cloud_pairs): [KiB per op, ...]}"""
     out = collections.defaultdict(list)
     pending = last_fwd = None
+    pair_bwd.clear()
     for _, name, tmpl, grid, val in rows:
         if name == "chamfer_tile_kernel":
             pending = val
@@ -54,6 +58,8 @@ def ops(rows):
             out[("chamfer_fwd", grid * R // (4096 * W))].append(val)
         elif name == "chamfer_bwd_sorted_kernel":
             out[("chamfer_bwd", grid // 2048)].append(val)
+            if tmpl.replace(" ", "").endswith(",true>"):      # <REG_SORT, PAIR = true>: fpsg_chamfer_bwd_losses
+                pair_bwd.add(grid // 2048)
         elif name == "chamfer_bwd_kernel":
             out[("chamfer_bwd", grid // 4096)].append(val)
     return {k: sum(v) / len(v) for k, v in out.items()}
@@ -69,7 +75,7 @@ def main():
         op, pairs = key
         f, w = fetch.get(key), write.get(key)
         rec = {"op": op, "cloud_pairs": pairs, "FETCH_SIZE_KiB": f, "WRITE_SIZE_KiB": w,
-               "algorithmic_bytes": pairs * (81920 if op == "chamfer_fwd" else 131072)}
+               "algorithmic_bytes": pairs * (81920 if op == "chamfer_fwd" else (114688 if pairs in pair_bwd else 131072))}
         if f is not None and w is not None:
             rec["hbm_bytes_per_op"] = (2 * f + w) * 1024
             rec["ratio_to_algorithmic"] = rec["hbm_bytes_per_op"] / rec["algorithmic_bytes"]
