@@ -61,6 +61,9 @@ SIGNATURES = {
     "fpsg_edgeconv_prep_blocks": [ctypes.c_long],
     "fpsg_edgeconv_stats_finalize": [_c_f32p, _c_int, _c_f32p, _c_f32p, _c_f32p, _c_f32p, ctypes.c_float, ctypes.c_float,
                                      ctypes.c_double, _c_int, _c_int, _c_f32p, _c_stream],
+    "fpsg_edgeconv_stats_ws_floats": [_c_int, _c_int],
+    "fpsg_edgeconv_stats_finalize_ws": [_c_f32p, _c_int, _c_f32p, _c_f32p, _c_f32p, _c_f32p, ctypes.c_float, ctypes.c_float,
+                                        ctypes.c_double, _c_int, _c_int, _c_f32p, _c_f32p, _c_stream],
     "fpsg_edgeconv_bwd_finalize": [_c_f32p, _c_int, _c_f32p, ctypes.c_double, _c_int, _c_int, _c_f32p, _c_f32p, _c_f32p,
                                    _c_stream],
     "fpsg_edgeconv_act": [_c_f32p, _c_f32p, _c_f32p, ctypes.c_float, ctypes.c_long, _c_int, _c_f32p, _c_stream],
@@ -169,7 +172,7 @@ _RESTYPES = {"fpsg_last_error": ctypes.c_char_p, "fpsg_chamfer_workspace_bytes":
              "fpsg_sinkhorn_workspace_floats": ctypes.c_size_t,
              "fpsg_knn_workspace_floats": ctypes.c_size_t,
              "fpsg_bn_workspace_floats": ctypes.c_size_t, "fpsg_bn_pool_workspace_floats": ctypes.c_size_t, "fpsg_bn_max_workspace_floats": ctypes.c_size_t, "fpsg_bn_max_dz_offset": ctypes.c_size_t, "fpsg_conv_first_dw_workspace_floats": ctypes.c_size_t, "fpsg_emd_workspace_floats": ctypes.c_size_t, "fpsg_max_bwd_scatter_workspace_floats": ctypes.c_size_t,
-             "fpsg_wino_dw_fused_workspace_floats": ctypes.c_size_t}
+             "fpsg_wino_dw_fused_workspace_floats": ctypes.c_size_t, "fpsg_edgeconv_stats_ws_floats": ctypes.c_size_t}
 
 _lib = None
 _lock = threading.Lock()

@@ -560,6 +560,72 @@ __global__ __launch_bounds__(kFinThreads) void edgeconv_stats_finalize_kernel(co
   chan[3 * Co + c] = rstd;
 }
 
+// Two stages for the forward's 8,192-16,384 partial rows (round 4): the one-launch form above keeps Co / 4 workgroups busy with
+// 32-64 strided 16-byte reads per thread and a 256-long serial fp64 sum (13 / 13 / 38 / 96 us for DGCNN's four layers at 64
+// clouds).  Stage 1: a workgroup takes a slice of the rows and 128 of the 2 Co columns -- whole 512-byte row pieces,
+// coalesced -- thread (row phase, column) adds its rows in ascending order in fp64, the two phases are joined in LDS
+// (phase 0 first) -> slice sums [Z][2 Co] doubles.  Stage 2: one wave per channel, lane l adds slices l, l + 64, ... in
+// ascending order, then the fixed shuffle tree (wave_sum2), then the same finalize arithmetic.  Deterministic.
+constexpr int kS1Threads = 256, kS1Cols = 128;
+__device__ __forceinline__ void wave_sum2(double& a, double& b) {      // lane 0 receives the sums; fixed tree
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) { a += __shfl_down(a, off, 64); b += __shfl_down(b, off, 64); }
+}
+inline int stats_slices(int blocks, int Co) {          // so that stage 1 is ~256-512 workgroups and a slice >= 8 rows
+  const int groups = (2 * Co + kS1Cols - 1) / kS1Cols;
+  int Z = 512 / groups;
+  while (Z > 1 && blocks / Z < 8) Z >>= 1;
+  return Z < 1 ? 1 : Z;
+}
+
+__global__ __launch_bounds__(kS1Threads) void edgeconv_stats_slices_kernel(const float* __restrict__ part, int blocks, int Co,
+                                                                          int Z, double* __restrict__ slices /*[Z][2 Co]*/) {
+  __shared__ double red[kS1Cols];
+  const int z = blockIdx.x, col = blockIdx.y * kS1Cols + (threadIdx.x & (kS1Cols - 1)), phase = threadIdx.x / kS1Cols;
+  const int per = (blocks + Z - 1) / Z;
+  const int b0 = z * per, b1 = (b0 + per < blocks) ? b0 + per : blocks;
+  double a = 0.0;
+  if (col < 2 * Co) {
+    int b = b0 + phase;
+    for (; b + 6 < b1; b += 8) {                       // four loads of a thread in flight
+      const float v0 = part[(size_t)b * 2 * Co + col], v1 = part[(size_t)(b + 2) * 2 * Co + col];
+      const float v2 = part[(size_t)(b + 4) * 2 * Co + col], v3 = part[(size_t)(b + 6) * 2 * Co + col];
+      a += v0; a += v1; a += v2; a += v3;
+    }
+    for (; b < b1; b += 2) a += part[(size_t)b * 2 * Co + col];
+  }
+  if (phase == 1) red[threadIdx.x & (kS1Cols - 1)] = a;
+  __syncthreads();
+  if (phase == 0 && col < 2 * Co) slices[(size_t)z * 2 * Co + col] = a + red[threadIdx.x];
+}
+
+__global__ __launch_bounds__(256) void edgeconv_stats_finalize2_kernel(const double* __restrict__ slices, int Z, const float* __restrict__ gamma,
+                                                const float* __restrict__ beta, float* __restrict__ run_mean,
+                                                float* __restrict__ run_var, float momentum, float eps, double count,
+                                                int Co, float* __restrict__ chan) {
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (c >= Co) return;                                  // whole wave
+  double s0 = 0.0, s1 = 0.0;
+  for (int z = lane; z < Z; z += 64) { s0 += slices[(size_t)z * 2 * Co + c]; s1 += slices[(size_t)z * 2 * Co + Co + c]; }
+  wave_sum2(s0, s1);
+  if (lane != 0) return;
+  const double m = s0 / count;
+  double v = s1 / count - m * m;
+  v = v > 0.0 ? v : 0.0;
+  const float mean = (float)m, var = (float)v;
+  if (run_mean) {
+    const float unbiased = var * (float)(count / (count > 1.0 ? count - 1.0 : 1.0));
+    run_mean[c] = fma_rn(momentum, mean, (1.0f - momentum) * run_mean[c]);
+    run_var[c] = fma_rn(momentum, unbiased, (1.0f - momentum) * run_var[c]);
+  }
+  const float rstd = 1.0f / sqrtf(var + eps);
+  const float scale = gamma[c] * rstd;
+  chan[c] = scale;
+  chan[Co + c] = beta[c] - mean * scale;
+  chan[2 * Co + c] = mean;
+  chan[3 * Co + c] = rstd;
+}
+
 // backward: the sums of dz and dz * ysel -> dbeta, dgamma = (sum dz*ysel - mean * sum dz) * rstd, and the coefficients
 // coef [3][Co] = (scale * dbeta / count, scale * rstd * dgamma / count, mean) of fpsg_edgeconv_bwd (zeros in eval mode)
 __global__ __launch_bounds__(kFinBwdThreads) void edgeconv_bwd_finalize_kernel(const float* __restrict__ part, int blocks, const float* __restrict__ chan,
@@ -792,6 +858,34 @@ extern "C" int fpsg_edgeconv_stats_finalize(const float* part, int blocks, const
   hipLaunchKernelGGL(edgeconv_stats_finalize_kernel, dim3((unsigned)((Co + kFinCh - 1) / kFinCh)), dim3(kFinThreads), 0, static_cast<hipStream_t>(stream),
                      part, blocks, gamma, beta, running_mean, running_var, momentum, eps, count, Co, training, chan);
   return launch_status("fpsg_edgeconv_stats_finalize");
+}
+
+extern "C" size_t fpsg_edgeconv_stats_ws_floats(int blocks, int Co) {
+  if (blocks <= 0 || Co <= 0) return 0;
+  return (size_t)fpsg::stats_slices(blocks, Co) * 2 * Co * 2;          // [Z][2 Co] doubles
+}
+
+extern "C" int fpsg_edgeconv_stats_finalize_ws(const float* part, int blocks, const float* gamma, const float* beta,
+                                               float* running_mean, float* running_var, float momentum, float eps,
+                                               double count, int Co, int training, float* chan, float* ws,
+                                               fpsg_stream_t stream) {
+  using namespace fpsg;
+  if (!training || ws == nullptr || blocks < 256)       // nothing to sum / few rows: the one-launch form
+    return fpsg_edgeconv_stats_finalize(part, blocks, gamma, beta, running_mean, running_var, momentum, eps, count, Co,
+                                        training, chan, stream);
+  FPSG_REQUIRE(Co > 0 && count > 0.0, FPSG_E_SHAPE, "fpsg_edgeconv_stats_finalize_ws: Co and count must be positive (got %d, %g)", Co, count);
+  FPSG_REQUIRE_PTR(part); FPSG_REQUIRE_PTR(gamma); FPSG_REQUIRE_PTR(beta); FPSG_REQUIRE_PTR(chan);
+  FPSG_REQUIRE((reinterpret_cast<uintptr_t>(ws) & 7) == 0, FPSG_E_ALIGN, "fpsg_edgeconv_stats_finalize_ws: ws must be 8-byte aligned");
+  const int Z = stats_slices(blocks, Co);
+  double* slices = reinterpret_cast<double*>(ws);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(edgeconv_stats_slices_kernel, dim3((unsigned)Z, (unsigned)((2 * Co + kS1Cols - 1) / kS1Cols)), dim3(kS1Threads), 0,
+                     s, part, blocks, Co, Z, slices);
+  int rc = launch_status("fpsg_edgeconv_stats_finalize_ws(slices)");
+  if (rc) return rc;
+  hipLaunchKernelGGL(edgeconv_stats_finalize2_kernel, dim3((unsigned)((Co + 3) / 4)), dim3(256), 0, s, slices, Z, gamma, beta,
+                     running_mean, running_var, momentum, eps, count, Co, chan);
+  return launch_status("fpsg_edgeconv_stats_finalize_ws");
 }
 
 extern "C" int fpsg_edgeconv_bwd_finalize(const float* part, int blocks, const float* chan, double count, int Co,

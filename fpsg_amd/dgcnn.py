@@ -218,10 +218,12 @@ class _EdgeConvBNMax(torch.autograd.Function):
             _hip.check(lib.fpsg_edgeconv_fwd(_hip.ptr(PQ), _hip.ptr(idx32), _hip.ptr(gam), B, N, k, Co, _hip.ptr(ysel),
                                              _hip.ptr(jsel), opt(s1), opt(part), st), "fpsg_edgeconv_fwd")
             # statistics -> (scale, shift, mean, rstd), running statistics updated: one launch
-            _hip.check(lib.fpsg_edgeconv_stats_finalize(opt(part), blocks, _hip.ptr(gam), _hip.ptr(bet),
-                                                        _hip.ptr(running_mean), _hip.ptr(running_var), float(momentum),
-                                                        float(eps), float(B * N * k), Co, 1 if training else 0,
-                                                        _hip.ptr(chan), st), "fpsg_edgeconv_stats_finalize")
+            ws = (torch.empty((lib.fpsg_edgeconv_stats_ws_floats(blocks, Co),), dtype=torch.float32, device=dev)
+                  if training else None)
+            _hip.check(lib.fpsg_edgeconv_stats_finalize_ws(opt(part), blocks, _hip.ptr(gam), _hip.ptr(bet),
+                                                           _hip.ptr(running_mean), _hip.ptr(running_var), float(momentum),
+                                                           float(eps), float(B * N * k), Co, 1 if training else 0,
+                                                           _hip.ptr(chan), opt(ws), st), "fpsg_edgeconv_stats_finalize")
             # LeakyReLU(fma(ysel, scale, shift)): one pass
             _hip.check(lib.fpsg_edgeconv_act(_hip.ptr(ysel), _hip.ptr(chan[0]), _hip.ptr(chan[1]), float(slope), B * N, Co,
                                              _hip.ptr(out), st), "fpsg_edgeconv_act")

@@ -249,6 +249,14 @@ int fpsg_edgeconv_prep_blocks(long rows);
 int fpsg_edgeconv_stats_finalize(const float* part, int blocks, const float* gamma, const float* beta,
                                  float* running_mean, float* running_var, float momentum, float eps, double count, int Co,
                                  int training, float* chan, fpsg_stream_t stream);
+/* The same with the partial rows summed in two stages (round 4): slice sums over whole coalesced row pieces by ~256-512
+ * workgroups into ws (fpsg_edgeconv_stats_ws_floats(blocks, Co) floats, 8-byte aligned: [Z][2 Co] doubles), then one wave per
+ * channel.  Deterministic; equal to the one-launch form up to the order of its fp64 sums.  ws NULL, eval mode or fewer than
+ * 256 rows: the one-launch form. */
+size_t fpsg_edgeconv_stats_ws_floats(int blocks, int Co);
+int fpsg_edgeconv_stats_finalize_ws(const float* part, int blocks, const float* gamma, const float* beta,
+                                    float* running_mean, float* running_var, float momentum, float eps, double count,
+                                    int Co, int training, float* chan, float* ws, fpsg_stream_t stream);
 int fpsg_edgeconv_bwd_finalize(const float* part, int blocks, const float* chan, double count, int Co, int training,
                                float* dgamma, float* dbeta, float* coef, fpsg_stream_t stream);
 int fpsg_edgeconv_act(const float* ysel, const float* scale, const float* shift, float slope, long rows, int Co,

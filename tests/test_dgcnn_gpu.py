@@ -374,3 +374,43 @@ def test_edgeconv_forward_forms_agree(gpu, monkeypatch, Co):
     assert bool((a[1][1] == 0).all())
     assert float((a[2] - b[2]).abs().max()) <= 1e-5 * float(b[2].abs().max())
     assert float((a[3] - b[3]).abs().max()) <= 1e-5 * float(b[3].abs().max())
+
+
+@pytest.mark.parametrize("blocks,Co", [(8192, 64), (8192, 128), (16384, 256), (300, 64), (257, 256), (64, 128)])
+def test_edgeconv_statistics_finalize_in_two_stages(gpu, blocks, Co):
+    """fpsg_edgeconv_stats_finalize_ws (slice sums over coalesced row pieces, then one wave per channel) against the
+    one-launch form and float64 sums of the same partial rows: scale / shift / mean / rstd and the running statistics."""
+    from fpsg_amd import _hip
+    lib = _hip.load()
+    g = torch.Generator().manual_seed(blocks + Co)
+    count = float(blocks * 256 * 20)
+    n_b = 256 * 20                                                             # edge activations per block
+    s0 = n_b * (0.3 + 0.05 * torch.randn(blocks, Co, generator=g))             # per-block sums of y (mean ~0.3, std ~1)
+    s1 = n_b * (1.09 + 0.05 * torch.randn(blocks, Co, generator=g))            # ... and of y^2
+    part = torch.stack([s0, s1], dim=1).contiguous().to(gpu)
+    gamma = (torch.randn(Co, generator=g) * 0.5 + 1).to(gpu)
+    beta = (torch.randn(Co, generator=g) * 0.1).to(gpu)
+    st = torch.cuda.current_stream().cuda_stream
+    res = []
+    for two_stage in (False, True):
+        rm, rv = torch.zeros(Co, device=gpu), torch.ones(Co, device=gpu)
+        chan = torch.empty(4, Co, device=gpu)
+        if two_stage:
+            ws = torch.empty(lib.fpsg_edgeconv_stats_ws_floats(blocks, Co), device=gpu)
+            rc = lib.fpsg_edgeconv_stats_finalize_ws(part.data_ptr(), blocks, gamma.data_ptr(), beta.data_ptr(), rm.data_ptr(),
+                                                     rv.data_ptr(), 0.1, 1e-5, count, Co, 1, chan.data_ptr(), ws.data_ptr(), st)
+        else:
+            rc = lib.fpsg_edgeconv_stats_finalize(part.data_ptr(), blocks, gamma.data_ptr(), beta.data_ptr(), rm.data_ptr(),
+                                                  rv.data_ptr(), 0.1, 1e-5, count, Co, 1, chan.data_ptr(), st)
+        assert rc == 0, lib.fpsg_last_error()
+        res.append((chan.cpu(), rm.cpu(), rv.cpu()))
+    for a, b in zip(res[0], res[1]):
+        assert torch.allclose(a, b, rtol=2e-6, atol=1e-7)
+    p64 = part.double().cpu()
+    mean = p64[:, 0].sum(0) / count
+    var = (p64[:, 1].sum(0) / count - mean * mean).clamp_min(0)
+    rstd = 1.0 / torch.sqrt(var + 1e-5)
+    chan = res[1][0].double()
+    assert torch.allclose(chan[2], mean, rtol=1e-6) and torch.allclose(chan[3], rstd, rtol=1e-5)
+    assert torch.allclose(chan[0], gamma.double().cpu() * rstd, rtol=1e-5)
+    assert torch.allclose(res[1][1].double(), 0.1 * mean, rtol=1e-6)
