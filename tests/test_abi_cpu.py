@@ -51,6 +51,29 @@ def test_version_and_argument_checks(lib):
     assert rc == -2
 
 
+def test_round4_entry_points_check_their_arguments(lib):
+    """The entry points added in round 4 refuse bad arguments on the host, before any HIP call (no GPU needed)."""
+    f = ctypes.c_float
+    # K1 + loss sums: null clouds, then a bad n_first (caught behind the pointer checks: give fake non-null pointers)
+    assert lib.fpsg_chamfer_fwd_tiled_losses(None, None, 8, 2048, 2048, None, None, None, None, None, 0, -1, 1, f(1), f(1),
+                                             None, None) == -1
+    assert lib.fpsg_chamfer_fwd_tiled_losses(None, None, 0, 2048, 2048, None, None, None, None, None, 0, -1, 1, f(1), f(1),
+                                             None, None) == -2
+    assert lib.fpsg_chamfer_bwd_losses(None, None, None, None, None, None, None, 4, 100, 100, 9, f(1), f(1), None, None,
+                                       None) == -2 and b"n_first" in lib.fpsg_last_error()
+    assert lib.fpsg_chamfer_bwd_losses(None, None, None, None, None, None, None, 4, 5000, 100, 1, f(1), f(1), None, None,
+                                       None) == -4                                   # beyond 4096 points: FPSG_E_LIMIT
+    assert lib.fpsg_chamfer_workspace_bytes(37, 2048, 2048, -1) == 37 * (8 + 4) * 2048 * 4 + 37 * 16 * 4
+    # K2 variants
+    assert lib.fpsg_emd_approx_variant(None, None, 2, 64, 64, None, None, None, None, 7, None) == -2
+    assert lib.fpsg_emd_approx_variant(None, None, 2, 64, 64, None, None, None, None, 3, None) == -1
+    # K8 with the BatchNorm backward folded in, K5's sums-only backward
+    assert lib.fpsg_conv_first_dw_fold(None, None, None, None, None, None, 2, 3, 64, 32, 32, None, None, None) == -1
+    assert lib.fpsg_bn_act_bwd_coef(None, None, None, None, 2, 64, 100, 1, 1, f(0), None, None, None, None, None) in (-1, -4)
+    assert lib.fpsg_edgeconv_stats_ws_floats(8192, 64) == 512 * 2 * 64 * 2 and lib.fpsg_edgeconv_stats_ws_floats(0, 64) == 0
+    assert lib.fpsg_bn_max_dz_offset(64, 1024, 2048) + 64 * 1024 == lib.fpsg_bn_max_workspace_floats(64, 1024, 2048)
+
+
 def test_product_path_has_no_cpu_fallback():
     import torch
     from fpsg_amd._hip import FpsgHipError
