@@ -44,6 +44,7 @@ def test_knn_ties_and_duplicates(gpu, oracle):
 # the streaming kernel's range (C <= 128, k <= 24), sizes around its tiles: 16-candidate tiles, 32-/64-/512-candidate
 # stages, 128-query workgroups, more than 8 clouds (the cloud -> XCD mapping), k odd / 1 / 24
 STREAM_SHAPES = [(1, 3, 16, 5), (1, 3, 31, 20), (2, 3, 129, 20), (9, 3, 300, 20), (1, 3, 513, 7), (3, 3, 1024, 24),
+                 (2, 4, 700, 24), (1, 1, 257, 3), (2, 2, 2048, 20), (17, 3, 255, 20), (1, 3, 24, 24),     # C = 1..4, k = N
                  (1, 64, 64, 20), (2, 64, 65, 1), (1, 64, 1000, 20), (1, 48, 257, 9), (1, 128, 33, 20), (2, 128, 200, 13),
                  (1, 100, 777, 20), (1, 17, 2048, 20), (10, 64, 256, 20)]
 
@@ -94,6 +95,23 @@ def test_knn_adversarial_candidate_orders(gpu, oracle, order):
     assert np.array_equal(got, oracle.knn(x, 20))
     x64 = np.concatenate([x, np.zeros((2, 61, N), np.float32)], axis=1)         # the same through the C = 64 kernel
     assert np.array_equal(knn_int32(torch.from_numpy(x64).to(gpu), 20).cpu().numpy(), oracle.knn(x64, 20))
+
+
+def test_knn_three_channels_many_equal_scores_and_signed_zeros(gpu, oracle):
+    """C = 3 (DGCNN's first layer) where the tie rule matters: hundreds of coincident points (every later candidate ties
+    with the k-th kept one and must lose to the lower indices), a cloud collapsed to the origin (scores +0 / -0),
+    coordinates with both signs of zero."""
+    from fpsg_amd.dgcnn import knn_int32
+    rng = np.random.default_rng(6)
+    x = rng.standard_normal((3, 3, 900)).astype(np.float32)
+    x[0, :, 100:500] = x[0, :, 100:101]                 # 400 copies of one point
+    x[1] = 0.0
+    x[1, :, ::2] = -0.0                                 # signed zeros: every score is +-0
+    x[2, 1] = 0.0                                       # a flat cloud
+    got = knn_int32(torch.from_numpy(x).to(gpu), 20).cpu().numpy()
+    assert np.array_equal(got, oracle.knn(x, 20))
+    got = knn_int32(torch.from_numpy(x[:, :, :300].copy()).to(gpu), 24).cpu().numpy()
+    assert np.array_equal(got, oracle.knn(x[:, :, :300].copy(), 24))
 
 
 def test_knn_point_major_is_refused_outside_the_streaming_range(gpu):
