@@ -1,3 +1,7 @@
+// ARCHIVED EXPERIMENT (round 4) -- not part of libfpsg_hip.so: measured slower than the streaming kernel (342 vs 256 us,
+// profiles/r04/k3_row_per_lane_kernel_rejected.txt).  To rebuild it: copy next to knn_internal.h, add it to the Makefile,
+// declare knn_rows_launch in knn_internal.h and call it from fpsg_knn_ex for C <= 4.
+//
 // knn_rows.hip -- K3 for C <= 4 (DGCNN's first EdgeConv layer: raw xyz): one query row per LANE, distances on the
 // vector ALU, selection in per-lane buffers.  gfx950.  Replaces `knn` of reference src/dgcnn/model.py:13-20 for that
 // layer; the streaming MFMA kernel (knn_stream.hip) keeps C = 64 / 128.
@@ -22,7 +26,7 @@
 //   * after the sweep one more sort, and the first k indices are written.
 // Results are bit-identical to oracle_knn (tests/test_dgcnn_gpu.py: the same shapes, ties and adversarial orders as the
 // other two kernels).  Deterministic.
-#include "knn_internal.h"
+#include "../../fpsg_amd/csrc/knn_internal.h"
 
 namespace fpsg {
 namespace {
