@@ -386,7 +386,8 @@ def eval_leg(device, probe, items=20, warmup=3):
     eps = make_episodes(S, Q, 4, seed=77, device=device)
     keep, keep_enabled = list(probe.records), probe.enabled
     probe.records, probe.enabled = [], False
-    with torch.no_grad():
+    from fpsg_amd import winograd
+    with torch.no_grad(), winograd.weights_frozen():       # as evaluate_Network.main wraps its loop
         for i in range(warmup):
             out = model._return_reconstruction(eps[i % len(eps)])
             out["cd_loss"].item(), out["emd_loss"].item()

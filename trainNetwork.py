@@ -23,7 +23,7 @@ from collections import defaultdict
 
 import torch
 
-from fpsg_amd import cli
+from fpsg_amd import cli, winograd
 from fpsg_amd import dist as fdist
 from fpsg_amd.engine import TrainStep, build_model, build_optimizer, to_device
 from fpsg_amd.episodes import EpisodePrefetcher
@@ -37,7 +37,7 @@ def evaluate(model, dl_test, n_query, n_shot, device, log, rank: int = 0, world:
     collective while another evaluates, and the report lines are those of one process."""
     model.eval()
     mine = []
-    with torch.no_grad():
+    with torch.no_grad(), winograd.weights_frozen():     # no parameter changes while evaluating: filters / stacks made once
         for n, sample in enumerate(dl_test):
             if n % world != rank:
                 continue
