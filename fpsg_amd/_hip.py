@@ -131,6 +131,7 @@ SIGNATURES = {
     "fpsg_wino_output_transform_stats": [_c_int, _c_f32p, _c_int, _c_int, _c_int, _c_int, _c_f32p, _c_f32p, _c_f32p,
                                          _c_stream],
     "fpsg_wino_grad_output_transform": [_c_int, _c_f32p, _c_int, _c_int, _c_int, _c_int, _c_f32p, _c_stream],
+    "fpsg_wino_grad_transforms": [_c_int, _c_f32p, _c_int, _c_int, _c_int, _c_int, _c_f32p, _c_f32p, _c_stream],
     "fpsg_wino_filter_transform": [_c_int, _c_f32p, _c_int, _c_int, _c_int, _c_f32p, _c_stream],
     "fpsg_wino_output_transform_bwd_stats": [_c_int, _c_f32p, _c_int, _c_int, _c_int, _c_int, _c_f32p, _c_f32p, _c_f32p,
                                              _c_f32p, _c_f32p, _c_stream],

@@ -139,11 +139,16 @@ __device__ __forceinline__ TileIndex tile_of(long p, int Th, int Tw) {
 // RAG (m = 4 only): H, W even but not multiples of 4 -- the tile grid is ceil(H/4) x ceil(W/4), pixels beyond the
 // image enter as zeros (the last tile row / column is half empty); rows are then only 8-byte aligned, so a tile row is
 // read as two 8-byte halves and the second half of a last-column tile is not read at all.
-template <int M, bool ACT, bool NT = false, bool RAG = false>
+// GO (round 4): x is an output GRADIENT whose two Winograd transforms the backward of a convolution needs -- B^T d B of the
+// 6 x 6 patches (the data gradient's "input" transform) and A g A^T of the 4 x 4 tiles (the weight gradient's): the tile is
+// the patch's interior, so one read serves both and dM [A*A, C, P] is written beside V (wino_grad_output_kernel's
+// arithmetic on the same values: bit-identical to the two separate launches).
+template <int M, bool ACT, bool NT = false, bool RAG = false, bool GO = false>
 __global__ __launch_bounds__(kWinoThreads) void wino_input_kernel(const float* __restrict__ x, int C, int H, int W,
                                                                    int Th, int Tw, long P, float* __restrict__ V,
                                                                    const float* __restrict__ chan,
-                                                                   const float* __restrict__ pre_bias) {
+                                                                   const float* __restrict__ pre_bias,
+                                                                   float* __restrict__ dM = nullptr) {
   constexpr int A = Wino<M>::A;
   typedef float vin __attribute__((ext_vector_type(M)));
   const long p_raw = (long)blockIdx.x * kWinoThreads + threadIdx.x;
@@ -225,6 +230,28 @@ __global__ __launch_bounds__(kWinoThreads) void wino_input_kernel(const float* _
     Wino<M>::in(row, v);
 #pragma unroll
     for (int j = 0; j < A; ++j) stream_store<NT>(vp + (size_t)(A * i + j) * plane, v[j]);
+  }
+  if constexpr (GO) {
+    static_assert(!ACT, "an output gradient is not activated");
+    // the tile = rows 1 .. M of the patch, its interior columns (zero beyond the image: mid[] was zeroed above)
+    float r[M][A];        // r[j][i]: column j after the transform along rows
+#pragma unroll
+    for (int j = 0; j < M; ++j) {
+      float col[M];
+#pragma unroll
+      for (int i = 0; i < M; ++i) col[i] = mid[1 + i][j];
+      Wino<M>::gout(col, r[j]);
+    }
+    float* mp = dM + (size_t)c * P + p;
+#pragma unroll
+    for (int i = 0; i < A; ++i) {
+      float row[M], o[A];
+#pragma unroll
+      for (int j = 0; j < M; ++j) row[j] = r[j][i];
+      Wino<M>::gout(row, o);
+#pragma unroll
+      for (int j = 0; j < A; ++j) stream_store<NT>(mp + (size_t)(A * i + j) * plane, o[j]);
+    }
   }
 }
 
@@ -609,6 +636,23 @@ extern "C" int fpsg_wino_grad_output_transform(int m, const float* dy, int N, in
   else if ((size_t)36 * K * P * sizeof(float) > kStreamBytes) hipLaunchKernelGGL((wino_grad_output_kernel<4, true>), grid, dim3(kWinoThreads), 0, hs, dy, K, H, W, tiles_of(H, m), tiles_of(W, m), P, dM);
   else hipLaunchKernelGGL((wino_grad_output_kernel<4>), grid, dim3(kWinoThreads), 0, hs, dy, K, H, W, tiles_of(H, m), tiles_of(W, m), P, dM);
   return launch_status("fpsg_wino_grad_output_transform");
+}
+
+extern "C" int fpsg_wino_grad_transforms(int m, const float* dy, int N, int K, int H, int W, float* V, float* dM,
+                                         fpsg_stream_t stream) {
+  using namespace fpsg;
+  int rc = check_image("fpsg_wino_grad_transforms", m, N, K, H, W);
+  if (rc) return rc;
+  FPSG_REQUIRE_PTR(dy); FPSG_REQUIRE_PTR(V); FPSG_REQUIRE_PTR(dM);
+  FPSG_REQUIRE((reinterpret_cast<uintptr_t>(dy) & 15) == 0, FPSG_E_ALIGN, "fpsg_wino_grad_transforms: dy must be 16-byte aligned");
+  const long P = (long)N * tiles_of(H, m) * tiles_of(W, m);
+  dim3 grid((unsigned)((P + kWinoThreads - 1) / kWinoThreads), K);
+  hipStream_t hs = static_cast<hipStream_t>(stream);
+  if (m == 2) hipLaunchKernelGGL((wino_input_kernel<2, false, false, false, true>), grid, dim3(kWinoThreads), 0, hs, dy, K, H, W, tiles_of(H, m), tiles_of(W, m), P, V, nullptr, nullptr, dM);
+  else if (ragged(m, H, W)) hipLaunchKernelGGL((wino_input_kernel<4, false, false, true, true>), grid, dim3(kWinoThreads), 0, hs, dy, K, H, W, tiles_of(H, m), tiles_of(W, m), P, V, nullptr, nullptr, dM);
+  else if ((size_t)36 * K * P * sizeof(float) > kStreamBytes) hipLaunchKernelGGL((wino_input_kernel<4, false, true, false, true>), grid, dim3(kWinoThreads), 0, hs, dy, K, H, W, tiles_of(H, m), tiles_of(W, m), P, V, nullptr, nullptr, dM);
+  else hipLaunchKernelGGL((wino_input_kernel<4, false, false, false, true>), grid, dim3(kWinoThreads), 0, hs, dy, K, H, W, tiles_of(H, m), tiles_of(W, m), P, V, nullptr, nullptr, dM);
+  return launch_status("fpsg_wino_grad_transforms");
 }
 
 extern "C" int fpsg_wino_filter_transform(int m, const float* w, int K, int C, int flip_transpose, float* U,

@@ -340,6 +340,22 @@ def _grad_output(m, gy):
     return dM
 
 
+def grad_transforms_enabled() -> bool:
+    """``FPSG_GRAD_TRANSFORMS=0``: the output gradient's two transforms as two launches (A/B measurements)."""
+    return os.environ.get("FPSG_GRAD_TRANSFORMS", "1") != "0"
+
+
+def _grad_transforms(m, gy):
+    """``(_input(m, gy), _grad_output(m, gy))`` from ONE pass over ``gy`` (``fpsg_wino_grad_transforms``): the weight
+    gradient's tile is the interior of the data gradient's patch.  Bit-identical to the two launches."""
+    N, K, H, W = gy.shape
+    P = N * _tiles(H, W, m)
+    V = torch.empty(((m + 2) ** 2, K, P), dtype=torch.float32, device=gy.device)
+    dM = torch.empty_like(V)
+    _call("fpsg_wino_grad_transforms", m, _hip.ptr(gy), N, K, H, W, _hip.ptr(V), _hip.ptr(dM), _hip.stream_of(gy))
+    return V, dM
+
+
 def _filter_grad(m, dU, like):
     gw = torch.empty_like(like)
     _call("fpsg_wino_filter_grad_transform", m, _hip.ptr(dU), like.shape[0], like.shape[1], _hip.ptr(gw),
@@ -391,17 +407,24 @@ class _Conv3x3(torch.autograd.Function):
         gy = gy.contiguous()
         gx = gw = None
         with torch.cuda.device(gy.device):
+            fuse_dx = _can_fuse(m, K, C, N * H * W, H, W)                   # the data gradient is a convolution K -> C
+            fuse_dw = not kept_is_v and _can_fuse_dw(m, C, K, N, H, W)
+            Vg = dM = None
+            if (ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and not fuse_dx and not fuse_dw
+                    and grad_transforms_enabled()):
+                Vg, dM = _grad_transforms(m, gy)                            # both transforms of gy from one read
             if ctx.needs_input_grad[0]:
-                if _can_fuse(m, K, C, N * H * W, H, W):                     # the data gradient is a convolution K -> C
+                if fuse_dx:
                     gx = _fused(gy, _filter(m, w, True))
                 else:
-                    gx = _output(m, torch.bmm(_filter(m, w, True), _input(m, gy)), N, H, W)
+                    gx = _output(m, torch.bmm(_filter(m, w, True), Vg if Vg is not None else _input(m, gy)), N, H, W)
+                    Vg = None
             if ctx.needs_input_grad[1]:
-                if not kept_is_v and _can_fuse_dw(m, C, K, N, H, W):
+                if fuse_dw:
                     gw = _filter_grad(m, _fused_dw(kept, None, None, gy), w)
                 else:
                     V = kept if kept_is_v else _input(m, kept)
-                    gw = _filter_grad(m, torch.bmm(_grad_output(m, gy), V.transpose(1, 2)), w)
+                    gw = _filter_grad(m, torch.bmm(dM if dM is not None else _grad_output(m, gy), V.transpose(1, 2)), w)
         return gx, gw, None, None, None
 
 
@@ -492,20 +515,27 @@ class _BNReluConv3x3(torch.autograd.Function):
         with torch.cuda.device(dev):
             # convolution backward: gradient of the (never stored) activation, and of the filter
             bwd_parts = None
-            if _can_fuse(m, K, C, N * H * W, H, W):
+            fuse_dx = _can_fuse(m, K, C, N * H * W, H, W)
+            fuse_dw = V is None and _can_fuse_dw(m, C, K, N, H, W)
+            Vg = dM = None
+            if ctx.needs_input_grad[9] and not fuse_dx and not fuse_dw and grad_transforms_enabled():
+                Vg, dM = _grad_transforms(m, gout)                          # both transforms of gout from one read
+            if fuse_dx:
                 ga = _fused(gout, _filter(m, w, True))
             elif bwd_stats_enabled() and N * H * W > _BN_SMALL_MAX:
                 # the output transform that writes ga also delivers the sums K5's backward starts from
-                ga, bwd_parts = _output_bwd_stats(m, torch.bmm(_filter(m, w, True), _input(m, gout)), N, H, W, y, pre_bias, chan)
+                ga, bwd_parts = _output_bwd_stats(m, torch.bmm(_filter(m, w, True), Vg if Vg is not None else _input(m, gout)),
+                                                  N, H, W, y, pre_bias, chan)
             else:
-                ga = _output(m, torch.bmm(_filter(m, w, True), _input(m, gout)), N, H, W)
+                ga = _output(m, torch.bmm(_filter(m, w, True), Vg if Vg is not None else _input(m, gout)), N, H, W)
+            Vg = None
             if ctx.needs_input_grad[9]:
-                if V is None and _can_fuse_dw(m, C, K, N, H, W):
+                if fuse_dw:
                     gw = _filter_grad(m, _fused_dw(y, chan, pre_bias, gout), w)
                 else:
                     if V is None:
                         V = _input_act(m, y, chan, pre_bias)
-                    gw = _filter_grad(m, torch.bmm(_grad_output(m, gout), V.transpose(1, 2)), w)
+                    gw = _filter_grad(m, torch.bmm(dM if dM is not None else _grad_output(m, gout), V.transpose(1, 2)), w)
             # BatchNorm + ReLU backward on y (K5)
             want_dpb = pre_bias is not None and ctx.needs_input_grad[1]
             dy = torch.empty_like(y)

@@ -492,6 +492,12 @@ int fpsg_wino_output_transform_bwd_stats(int m, const float* M, int N, int K, in
                                          float* parts, fpsg_stream_t stream);
 int fpsg_wino_grad_output_transform(int m, const float* dy, int N, int K, int H, int W, float* dM,
                                     fpsg_stream_t stream);
+/* Both transforms of an output gradient dy [N,K,H,W] in ONE pass (round 4): V = B^T d B of its 6x6 (4x4) patches -- the
+ * "input" transform of the data gradient's convolution -- and dM = A dy A^T of its tiles -- the weight gradient's -- the
+ * tile being the patch's interior.  V, dM [A*A, K, P]; values bit-identical to fpsg_wino_input_transform(dy) and
+ * fpsg_wino_grad_output_transform(dy); one read of dy instead of two. */
+int fpsg_wino_grad_transforms(int m, const float* dy, int N, int K, int H, int W, float* V, float* dM,
+                              fpsg_stream_t stream);
 int fpsg_wino_filter_transform(int m, const float* w, int K, int C, int flip_transpose, float* U,
                                fpsg_stream_t stream);
 /* Every filter transform of an optimizer step in one launch (the weights change once per step): jobs [n_jobs][6]

@@ -729,3 +729,29 @@ def test_trunk_with_the_stem_as_one_function_equals_two_functions(gpu, monkeypat
             assert float(g0[n].abs().max()) <= 1e-4 * float(g0["img_feature_extractor.0.weight"].abs().max())
             continue
         assert torch.equal(g1[n], g0[n]), n
+
+
+@pytest.mark.parametrize("m,shape", [(4, (3, 128, 112, 112)), (4, (37, 40, 28, 28)), (4, (5, 24, 14, 14)), (4, (2, 8, 18, 12)),
+                                     (2, (3, 16, 14, 14)), (4, (1, 3, 4, 4)), (4, (37, 256, 56, 56))])
+def test_both_transforms_of_an_output_gradient_from_one_pass(gpu, m, shape, monkeypatch):
+    """fpsg_wino_grad_transforms (the weight gradient's A g A^T tiles are the interior of the data gradient's B^T d B
+    patches: one read of the gradient) against the two separate launches: bit for bit, ragged planes and the tensors
+    beyond the non-temporal threshold included; and conv3x3's gradients with the switch on and off."""
+    from fpsg_amd import winograd as wg
+    torch.manual_seed(shape[1] + shape[2])
+    gy = torch.randn(*shape, device=gpu)
+    V, dM = wg._grad_transforms(m, gy)
+    assert torch.equal(V, wg._input(m, gy)) and torch.equal(dM, wg._grad_output(m, gy))
+    N, K, H, W = shape
+    if K * H * W * N > 4e7:
+        return
+    C = 16
+    x = torch.randn(N, C, H, W, device=gpu)
+    w = torch.randn(K, C, 3, 3, device=gpu) * 0.1
+    res = []
+    for sw in ("1", "0"):
+        monkeypatch.setenv("FPSG_GRAD_TRANSFORMS", sw)
+        xr, wr = x.clone().requires_grad_(), w.clone().requires_grad_()
+        wg.conv3x3(xr, wr, m).backward(gy)
+        res.append((xr.grad, wr.grad))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
