@@ -424,7 +424,7 @@ extern "C" int fpsg_adam_step_segments(float* param, const float* const* grad_pt
   const float inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
   const size_t n4 = n / 4;
   size_t blocks = (n4 + 1 + kAdamThreads - 1) / kAdamThreads;
-  if (blocks > 256 * 16) blocks = 256 * 16;
+  // no grid-stride cap, as adam_kernel (c3 same box, three alternating pairs: 43.99-44.01 -> 44.01-44.14 episodes/s)
   hipLaunchKernelGGL(adam_ptr_kernel, dim3((unsigned)blocks), dim3(kAdamThreads), 0, static_cast<hipStream_t>(stream),
                      param, grad_ptrs, seg_off, nseg, exp_avg, exp_avg_sq, n4, n, step_size, beta1, beta2, eps,
                      inv_sqrt_bc2, grad_scale);
@@ -448,7 +448,10 @@ extern "C" int fpsg_adam_step(float* param, const float* grad, float* exp_avg, f
   const float inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
   const size_t n4 = n / 4;
   size_t blocks = (n4 + kAdamThreads - 1) / kAdamThreads;
-  if (blocks > 256 * 16) blocks = 256 * 16;        // grid-stride: 16 workgroups per CU
+  // One vector per thread, no grid-stride cap (round 4): rounds 2-3 launched 16 workgroups per CU walking the buffers with a
+  // 16 MB stride, two vectors per trip; alternating on one box (tools/bench_adam.py, 5 pairs) that form took 392-438 us,
+  // this one 356-389 us for the model's 77.4 M parameters (0.59 -> 0.64-0.75 of the HBM peak) -- a workgroup's 4 KB pieces of
+  // the seven streams stay next to its neighbours' in time, whatever the residency.  (2 / 4 vectors per thread: 361-408 us.)
   if (blocks == 0) blocks = 1;
   hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(kAdamThreads), 0, static_cast<hipStream_t>(stream), param,
                      grad, exp_avg, exp_avg_sq, n4, n, step_size, beta1, beta2, eps, inv_sqrt_bc2, grad_scale);
