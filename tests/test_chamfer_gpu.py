@@ -284,7 +284,7 @@ def test_chamfer_value_and_grad_vs_float64(gpu):
 
 
 @pytest.mark.parametrize("B,N,M,n_first", [(37, 2048, 2048, 5), (7, 301, 258, 3), (3, 64, 128, 0), (4, 100, 100, 4),
-                                           (64, 301, 258, 10), (9, 4096, 3000, 9), (2, 5000, 700, 1)])
+                                           (64, 301, 258, 10), (9, 4096, 3000, 9), (2, 5000, 700, 1), (300, 64, 80, 120), (1100, 40, 40, 7)])
 def test_episode_losses_equal_the_separate_operations(gpu, oracle, B, N, M, n_first):
     """K1l: the query sum, the support sum and the weighted total of few_shot.py:110-124 -- fused into the one-pass
     forward (fpsg_chamfer_fwd_tiled_losses: from ~7 pairs of 2048 points up) or one launch behind the two-pass forward
