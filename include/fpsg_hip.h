@@ -507,6 +507,24 @@ int fpsg_wino_filter_transform(int m, const float* w, int K, int C, int flip_tra
 int fpsg_wino_filter_transform_batch(const int64_t* jobs, int n_jobs, long total_blocks, fpsg_stream_t stream);
 int fpsg_wino_filter_grad_transform(int m, const float* dU, int K, int C, float* dw, fpsg_stream_t stream);
 
+/* ---- K10 (round 5, opt-in: FPSG_GEMM_SPLIT=1): batched fp32 GEMM on the bf16 matrix pipe, operands split three ways ----
+ * Replaces the library fp32 GEMMs (torch.bmm -> rocBLAS / hipBLASLt, fp32 MFMA at 1/16 of the bf16 rate) behind the
+ * Winograd-domain products of the trunk's 3x3 convolutions (torchvision vgg16_bn.features built at
+ * src/models/image_net.py:14, run at src/models/image_net.py:21-24).
+ *   transB = 0:  C[b] [M x N] = A[b] [M x K] . B[b] [K x N]     (forward / data gradient: U[xi] . V[xi])
+ *   transB = 1:  C[b] [M x N] = A[b] [M x K] . B[b]^T, B [N x K] (weight gradient: dM[xi] . V[xi]^T; the reduction is
+ *                split over workgroups, partial slabs in ws, added in a fixed order: deterministic)
+ * Row-major, leading dimensions lda / ldb / ldc and batch strides sA / sB / sC in floats.  Every fp32 operand x enters as
+ * bf16(x) + bf16(x - x1) + bf16(x - x1 - x2) (an exact split) and the six products of order <= 2^-18 are accumulated in
+ * fp32 by v_mfma_f32_32x32x16_bf16: fp32-grade results (error against float64: profiles/r05/), not the library's bits.
+ * variant: -1 automatic; else tile + 10 * splits, tile 0 = 256x256x16, 1 = 256x128x32, splits 0 = automatic.
+ * ws: fpsg_gemm_split_workspace_floats(...) floats (0 when the reduction is not split; then ws may be NULL); a split
+ * reduction needs a dense output (ldc == N, sC == M*N).  One batch entry of each matrix must stay below 2 GiB. */
+size_t fpsg_gemm_split_workspace_floats(int batch, int M, int N, int K, int transB, int variant);
+int fpsg_gemm_split(const float* A, const float* B, float* C, int batch, int M, int N, int K, int lda, int ldb, int ldc,
+                    long sA, long sB, long sC, int transB, int variant, float* ws, size_t ws_floats,
+                    fpsg_stream_t stream);
+
 /* K6 in one kernel for 64 input channels (F(4x4,3x3); conv1_2 / conv2_1 of the trunk and their data
  * gradients): y [N,K,H,W] = conv(x [N,64,H,W], w) from U = fpsg_wino_filter_transform(4, w, ...)
  * [36,K,64]; input transform, the 36 MFMA products and the output transform stay on chip -- with 64

@@ -1,0 +1,68 @@
+"""K10 ``fpsg_gemm_split`` (batched fp32 GEMM on the bf16 matrix pipe, three-way split operands) through the C ABI against a
+float64 product of the same operands: fp32-grade error on every tile variant, ragged edges in all three dimensions,
+reductions that are no multiple of the k-step (or of 4 floats: partly out-of-buffer 16-byte loads), split reductions.
+The Winograd-domain products it stands in for: torchvision ``vgg16_bn.features`` at reference
+``src/models/image_net.py:14,21-24``."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from fpsg_amd.gemm_split import bmm_split as gemm_split  # noqa: E402
+
+
+def _check(A, B, transB, variant, bound=4e-7):
+    C = gemm_split(A, B, transB, variant)
+    ref = torch.bmm(A.double(), B.double().transpose(1, 2) if transB else B.double())
+    scale = float(ref.pow(2).mean().sqrt())
+    err = float((C.double() - ref).abs().max()) / scale
+    lib = torch.bmm(A, B.transpose(1, 2) if transB else B)
+    lib_err = float((lib.double() - ref).abs().max()) / scale
+    # fp32-grade: within 1.5x the library fp32 GEMM's own error (and an absolute cap scaled with sqrt(K))
+    K = A.shape[2]
+    assert err <= max(1.5 * lib_err, bound * max(1.0, (K / 256) ** 0.5)), (err, lib_err, A.shape, B.shape, transB, variant)
+    return err, lib_err
+
+
+@pytest.mark.parametrize("variant", [0, 1, -1])
+@pytest.mark.parametrize("b,M,N,K", [(2, 256, 300, 32), (3, 100, 70, 48), (1, 512, 257, 128), (2, 37, 1000, 64)])
+def test_nn_matches_float64(gpu, variant, b, M, N, K):
+    g = torch.Generator(device="cpu").manual_seed(b * 1000 + M + N + K)
+    A = torch.randn(b, M, K, generator=g).to(gpu)
+    B = torch.randn(b, K, N, generator=g).to(gpu)
+    _check(A, B, False, variant)
+
+
+@pytest.mark.parametrize("variant", [0, 1, 20, 31, 70, -1])
+@pytest.mark.parametrize("b,M,N,K", [(2, 256, 256, 1813), (1, 100, 130, 53), (3, 256, 128, 592), (1, 512, 512, 7252)])
+def test_nt_split_reduction_matches_float64(gpu, variant, b, M, N, K):
+    g = torch.Generator(device="cpu").manual_seed(b * 1000 + M + N + K)
+    A = torch.randn(b, M, K, generator=g).to(gpu)
+    B = torch.randn(b, N, K, generator=g).to(gpu)
+    _check(A, B, True, variant)
+
+
+def test_exact_on_integers_and_asymmetric_operands(gpu):
+    """Small integers are exact in every piece: the result must equal the integer product bit for bit (catches any
+    lane / register map error, which a statistical bound could hide)."""
+    g = torch.Generator(device="cpu").manual_seed(5)
+    A = torch.randint(-8, 9, (2, 300, 80), generator=g).float().to(gpu)
+    B = torch.randint(-8, 9, (2, 80, 500), generator=g).float().to(gpu)
+    for v in (0, 1):
+        C = gemm_split(A, B, False, v)
+        assert torch.equal(C, torch.bmm(A.double(), B.double()).float())
+    Bt = B.transpose(1, 2).contiguous()
+    for v in (0, 1, 20):
+        C = gemm_split(A, Bt, True, v)
+        assert torch.equal(C, torch.bmm(A.double(), B.double()).float())
+
+
+def test_wide_dynamic_range(gpu):
+    """Operands spread over six decades per row (Winograd-domain magnitudes): the split is exact per element, so the error
+    stays relative to each product."""
+    g = torch.Generator(device="cpu").manual_seed(9)
+    A = (torch.randn(2, 256, 256, generator=g) * torch.logspace(-3, 3, 256).view(1, 1, 256)).to(gpu)
+    B = (torch.randn(2, 256, 384, generator=g) * torch.logspace(3, -3, 256).view(1, 256, 1)).to(gpu)
+    err, lib_err = _check(A, B, False, -1)
+    assert np.isfinite(err)

@@ -135,3 +135,21 @@ def test_chamfer_losses_order_is_a_valid_sum(oracle):
         np.testing.assert_allclose(out, want, rtol=3e-6, atol=1e-7)
     ones = np.ones((2, 1024), np.float32)
     assert np.array_equal(oracle.chamfer_losses(ones, ones, 1, 2.0, 3.0), np.array([2.0, 2.0, 10.0], np.float32))
+
+
+def test_graph_ops_match_reference_goldens(oracle):
+    """The oracle's kNN graph and edge features against the REFERENCE functions' own outputs (``dgcnn.model.knn`` /
+    ``get_graph_feature``, ``/root/reference/src/dgcnn/model.py:13-42``, captured by ``tests/golden/make_golden.py``):
+    the pin that makes "HIP == oracle" on the GPU box mean "HIP == reference".  Equal at every position on all four
+    kNN shapes and bit for bit on the edge features (measured; a change to ``oracle/fpsg_oracle.c`` that breaks either
+    goes red here, on the CPU)."""
+    gold = np.load(os.path.join(GOLDEN, "dgcnn_goldens.npz"))
+    for tag in ("c3_n256", "c3_n2048", "c64_n256", "c64_n2048"):
+        x, ref = gold[f"knn_x_{tag}"], gold[f"knn_idx_{tag}"]
+        got = oracle.knn(x, ref.shape[2])
+        assert got.shape == ref.shape and got.dtype == np.int32
+        assert np.array_equal(got, ref), (tag, float((got == ref).mean()))
+        assert np.array_equal(got[:, :, 0], np.broadcast_to(np.arange(x.shape[2]), got.shape[:2]))   # self first
+    x, ref = gold["ggf_x"], gold["ggf_out"]
+    out = oracle.edge_feature(x, oracle.knn(x, ref.shape[3]))
+    assert out.shape == ref.shape and np.array_equal(out, ref)
