@@ -146,6 +146,37 @@ def pmc_traffic(probe, kind):
     return total / n if n else None
 
 
+_SCLK_FILE = None
+
+
+def gpu_clock_mhz(device):
+    """The shader clock level the card reports RIGHT NOW (`pp_dpm_sclk`'s starred line, MHz), or None when sysfs does not
+    show it.  Called while a step's kernels are still executing (after its enqueue, before its synchronize), on the
+    last warm-up step and on one extra untimed step behind the timed region -- never inside the timed region -- so that
+    a bench line records the clock its box held under this load (box-to-box spread)."""
+    global _SCLK_FILE
+    import glob
+    import re
+    try:
+        if _SCLK_FILE is None:
+            cands = sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"))
+            want = None
+            try:
+                pr = torch.cuda.get_device_properties(device)
+                want = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}"
+            except Exception:
+                pass
+            pick = [c for c in cands if want and want in os.path.realpath(os.path.dirname(c))]
+            _SCLK_FILE = (pick or cands or [""])[0]
+        if not _SCLK_FILE:
+            return None
+        txt = open(_SCLK_FILE).read()
+        m = re.search(r"(\d+)\s*[Mm][Hh]z\s*\*", txt)
+        return int(m.group(1)) if m else None
+    except Exception:
+        return None
+
+
 def make_episodes(S, Q, count, seed, device):
     return [synthetic_episode(S, Q, n_pts=2048, img_size=224, seed=seed * 1000 + i, device=device)
             for i in range(count)]
@@ -218,6 +249,34 @@ def kernel_rooflines(device):
         return {"bound": bound, "achieved": achieved, "peak": peak, "unit": unit, "frac": achieved / peak,
                 "us": t * 1e6, "shape": shape, "work": work, **more}
 
+    # K1 sweep: N = M = 2048, B in {1, 5, 32, 37, 256, 2048}, forward and backward as the product path
+    # runs them (metrics._sided_forward / _sided_backward: the two-pass kernel below ~7 pairs, the one-pass tiled form
+    # above), event-timed back to back.  frac by EXECUTED work (one-pass: N*M distances per pair serve both directions;
+    # two-pass: 2*N*M), hbm_GBps by algorithmic bytes (81,920 B forward, 131,072 B backward per pair).  B = 2048 is the
+    # kernel's own ceiling; the in-step B = 37 figure stays the headline `roofline`.
+    from fpsg_amd import metrics as _m
+    lib = _hip.load()
+    for B1 in (1, 5, 32, 37, 256, 2048):
+        p1 = (torch.rand(B1, N, 3, generator=g) * 2 - 1).to(device)
+        p2 = torch.tanh(torch.randn(B1, N, 3, generator=g)).to(device)
+        one_pass = lib.fpsg_chamfer_workspace_bytes(B1, N, N, -1) > 0 and _m._tiled_enabled()
+        reps = 200 if B1 <= 256 else 20
+        t = _event_time(lambda: _m._sided_forward(p1, p2), reps, warm=20)
+        flop = B1 * float(N) * N * 8 * (1 if one_pass else 2)
+        out[f"K1_chamfer_fwd_B{B1}"] = entry(
+            "valu", flop / t / 1e12, F32_PEAK / 1e12, "TFLOP/s", t, f"B={B1} N=M=2048",
+            ("one-pass tiled form: N*M distances per pair x 8 flop, tiles + finalize launches" if one_pass else
+             "two-pass form: 2*N*M distances per pair x 8 flop, one launch"),
+            hbm_GBps=B1 * 81920.0 / t / 1e9, hbm_frac=B1 * 81920.0 / t / HBM_PEAK,
+            frac_2NM_convention=B1 * 2.0 * N * N * 8 / t / F32_PEAK)
+        d1, d2, i1, i2 = _m._sided_forward(p1, p2)
+        g1, g2 = torch.randn(B1, N, generator=g).to(device), torch.randn(B1, N, generator=g).to(device)
+        t = _event_time(lambda: _m._sided_backward(p1, p2, i1, i2, g1, g2), reps, warm=20)
+        out[f"K1_chamfer_bwd_B{B1}"] = entry(
+            "hbm", B1 * 131072.0 / t / 1e9, HBM_PEAK / 1e9, "GB/s", t, f"B={B1} N=M=2048",
+            "algorithmic bytes: idx + grad read, clouds re-read, gradients written (131,072 B per pair); in-degree "
+            "gathers are served by L2")
+        del p1, p2, d1, d2, i1, i2, g1, g2
     # K2: approximate-assignment EMD, forward (evaluation): 10 levels x 3 sweeps of N*M pairs; a pair of the
     # assignment sweep = distance (8 flop) + exp + sqrt + 4 mul/add, of the two normaliser sweeps = 8 + exp + 3
     t = _event_time(lambda: emd_approx(x, y), 20)
@@ -472,6 +531,7 @@ def run_workload(wl, args, rank, world, device, steps, warmup, probe=None, graph
 
     for _ in range(warmup):
         step(episodes, n_episodes_global=epr * world)
+    sclk_before = gpu_clock_mhz(device)       # the last warm-up step is still executing
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
@@ -484,6 +544,14 @@ def run_workload(wl, args, rank, world, device, steps, warmup, probe=None, graph
     barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    sclk_after = None
+    if probe is not None and world == 1:      # the headline run on one GPU: one extra untimed step, clock read under it
+        was = probe.enabled
+        probe.enabled = False
+        step(episodes, n_episodes_global=epr * world)
+        sclk_after = gpu_clock_mhz(device)
+        torch.cuda.synchronize()
+        probe.enabled = was
     if probe is not None and graph:
         # HIP events cannot be timed inside a captured graph: the K1 launches are bracketed in
         # an eager replica of the same episodes (same tensors, same neighbouring kernels) run
@@ -508,6 +576,10 @@ def run_workload(wl, args, rank, world, device, steps, warmup, probe=None, graph
             "loss": float(out[-1]["ttl_loss"].sum().item()), "desc": desc, "S": S, "Q": Q, "intra": intra,
             "encoder": encoder, "params": sum(p.numel() for p in model.parameters()), "step": step,
             "ranks_seen": ranks_seen,
+            "clock": {"sclk_mhz_under_last_warmup_step": sclk_before, "sclk_mhz_under_a_step_behind_the_timed_region": sclk_after,
+                      "source": _SCLK_FILE or "unavailable",
+                      "note": "pp_dpm_sclk's current level, read on the host while the step's kernels execute; outside the "
+                              "timed region"},
             "mfu": {"direct_equivalent_tflop_per_episode": flops / 1e12,
                     "direct_equivalent_tflops": eps_per_s / world * flops / 1e12,
                     "fraction_of_fp32_peak": eps_per_s / world * flops / F32_PEAK,
@@ -519,19 +591,19 @@ def run_workload(wl, args, rank, world, device, steps, warmup, probe=None, graph
 
 def self_launch(n_gpus):
     """``python bench.py --gpus N`` (N > 1) without a torchrun environment: runs
-    ``python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free>
-    bench.py <the same arguments>`` as a child process, passes its stdout / stderr through (rank 0 prints the one
-    JSON line) and returns its exit code.  Called before anything touches the GPU."""
-    import socket
+    ``python -m torch.distributed.run --nnodes=1 --nproc-per-node N --rdzv-backend c10d --rdzv-endpoint 127.0.0.1:0
+    --local-addr 127.0.0.1 bench.py <the same arguments>`` as a child process, passes its stdout / stderr through (rank 0
+    prints the one JSON line) and returns its exit code.  The rendezvous store binds port 0 itself (the kernel picks a
+    free port while the socket is held: no window between choosing and using it, concurrent runs cannot collide); the
+    workers get MASTER_ADDR / MASTER_PORT from it.  Called before anything touches the GPU."""
     import subprocess
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
+    import uuid
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL's intra-node transport needs it on this driver
     env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n_gpus) // n_gpus)))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_gpus),
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+           "--rdzv-backend", "c10d", "--rdzv-endpoint", "127.0.0.1:0", "--rdzv-id", uuid.uuid4().hex,
+           "--local-addr", "127.0.0.1", os.path.abspath(__file__)] + sys.argv[1:]
     print("[bench] no torchrun environment: launching " + " ".join(cmd), file=sys.stderr, flush=True)
     return subprocess.run(cmd, env=env, cwd=ROOT).returncode
 
@@ -566,8 +638,9 @@ def main():
     S, Q, intra, encoder, epr, desc = WORKLOADS[args.workload]
     if args.episodes_per_rank:
         epr = args.episodes_per_rank
-    steps = args.steps if args.steps is not None else (5 if epr > 1 else 20)
-    warmup = args.warmup if args.warmup is not None else (2 if epr > 1 else 5)
+    # the driver's form: `python bench.py --gpus 1 --steps 20 --warmup 5`; the bare command is the same run
+    steps = args.steps if args.steps is not None else 20
+    warmup = args.warmup if args.warmup is not None else 5
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # typed as `python bench.py --gpus N` with no launcher around it: start one rank per GPU as CHILD processes of
@@ -613,6 +686,7 @@ def main():
             "final_loss": main_run["loss"],
             "hbm_peak_allocated_gb": round(torch.cuda.max_memory_allocated(device) / 1e9, 2),
             "mfu_direct_equivalent": main_run["mfu"],
+            "clock": main_run["clock"],
         }
         if torch.distributed.is_initialized():
             # what the process group itself reports (N > 1: RCCL over xGMI), so the line shows that N ranks took part

@@ -17,7 +17,9 @@
 //     per call, the distance evaluated once for both); the levels are a factor 4 apart, so the assignment's
 //     exp(4 l d^2) is the square of the square of the normaliser's exp(l d^2) -- two packed multiplications instead of
 //     a second quarter-rate v_exp_f32 (relative difference ~4e-7 per weight; the cost is checked against the CPU
-//     restatement, which calls expf per level, to 1e-5); a wave owns FOUR points (half the vector-memory instructions
+//     restatement, which calls expf per level, to 5e-5 -- tests/test_emd_gpu.py; measured 5e-7 at 2048 points and
+//     2.6e-5 on a 101 x 67 pair, where the auction's clamps amplify the per-weight difference, so the automatic choice
+//     keeps the separate sweeps (expf per level: <= 2e-6) for pairs below 256 x 256); a wave owns FOUR points (half the vector-memory instructions
 //     per pair: the sweeps were close to the CU's 64 B/clk load path).
 #include "fpsg_common.h"
 
@@ -309,7 +311,9 @@ extern "C" int fpsg_emd_approx_variant(const float* xyz1, const float* xyz2, int
   const bool forward_only = gxyz1 == nullptr && gxyz2 == nullptr;
   // measured on MI355X (profiles/r04/k2_variants.txt): the merged sweeps win at every size (B = 5: 372 -> 297 us); four
   // owners per wave only once the grid has waves to spare (B = 37: 1630 -> 1565 us; B = 5: 297 -> 348: 2.5 waves per SIMD)
-  if (variant < 0) variant = 1 | ((long)B * (N > M ? N : M) >= 32768 ? 2 : 0);
+  // small pairs keep the separate sweeps: the merged form's exp(l d^2)^4 deviates 25x more there and the
+  // launches saved are a few microseconds
+  if (variant < 0) variant = ((long)N * M >= 256L * 256L ? 1 : 0) | ((long)B * (N > M ? N : M) >= 32768 ? 2 : 0);
   const bool merged = forward_only && (variant & 1);
   const bool own4 = forward_only && (variant & 2);
   int rc;

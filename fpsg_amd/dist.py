@@ -134,15 +134,20 @@ class FlatGradBuckets:
         self._stash: list = []
         self._stash_first = False
         # the stash keeps whole gradient sets alive (310 MB each for the full model): at most _MAX_STASH of them, at most
-        # FPSG_STASH_MB megabytes [4096], and never more than an eighth of the memory that was free when the buckets
-        # were built -- a nearly full device flushes after every episode or two instead of failing an allocation
-        budget = float(os.environ.get("FPSG_STASH_MB", "4096")) * (1 << 20)
-        if dev.type == "cuda":
-            try:
-                budget = min(budget, torch.cuda.mem_get_info(dev)[0] / 8)
-            except RuntimeError:
-                pass
-        self._stash_cap = max(1, min(self._MAX_STASH, int(budget // max(1, self.flat.numel() * self.flat.element_size()))))
+        # FPSG_STASH_MB megabytes [4096], and never more than an eighth of the memory that is free when a step's first
+        # episode is stashed (``_current_stash_cap``: activations and the allocator's pools exist by then) -- a nearly
+        # full device flushes after every episode or two instead of failing an allocation.  The cap is rank-local and
+        # changes only WHEN the adds happen: flush() adds the stashed sets in episode order, so the sums are the same
+        # for every cap (tests/test_step_switches_gpu.py: cap 1 against _MAX_STASH, bit for bit).
+        raw = os.environ.get("FPSG_STASH_MB", "4096")
+        try:
+            self._stash_budget = float(raw) * (1 << 20)
+        except ValueError:
+            raise ValueError(f"FPSG_STASH_MB={raw!r}: expected a number of megabytes") from None
+        if not (self._stash_budget >= 0.0):
+            raise ValueError(f"FPSG_STASH_MB={raw!r}: expected a non-negative number of megabytes")
+        self.stash_cap_override = None       # tests / experiments: a fixed number of episodes per flush
+        self._stash_cap = self._current_stash_cap()
         self.attach()
 
     # -- bookkeeping ---------------------------------------------------------------
@@ -211,6 +216,21 @@ class FlatGradBuckets:
                 return None
         return ptrs
 
+    def _current_stash_cap(self) -> int:
+        """Episodes per flush for the step that starts now: the budget over the size of one gradient set, with the
+        device's free memory (outside plus inside the caching allocator's pools) sampled at this moment."""
+        if self.stash_cap_override is not None:
+            return max(1, min(self._MAX_STASH, int(self.stash_cap_override)))
+        budget = self._stash_budget
+        dev = self.flat.device
+        if dev.type == "cuda":
+            try:
+                free = torch.cuda.mem_get_info(dev)[0] + torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)
+                budget = min(budget, free / 8)
+            except RuntimeError:
+                pass
+        return max(1, min(self._MAX_STASH, int(budget // max(1, self.flat.numel() * self.flat.element_size()))))
+
     def _stash_episode(self, first: bool) -> bool:
         """``absorb`` deferred: the episode's gradient tensors are kept (``detach()`` drops the parameters' references,
         not these) and added by ``flush()`` together with the following episodes'.  False -> not applicable here."""
@@ -224,6 +244,7 @@ class FlatGradBuckets:
             self.flush()
         if not self._stash:
             self._stash_first = bool(first)
+            self._stash_cap = self._current_stash_cap()      # re-sampled per group: peak-time free memory, not construction-time
         self._stash.append((ptrs, [p.grad for p in self._layout_params]))
         if len(self._stash) >= self._stash_cap:
             self.flush()
@@ -328,9 +349,13 @@ class FlatGradBuckets:
                 dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.group,
                                 async_op=True))
 
-    def finish(self, n_episodes_global: int) -> None:
+    def finish(self, n_episodes_global: int, scale: bool = True) -> None:
         """Waits for the in-flight buckets, reduces any bucket whose parameters received no
-        gradient in the armed backward, and turns the sum into the mean over episodes."""
+        gradient in the armed backward, and turns the sum into the mean over episodes --
+        unless ``scale`` is False: the caller's optimizer then applies 1/E itself while it
+        reads the buffer (``fpsg_adam_step``'s ``grad_scale``: the same fp32 product per
+        element, without a separate read-modify-write pass over the 310 MB buffer on the
+        critical path behind the last all-reduce), and the buffer keeps the SUM."""
         self.flush()
         if self._armed:
             cur = torch.cuda.current_stream(self.flat.device) if self.flat.is_cuda else None
@@ -351,7 +376,7 @@ class FlatGradBuckets:
                 h.wait()
             self._handles = []
             self._armed = False
-        if n_episodes_global > 1:
+        if scale and n_episodes_global > 1:
             self.flat.mul_(1.0 / n_episodes_global)
 
     def remove(self) -> None:

@@ -191,7 +191,17 @@ class TrainStep:
                 else:
                     results.append(self._episode(sample, first, absorb=not direct))
         if not direct:
-            self.buckets.finish(n_episodes_global)
+            # K7 multiplies the gradient by 1/E as it reads it (bit-identical to scaling the buffer first: one fp32
+            # product per element either way); the flat buffer then holds the SUM over the step's episodes.
+            # FPSG_FOLD_GRAD_SCALE=0: the separate pass (A/B).
+            fold = isinstance(self.optimizer, FlatAdam) and os.environ.get("FPSG_FOLD_GRAD_SCALE", "1") != "0"
+            self.buckets.finish(n_episodes_global, scale=not fold)
             self.buckets.attach()       # the optimizer reads the step's gradient from the flat buffer
-        self.optimizer.step()
+            if fold:
+                self.optimizer.grad_scale = 1.0 / n_episodes_global if n_episodes_global > 1 else 1.0
+        try:
+            self.optimizer.step()
+        finally:
+            if isinstance(self.optimizer, FlatAdam):
+                self.optimizer.grad_scale = 1.0
         return results

@@ -87,6 +87,7 @@ class FlatAdam(Optimizer):
         self._gtab = torch.zeros(len(self._layout), dtype=torch.int64, device=dev)
         self._gtab_host = None                 # the pointers currently in _gtab
         self._t = 0
+        self.grad_scale = 1.0                  # multiplies the gradient as the step reads it (TrainStep: 1/E, then reset)
         self._step_tensor = torch.zeros((), dtype=torch.float32)       # shared by every state entry
         with torch.no_grad():
             for p, off, n in self._layout:
@@ -169,8 +170,8 @@ class FlatAdam(Optimizer):
         self._t += 1
         self._step_tensor.fill_(float(self._t))
         lib = _hip.load()
-        hyper = (float(group["lr"]), float(group["betas"][0]), float(group["betas"][1]), float(group["eps"]), self._t, 1.0,
-                 _hip.stream_of(self.flat_param))
+        hyper = (float(group["lr"]), float(group["betas"][0]), float(group["betas"][1]), float(group["eps"]), self._t,
+                 float(self.grad_scale), _hip.stream_of(self.flat_param))
         with torch.cuda.device(self.flat_param.device):
             if g is not None:
                 rc = lib.fpsg_adam_step(_hip.ptr(self.flat_param), _hip.ptr(g), _hip.ptr(self.flat_exp_avg),

@@ -64,7 +64,8 @@ def summarize(dev: dict) -> dict:
 
 
 def assert_like_yardstick(got: dict, yard: dict, truth64: dict, what: str, factor: float = 4.0,
-                          hard_max: float = 0.15, cancelled_max: float = 2e-2, ill_conditioned_ok: bool = False):
+                          hard_max: float = 0.15, cancelled_max: float = 2e-2, ill_conditioned_ok: bool = False,
+                          set_aside: dict | None = None):
     """`got` (HIP path, fp32), `yard` (reference arithmetic, fp32, CPU), `truth64` (float64).
     `ill_conditioned_ok`: tensors on which the REFERENCE arithmetic itself misses the float64 gradient by more than
     `hard_max` are set aside -- with a BatchNorm over a batch of two (1-shot episodes) the normalised values are +-1
@@ -84,6 +85,9 @@ def assert_like_yardstick(got: dict, yard: dict, truth64: dict, what: str, facto
         for k in sorted(cg):
             a, b = float(np.abs(_np(got[k])).max()), float(np.abs(_np(yard[k])).max())
             assert a <= 10.0 * b + 1e-30, (what, "cancelled tensor off the reference arithmetic's scale", k, a, b)
+        if set_aside is not None:       # the caller pins WHICH tensors may be set aside (a regression must not hide there)
+            set_aside["ill_conditioned"] = list(ill)
+            set_aside["cancelled"] = sorted(cg)
         print(f"{what}: {len(ill)} + {len(cg)} tensors set aside (the reference fp32 arithmetic itself is > {hard_max} from "
               f"float64 on them / their float64 gradient is zero)")
         cg = {}

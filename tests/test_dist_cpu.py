@@ -265,7 +265,9 @@ def test_bench_gpus_n_without_a_launcher_starts_one_as_a_child():
            if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "1", "--warmup", "0"], cwd=root, env=env,
                        capture_output=True, text=True, timeout=300)
-    assert "launching" in r.stderr and "--nproc-per-node 2" in r.stderr and "--master-addr 127.0.0.1" in r.stderr
+    # the rendezvous store binds port 0 itself (no pre-picked port that another process could take: ADVICE r4)
+    assert "launching" in r.stderr and "--nproc-per-node 2" in r.stderr and "--rdzv-endpoint 127.0.0.1:0" in r.stderr
+    assert "--master-port" not in r.stderr
     assert r.returncode != 0
     # the first rank to fail ends the launch (the launcher stops the other one, which may not have printed yet)
     assert r.stderr.count("bench.py needs a ROCm GPU") >= 1 and "local_rank: 1" in r.stderr, r.stderr[-3000:]

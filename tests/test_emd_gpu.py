@@ -35,6 +35,11 @@ def test_cost_and_grads_vs_oracle(gpu, oracle, B, N, M):
     # ulps, 10x under north_star's 1e-4): the last bits of v_exp_f32 and of the DPP tree sums follow the compiler's
     # scheduling, a bound of 3x one build's deviation would trip on a toolchain change without any regression.
     np.testing.assert_allclose(cost.detach().cpu().numpy(), ocost, rtol=1e-5)
+    # same-build regression guard: 10x the largest deviation recorded for this build's kernels
+    # (profiles/r04/emd_deviation.txt: 5.4e-7) -- the portable bound above stays what a toolchain change is held to
+    dev_cost = float(np.max(np.abs(cost.detach().cpu().numpy() - ocost) / np.abs(ocost)))
+    print(f"emd_approx B={B} N={N} M={M}: cost deviation {dev_cost:.3e} (recorded max 5.4e-7)")
+    assert dev_cost <= 10 * 5.4e-7, dev_cost
     s1, s2 = np.abs(og1).max(), np.abs(og2).max()
     assert np.abs(t1.grad.cpu().numpy() - og1).max() <= 3.5e-3 * s1
     assert np.abs(t2.grad.cpu().numpy() - og2).max() <= 3.5e-3 * s2
@@ -118,6 +123,9 @@ def test_sinkhorn_divergence(gpu, oracle):
     # largest deviation measured on MI355X: 8.3e-8 (profiles/r03/emd_deviation.txt); bound 1e-5 for the same reason as
     # test_cost_and_grads_vs_oracle's
     np.testing.assert_allclose(got.cpu().numpy(), exp, rtol=1e-5)
+    dev_s = float(np.max(np.abs(got.cpu().numpy() - exp) / np.abs(exp)))
+    print(f"sinkhorn_divergence: deviation {dev_s:.3e} (recorded max 8.3e-8, profiles/r04/emd_deviation.txt)")
+    assert dev_s <= 10 * 8.3e-8, dev_s          # same-build regression guard; sinkhorn.hip is unchanged since round 3
     for b in range(3):
         C = 0.5 * ((x[b][:, None] - y[b][None]) ** 2).sum(-1)
         r, c = linear_sum_assignment(C)

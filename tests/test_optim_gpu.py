@@ -121,6 +121,32 @@ def test_train_step_uses_the_flat_gradient_buffer_in_place(gpu):
     assert not torch.equal(before, optimizer.flat_param) and bool(torch.isfinite(optimizer.flat_param).all())
 
 
+def test_mean_over_episodes_inside_the_adam_step_equals_the_separate_pass(gpu):
+    """K7's ``grad_scale`` (1/E applied while the step reads the flat gradient buffer) against scaling the buffer first
+    and stepping with scale 1: the same fp32 product per element, so parameters and both moments are equal bit for
+    bit; ``TrainStep`` uses the folded form (the buffer then keeps the SUM) and resets the scale afterwards."""
+    from fpsg_amd.optim import FlatAdam
+    a, b = _net().to(gpu), _net().to(gpu)
+    b.load_state_dict(a.state_dict())
+    opt_a, opt_b = FlatAdam(a.parameters(), lr=2e-3), FlatAdam(b.parameters(), lr=2e-3)
+    g = torch.Generator(device=gpu).manual_seed(11)
+    for _ in range(3):
+        flat = torch.randn(opt_a.flat_param.numel(), device=gpu, generator=g) * 3.0
+        fa, fb = flat.clone(), flat.clone()
+        for opt, f in ((opt_a, fa), (opt_b, fb)):
+            for p, off, n in opt._layout:
+                p.grad = f[off:off + n].view(p.shape)
+            opt.bind_gradients(f)
+        opt_a.grad_scale = 1.0 / 7
+        opt_a.step()
+        fb.mul_(1.0 / 7)
+        opt_b.step()
+        assert torch.equal(fa, flat)                                       # the folded form leaves the sum in place
+    for x, y in ((opt_a.flat_param, opt_b.flat_param), (opt_a.flat_exp_avg, opt_b.flat_exp_avg),
+                 (opt_a.flat_exp_avg_sq, opt_b.flat_exp_avg_sq)):
+        assert torch.equal(x, y)
+
+
 def test_pointer_table_step_equals_flat_step(gpu):
     """fpsg_adam_step_segments (gradients read where autograd left them) == fpsg_adam_step on a flat
     copy of the same gradients, bit for bit; a parameter without gradient counts as zero; the

@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 SWITCHES = ("FPSG_DECODE_PAIR", "FPSG_FUSED_LOSSES", "FPSG_ABSORB_LAZY")
 
 
-def _run(gpu, monkeypatch, base, eps, off):
+def _run(gpu, monkeypatch, base, eps, off, stash_cap=None):
     from fpsg_amd.engine import TrainStep, build_optimizer, default_options
     for name in SWITCHES:
         monkeypatch.delenv(name, raising=False)
@@ -23,6 +23,7 @@ def _run(gpu, monkeypatch, base, eps, off):
     m = copy.deepcopy(base)
     optimizer, _ = build_optimizer(m, opt)
     step = TrainStep(m, optimizer)
+    step.buckets.stash_cap_override = stash_cap
     fixed = {b: m.pc_decoder.sample_grids(b, gpu, torch.Generator(device=gpu).manual_seed(5 + b)) for b in (4, 2)}
     orig, pair = m.pc_decoder.forward, m.pc_decoder.forward_pair
     m.pc_decoder.forward = lambda h, grid=None, generator=None, pack=None: orig(h, grid=fixed[h.size(0)], pack=pack)
@@ -60,3 +61,7 @@ def test_step_equals_the_step_with_each_fusion_off(gpu, monkeypatch):
     gb, _, _ = _run(gpu, monkeypatch, base, eps, SWITCHES)
     print(f"deferred vs per-episode accumulation: max |difference| = {float((ga - gb).abs().max()):.2e}")
     assert torch.equal(ga, gb)
+    # ... and whatever the number of episodes per flush (the stash cap is rank-local and follows free memory: ADVICE r4)
+    g1, _, _ = _run(gpu, monkeypatch, base, eps, ("FPSG_DECODE_PAIR", "FPSG_FUSED_LOSSES"), stash_cap=1)
+    g2, _, _ = _run(gpu, monkeypatch, base, eps, ("FPSG_DECODE_PAIR", "FPSG_FUSED_LOSSES"), stash_cap=2)
+    assert torch.equal(ga, g1) and torch.equal(ga, g2)

@@ -80,8 +80,12 @@ def main():
             gbps = B * nbytes * scale / t / 1e9
             line = f"{name:22s} B={B:5d} N={N}: {t*1e6:9.2f} us  {gbps:8.1f} GB/s ({gbps*1e9/PEAK_HBM*100:5.2f}% HBM)"
             if name.startswith("fwd"):
-                tf = B * PAIRS * scale * scale * 8 / t
-                line += f"  {tf/1e12:7.2f} TFLOP/s ({tf/PEAK_F32*100:5.1f}% fp32 peak, 2NM pair evaluations x 8 flop)"
+                # executed work: the one-pass tiled form evaluates each of the N*M distances once (it serves both
+                # directions), the two-pass form 2*N*M; the second column is SURVEY.md 8(d)'s 2*N*M convention
+                tf2 = B * PAIRS * scale * scale * 8 / t
+                tfx = tf2 * (0.5 if "tiled" in name else 1.0)
+                line += (f"  {tfx/1e12:7.2f} TFLOP/s executed ({tfx/PEAK_F32*100:5.1f}% fp32 peak)"
+                         f"  [2NM convention: {tf2/1e12:7.2f} TFLOP/s, {tf2/PEAK_F32*100:5.1f}%]")
             print(line, flush=True)
 
 
