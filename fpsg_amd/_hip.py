@@ -166,6 +166,10 @@ SIGNATURES = {
     "fpsg_gemm_split_workspace_floats": [_c_int, _c_int, _c_int, _c_int, _c_int, _c_int],
     "fpsg_gemm_split": [_c_f32p, _c_f32p, _c_f32p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, ctypes.c_long,
                         ctypes.c_long, ctypes.c_long, _c_int, _c_int, _c_f32p, ctypes.c_size_t, _c_stream],
+    "fpsg_gemm_split_packed_a_bytes": [_c_int, _c_int, _c_int, _c_int],
+    "fpsg_gemm_split_pack_a": [_c_f32p, _c_int, _c_int, _c_int, _c_int, ctypes.c_long, _c_int, ctypes.c_void_p, _c_stream],
+    "fpsg_gemm_split_nn_packed": [ctypes.c_void_p, _c_f32p, _c_f32p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
+                                  ctypes.c_long, ctypes.c_long, _c_int, _c_stream],
     "fpsg_emd_workspace_floats": [_c_int, _c_int, _c_int],
     "fpsg_emd_approx": [_c_f32p, _c_f32p, _c_int, _c_int, _c_int, _c_f32p, _c_f32p, _c_f32p, _c_f32p,
                         _c_stream],
@@ -176,7 +180,7 @@ _RESTYPES = {"fpsg_last_error": ctypes.c_char_p, "fpsg_chamfer_workspace_bytes":
              "fpsg_sinkhorn_workspace_floats": ctypes.c_size_t,
              "fpsg_knn_workspace_floats": ctypes.c_size_t,
              "fpsg_bn_workspace_floats": ctypes.c_size_t, "fpsg_bn_pool_workspace_floats": ctypes.c_size_t, "fpsg_bn_max_workspace_floats": ctypes.c_size_t, "fpsg_bn_max_dz_offset": ctypes.c_size_t, "fpsg_conv_first_dw_workspace_floats": ctypes.c_size_t, "fpsg_emd_workspace_floats": ctypes.c_size_t, "fpsg_max_bwd_scatter_workspace_floats": ctypes.c_size_t,
-             "fpsg_wino_dw_fused_workspace_floats": ctypes.c_size_t, "fpsg_gemm_split_workspace_floats": ctypes.c_size_t, "fpsg_edgeconv_stats_ws_floats": ctypes.c_size_t}
+             "fpsg_wino_dw_fused_workspace_floats": ctypes.c_size_t, "fpsg_gemm_split_workspace_floats": ctypes.c_size_t, "fpsg_gemm_split_packed_a_bytes": ctypes.c_size_t, "fpsg_edgeconv_stats_ws_floats": ctypes.c_size_t}
 
 _lib = None
 _lock = threading.Lock()

@@ -37,7 +37,6 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int kThreads = 512;
 
 struct GemmArgs {
   const float* A;
@@ -70,6 +69,14 @@ __device__ __forceinline__ void split8(const float (&x)[8], u32x4& p1, u32x4& p2
   }
 }
 
+// s_setprio takes an immediate: a wave-uniform switch
+__device__ __forceinline__ void set_wave_priority(int p) {
+  if (p == 0) __builtin_amdgcn_s_setprio(0);
+  else if (p == 1) __builtin_amdgcn_s_setprio(1);
+  else if (p == 2) __builtin_amdgcn_s_setprio(2);
+  else __builtin_amdgcn_s_setprio(3);
+}
+
 constexpr unsigned kOut = 0x7fffffffu;     // a lane offset beyond every buffer: the load returns 0, the store is dropped
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* p, long floats) {
@@ -79,13 +86,14 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* p, long
 // One operand tile of R rows x BK k, K-contiguous in memory ([rows][K]): item = (row, k-group), 8 consecutive k per
 // item as two 16-byte buffer loads: descriptor + the lane's fixed byte offset + the step's scalar offset -- no address
 // arithmetic in the loop; a row beyond the matrix has an offset beyond the buffer and reads zeros.
-template <int R, int BK>
+template <int R, int BK, int kThreads>
 struct ContigStage {
   static constexpr int KG = BK / 8;
   static constexpr int PS = R * 16 + 128 / KG;          // plane stride (bytes)
   static constexpr int BYTES = 3 * KG * PS;
-  static constexpr int ITEMS = R * KG / kThreads;
-  static_assert(R * KG % kThreads == 0, "tile / thread mismatch");
+  static constexpr int ITEMS = (R * KG + kThreads - 1) / kThreads;
+  static constexpr bool PARTIAL = R * KG % kThreads != 0;     // fewer items than threads: the upper threads carry none
+  static_assert(!PARTIAL || ITEMS == 1, "tile / thread mismatch");
   float v[ITEMS][8];
   unsigned off[ITEMS];                                   // byte offset of the item's first element at k = 0
 
@@ -94,7 +102,7 @@ struct ContigStage {
     for (int n = 0; n < ITEMS; ++n) {
       const int it = tid + n * kThreads;
       const int row = row0 + it / KG;
-      off[n] = row < rows ? ((unsigned)row * (unsigned)ld + (it % KG) * 8) * 4u : kOut;
+      off[n] = (row < rows && it < R * KG) ? ((unsigned)row * (unsigned)ld + (it % KG) * 8) * 4u : kOut;
     }
   }
   __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t rs, int k0) {
@@ -116,10 +124,20 @@ struct ContigStage {
       for (int j = 0; j < 8; ++j) v[n][j] = k + j < k_end ? v[n][j] : 0.f;
     }
   }
+  __device__ __forceinline__ void split_only() {        // ablation builds: the arithmetic kept alive, nothing stored
+#pragma unroll
+    for (int n = 0; n < ITEMS; ++n) {
+      u32x4 p1, p2, p3;
+      split8(v[n], p1, p2, p3);
+      asm volatile("" ::"v"(p1), "v"(p2), "v"(p3));
+      v[n][0] = __uint_as_float(p3[0] ^ p2[1]);
+    }
+  }
   __device__ __forceinline__ void store(unsigned char* lds, int tid) const {
 #pragma unroll
     for (int n = 0; n < ITEMS; ++n) {
       const int it = tid + n * kThreads;
+      if (PARTIAL && it >= R * KG) break;
       const int row = it / KG, g = it % KG;
       u32x4 p1, p2, p3;
       split8(v[n], p1, p2, p3);
@@ -134,13 +152,14 @@ struct ContigStage {
 // One operand tile of BK k x R columns, column-contiguous in memory ([K][N]): item = (column, k-group), a lane reads its
 // column of 8 consecutive rows (each wave-instruction is one coalesced 256-byte row segment; the row enters as the
 // scalar offset).  Rows beyond K lie beyond the buffer (zeros); columns beyond N get the out-of-buffer lane offset.
-template <int R, int BK>
+template <int R, int BK, int kThreads>
 struct StridedStage {
   static constexpr int KG = BK / 8;
   static constexpr int PS = R * 16 + 128 / KG;
   static constexpr int BYTES = 3 * KG * PS;
-  static constexpr int ITEMS = R * KG / kThreads;
-  static_assert(R * KG % kThreads == 0, "tile / thread mismatch");
+  static constexpr int ITEMS = (R * KG + kThreads - 1) / kThreads;
+  static constexpr bool PARTIAL = R * KG % kThreads != 0;
+  static_assert(!PARTIAL || ITEMS == 1, "tile / thread mismatch");
   float v[ITEMS][8];
   unsigned off[ITEMS];
   unsigned ld4;
@@ -151,7 +170,7 @@ struct StridedStage {
     for (int n = 0; n < ITEMS; ++n) {
       const int it = tid + n * kThreads;
       const int col = col0 + it % R;
-      off[n] = col < cols ? (unsigned)col * 4u + (unsigned)(it / R) * 8u * ld4 : kOut;
+      off[n] = (col < cols && it < R * KG) ? (unsigned)col * 4u + (unsigned)(it / R) * 8u * ld4 : kOut;
     }
   }
   __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t rs, int k0) {
@@ -162,10 +181,20 @@ struct StridedStage {
         v[n][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, off[n], (unsigned)(k0 + j) * ld4, 0));
   }
   __device__ __forceinline__ void mask_tail(int, int, int) {}      // rows beyond K lie beyond the buffer: zeros already
+  __device__ __forceinline__ void split_only() {
+#pragma unroll
+    for (int n = 0; n < ITEMS; ++n) {
+      u32x4 p1, p2, p3;
+      split8(v[n], p1, p2, p3);
+      asm volatile("" ::"v"(p1), "v"(p2), "v"(p3));
+      v[n][0] = __uint_as_float(p3[0] ^ p2[1]);
+    }
+  }
   __device__ __forceinline__ void store(unsigned char* lds, int tid) const {
 #pragma unroll
     for (int n = 0; n < ITEMS; ++n) {
       const int it = tid + n * kThreads;
+      if (PARTIAL && it >= R * KG) break;
       const int col = it % R, g = it / R;
       u32x4 p1, p2, p3;
       split8(v[n], p1, p2, p3);
@@ -177,13 +206,15 @@ struct StridedStage {
   }
 };
 
-template <int BM, int BN, int BK, bool TRANSB>
-__global__ __launch_bounds__(kThreads) void gemm_split_kernel(const GemmArgs g) {
-  constexpr int WR = 2, WC = 4;                        // waves: rows x columns
+// WR x WC waves (rows x columns of the tile); MINW: waves per SIMD the register allocation must leave room for
+// ABL (measurements only, results wrong): 1 = no global loads in the loop, 2 = nor LDS stores, 3 = nor the split
+template <int BM, int BN, int BK, int WR, int WC, int MINW, bool TRANSB, bool PRIO, bool PIPE = false, int ABL = 0>
+__global__ __launch_bounds__(64 * WR * WC, MINW) void gemm_split_kernel(const GemmArgs g) {
+  constexpr int kThreads = 64 * WR * WC;
   constexpr int WM = BM / WR, WN = BN / WC, TI = WM / 32, TJ = WN / 32;
   constexpr int KG = BK / 8;
-  using StageA = ContigStage<BM, BK>;
-  using StageB = typename std::conditional<TRANSB, ContigStage<BN, BK>, StridedStage<BN, BK>>::type;
+  using StageA = ContigStage<BM, BK, kThreads>;
+  using StageB = typename std::conditional<TRANSB, ContigStage<BN, BK, kThreads>, StridedStage<BN, BK, kThreads>>::type;
   constexpr int PSA = StageA::PS, PSB = StageB::PS;
   constexpr int STAGE = StageA::BYTES + StageB::BYTES;
   __shared__ __attribute__((aligned(16))) unsigned char lds[2 * STAGE];
@@ -199,6 +230,11 @@ __global__ __launch_bounds__(kThreads) void gemm_split_kernel(const GemmArgs g) 
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform for the compiler too (scalar offsets, no waterfall)
+  // Co-resident waves of one SIMD run the same program; under the default (round-robin) arbitration they fall into
+  // lock-step -- all in their MFMA block, then all in their conversion block with the matrix pipe idle (measured:
+  // SQ_WAIT_INST_ANY = 3x the MFMA busy time, pipe 46 % busy).  Distinct static priorities make the arbitration strict:
+  // the higher wave runs its MFMA block at full rate and the others fill the pipe while it converts.
+  if (PRIO) set_wave_priority(WR * WC >= 8 ? (2 * (bid & 1) + (wave >= WR * WC / 2 ? 1 : 0)) : bid % 3);
   const int m0 = tm * BM, n0 = tn * BN;
   const int k_begin = split * g.k_per_split;
   const int k_end = min(g.K, k_begin + g.k_per_split);
@@ -213,16 +249,23 @@ __global__ __launch_bounds__(kThreads) void gemm_split_kernel(const GemmArgs g) 
   rb.init(g.ldb, n0, g.N, tid);
   auto load = [&](int kt) {                             // stage kt -> registers
     const int k0 = k_begin + kt * BK;
+    if (ABL >= 1 && kt > 1) return;
     ra.load(rsA, k0);
     rb.load(rsB, k0);
   };
   auto store = [&](int kt) {                            // registers -> split -> LDS stage kt & 1
     const int k0 = k_begin + kt * BK;
+    if (ABL >= 3 && kt > 1) return;
     if (k0 + BK > k_end) {                              // workgroup-uniform
       ra.mask_tail(k0, k_end, tid);
       rb.mask_tail(k0, k_end, tid);
     }
     unsigned char* d = lds + (kt & 1) * STAGE;
+    if (ABL == 2 && kt > 1) {                           // the split's arithmetic without its LDS stores
+      ra.split_only();
+      rb.split_only();
+      return;
+    }
     ra.store(d, tid);
     rb.store(d + StageA::BYTES, tid);
   };
@@ -243,58 +286,349 @@ __global__ __launch_bounds__(kThreads) void gemm_split_kernel(const GemmArgs g) 
     const unsigned char* cur = lds + (kt & 1) * STAGE;
 #pragma unroll
     for (int s = 0; s < BK / 16; ++s) {
-      bf16x8 fa[3][TI], fb[3][TJ];
+      // The B fragments of the k-step stay in registers; the A fragments come per block of 32 rows, the next block's
+      // three reads issued before this block's MFMAs.  sched_barrier(0) pins that order: left alone, the scheduler
+      // hoists every fragment read of the step to its top (3 x (TI + TJ) fragments live: spills beyond 256 registers
+      // at 128 x 64 per wave).
+      bf16x8 fb[3][TJ], fa[2][3];
+      auto read_a = [&](int i, bf16x8 (&dst)[3]) {
 #pragma unroll
-      for (int t = 0; t < 3; ++t) {
+        for (int t = 0; t < 3; ++t)
+          dst[t] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(cur + a_off + (t * KG + 2 * s) * PSA + i * 512));
+      };
 #pragma unroll
-        for (int i = 0; i < TI; ++i)
-          fa[t][i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(cur + a_off + (t * KG + 2 * s) * PSA + i * 512));
+      for (int t = 0; t < 3; ++t)
 #pragma unroll
         for (int j = 0; j < TJ; ++j)
           fb[t][j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(cur + b_off + (t * KG + 2 * s) * PSB + j * 512));
-      }
+      read_a(0, fa[0]);
 #pragma unroll
-      for (int i = 0; i < TI; ++i)
+      for (int i = 0; i < TI; ++i) {
+        if (i + 1 < TI) read_a(i + 1, fa[(i + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+        const bf16x8 (&a)[3] = fa[i & 1];
 #pragma unroll
         for (int j = 0; j < TJ; ++j) {
           f32x16 c = acc[i][j];
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[2][i], fb[0][j], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1][i], fb[1][j], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][i], fb[2][j], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1][i], fb[0][j], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][i], fb[1][j], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][i], fb[0][j], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], fb[0][j], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], fb[1][j], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], fb[2][j], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], fb[0][j], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], fb[1][j], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], fb[0][j], c, 0, 0, 0);
           acc[i][j] = c;
         }
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
   };
 
-  // Stage kt+1 is split and written (into the buffer step kt-1 read: the barrier behind it has passed) while stage kt
-  // is multiplied; its global loads were issued one step earlier, those of stage kt+2 follow into the freed registers.
-  // The two waves of a SIMD (w and w+4) take the two halves in opposite order, so that one's vector work runs beside
-  // the other's MFMAs instead of both idling the matrix pipe together.
+  // Stage kt+1 is split and written (into the buffer step kt-1 read: the barrier behind it has passed) around the
+  // products of stage kt; its global loads were issued one step earlier, those of the next stage follow into the freed
+  // registers.  With two waves per SIMD (w and w+4) the halves are staggered: waves 4-7 convert behind their MFMAs
+  // (before the barrier), waves 0-3 behind the barrier -- i.e. in front of the next step's MFMAs -- so that one wave's
+  // vector work runs beside its partner's MFMAs instead of both idling the matrix pipe together.  One copy of the
+  // product code: the two orders differ only in where the (small) conversion block sits.
+  if constexpr (PIPE) {
+    // One wave's stream carries everything at once: the products of stage kt with the split of stage kt+1 (5.5 vector
+    // instructions per element), its LDS stores and the global loads of stage kt+2 placed in the shadows of the MFMAs
+    // (an MFMA holds the SIMD's vector issue for 8 of its 32 cycles).  Measured before: with the conversion as a block
+    // behind the MFMA block, co-resident waves fell into step and the matrix pipe idled half the time
+    // (profiles/r05/pmc_gemm_split_v3.txt: SQ_WAIT_INST_ANY 3x the MFMA time, pipe 46 % busy) whatever the occupancy.
+    // The main loop body is one basic block (no workgroup-uniform branches: the last two steps are peeled, a partial
+    // last stage is masked there); sched_group_barrier lays out the order.
+    static_assert(BK == 16, "pipelined form: one 16-deep k-step per barrier");
+    auto step = [&](int kt, auto store_c, auto load_c, auto mask_c) {
+      constexpr bool STORE = decltype(store_c)::value, LOAD = decltype(load_c)::value, MASK = decltype(mask_c)::value;
+      const unsigned char* cur = lds + (kt & 1) * STAGE;
+      unsigned char* nxt = lds + ((kt + 1) & 1) * STAGE;
+      bf16x8 fb[3][TJ], fa[2][3];
+      auto read_a = [&](int i, bf16x8 (&dst)[3]) {
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+          dst[t] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(cur + a_off + t * KG * PSA + i * 512));
+      };
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j)
+          fb[t][j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(cur + b_off + t * KG * PSB + j * 512));
+      read_a(0, fa[0]);
+      if (TI > 1) read_a(1, fa[1]);
+      if constexpr (STORE && MASK) {
+        const int k0 = k_begin + (kt + 1) * BK;
+        ra.mask_tail(k0, k_end, tid);
+        rb.mask_tail(k0, k_end, tid);
+      }
+#pragma unroll
+      for (int i = 0; i < TI; ++i) {
+        const bf16x8 (&a)[3] = fa[i & 1];
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) {
+          f32x16 c = acc[i][j];
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], fb[0][j], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], fb[1][j], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], fb[2][j], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], fb[0][j], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], fb[1][j], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], fb[0][j], c, 0, 0, 0);
+          acc[i][j] = c;
+        }
+        if (i + 2 < TI) read_a(i + 2, fa[i & 1]);
+      }
+      if constexpr (STORE) {
+        ra.store(nxt, tid);
+        rb.store(nxt + StageA::BYTES, tid);
+      }
+      if constexpr (LOAD) {
+        const int k0 = k_begin + (kt + 2) * BK;
+        ra.load(rsA, k0);
+        rb.load(rsB, k0);
+      }
+      // the order: fragment reads of the first two row blocks, then per row block its 6 * TJ MFMAs, each followed by
+      // vector instructions of the split; the later row blocks' reads ride behind their predecessors; LDS stores and
+      // global loads (whose registers the split has just released) in the last row block's shadows
+      __builtin_amdgcn_sched_group_barrier(0x100, 3 * TJ + (TI > 1 ? 6 : 3), 0);
+      constexpr int PER = 6 * TJ;                          // MFMAs per row block
+      constexpr int VAL = STORE ? (TI >= 4 ? 3 : 4) : 0;   // vector instructions behind each MFMA of the early blocks
+#pragma unroll
+      for (int i = 0; i < TI; ++i) {
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          if (i + 1 < TI || TI == 1) {
+            if (VAL) __builtin_amdgcn_sched_group_barrier(0x002, VAL, 0);
+          } else {
+            if (VAL) __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+            if (STORE && q % 2 == 0) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+            if (LOAD && q % 2 == 1) __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+          }
+        }
+        if (i + 2 < TI) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+      }
+    };
+    using T = std::true_type;
+    using F = std::false_type;
+    load(0);
+    store(0);
+    if (nsteps > 1) load(1);
+    __syncthreads();
+    int kt = 0;
+    for (; kt + 2 < nsteps; ++kt) {
+      step(kt, T{}, T{}, F{});
+      __syncthreads();
+    }
+    if (kt + 1 < nsteps) {                                 // stage nsteps-1 may be partial; nothing left to load
+      step(kt, T{}, F{}, T{});
+      __syncthreads();
+      ++kt;
+    }
+    step(kt, F{}, F{}, F{});
+  } else {
+  const bool early = WR * WC >= 8 && wave < WR * WC / 2;       // converts one step ahead, behind the barrier
   load(0);
   store(0);
   if (nsteps > 1) load(1);
   __syncthreads();
-  const bool convert_first = wave < 4;
+  if (early) {
+    if (nsteps > 1) store(1);
+    if (nsteps > 2) load(2);
+  }
   for (int kt = 0; kt < nsteps; ++kt) {
-    if (convert_first) {
-      if (kt + 1 < nsteps) store(kt + 1);
-      if (kt + 2 < nsteps) load(kt + 2);
-      compute(kt);
-    } else {
-      compute(kt);
+    compute(kt);
+    if (!early) {
       if (kt + 1 < nsteps) store(kt + 1);
       if (kt + 2 < nsteps) load(kt + 2);
     }
     __syncthreads();
+    if (early) {
+      if (kt + 2 < nsteps) store(kt + 2);
+      if (kt + 3 < nsteps) load(kt + 3);
+    }
+  }
   }
 
   // C/D layout of the 32x32 MFMA: column = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5); buffer stores:
   // a row beyond M lies beyond the buffer, a column beyond N gets the out-of-buffer lane offset (dropped)
   const __amdgpu_buffer_rsrc_t rsC =
       make_rsrc(g.C + split * g.s_split + batch * g.sC, (long)(g.M - 1) * g.ldc + g.N);
+#pragma unroll
+  for (int j = 0; j < TJ; ++j) {
+    const int col = n0 + wn0 + 32 * j + r;
+    const unsigned voff = col < g.N ? ((unsigned)col + (unsigned)(4 * h) * g.ldc) * 4u : kOut;
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = m0 + wm0 + 32 * i + (e & 3) + 8 * (e >> 2);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[i][j][e]), rsC, voff, (unsigned)row * g.ldc * 4u, 0);
+      }
+  }
+}
+
+// ---- forward / data-gradient form with the A operand (the transformed filters: small, constant over an optimizer step)
+// split ONCE into three bf16 planes that have the layout of the LDS image: [batch][row tile][stage][piece][k-group]
+// [BM rows] x 16 B, zero-padded in rows and k.  The GEMM then brings A in by LDS-DMA (buffer_load_dwordx4 ... lds: 1 KB
+// per wave instruction, fully coalesced, no vector instruction, no LDS store) and only the streamed B operand (the
+// transformed activations, read once from HBM) is split on the way into LDS.  Half the conversion work, LDS stores and
+// vector-memory instructions of the generic kernel, whose units were all 60-90 % busy.
+template <int BM, int BK>
+__global__ __launch_bounds__(256) void gemm_split_pack_a_kernel(const float* __restrict__ A, int M, int K, int lda, long sA,
+                                                                int tiles_m, int stages, u32x4* __restrict__ out, long items) {
+  constexpr int KG = BK / 8;
+  const long it = (long)blockIdx.x * 256 + threadIdx.x;       // one item = 8 consecutive k of one padded row
+  if (it >= items) return;
+  const int row_in = (int)(it % BM);
+  long r = it / BM;
+  const int g = (int)(r % KG); r /= KG;
+  const int stage = (int)(r % stages); r /= stages;
+  const int tm = (int)(r % tiles_m);
+  const long batch = r / tiles_m;
+  const int row = tm * BM + row_in, k0 = stage * BK + g * 8;
+  float x[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) x[j] = (row < M && k0 + j < K) ? A[batch * sA + (long)row * lda + k0 + j] : 0.f;
+  u32x4 p1, p2, p3;
+  split8(x, p1, p2, p3);
+  const long base = (((batch * tiles_m + tm) * stages + stage) * 3) * (long)(KG * BM) + (long)g * BM + row_in;
+  out[base] = p1;
+  out[base + (long)KG * BM] = p2;
+  out[base + 2L * KG * BM] = p3;
+}
+
+struct PackedArgs {
+  const u32x4* Ap;
+  const float* B;
+  float* C;
+  int M, N, K;
+  int ldb, ldc;
+  long sB, sC;
+  int tiles_m, tiles_n, stages;
+};
+
+template <int BM, int BN, int BK, int WR, int WC, int MINW>
+__global__ __launch_bounds__(64 * WR * WC, MINW) void gemm_split_pa_kernel(const PackedArgs g) {
+  constexpr int NW = WR * WC;
+  constexpr int WM = BM / WR, WN = BN / WC, TI = WM / 32, TJ = WN / 32;
+  constexpr int KG = BK / 8;
+  constexpr int PSA = BM * 16 + 128 / KG;                    // LDS plane strides as in the generic kernel
+  constexpr int A_BYTES = 3 * KG * PSA;
+  constexpr int kBThreads = BN * KG;                         // one item per thread of the converting waves
+  static_assert(kBThreads % 64 == 0 && kBThreads <= 64 * NW, "B tile / wave mismatch");
+  constexpr int NWB = kBThreads / 64;                        // waves 0 .. NWB-1 convert B, the others issue the DMAs
+  using StageB = StridedStage<BN, BK, kBThreads>;
+  constexpr int PSB = StageB::PS;
+  constexpr int STAGE = A_BYTES + StageB::BYTES;
+  constexpr int CHUNKS = 3 * KG * BM / 64;                   // 1 KB pieces of a packed A stage
+  constexpr int NWD = NW - NWB > 0 ? NW - NWB : NW;          // waves that issue DMAs (all, when every wave converts)
+  constexpr int DMA_PER_WAVE = (CHUNKS + NWD - 1) / NWD;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * STAGE];
+
+  const int nb = gridDim.x, bid = blockIdx.x;
+  const int q8 = nb / 8, r8 = nb % 8, x8 = bid % 8;
+  int id = (x8 < r8 ? x8 * (q8 + 1) : r8 * (q8 + 1) + (x8 - r8) * q8) + bid / 8;
+  const int tm = id % g.tiles_m; id /= g.tiles_m;
+  const int tn = id % g.tiles_n;
+  const int batch = id / g.tiles_n;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  set_wave_priority(NW >= 8 ? (2 * (bid & 1) + (wave >= NW / 2 ? 1 : 0)) : bid % 3);   // see gemm_split_kernel
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int nsteps = g.stages;
+  const long a_tile_u4 = (long)nsteps * 3 * KG * BM;          // 16-byte units of one (batch, row tile)
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<u32x4*>(g.Ap + ((long)batch * g.tiles_m + tm) * a_tile_u4), 0, (int)(a_tile_u4 * 16), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB = make_rsrc(g.B + batch * g.sB, (long)(g.K - 1) * g.ldb + g.N);
+
+  const bool converts = wave < NWB;
+  const bool dmas = NWB == NW || wave >= NWB;
+  const int dwave = NWB == NW ? wave : wave - NWB;
+  StageB rb;
+  rb.init(g.ldb, n0, g.N, tid);
+  auto dma_a = [&](int kt) {                                // packed stage kt -> LDS stage kt & 1, chunk by chunk
+    unsigned char* d = lds + (kt & 1) * STAGE;
+#pragma unroll
+    for (int q = 0; q < DMA_PER_WAVE; ++q) {
+      const int c = dwave + q * NWD;                        // wave-uniform
+      if (CHUNKS % NWD == 0 || c < CHUNKS) {
+        const int plane = c / (BM / 64), r64 = c % (BM / 64);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(d + plane * PSA + r64 * 1024), 16,
+                                                 lane * 16, (kt * CHUNKS + c) * 1024, 0, 0);
+      }
+    }
+  };
+
+  f32x16 acc[TI][TJ];
+#pragma unroll
+  for (int i = 0; i < TI; ++i)
+#pragma unroll
+    for (int j = 0; j < TJ; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int r = lane & 31, h = lane >> 5;
+  const int wm0 = (wave / WC) * WM, wn0 = (wave % WC) * WN;
+  const int a_off = h * PSA + (wm0 + r) * 16;
+  const int b_off = A_BYTES + h * PSB + (wn0 + r) * 16;
+  auto compute = [&](int kt) {
+    const unsigned char* cur = lds + (kt & 1) * STAGE;
+#pragma unroll
+    for (int s = 0; s < BK / 16; ++s) {
+      bf16x8 fb[3][TJ], fa[2][3];
+      auto read_a = [&](int i, bf16x8 (&dst)[3]) {
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+          dst[t] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(cur + a_off + (t * KG + 2 * s) * PSA + i * 512));
+      };
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j)
+          fb[t][j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(cur + b_off + (t * KG + 2 * s) * PSB + j * 512));
+      read_a(0, fa[0]);
+#pragma unroll
+      for (int i = 0; i < TI; ++i) {
+        if (i + 1 < TI) read_a(i + 1, fa[(i + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+        const bf16x8 (&a)[3] = fa[i & 1];
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) {
+          f32x16 c = acc[i][j];
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], fb[0][j], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], fb[1][j], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], fb[2][j], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], fb[0][j], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], fb[1][j], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], fb[0][j], c, 0, 0, 0);
+          acc[i][j] = c;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  };
+
+  // A(kt+1) is on its way by DMA while stage kt is multiplied; B(kt+1) -- loaded into registers behind the previous
+  // barrier -- is split and stored behind the products; the wait in front of the barrier only ever sees the DMA (long
+  // landed) and the LDS stores: the register loads of B(kt+2) are issued BEHIND the barrier and have a whole step.
+  if (dmas) dma_a(0);
+  if (converts) {
+    rb.load(rsB, 0);
+    rb.store(lds + A_BYTES, tid);
+    if (nsteps > 1) rb.load(rsB, BK);
+  }
+  __builtin_amdgcn_s_waitcnt(0);
+  __syncthreads();
+  for (int kt = 0; kt < nsteps; ++kt) {
+    if (dmas && kt + 1 < nsteps) dma_a(kt + 1);
+    compute(kt);
+    if (converts && kt + 1 < nsteps) rb.store(lds + ((kt + 1) & 1) * STAGE + A_BYTES, tid);
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    if (converts && kt + 2 < nsteps) rb.load(rsB, (kt + 2) * BK);
+  }
+
+  const __amdgpu_buffer_rsrc_t rsC = make_rsrc(g.C + batch * g.sC, (long)(g.M - 1) * g.ldc + g.N);
 #pragma unroll
   for (int j = 0; j < TJ; ++j) {
     const int col = n0 + wn0 + 32 * j + r;
@@ -320,34 +654,48 @@ __global__ __launch_bounds__(256) void gemm_split_reduce_kernel(const float* __r
   }
 }
 
+struct Tile {
+  int bm, bn, bk, threads, per_cu;
+};
+// tile ids of `variant` (rows x columns x k-step, waves as rows x columns, workgroups per CU by LDS / registers)
+constexpr Tile kTiles[] = {
+    {256, 256, 16, 512, 1},   // 0: 2 x 4 waves of 128 x 64
+    {256, 128, 32, 512, 1},   // 1: 2 x 4 waves of 128 x 32
+    {128, 128, 16, 256, 3},   // 2: 2 x 2 waves of 64 x 64, 49 KB of LDS: three workgroups per CU overlap each other's
+                              //    prologue, conversion and epilogue
+    {128, 256, 16, 256, 2},   // 3: 1 x 4 waves of 128 x 64, 74 KB
+    {256, 256, 16, 512, 1},   // 4: tile 0 with the split, LDS stores and loads placed among the MFMAs of one stream
+    {128, 128, 16, 256, 3},   // 5: tile 2, the same
+    {128, 256, 16, 256, 2},   // 6: tile 3, the same
+};
+constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
+
 struct Plan {
-  int bm, bn, bk, tiles_m, tiles_n, splits, k_per_split;
+  int tile, bm, bn, bk, tiles_m, tiles_n, splits, k_per_split;
+  bool prio;
+  int abl;
 };
 
-// variant: -1 automatic; else tile + 10 * splits with tile 0 = 256x256x16, 1 = 256x128x32 (splits 0 = automatic)
+// variant: -1 automatic; else tile + 10 * splits (splits 0 = automatic)
 bool plan_for(int batch, int M, int N, int K, int transB, int variant, Plan* p) {
   int tile = variant < 0 ? -1 : variant % 10;
-  int splits = variant < 0 ? 0 : variant / 10;
-  if (tile > 1) return false;
+  int splits = variant < 0 ? 0 : (variant / 10) % 100;
+  p->prio = variant < 0 || variant < 1000 || variant >= 2000;   // + 1000: without the static wave priorities (A/B)
+  p->abl = variant >= 2000 ? variant / 1000 - 1 : 0;             // + 2000 / 3000 / 4000: ablation builds (tiles 0, 2; NN)
+  if (tile >= kNumTiles) return false;
   const long cus = 256;
-  if (tile < 0) {
-    // the smaller tile when the large one would leave the chip's last round less than 60 % full (or fill no round)
-    const long t0 = (long)batch * ((M + 255) / 256) * ((N + 255) / 256);
-    const long t1 = (long)batch * ((M + 255) / 256) * ((N + 127) / 128);
-    const double e0 = (double)t0 / (double)(((t0 + cus - 1) / cus) * cus);
-    const double e1 = (double)t1 / (double)(((t1 + cus - 1) / cus) * cus);
-    tile = (transB || e0 >= e1 - 0.02) ? 0 : 1;
-  }
-  p->bm = 256;
-  p->bn = tile == 0 ? 256 : 128;
-  p->bk = tile == 0 ? 16 : 32;
+  if (tile < 0) tile = transB ? 3 : 2;                    // measured: tools/bench_gemm_split.py, profiles/r05/
+  const Tile& t = kTiles[tile];
+  p->tile = tile;
+  p->bm = t.bm; p->bn = t.bn; p->bk = t.bk;
   p->tiles_m = (M + p->bm - 1) / p->bm;
   p->tiles_n = (N + p->bn - 1) / p->bn;
   const long tiles = (long)batch * p->tiles_m * p->tiles_n;
+  const long slots = cus * t.per_cu;
   if (splits <= 0) {
     splits = 1;
-    if (transB && tiles < cus) {                          // long reduction, few tiles: fill the chip with K ranges
-      splits = (int)(cus / tiles);
+    if (transB && tiles < slots) {                        // long reduction, few tiles: fill the chip with K ranges
+      splits = (int)(slots / tiles);
       const int max_splits = (K + 8 * p->bk - 1) / (8 * p->bk);   // at least 8 k-steps per range
       if (splits > max_splits) splits = max_splits;
       if (splits < 1) splits = 1;
@@ -362,6 +710,75 @@ bool plan_for(int batch, int M, int N, int K, int transB, int variant, Plan* p) 
 
 }  // namespace
 }  // namespace fpsg
+
+namespace fpsg {
+namespace {
+// packed-A tiles: variant 0 = 256 x 128 x 16 (2 x 4 waves of 128 x 32, two workgroups per CU), 1 = 256 x 256 x 16
+// (2 x 4 waves of 128 x 64, one per CU), 2 = 128 x 128 x 16 (2 x 2 waves of 64 x 64, three per CU)
+struct PaTile { int bm, bn, bk, threads; };
+constexpr PaTile kPaTiles[] = {{256, 128, 16, 512}, {256, 256, 16, 512}, {128, 128, 16, 256}};
+constexpr int kNumPaTiles = sizeof(kPaTiles) / sizeof(kPaTiles[0]);
+inline int pa_tile(int variant) { return variant < 0 ? 0 : variant; }
+}  // namespace
+}  // namespace fpsg
+
+extern "C" size_t fpsg_gemm_split_packed_a_bytes(int batch, int M, int K, int variant) {
+  const int t = fpsg::pa_tile(variant);
+  if (batch <= 0 || M <= 0 || K <= 0 || t >= fpsg::kNumPaTiles) return 0;
+  const fpsg::PaTile& p = fpsg::kPaTiles[t];
+  const long tiles_m = (M + p.bm - 1) / p.bm, stages = (K + p.bk - 1) / p.bk;
+  return (size_t)batch * tiles_m * stages * 3 * (p.bk / 8) * p.bm * 16;
+}
+
+extern "C" int fpsg_gemm_split_pack_a(const float* A, int batch, int M, int K, int lda, long sA, int variant, void* Ap,
+                                      fpsg_stream_t stream) {
+  using namespace fpsg;
+  const int t = pa_tile(variant);
+  FPSG_REQUIRE(batch > 0 && M > 0 && K > 0 && lda >= K, FPSG_E_SHAPE, "fpsg_gemm_split_pack_a: bad shape");
+  FPSG_REQUIRE(t < kNumPaTiles, FPSG_E_SHAPE, "fpsg_gemm_split_pack_a: unknown variant %d", variant);
+  FPSG_REQUIRE_PTR(A);
+  FPSG_REQUIRE_PTR(Ap);
+  FPSG_REQUIRE((reinterpret_cast<uintptr_t>(Ap) & 15) == 0, FPSG_E_ALIGN, "fpsg_gemm_split_pack_a: Ap must be 16-byte aligned");
+  const PaTile& p = kPaTiles[t];
+  const int tiles_m = (M + p.bm - 1) / p.bm, stages = (K + p.bk - 1) / p.bk;
+  const long items = (long)batch * tiles_m * stages * (p.bk / 8) * p.bm;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const dim3 grid((unsigned)((items + 255) / 256)), block(256);
+  if (p.bm == 256) hipLaunchKernelGGL((gemm_split_pack_a_kernel<256, 16>), grid, block, 0, s, A, M, K, lda, sA, tiles_m, stages,
+                                      static_cast<u32x4*>(Ap), items);
+  else hipLaunchKernelGGL((gemm_split_pack_a_kernel<128, 16>), grid, block, 0, s, A, M, K, lda, sA, tiles_m, stages,
+                          static_cast<u32x4*>(Ap), items);
+  return launch_status("fpsg_gemm_split_pack_a");
+}
+
+extern "C" int fpsg_gemm_split_nn_packed(const void* Ap, const float* B, float* C, int batch, int M, int N, int K, int ldb,
+                                         int ldc, long sB, long sC, int variant, fpsg_stream_t stream) {
+  using namespace fpsg;
+  const int t = pa_tile(variant);
+  FPSG_REQUIRE(batch > 0 && M > 0 && N > 0 && K > 0 && ldb >= N && ldc >= N, FPSG_E_SHAPE, "fpsg_gemm_split_nn_packed: bad shape");
+  FPSG_REQUIRE(t < kNumPaTiles, FPSG_E_SHAPE, "fpsg_gemm_split_nn_packed: unknown variant %d", variant);
+  FPSG_REQUIRE_PTR(Ap);
+  FPSG_REQUIRE_PTR(B);
+  FPSG_REQUIRE_PTR(C);
+  FPSG_REQUIRE((long)K * ldb < (1L << 29) && (long)M * ldc < (1L << 29), FPSG_E_LIMIT,
+               "fpsg_gemm_split_nn_packed: a matrix of one batch entry must stay below 2 GiB (32-bit buffer offsets)");
+  const PaTile& p = kPaTiles[t];
+  PackedArgs g;
+  g.Ap = static_cast<const u32x4*>(Ap); g.B = B; g.C = C;
+  g.M = M; g.N = N; g.K = K; g.ldb = ldb; g.ldc = ldc; g.sB = sB; g.sC = sC;
+  g.tiles_m = (M + p.bm - 1) / p.bm; g.tiles_n = (N + p.bn - 1) / p.bn; g.stages = (K + p.bk - 1) / p.bk;
+  FPSG_REQUIRE((long)g.stages * 3 * (p.bk / 8) * p.bm * 16 < (1L << 31), FPSG_E_LIMIT, "fpsg_gemm_split_nn_packed: K too long");
+  const long blocks = (long)batch * g.tiles_m * g.tiles_n;
+  FPSG_REQUIRE(blocks < (1L << 30), FPSG_E_LIMIT, "fpsg_gemm_split_nn_packed: too many tiles");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const dim3 grid((unsigned)blocks), block(p.threads);
+  switch (t) {
+    case 0: hipLaunchKernelGGL((gemm_split_pa_kernel<256, 128, 16, 2, 4, 4>), grid, block, 0, s, g); break;
+    case 1: hipLaunchKernelGGL((gemm_split_pa_kernel<256, 256, 16, 2, 4, 2>), grid, block, 0, s, g); break;
+    default: hipLaunchKernelGGL((gemm_split_pa_kernel<128, 128, 16, 2, 2, 3>), grid, block, 0, s, g); break;
+  }
+  return launch_status("fpsg_gemm_split_nn_packed");
+}
 
 extern "C" size_t fpsg_gemm_split_workspace_floats(int batch, int M, int N, int K, int transB, int variant) {
   fpsg::Plan p;
@@ -399,14 +816,47 @@ extern "C" int fpsg_gemm_split(const float* A, const float* B, float* C, int bat
   FPSG_REQUIRE((long)M * lda < (1L << 29) && (long)(transB ? N : K) * ldb < (1L << 29) && (long)M * ldc < (1L << 29),
                FPSG_E_LIMIT, "fpsg_gemm_split: a matrix of one batch entry must stay below 2 GiB (32-bit buffer offsets)");
   hipStream_t s = static_cast<hipStream_t>(stream);
-  const dim3 grid((unsigned)blocks), block(kThreads);
-  if (p.bn == 256) {
-    if (transB) hipLaunchKernelGGL((gemm_split_kernel<256, 256, 16, true>), grid, block, 0, s, g);
-    else hipLaunchKernelGGL((gemm_split_kernel<256, 256, 16, false>), grid, block, 0, s, g);
-  } else {
-    if (transB) hipLaunchKernelGGL((gemm_split_kernel<256, 128, 32, true>), grid, block, 0, s, g);
-    else hipLaunchKernelGGL((gemm_split_kernel<256, 128, 32, false>), grid, block, 0, s, g);
+  const dim3 grid((unsigned)blocks), block(kTiles[p.tile].threads);
+  const bool prio = p.prio;
+#define FPSG_GEMM_LAUNCH_PIPE(BM, BN, BK, WR, WC, MINW)                                                           \
+  do {                                                                                                            \
+    if (transB) hipLaunchKernelGGL((gemm_split_kernel<BM, BN, BK, WR, WC, MINW, true, true, true>), grid, block, 0, s, g);  \
+    else hipLaunchKernelGGL((gemm_split_kernel<BM, BN, BK, WR, WC, MINW, false, true, true>), grid, block, 0, s, g);        \
+  } while (0)
+#define FPSG_GEMM_LAUNCH(BM, BN, BK, WR, WC, MINW)                                                                \
+  do {                                                                                                            \
+    if (prio) {                                                                                                    \
+      if (transB) hipLaunchKernelGGL((gemm_split_kernel<BM, BN, BK, WR, WC, MINW, true, true>), grid, block, 0, s, g);  \
+      else hipLaunchKernelGGL((gemm_split_kernel<BM, BN, BK, WR, WC, MINW, false, true>), grid, block, 0, s, g);        \
+    } else {                                                                                                       \
+      if (transB) hipLaunchKernelGGL((gemm_split_kernel<BM, BN, BK, WR, WC, MINW, true, false>), grid, block, 0, s, g); \
+      else hipLaunchKernelGGL((gemm_split_kernel<BM, BN, BK, WR, WC, MINW, false, false>), grid, block, 0, s, g);       \
+    }                                                                                                              \
+  } while (0)
+  if (p.abl > 0) {        // measurement builds (tools/bench_gemm_split.py --variants 2000 ...): wrong results by design
+    FPSG_REQUIRE(!transB && (p.tile == 0 || p.tile == 2) && p.abl <= 3, FPSG_E_SHAPE, "fpsg_gemm_split: no such ablation build");
+#define FPSG_ABL(A)                                                                                                     \
+    do {                                                                                                                \
+      if (p.tile == 0) hipLaunchKernelGGL((gemm_split_kernel<256, 256, 16, 2, 4, 2, false, true, false, A>), grid, block, 0, s, g); \
+      else hipLaunchKernelGGL((gemm_split_kernel<128, 128, 16, 2, 2, 3, false, true, false, A>), grid, block, 0, s, g);             \
+    } while (0)
+    if (p.abl == 1) FPSG_ABL(1);
+    else if (p.abl == 2) FPSG_ABL(2);
+    else FPSG_ABL(3);
+#undef FPSG_ABL
+    return launch_status("fpsg_gemm_split (ablation)");
   }
+  switch (p.tile) {
+    case 0: FPSG_GEMM_LAUNCH(256, 256, 16, 2, 4, 2); break;
+    case 1: FPSG_GEMM_LAUNCH(256, 128, 32, 2, 4, 2); break;
+    case 2: FPSG_GEMM_LAUNCH(128, 128, 16, 2, 2, 3); break;
+    case 3: FPSG_GEMM_LAUNCH(128, 256, 16, 1, 4, 2); break;
+    case 4: FPSG_GEMM_LAUNCH_PIPE(256, 256, 16, 2, 4, 2); break;
+    case 5: FPSG_GEMM_LAUNCH_PIPE(128, 128, 16, 2, 2, 3); break;
+    default: FPSG_GEMM_LAUNCH_PIPE(128, 256, 16, 1, 4, 2); break;
+  }
+#undef FPSG_GEMM_LAUNCH
+#undef FPSG_GEMM_LAUNCH_PIPE
   int rc = launch_status("fpsg_gemm_split");
   if (rc != 0 || p.splits == 1) return rc;
   const long n = (long)batch * M * N;

@@ -39,3 +39,36 @@ def bmm_split(A: torch.Tensor, B: torch.Tensor, transB: bool = False, variant: i
                                        _hip.ptr(ws) if ws is not None else None, nws, _hip.stream_of(A)),
                    "fpsg_gemm_split")
     return C
+
+
+def pack_a(A: torch.Tensor, variant: int = -1) -> torch.Tensor:
+    """The A operand ``[b, M, K]`` of ``bmm_packed`` split once into three bf16 planes in the layout of the GEMM's LDS
+    image (``fpsg_gemm_split_pack_a``): for operands that stay constant over many products -- the transformed filters
+    of an optimizer step.  Returns an opaque uint8 tensor (about 1.5x the bytes of ``A``)."""
+    lib = _hip.load()
+    _hip.dev_tensor(A, torch.float32, "A")
+    b, M, K = A.shape
+    nbytes = lib.fpsg_gemm_split_packed_a_bytes(b, M, K, variant)
+    if nbytes == 0:
+        raise ValueError(f"pack_a: variant {variant} unknown")
+    Ap = torch.empty((nbytes,), dtype=torch.uint8, device=A.device)
+    with torch.cuda.device(A.device):
+        _hip.check(lib.fpsg_gemm_split_pack_a(_hip.ptr(A), b, M, K, K, M * K, variant, _hip.ptr(Ap), _hip.stream_of(A)),
+                   "fpsg_gemm_split_pack_a")
+    return Ap
+
+
+def bmm_packed(Ap: torch.Tensor, shape_a, B: torch.Tensor, variant: int = -1, out: torch.Tensor | None = None):
+    """``torch.bmm(A, B)`` for ``Ap = pack_a(A, variant)``, ``shape_a = A.shape`` and contiguous fp32 ``B [b, K, N]``:
+    the same values as ``bmm_split(A, B)``; A comes in by LDS-DMA, only B is split inside the kernel."""
+    lib = _hip.load()
+    _hip.dev_tensor(B, torch.float32, "B")
+    b, M, K = shape_a
+    if B.shape[0] != b or B.shape[1] != K:
+        raise ValueError(f"bmm_packed: shapes {tuple(shape_a)} x {tuple(B.shape)} do not match")
+    N = B.shape[2]
+    C = out if out is not None else torch.empty((b, M, N), dtype=torch.float32, device=B.device)
+    with torch.cuda.device(B.device):
+        _hip.check(lib.fpsg_gemm_split_nn_packed(_hip.ptr(Ap), _hip.ptr(B), _hip.ptr(C), b, M, N, K, N, N, K * N, M * N,
+                                                 variant, _hip.stream_of(B)), "fpsg_gemm_split_nn_packed")
+    return C

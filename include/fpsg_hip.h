@@ -525,6 +525,18 @@ int fpsg_gemm_split(const float* A, const float* B, float* C, int batch, int M, 
                     long sA, long sB, long sC, int transB, int variant, float* ws, size_t ws_floats,
                     fpsg_stream_t stream);
 
+/* K10 with the A operand split once (the transformed filters: constant over an optimizer step).  fpsg_gemm_split_pack_a writes
+ * A [batch][M][K] (row-major, lda, batch stride sA) as three bf16 planes in the layout of the GEMM's LDS image, zero-padded
+ * (fpsg_gemm_split_packed_a_bytes bytes, 16-byte aligned; about 1.5x the fp32 matrix); fpsg_gemm_split_nn_packed computes
+ * C[b] [M x N] = A[b] . B[b] [K x N] with A brought in by LDS-DMA and only B split on the way into LDS: the same values as
+ * fpsg_gemm_split(transB = 0), bit for bit.  variant (the same for the three calls): -1 / 0 = 256 x 128 x 16 tiles, two
+ * workgroups per CU; 1 = 256 x 256 x 16; 2 = 128 x 128 x 16. */
+size_t fpsg_gemm_split_packed_a_bytes(int batch, int M, int K, int variant);
+int fpsg_gemm_split_pack_a(const float* A, int batch, int M, int K, int lda, long sA, int variant, void* Ap,
+                           fpsg_stream_t stream);
+int fpsg_gemm_split_nn_packed(const void* Ap, const float* B, float* C, int batch, int M, int N, int K, int ldb, int ldc,
+                              long sB, long sC, int variant, fpsg_stream_t stream);
+
 /* K6 in one kernel for 64 input channels (F(4x4,3x3); conv1_2 / conv2_1 of the trunk and their data
  * gradients): y [N,K,H,W] = conv(x [N,64,H,W], w) from U = fpsg_wino_filter_transform(4, w, ...)
  * [36,K,64]; input transform, the 36 MFMA products and the output transform stay on chip -- with 64

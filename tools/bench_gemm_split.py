@@ -16,7 +16,7 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from fpsg_amd.gemm_split import bmm_split as gemm_split  # noqa: E402
+from fpsg_amd.gemm_split import bmm_packed, bmm_split as gemm_split, pack_a  # noqa: E402
 
 
 def _time(fn, reps):
@@ -39,16 +39,21 @@ def _errors(C, ref64):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--variants", default="-1")
+    ap.add_argument("--packed", default="", help="variants of the packed-A forward form to time (p0,p1,p2 columns)")
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--n-img", type=int, default=37)
     ap.add_argument("--quick", action="store_true", help="256 -> 256 @56 only")
     ap.add_argument("--err-batches", type=int, default=3)
     ap.add_argument("--dist", default="randn", choices=["randn", "wino"])
+    ap.add_argument("--no-tuning", action="store_true", help="library GEMMs by the libraries' default heuristic")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
-    variants = [int(v) for v in args.variants.split(",")]
+    if not args.no_tuning:      # the library side as the step runs it: the recorded kernel per shape (fpsg_amd/tuning)
+        from fpsg_amd import gemm_tuning
+        print(json.dumps(gemm_tuning.enable()), file=sys.stderr)
+    base_variants = [int(v) for v in args.variants.split(",")]
     shapes = ((256, 256, 56),) if args.quick else ((128, 128, 112), (128, 256, 56), (256, 256, 56), (256, 512, 28),
                                                    (512, 512, 28), (512, 512, 14))
     for C, K, H in shapes:
@@ -60,11 +65,17 @@ def main():
             s = torch.logspace(-1.5, 1.5, 36, device=dev).view(36, 1, 1)
             U, V, gM = U / s, V * s, gM * s
         flop = 2.0 * 36 * K * C * P
+        packed = {int(v): pack_a(U, int(v)) for v in args.packed.split(",") if v != ""}
+
+        def fwd_fn(v):      # variant ids >= 100: the packed-A form's variant v - 100
+            return bmm_packed(packed[v - 100], U.shape, V, v - 100) if 100 <= v < 110 else gemm_split(U, V, False, v)
+
         legs = {
-            "fwd": (lambda: torch.bmm(U, V), lambda v: gemm_split(U, V, False, v)),
+            "fwd": (lambda: torch.bmm(U, V), fwd_fn),
             "dw": (lambda: torch.bmm(gM, V.transpose(1, 2)), lambda v: gemm_split(gM, V, True, v)),
         }
         for leg, (lib_fn, split_fn) in legs.items():
+            variants = base_variants + ([100 + v for v in packed] if leg == "fwd" else [])
             # errors on the first batches against float64
             nb = args.err_batches
             if leg == "fwd":
@@ -102,7 +113,10 @@ def main():
                                 "err_max": outs[v][0], "err_med": outs[v][1],
                                 "err_max_ratio": round(outs[v][0] / e_lib[0], 3), "err_med_ratio": round(outs[v][1] / e_lib[1], 3)}
             print(json.dumps(row), flush=True)
-        del U, V, gM
+        if packed:
+            t = _time(lambda: pack_a(U, next(iter(packed))), args.reps)
+            print(json.dumps({"shape": f"{C}->{K} @{H}", "leg": "pack_a", "us": round(t * 1e6, 1)}), flush=True)
+        del U, V, gM, packed
 
 
 if __name__ == "__main__":
