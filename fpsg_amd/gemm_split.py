@@ -72,3 +72,18 @@ def bmm_packed(Ap: torch.Tensor, shape_a, B: torch.Tensor, variant: int = -1, ou
         _hip.check(lib.fpsg_gemm_split_nn_packed(_hip.ptr(Ap), _hip.ptr(B), _hip.ptr(C), b, M, N, K, N, N, K * N, M * N,
                                                  variant, _hip.stream_of(B)), "fpsg_gemm_split_nn_packed")
     return C
+
+
+def bmm_persistent(Ap: torch.Tensor, shape_a, B: torch.Tensor, variant: int = -1, out: torch.Tensor | None = None):
+    """``bmm_packed`` as one persistent launch (``fpsg_gemm_split_nn_persistent``); ``Ap = pack_a(A, 0)``."""
+    lib = _hip.load()
+    _hip.dev_tensor(B, torch.float32, "B")
+    b, M, K = shape_a
+    if B.shape[0] != b or B.shape[1] != K:
+        raise ValueError(f"bmm_persistent: shapes {tuple(shape_a)} x {tuple(B.shape)} do not match")
+    N = B.shape[2]
+    C = out if out is not None else torch.empty((b, M, N), dtype=torch.float32, device=B.device)
+    with torch.cuda.device(B.device):
+        _hip.check(lib.fpsg_gemm_split_nn_persistent(_hip.ptr(Ap), _hip.ptr(B), _hip.ptr(C), b, M, N, K, N, N, K * N,
+                                                     M * N, variant, _hip.stream_of(B)), "fpsg_gemm_split_nn_persistent")
+    return C

@@ -537,6 +537,14 @@ int fpsg_gemm_split_pack_a(const float* A, int batch, int M, int K, int lda, lon
 int fpsg_gemm_split_nn_packed(const void* Ap, const float* B, float* C, int batch, int M, int N, int K, int ldb, int ldc,
                               long sB, long sC, int variant, fpsg_stream_t stream);
 
+/* The same product as fpsg_gemm_split_nn_packed (Ap packed with variant 0 or 1: 256-row tiles) as ONE persistent launch:
+ * a workgroup per CU walks an equal share of the flattened (batch, row tile, column) space, the load / split / MFMA
+ * pipeline runs across tile boundaries (no per-tile launch, prologue or drain; 1044 tiles on 256 CUs cost 4.08 rounds, not
+ * 5).  Same values as fpsg_gemm_split_nn_packed bit for bit.  variant: -1 / 0 = 256 columns per tile, 1 = 128.  B below
+ * 4 GiB in total, one C matrix and the packed A below 2 GiB. */
+int fpsg_gemm_split_nn_persistent(const void* Ap, const float* B, float* C, int batch, int M, int N, int K, int ldb, int ldc,
+                                  long sB, long sC, int variant, fpsg_stream_t stream);
+
 /* K6 in one kernel for 64 input channels (F(4x4,3x3); conv1_2 / conv2_1 of the trunk and their data
  * gradients): y [N,K,H,W] = conv(x [N,64,H,W], w) from U = fpsg_wino_filter_transform(4, w, ...)
  * [36,K,64]; input transform, the 36 MFMA products and the output transform stay on chip -- with 64

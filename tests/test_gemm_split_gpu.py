@@ -97,3 +97,19 @@ def test_packed_a_exact_on_integers(gpu):
     B = torch.randint(-8, 9, (2, 80, 500), generator=g).float().to(gpu)
     for v in (0, 1, 2):
         assert torch.equal(bmm_packed(pack_a(A, v), A.shape, B, v), torch.bmm(A.double(), B.double()).float())
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("b,M,N,K", [(2, 256, 300, 32), (3, 100, 70, 48), (1, 512, 257, 128), (2, 37, 1000, 72),
+                                     (36, 256, 592, 256), (5, 512, 1813, 64), (1, 256, 40000, 16), (7, 300, 33, 16)])
+def test_persistent_form_equals_the_tiled_kernels(gpu, variant, b, M, N, K):
+    """``fpsg_gemm_split_nn_persistent`` (one launch, a range of the flattened column space per workgroup, pipeline across
+    tile boundaries) against the generic tiled kernel with the same 16-deep k-steps: bit-identical; ranges that start in
+    the middle of a batch entry, span several, hold one ragged tile or dozens."""
+    from fpsg_amd.gemm_split import bmm_persistent, pack_a
+    g = torch.Generator(device="cpu").manual_seed(b * 999 + M + N + K)
+    A = torch.randn(b, M, K, generator=g).to(gpu)
+    B = torch.randn(b, K, N, generator=g).to(gpu)
+    C = torch.full((b, M, N), float("nan"), device=gpu)
+    bmm_persistent(pack_a(A, 0), A.shape, B, variant, out=C)
+    assert torch.equal(C, gemm_split(A, B, False, 2))

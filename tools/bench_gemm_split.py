@@ -16,7 +16,7 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from fpsg_amd.gemm_split import bmm_packed, bmm_split as gemm_split, pack_a  # noqa: E402
+from fpsg_amd.gemm_split import bmm_packed, bmm_persistent, bmm_split as gemm_split, pack_a  # noqa: E402
 
 
 def _time(fn, reps):
@@ -39,7 +39,8 @@ def _errors(C, ref64):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--variants", default="-1")
-    ap.add_argument("--packed", default="", help="variants of the packed-A forward form to time (p0,p1,p2 columns)")
+    ap.add_argument("--packed", default="", help="variants of the packed-A forward form to time (v100.. columns)")
+    ap.add_argument("--persistent", default="", help="variants of the persistent forward form to time (v200.. columns)")
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--n-img", type=int, default=37)
@@ -67,7 +68,12 @@ def main():
         flop = 2.0 * 36 * K * C * P
         packed = {int(v): pack_a(U, int(v)) for v in args.packed.split(",") if v != ""}
 
-        def fwd_fn(v):      # variant ids >= 100: the packed-A form's variant v - 100
+        if args.persistent and 0 not in packed:
+            packed[0] = pack_a(U, 0)
+
+        def fwd_fn(v):      # variant ids 100 ..: the packed-A form's variant v - 100; 200 ..: the persistent form's
+            if 200 <= v < 210:
+                return bmm_persistent(packed[0], U.shape, V, v - 200)
             return bmm_packed(packed[v - 100], U.shape, V, v - 100) if 100 <= v < 110 else gemm_split(U, V, False, v)
 
         legs = {
@@ -75,7 +81,8 @@ def main():
             "dw": (lambda: torch.bmm(gM, V.transpose(1, 2)), lambda v: gemm_split(gM, V, True, v)),
         }
         for leg, (lib_fn, split_fn) in legs.items():
-            variants = base_variants + ([100 + v for v in packed] if leg == "fwd" else [])
+            variants = base_variants + ([100 + v for v in packed if str(v) in args.packed.split(",")] +
+                                        [200 + int(v) for v in args.persistent.split(",") if v != ""] if leg == "fwd" else [])
             # errors on the first batches against float64
             nb = args.err_batches
             if leg == "fwd":

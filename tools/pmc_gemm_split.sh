@@ -11,7 +11,7 @@ for pass in 1 2 3; do
     3) C="SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVES SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_FLAT";;
   esac
   rm -rf $R/gpurun_out/pmc_${TAG}_$pass
-  rocprofv3 --pmc $C --kernel-include-regex "gemm_split_(pa_)?kernel" --output-format csv -d $R/gpurun_out/pmc_${TAG}_$pass -o k -- \
+  rocprofv3 --pmc $C --kernel-include-regex "gemm_split_(pa_|pnn_)?kernel" --output-format csv -d $R/gpurun_out/pmc_${TAG}_$pass -o k -- \
     python3 $R/tools/bench_gemm_split.py $ARGS > $R/gpurun_out/pmc_${TAG}_$pass.log 2>&1 || { tail -5 $R/gpurun_out/pmc_${TAG}_$pass.log; }
 done
 python3 - <<PY
