@@ -433,6 +433,32 @@ def trunk_kernel_rooflines(device, entry):
     return out
 
 
+def split_gemm_error(device):
+    """K10 and the library fp32 GEMM against a float64 product of the same operands at the 256 -> 256 @56 products of the
+    step (three of the 36 batch entries): max and median error over the product's RMS, and K10's time against the
+    library's (tuned record) on this box."""
+    from fpsg_amd.gemm_split import bmm_split
+    g = torch.Generator(device="cpu").manual_seed(11)
+    U = torch.randn(36, 256, 256, generator=g).to(device)
+    V = torch.randn(36, 256, 37 * 196, generator=g).to(device)
+    ref = torch.bmm(U[:3].double(), V[:3].double())
+    scale = ref.pow(2).mean().sqrt()
+
+    def err(C):
+        d = (C[:3].double() - ref).abs()
+        return float(d.max() / scale), float(d.flatten()[::7].median() / scale)
+
+    e_lib, e_split = err(torch.bmm(U, V)), err(bmm_split(U, V))
+    t_lib = _event_time(lambda: torch.bmm(U, V), 10)
+    t_split = _event_time(lambda: bmm_split(U, V), 10)
+    return {"shape": "36 x [256x256].[256x7252]", "library_fp32_max": e_lib[0], "library_fp32_median": e_lib[1],
+            "split_max": e_split[0], "split_median": e_split[1], "max_ratio": e_split[0] / e_lib[0],
+            "median_ratio": e_split[1] / e_lib[1], "library_us": t_lib * 1e6, "split_us": t_split * 1e6,
+            "speedup": t_lib / t_split,
+            "gate": "VERDICT r4 item 1: >= 1.6x and error <= 1.5x the library's; the error bound holds, the speed-up "
+                    "does not (DESIGN.md K10): wired as an opt-in, the headline stays on the fp32 MFMA"}
+
+
 def eval_leg(device, probe, items=20, warmup=3):
     """The evaluation hot loop (reference src/evaluate_Network.py:107-118 around few_shot.py:131-176) on the configs[2]
     episode: eval mode, no_grad, per item ``_return_reconstruction`` (image + point encoders, query decode, K1 Chamfer,
@@ -445,19 +471,20 @@ def eval_leg(device, probe, items=20, warmup=3):
     eps = make_episodes(S, Q, 4, seed=77, device=device)
     keep, keep_enabled = list(probe.records), probe.enabled
     probe.records, probe.enabled = [], False
-    from fpsg_amd import winograd
-    with torch.no_grad(), winograd.weights_frozen():       # as evaluate_Network.main wraps its loop
-        for i in range(warmup):
-            out = model._return_reconstruction(eps[i % len(eps)])
+    from fpsg_amd.engine import EvalItem
+    with EvalItem(model) as run_item:                      # as evaluate_Network.main runs its loop
+        for i in range(max(warmup, 4)):                    # (two eager items, the capture, one replay)
+            out = run_item(eps[i % len(eps)])
             out["cd_loss"].item(), out["emd_loss"].item()
         torch.cuda.synchronize()
         probe.enabled = True
         t0 = time.perf_counter()
         for i in range(items):
-            out = model._return_reconstruction(eps[i % len(eps)])
+            out = run_item(eps[i % len(eps)])
             cd, emd = out["cd_loss"].item() / Q, out["emd_loss"].item() / Q
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
+        graphed = bool(run_item._graphs)
     probe.enabled = False
     sec = {}
     for (k, B, N, M), e0, e1 in probe.records:
@@ -469,6 +496,7 @@ def eval_leg(device, probe, items=20, warmup=3):
             "workload": "evaluation loop, configs[2] episode: 32-shot 5-query PointNet, eval mode, no_grad; per item "
                         "_return_reconstruction (37 images + 64 clouds encoded, 5 query clouds decoded, Chamfer K1 + "
                         "Sinkhorn-form EMD K2b on B=5 x 2048 x 2048) + two .item() reads",
+            "hip_graph": graphed,
             "k1_chamfer_us_per_item": sec.get("chamfer_fwd", 0.0) / items * 1e6,
             "k2b_sinkhorn_us_per_item": sec.get("sinkhorn", 0.0) / items * 1e6,
             "k2b_share_of_item": sec.get("sinkhorn", 0.0) / el,
@@ -750,6 +778,26 @@ def main():
                     torch.cuda.empty_cache()
                 except Exception as e:      # the headline numbers stay valid without a leg
                     configs[wl] = {"error": repr(e)}
+            # K10 (opt-in, NOT the headline): the same c5 step with the trunk's transform-domain products on the bf16 matrix
+            # pipe, fp32 operands split exactly into three bf16 pieces (FPSG_GEMM_SPLIT=1); its own error beside it
+            if args.workload == "c5":
+                try:
+                    os.environ["FPSG_GEMM_SPLIT"] = "1"
+                    r = run_workload("c5", args, rank, world, device, steps=10, warmup=3)
+                    configs["c5_split"] = {
+                        "episodes_per_s": r["value"], "ms_per_episode": 1e3 / r["value"], "steps": r["steps"],
+                        "vs_headline": r["value"] / main_run["value"],
+                        "arithmetic": "FPSG_GEMM_SPLIT=1: Winograd-domain products of the >= 128-channel layers by "
+                                      "fpsg_gemm_split -- fp32 operands split exactly into 3 x bf16, the six products of "
+                                      "order <= 2^-18 on v_mfma_f32_32x32x16_bf16, fp32 accumulation; everything else as "
+                                      "the headline (fp32 MFMA / VALU).  Opt-in: the headline line stays on the fp32 MFMA",
+                        "final_loss": r["loss"], "gemm_error": split_gemm_error(device)}
+                    del r
+                except Exception as e:
+                    configs["c5_split"] = {"error": repr(e)}
+                finally:
+                    os.environ.pop("FPSG_GEMM_SPLIT", None)
+                    torch.cuda.empty_cache()
             try:
                 configs["eval"] = eval_leg(device, probe)
             except Exception as e:

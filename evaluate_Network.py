@@ -19,8 +19,8 @@ from collections import defaultdict
 
 import torch
 
-from fpsg_amd import cli, winograd
-from fpsg_amd.engine import build_model, to_device
+from fpsg_amd import cli
+from fpsg_amd.engine import EvalItem, build_model, to_device
 
 
 def main(opt):
@@ -42,15 +42,16 @@ def main(opt):
     model = model.to(device).eval()
 
     per_class_cd, per_class_emd = defaultdict(list), defaultdict(list)
-    # the weights do not change while evaluating: transformed filters and stacked decoder weights are made once, not per item
-    with torch.no_grad(), winograd.weights_frozen():
+    # the weights do not change while evaluating: transformed filters, stacked decoder weights and BatchNorm coefficients
+    # are made once, not per item; on a GPU the item in front of the EMD is replayed as a hipGraph (engine.EvalItem)
+    with EvalItem(model) as run_item:
         for item, sample in enumerate(dl_test):
             sample = to_device(sample, device)
             if getattr(opt, "npy_folder", ""):
                 os.makedirs(opt.npy_folder, exist_ok=True)
                 model.draw_reconstruction(sample, [item, opt.npy_folder])
                 continue
-            out = model._return_reconstruction(sample)
+            out = run_item(sample)
             name = sample["class"][0]
             per_class_cd[name].append(out["cd_loss"].item() / n_query)
             per_class_emd[name].append(out["emd_loss"].item() / n_query)

@@ -1073,9 +1073,13 @@ extern "C" int fpsg_bn_act_fwd(const float* x, const float* pre_bias, const floa
   FPSG_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0, FPSG_E_ALIGN,
                "fpsg_bn_act_fwd: x and y must be 16-byte aligned");
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (!training) { FPSG_REQUIRE_PTR(running_mean); FPSG_REQUIRE_PTR(running_var); }
+  // training == 2: evaluation mode with `chan` already holding the channel coefficients (the caller computed them once
+  // for a block of calls during which the running statistics do not change: fpsg_bn_stats(training = 0))
+  const bool chan_given = training == 2;
+  if (chan_given) training = 0;
+  if (!training && !chan_given) { FPSG_REQUIRE_PTR(running_mean); FPSG_REQUIRE_PTR(running_var); }
   if ((long)N * L <= kBnSmallMax) {
-    if (!training) {
+    if (!training && !chan_given) {
       hipLaunchKernelGGL(bn_eval_chan_kernel, dim3((C + 255) / 256), dim3(256), 0, s, running_mean, running_var,
                          gamma, beta, C, eps, chan);
       if ((rc = launch_status("fpsg_bn_act_fwd(eval)"))) return rc;
@@ -1093,7 +1097,7 @@ extern "C" int fpsg_bn_act_fwd(const float* x, const float* pre_bias, const floa
                        (double)N * (double)L, eps, chan, batch_mean, batch_var_unbiased, running_mean, running_var,
                        momentum);
     if ((rc = launch_status("fpsg_bn_act_fwd(finalize)"))) return rc;
-  } else {
+  } else if (!chan_given) {
     hipLaunchKernelGGL(bn_eval_chan_kernel, dim3((C + 255) / 256), dim3(256), 0, s, running_mean, running_var,
                        gamma, beta, C, eps, chan);
     if ((rc = launch_status("fpsg_bn_act_fwd(eval)"))) return rc;
@@ -1298,6 +1302,8 @@ extern "C" int fpsg_bn_act_pool_fwd(const float* x, const float* pre_bias, const
                "fpsg_bn_act_pool_fwd: x and y_pooled must be 16-byte aligned");
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int L = H * W;
+  const bool chan_given = training == 2;        // as in fpsg_bn_act_fwd
+  if (chan_given) training = 0;
   if (training) {
     int S = n_parts;
     if (parts) {
@@ -1312,7 +1318,7 @@ extern "C" int fpsg_bn_act_pool_fwd(const float* x, const float* pre_bias, const
                        (double)N * (double)L, eps, chan, batch_mean, batch_var_unbiased, running_mean, running_var,
                        momentum);
     if ((rc = launch_status("fpsg_bn_act_pool_fwd(finalize)"))) return rc;
-  } else {
+  } else if (!chan_given) {
     FPSG_REQUIRE_PTR(running_mean); FPSG_REQUIRE_PTR(running_var);
     hipLaunchKernelGGL(bn_eval_chan_kernel, dim3((C + 255) / 256), dim3(256), 0, s, running_mean, running_var,
                        gamma, beta, C, eps, chan);
@@ -1382,6 +1388,8 @@ extern "C" int fpsg_bn_act_max_fwd(const float* x, const float* pre_bias, const 
   const int S = items_max >= 4 * kBnSlices ? kBnSlices : (items_max + 3) / 4;
   RowExt* ext = reinterpret_cast<RowExt*>(ws + (size_t)C * kBnSlices * 2);
   dim3 grid(C, S);
+  const bool chan_given = training == 2;        // as in fpsg_bn_act_fwd
+  if (chan_given) training = 0;
   if (training) {
     if (beyond_cache((size_t)N * C * L * sizeof(float))) hipLaunchKernelGGL((bn_reduce_ext_kernel<1, true>), grid, dim3(kBnThreads), 0, s, x, pre_bias, N, C, L, S, ws, ext);
     else hipLaunchKernelGGL(bn_reduce_ext_kernel<1>, grid, dim3(kBnThreads), 0, s, x, pre_bias, N, C, L, S, ws, ext);
@@ -1391,12 +1399,14 @@ extern "C" int fpsg_bn_act_max_fwd(const float* x, const float* pre_bias, const 
                        momentum);
     if ((rc = launch_status("fpsg_bn_act_max_fwd(finalize)"))) return rc;
   } else {
-    FPSG_REQUIRE_PTR(running_mean); FPSG_REQUIRE_PTR(running_var);
+    if (!chan_given) { FPSG_REQUIRE_PTR(running_mean); FPSG_REQUIRE_PTR(running_var); }
     hipLaunchKernelGGL(bn_reduce_ext_kernel<0>, grid, dim3(kBnThreads), 0, s, x, pre_bias, N, C, L, S, ws, ext);
     if ((rc = launch_status("fpsg_bn_act_max_fwd(extremes)"))) return rc;
-    hipLaunchKernelGGL(bn_eval_chan_kernel, dim3((C + 255) / 256), dim3(256), 0, s, running_mean, running_var,
-                       gamma, beta, C, eps, chan);
-    if ((rc = launch_status("fpsg_bn_act_max_fwd(eval)"))) return rc;
+    if (!chan_given) {
+      hipLaunchKernelGGL(bn_eval_chan_kernel, dim3((C + 255) / 256), dim3(256), 0, s, running_mean, running_var,
+                         gamma, beta, C, eps, chan);
+      if ((rc = launch_status("fpsg_bn_act_max_fwd(eval)"))) return rc;
+    }
   }
   const int rows = N * C;
   dim3 og((rows + 255) / 256);

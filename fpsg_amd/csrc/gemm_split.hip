@@ -976,7 +976,10 @@ bool plan_for(int batch, int M, int N, int K, int transB, int variant, Plan* p) 
   p->abl = variant >= 2000 ? variant / 1000 - 1 : 0;             // + 2000 / 3000 / 4000: ablation builds (tiles 0, 2; NN)
   if (tile >= kNumTiles) return false;
   const long cus = 256;
-  if (tile < 0) tile = transB ? 3 : 2;                    // measured: tools/bench_gemm_split.py, profiles/r05/
+  // measured (tools/bench_gemm_split.py, profiles/r05/gemm_split_variants.txt): the 128 x 128 tiles with three
+  // workgroups per CU and the split placed among the MFMAs everywhere, except the long reductions of the weight
+  // gradient with at least 256 x 256 outputs: one 256 x 256 tile per CU, the reduction split over the chip
+  if (tile < 0) tile = (transB && M >= 256 && N >= 256 && K >= 1024) ? 0 : 5;
   const Tile& t = kTiles[tile];
   p->tile = tile;
   p->bm = t.bm; p->bn = t.bn; p->bk = t.bk;

@@ -183,6 +183,19 @@ class ImgPCProtoNet(nn.Module):
                 "support_rec_loss": loss_rec_s}
 
     # ---------------------------------------------------------------------- evaluation
+    def _reconstruct_for_eval(self, sample):
+        """The part of ``_return_reconstruction`` in front of the EMD: ``(syn_pc, ref_pc_q, cd_loss, diameter)`` with no host
+        read in it (``engine.EvalItem`` replays it as a hipGraph).  ``diameter`` (0-dim device tensor) is what the Sinkhorn
+        form's annealing schedule starts from -- ``metrics.sinkhorn_divergence`` would compute the same value itself."""
+        img_zad, img_zq, pc_z_proto, _ = self._encode(sample["xs"], sample["xq"], sample["xad"],
+                                                      sample["pcs"], sample["pcad"])
+        syn_pc = self._decode_queries(img_zq, pc_z_proto)
+        ref_pc_q = sample["pcq"].squeeze(0).contiguous()
+        loss_rec_q = self.pc_metric(syn_pc, ref_pc_q).sum()
+        pts = torch.cat([syn_pc.detach().reshape(-1, 3), ref_pc_q.reshape(-1, 3)])
+        diameter = (pts.amax(0) - pts.amin(0)).norm()
+        return syn_pc, ref_pc_q, self.query_factor * loss_rec_q, diameter
+
     def _return_reconstruction(self, sample):
         img_zad, img_zq, pc_z_proto, _ = self._encode(sample["xs"], sample["xq"], sample["xad"],
                                                       sample["pcs"], sample["pcad"])

@@ -41,6 +41,17 @@ def _parse_act(act):
     return _ACT_CODES[act], 0.0
 
 
+def _chan_and_mode(training, weight, bias, running_mean, running_var, eps, C, dev):
+    """``(chan [4, C], training argument of the K5 forward)``: 1 = batch statistics; 0 = evaluation, coefficients formed by
+    the call; 2 = evaluation inside a ``winograd.weights_frozen`` block, coefficients formed once for the block
+    (``winograd.eval_chan``).  ``FPSG_EVAL_CHAN_CACHE=0``: always 0 in evaluation (A/B)."""
+    if training:
+        return torch.empty((4, C), dtype=torch.float32, device=dev), 1
+    if os.environ.get("FPSG_EVAL_CHAN_CACHE", "1") == "0":
+        return torch.empty((4, C), dtype=torch.float32, device=dev), 0
+    return winograd.eval_chan(weight, bias, running_mean, running_var, eps, C, dev)
+
+
 class _BNAct(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, running_mean, running_var, training, eps, act_code, slope, want_stats,
@@ -51,7 +62,7 @@ class _BNAct(torch.autograd.Function):
         dev = x.device
         ctx.set_materialize_grads(False)        # no zero tensors for the (non-differentiable) statistics outputs
         y = torch.empty_like(x)
-        chan = torch.empty((4, C), dtype=torch.float32, device=dev)
+        chan, mode = _chan_and_mode(training, weight, bias, running_mean, running_var, eps, C, dev)
         ws = torch.empty((lib.fpsg_bn_workspace_floats(N, C, L),), dtype=torch.float32, device=dev)
         bmean = bvar = None
         if training and want_stats:
@@ -64,7 +75,7 @@ class _BNAct(torch.autograd.Function):
                 _hip.ptr(bias) if bias is not None else None,
                 _hip.ptr(running_mean) if running_mean is not None else None,
                 _hip.ptr(running_var) if running_var is not None else None, float(momentum),
-                N, C, L, 1 if training else 0, float(eps), act_code, float(slope), _hip.ptr(y), _hip.ptr(chan),
+                N, C, L, mode, float(eps), act_code, float(slope), _hip.ptr(y), _hip.ptr(chan),
                 _hip.ptr(bmean) if bmean is not None else None, _hip.ptr(bvar) if bvar is not None else None,
                 _hip.ptr(ws), _hip.stream_of(x))
         _hip.check(rc, "fpsg_bn_act_fwd")
@@ -172,14 +183,14 @@ class _BNActPool(torch.autograd.Function):
         lib = _hip.load()
         dev = x.device
         yp = torch.empty((N, C, H // 2, W // 2), dtype=torch.float32, device=dev)
-        chan = torch.empty((4, C), dtype=torch.float32, device=dev)
+        chan, mode = _chan_and_mode(training, weight, bias, running_mean, running_var, eps, C, dev)
         use_parts = parts is not None and training
         ws = None if use_parts else torch.empty((lib.fpsg_bn_pool_workspace_floats(N, C, H, W),), dtype=torch.float32,
                                                 device=dev)
         opt = lambda t: _hip.ptr(t) if t is not None else None
         with torch.cuda.device(dev):
             rc = lib.fpsg_bn_act_pool_fwd(_hip.ptr(x), opt(pre_bias), opt(weight), opt(bias), opt(running_mean),
-                                          opt(running_var), float(momentum), N, C, H, W, 1 if training else 0,
+                                          opt(running_var), float(momentum), N, C, H, W, mode,
                                           float(eps), act_code, float(slope), _hip.ptr(yp), _hip.ptr(chan), None, None,
                                           opt(ws), _hip.ptr(parts) if use_parts else None,
                                           parts.shape[1] if use_parts else 0, _hip.stream_of(x))
@@ -225,12 +236,12 @@ class _BNActMax(torch.autograd.Function):
         dev = x.device
         out = torch.empty((N, C), dtype=torch.float32, device=dev)
         idx = torch.empty((N, C), dtype=torch.int32, device=dev)
-        chan = torch.empty((4, C), dtype=torch.float32, device=dev)
+        chan, mode = _chan_and_mode(training, weight, bias, running_mean, running_var, eps, C, dev)
         ws = torch.empty((lib.fpsg_bn_max_workspace_floats(N, C, L),), dtype=torch.float32, device=dev)
         opt = lambda t: _hip.ptr(t) if t is not None else None
         with torch.cuda.device(dev):
             rc = lib.fpsg_bn_act_max_fwd(_hip.ptr(x), opt(pre_bias), opt(weight), opt(bias), opt(running_mean),
-                                         opt(running_var), float(momentum), N, C, L, 1 if training else 0, float(eps),
+                                         opt(running_var), float(momentum), N, C, L, mode, float(eps),
                                          act_code, float(slope), _hip.ptr(out), _hip.ptr(idx), _hip.ptr(chan), None,
                                          None, _hip.ptr(ws), _hip.stream_of(x))
         _hip.check(rc, "fpsg_bn_act_max_fwd")
@@ -296,12 +307,12 @@ class _ConvBNActMax(torch.autograd.Function):
         x = torch.bmm(W.unsqueeze(0).expand(B, -1, -1), a)              # [B, C, L], bias-free
         out = torch.empty((B, C), dtype=torch.float32, device=dev)
         idx = torch.empty((B, C), dtype=torch.int32, device=dev)
-        chan = torch.empty((4, C), dtype=torch.float32, device=dev)
+        chan, mode = _chan_and_mode(training, gamma, beta, running_mean, running_var, eps, C, dev)
         ws = torch.empty((lib.fpsg_bn_max_workspace_floats(B, C, L),), dtype=torch.float32, device=dev)
         opt = lambda t: _hip.ptr(t) if t is not None else None
         with torch.cuda.device(dev):
             rc = lib.fpsg_bn_act_max_fwd(_hip.ptr(x), opt(conv_bias), opt(gamma), opt(beta), opt(running_mean),
-                                         opt(running_var), float(momentum), B, C, L, 1 if training else 0, float(eps),
+                                         opt(running_var), float(momentum), B, C, L, mode, float(eps),
                                          act_code, float(slope), _hip.ptr(out), _hip.ptr(idx), _hip.ptr(chan), None,
                                          None, _hip.ptr(ws), _hip.stream_of(a))
         _hip.check(rc, "fpsg_bn_act_max_fwd")

@@ -22,7 +22,7 @@ import os
 
 import torch
 
-from . import _hip
+from . import _hip, gemm_split
 from .bn_counters import count_batch
 
 # Below these widths the transforms' HBM traffic (4x / 2.25x the image tensors) outweighs the saved
@@ -122,6 +122,22 @@ def _wide_enough(c_in: int, c_out: int, m: int) -> bool:
 
 def _call(name, *args):
     _hip.check(getattr(_hip.load(), name)(*args), name)
+
+
+def _bmm(A, B):
+    """The transform-domain products ``M[xi] = A[xi] . B[xi]`` (forward: U . V, data gradient: U' . V'): the library's
+    fp32-MFMA batched GEMM, or -- ``FPSG_GEMM_SPLIT=1``, layers of at least 128 channels -- K10 on the bf16 matrix pipe
+    with exactly split operands (``fpsg_amd/gemm_split.py``: fp32-grade, not the library's bits; opt-in)."""
+    if gemm_split.enabled() and min(A.shape[1], A.shape[2]) >= 128 and A.is_cuda:
+        return gemm_split.bmm_split(A.contiguous(), B.contiguous(), False)
+    return torch.bmm(A, B)
+
+
+def _bmm_nt(A, B):
+    """The weight gradient's ``dU[xi] = dM[xi] . V[xi]^T`` (reduction over the tiles, contiguous in both operands)."""
+    if gemm_split.enabled() and min(A.shape[1], B.shape[1]) >= 128 and A.is_cuda:
+        return gemm_split.bmm_split(A.contiguous(), B.contiguous(), True)
+    return torch.bmm(A, B.transpose(1, 2))
 
 
 _frozen_cache = None     # {(data_ptr, m, flip): U} while a ``weights_frozen`` block is active
@@ -238,6 +254,39 @@ def frozen_cache():
     if _frozen_cache is None or (torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()):
         return None
     return _frozen_cache
+
+
+def frozen_cache_ro():
+    """The step-scoped cache for READING, also while a hipGraph is captured (entries made before the capture are
+    ordinary persistent tensors; a capture must only never ADD its own)."""
+    return _frozen_cache
+
+
+def eval_chan(gamma, beta, running_mean, running_var, eps, C, dev):
+    """Evaluation-mode BatchNorm inside a ``weights_frozen`` block (the evaluation loop, ``evaluate_Network.py:107-118``:
+    neither the affine parameters nor the running statistics change): the channel coefficients ``chan [4, C]`` (scale,
+    shift, mean, rstd) are computed ONCE per BatchNorm and block -- ``fpsg_bn_stats(training = 0)``, one launch -- and
+    every later call of the layer passes them in (``training = 2`` of the K5 forward entry points) instead of launching
+    the coefficient kernel again: 23 launches per evaluated item of the PointNet model.  -> ``(chan, mode)``; outside a
+    block (or for a BatchNorm first seen while a graph is captured) a fresh buffer and mode 0, as before."""
+    cache = _frozen_cache
+    if cache is None or running_mean is None or running_var is None or os.environ.get("FPSG_EVAL_CHAN_CACHE", "1") == "0":
+        return torch.empty((4, C), dtype=torch.float32, device=dev), 0
+    key = ("bn_chan", running_mean.data_ptr(), running_var.data_ptr(), gamma.data_ptr() if gamma is not None else 0,
+           beta.data_ptr() if beta is not None else 0, float(eps))
+    chan = cache.get(key)
+    if chan is not None:
+        return chan, 2
+    chan = torch.empty((4, C), dtype=torch.float32, device=dev)
+    if dev.type != "cuda" or torch.cuda.is_current_stream_capturing():
+        return chan, 0
+    opt = lambda t: _hip.ptr(t) if t is not None else None
+    with torch.cuda.device(dev):
+        _call("fpsg_bn_stats", _hip.ptr(chan), None, opt(gamma), opt(beta), _hip.ptr(running_mean), _hip.ptr(running_var),
+              0.0, 1, C, 1, 0, float(eps), _hip.ptr(chan), None, None, None, None, 0,
+              torch.cuda.current_stream(dev).cuda_stream)
+    cache[key] = chan
+    return chan, 2
 
 
 def _filter(m, w, flip):
@@ -383,7 +432,7 @@ class _Conv3x3(torch.autograd.Function):
                 keep, kept_is_v = x, False                 # V is rebuilt for the weight gradient
             else:
                 V = _input(m, x)
-                Mt = torch.bmm(_filter(m, w, False), V)
+                Mt = _bmm(_filter(m, w, False), V)
                 if want_parts:
                     y, parts = _output(m, Mt, N, H, W, stats_bias, True)
                 else:
@@ -417,14 +466,14 @@ class _Conv3x3(torch.autograd.Function):
                 if fuse_dx:
                     gx = _fused(gy, _filter(m, w, True))
                 else:
-                    gx = _output(m, torch.bmm(_filter(m, w, True), Vg if Vg is not None else _input(m, gy)), N, H, W)
+                    gx = _output(m, _bmm(_filter(m, w, True), Vg if Vg is not None else _input(m, gy)), N, H, W)
                     Vg = None
             if ctx.needs_input_grad[1]:
                 if fuse_dw:
                     gw = _filter_grad(m, _fused_dw(kept, None, None, gy), w)
                 else:
                     V = kept if kept_is_v else _input(m, kept)
-                    gw = _filter_grad(m, torch.bmm(dM if dM is not None else _grad_output(m, gy), V.transpose(1, 2)), w)
+                    gw = _filter_grad(m, _bmm_nt(dM if dM is not None else _grad_output(m, gy), V), w)
         return gx, gw, None, None, None
 
 
@@ -470,16 +519,18 @@ class _BNReluConv3x3(torch.autograd.Function):
         K = w.shape[0]
         lib = _hip.load()
         dev = y.device
-        chan = torch.empty((4, C), dtype=torch.float32, device=dev)
+        chan, mode = (torch.empty((4, C), dtype=torch.float32, device=dev), 1) if training else \
+            eval_chan(gamma, beta, running_mean, running_var, eps, C, dev)
         use_parts = parts is not None and training
-        ws = None if use_parts else torch.empty((lib.fpsg_bn_workspace_floats(N, C, H * W),), dtype=torch.float32, device=dev)
+        ws = None if (use_parts or mode == 2) else torch.empty((lib.fpsg_bn_workspace_floats(N, C, H * W),), dtype=torch.float32, device=dev)
         opt = lambda t: _hip.ptr(t) if t is not None else None
         out_parts = None
         with torch.cuda.device(dev):
-            _call("fpsg_bn_stats", _hip.ptr(y), opt(pre_bias), opt(gamma), opt(beta), opt(running_mean), opt(running_var),
-                  float(momentum), N, C, H * W, 1 if training else 0, float(eps), _hip.ptr(chan), None, None,
-                  opt(ws), _hip.ptr(parts) if use_parts else None, parts.shape[1] if use_parts else 0,
-                  _hip.stream_of(y))
+            if mode != 2:       # (evaluation inside a weights_frozen block: the coefficients are the block's cached ones)
+                _call("fpsg_bn_stats", _hip.ptr(y), opt(pre_bias), opt(gamma), opt(beta), opt(running_mean), opt(running_var),
+                      float(momentum), N, C, H * W, 1 if training else 0, float(eps), _hip.ptr(chan), None, None,
+                      opt(ws), _hip.ptr(parts) if use_parts else None, parts.shape[1] if use_parts else 0,
+                      _hip.stream_of(y))
             if _can_fuse(m, C, K, N * H * W, H, W):
                 if want_parts:
                     out, out_parts = _fused_stats(y, chan, pre_bias, _filter(m, w, False), stats_bias)
@@ -488,7 +539,7 @@ class _BNReluConv3x3(torch.autograd.Function):
                 V = None                                     # rebuilt for the weight gradient
             else:
                 V = _input_act(m, y, chan, pre_bias)
-                Mt = torch.bmm(_filter(m, w, False), V)
+                Mt = _bmm(_filter(m, w, False), V)
                 if want_parts:
                     out, out_parts = _output(m, Mt, N, H, W, stats_bias, True)
                 else:
@@ -524,10 +575,10 @@ class _BNReluConv3x3(torch.autograd.Function):
                 ga = _fused(gout, _filter(m, w, True))
             elif bwd_stats_enabled() and N * H * W > _BN_SMALL_MAX:
                 # the output transform that writes ga also delivers the sums K5's backward starts from
-                ga, bwd_parts = _output_bwd_stats(m, torch.bmm(_filter(m, w, True), Vg if Vg is not None else _input(m, gout)),
+                ga, bwd_parts = _output_bwd_stats(m, _bmm(_filter(m, w, True), Vg if Vg is not None else _input(m, gout)),
                                                   N, H, W, y, pre_bias, chan)
             else:
-                ga = _output(m, torch.bmm(_filter(m, w, True), Vg if Vg is not None else _input(m, gout)), N, H, W)
+                ga = _output(m, _bmm(_filter(m, w, True), Vg if Vg is not None else _input(m, gout)), N, H, W)
             Vg = None
             if ctx.needs_input_grad[9]:
                 if fuse_dw:
@@ -535,7 +586,7 @@ class _BNReluConv3x3(torch.autograd.Function):
                 else:
                     if V is None:
                         V = _input_act(m, y, chan, pre_bias)
-                    gw = _filter_grad(m, torch.bmm(dM if dM is not None else _grad_output(m, gout), V.transpose(1, 2)), w)
+                    gw = _filter_grad(m, _bmm_nt(dM if dM is not None else _grad_output(m, gout), V), w)
             # BatchNorm + ReLU backward on y (K5)
             want_dpb = pre_bias is not None and ctx.needs_input_grad[1]
             dy = torch.empty_like(y)
@@ -601,7 +652,7 @@ class _StemConvBNReluConv(torch.autograd.Function):
                 V = None
             else:
                 V = _input_act(m, y1, chan, b1)
-                Mt = torch.bmm(_filter(m, w2c, False), V)
+                Mt = _bmm(_filter(m, w2c, False), V)
                 if want_parts:
                     out, out_parts = _output(m, Mt, N, H, W, stats_bias, True)
                 else:
@@ -629,14 +680,14 @@ class _StemConvBNReluConv(torch.autograd.Function):
             if _can_fuse(m, K, C, N * H * W, H, W):
                 ga = _fused(gout, _filter(m, w2, True))
             else:
-                ga = _output(m, torch.bmm(_filter(m, w2, True), _input(m, gout)), N, H, W)
+                ga = _output(m, _bmm(_filter(m, w2, True), _input(m, gout)), N, H, W)
             if ctx.needs_input_grad[9]:
                 if V is None and _can_fuse_dw(m, C, K, N, H, W):
                     gw2 = _filter_grad(m, _fused_dw(y1, chan, b1, gout), w2)
                 else:
                     if V is None:
                         V = _input_act(m, y1, chan, b1)
-                    gw2 = _filter_grad(m, torch.bmm(_grad_output(m, gout), V.transpose(1, 2)), w2)
+                    gw2 = _filter_grad(m, _bmm_nt(_grad_output(m, gout), V), w2)
             dgamma = torch.empty((C,), dtype=torch.float32, device=dev)
             dbeta = torch.empty((C,), dtype=torch.float32, device=dev)
             coef = torch.empty((3, C), dtype=torch.float32, device=dev)

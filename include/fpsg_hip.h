@@ -334,6 +334,10 @@ int fpsg_dec1_bwd_ld(const float* dout, int ld_dout, const float* hlat, int ld_h
  *        are then updated in place, running <- (1-momentum)*running + momentum*batch (unbiased
  *        variance), unless momentum < 0; batch_mean / batch_var_unbiased [C] are optional outputs
  *        for a caller with its own update rule.  training == 0: running_mean/var are the statistics.
+ *        training == 2 (fpsg_bn_act_fwd, fpsg_bn_act_pool_fwd, fpsg_bn_act_max_fwd): evaluation mode with chan ALREADY
+ *        holding the coefficients -- the caller got them once from fpsg_bn_stats(training = 0) for a block of calls in
+ *        which the running statistics do not change (the evaluation loop, src/evaluate_Network.py:107-118); saves the
+ *        coefficient launch of every layer and item.
  *   bwd: dx [N,C,L], dgamma [C], dbeta [C] from x, dy and chan (the activation mask is
  *        re-derived from x); coef [3][C] scratch.
  * pre_bias [C] (optional, NULL = none): the bias of the convolution in front of the BatchNorm

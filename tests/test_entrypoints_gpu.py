@@ -75,3 +75,41 @@ def test_gemm_tuning_records_load_and_keep_results(gpu):
         gemm_tuning.disable()
     import torch.cuda.tunable as tunable
     assert not tunable.is_enabled()
+
+
+def test_evaluation_item_replayed_as_a_graph_equals_the_plain_method(gpu, monkeypatch):
+    """``engine.EvalItem`` (the body of evaluate_Network's loop: everything in front of the EMD captured once per input
+    shape and replayed as a hipGraph, BatchNorm coefficients and transformed filters made once per block) against
+    ``ImgPCProtoNet._return_reconstruction`` on the same items with the decoder's patch grids pinned: ``cd_loss`` and
+    ``emd_loss`` within 1e-6, on items the graph was NOT captured on; no coefficient kernel runs
+    for a BatchNorm the block has already seen."""
+    import torch
+    from fpsg_amd import winograd
+    from fpsg_amd.engine import EvalItem, build_model, default_options
+    from fpsg_amd.episodes import synthetic_episode
+    torch.manual_seed(3)
+    model = build_model(default_options(device="cuda")).to(gpu).eval()
+    S, Q = 4, 2
+    grids = model.pc_decoder.sample_grids(Q, gpu, torch.Generator(device=gpu).manual_seed(9))
+    orig = model.pc_decoder.forward
+    model.pc_decoder.forward = lambda h, grid=None, generator=None, pack=None: orig(h, grid=grids, pack=pack)
+    eps = [synthetic_episode(S, Q, n_pts=2048, img_size=96, seed=40 + i, device=gpu) for i in range(5)]
+    monkeypatch.setenv("FPSG_EVAL_CHAN_CACHE", "0")
+    with torch.no_grad():
+        plain = [model._return_reconstruction(ep) for ep in eps]
+    monkeypatch.delenv("FPSG_EVAL_CHAN_CACHE")
+    with EvalItem(model) as item:
+        got = [item(ep) for ep in eps]                     # two eager items, then the capture and replays
+        assert item._graphs, "the third item of a shape must have been captured"
+        cache = winograd.frozen_cache_ro()
+        assert any(isinstance(k, tuple) and k and k[0] == "bn_chan" for k in cache), "coefficients cached for the block"
+    for a, b in zip(plain, got):
+        for key in ("cd_loss", "emd_loss"):
+            x, y = float(a[key]), float(b[key])
+            assert abs(x - y) <= 1e-6 * abs(x), (key, x, y)
+    # a model whose metrics were replaced takes the plain method (tests drive it with the oracle's functions)
+    model.emd_metric = lambda p, q: (p - q).abs().sum()
+    with EvalItem(model) as item:
+        for ep in eps[:4]:
+            item(ep)
+        assert not item._graphs

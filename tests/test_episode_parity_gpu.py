@@ -75,6 +75,13 @@ def test_pointnet_episode_loss_and_gradients(gpu, oracle, monkeypatch, mode, win
     _pointnet_episode(gpu, oracle, mode, wino_m, S=4, Q=2, intra=True)
 
 
+def test_pointnet_episode_with_split_operand_products(gpu, oracle, monkeypatch):
+    """``FPSG_GEMM_SPLIT=1`` (opt-in: K10, the trunk's transform-domain products on the bf16 matrix pipe with exactly split
+    fp32 operands): the 4-shot training episode's losses and every gradient under the SAME bounds as the default path."""
+    monkeypatch.setenv("FPSG_GEMM_SPLIT", "1")
+    _pointnet_episode(gpu, oracle, "train", "4", S=4, Q=2, intra=True)
+
+
 def test_config1_one_shot_episode_loss_and_gradients(gpu, oracle):
     """BASELINE configs[1] -- 1-way 1-shot 1-query, no intra-reconstruction (few_shot.py:75-129 with S = Q = 1): the
     image trunk's training-mode BatchNorm runs over TWO images (support + query; the ad pair is a second call), the

@@ -755,3 +755,50 @@ def test_both_transforms_of_an_output_gradient_from_one_pass(gpu, m, shape, monk
         wg.conv3x3(xr, wr, m).backward(gy)
         res.append((xr.grad, wr.grad))
     assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+
+
+SPLIT_SHAPES = [(7, 256, 128, 28, 28, 4), (3, 128, 256, 56, 56, 4), (5, 512, 512, 14, 14, 4), (2, 160, 136, 28, 36, 4),
+                (3, 128, 128, 14, 14, 2)]
+
+
+@pytest.mark.parametrize("shape", SPLIT_SHAPES)
+def test_forward_and_gradients_with_split_operand_products(gpu, shape, monkeypatch):
+    """``FPSG_GEMM_SPLIT=1`` (opt-in, round 5): the transform-domain products of the layers with at least 128 channels on
+    the bf16 matrix pipe with exactly split fp32 operands (K10, ``fpsg_gemm_split``) instead of the library's fp32
+    GEMMs.  The bounds of ``test_forward_and_gradients_match_conv2d`` UNCHANGED, and against the library-GEMM form of
+    the same Winograd convolution: no further from float64 than 1.5x that form (+ 1e-7 of the scale)."""
+    from fpsg_amd import gemm_split, winograd
+    from fpsg_amd.winograd import conv3x3
+    N, C, K, H, W, m = shape
+    torch.manual_seed(N * 1000 + C)
+    x = torch.randn(N, C, H, W)
+    w = torch.randn(K, C, 3, 3) * (2.0 / (9 * C)) ** 0.5
+    g = torch.randn(N, K, H, W)
+    x64, w64 = x.double().requires_grad_(), w.double().requires_grad_()
+    y64 = F.conv2d(x64, w64, None, 1, 1)
+    y64.backward(g.double())
+    res = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("FPSG_GEMM_SPLIT", flag)
+        assert gemm_split.enabled() == (flag == "1")
+        xg, wg = x.to(gpu).requires_grad_(), w.to(gpu).requires_grad_()
+        y = conv3x3(xg, wg, m)
+        y.backward(g.to(gpu))
+        res[flag] = [_errs(t.detach(), r.detach()) for t, r in ((y, y64), (xg.grad, x64.grad), (wg.grad, w64.grad))]
+    for e_split, e_lib in zip(res["1"], res["0"]):
+        assert e_split <= 1e-4 and e_split <= (4e-5 if m == 4 else 5e-6 + 8 * e_lib), (shape, res)
+        assert e_split <= 1.5 * e_lib + 1e-7, (shape, res)
+
+
+def test_split_products_are_used_only_from_128_channels(gpu, monkeypatch):
+    """Below 128 channels (and with the switch off) the products stay with the library: bit-identical results."""
+    from fpsg_amd.winograd import conv3x3
+    torch.manual_seed(3)
+    x = torch.randn(3, 64, 28, 28, device=gpu)
+    w = torch.randn(96, 64, 3, 3, device=gpu) * 0.05
+    monkeypatch.setenv("FPSG_GEMM_SPLIT", "0")
+    monkeypatch.setenv("FPSG_WINOGRAD_FUSED", "0")       # the three-kernel form (64 input channels would take K6f)
+    a = conv3x3(x, w, 4)
+    monkeypatch.setenv("FPSG_GEMM_SPLIT", "1")
+    b = conv3x3(x, w, 4)
+    assert torch.equal(a, b)
