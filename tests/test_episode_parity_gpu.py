@@ -160,7 +160,10 @@ def _pointnet_episode(gpu, oracle, mode, wino_m, S, Q, intra):
                         for top in ("img_encoder", "pc_encoder", "pc_decoder")}
             assert groups.get("pc_decoder", 0) == 0, aside["ill_conditioned"]
             assert all(groups.get(t, 0) <= n_params[t] for t in ("img_encoder", "pc_encoder")), (groups, n_params)
-            assert all(n.endswith(".bias") for n in aside["cancelled"]), aside["cancelled"]
+            # (measured: every encoder tensor -- weights too -- has an exactly cancelled float64 gradient behind the
+            # two-sample BatchNorm; in the decoder only biases in front of a BatchNorm may)
+            assert all(n.startswith(("img_encoder.", "pc_encoder.")) or n.endswith(".bias") for n in aside["cancelled"]), \
+                aside["cancelled"]
         measured["grad_dev_hip"], measured["grad_dev_cpu32"] = stats
         for top in ("img_encoder", "pc_encoder", "pc_decoder"):
             # (1-shot: behind a BatchNorm over a batch of two the encoders' true gradients are O(eps) and both fp32 runs
@@ -235,8 +238,9 @@ def test_config2_sized_episode_losses(gpu, oracle, monkeypatch):
 
 
 # 3x the distances measured on MI355X at configs[2] size (S = 32, Q = 5, 224 x 224; profiles/r05/episode_parity_deviation.jsonl)
-CONFIG2_GRAD_L2_BOUND = {"img_encoder": 1.0, "pc_encoder": 1.0, "pc_decoder": 1.0}     # PLACEHOLDER until measured
-DGCNN32_GRAD_L2_BOUND = {"img_encoder": 1.0, "pc_encoder": 1.0, "pc_decoder": 1.0}     # PLACEHOLDER until measured
+# measured: PointNet episode 0.0166 / 0.0229 / 0.0113, DGCNN episode (same graphs on both sides) 0.0160 / 0.0056 / 0.0054
+CONFIG2_GRAD_L2_BOUND = {"img_encoder": 0.050, "pc_encoder": 0.069, "pc_decoder": 0.034}
+DGCNN32_GRAD_L2_BOUND = {"img_encoder": 0.048, "pc_encoder": 0.017, "pc_decoder": 0.016}
 
 
 def test_evaluation_dict_with_emd(gpu, oracle):
@@ -287,11 +291,11 @@ def test_evaluation_dict_at_config2_size(gpu, oracle):
     for key in ("cd_loss", "emd_loss"):
         measured[key] = abs(float(a[key]) - float(b[key])) / abs(float(a[key]))
     _record("evaluation_dict_config2_size", measured)
-    assert measured["cd_loss"] <= 1e-4, measured
+    assert measured["cd_loss"] <= 1e-6, measured       # north_star: 1e-4; measured 9.4e-8
     assert measured["emd_loss"] <= EVAL_EMD_BOUND, measured
 
 
-EVAL_EMD_BOUND = 1e-4      # PLACEHOLDER until measured: 3x the measured deviation, at most 1e-4
+EVAL_EMD_BOUND = 1e-6      # measured on MI355X: cd_loss 9.4e-8, emd_loss 0.0 (profiles/r05/episode_parity_deviation.jsonl); floor 1e-6
 
 
 def test_dgcnn_encoder_forward_vs_oracle_graph_ops(gpu, oracle):
