@@ -215,9 +215,9 @@ class EvalItem:
             for sample in loader:
                 out = item(sample)            # {"cd_loss": 0-dim tensor, "emd_loss": 0-dim tensor}
 
-    The context is one ``winograd.weights_frozen`` block per phase -- weights and running statistics do not change while
-    evaluating, so transformed filters, stacked decoder weights and the BatchNorms' channel coefficients are made once,
-    not per item.  ``graph=True`` [default on a GPU, ``FPSG_EVAL_GRAPH=0`` to switch off]: an item is ~200 launches of a
+    The context is one ``winograd.weights_frozen(constant=True)`` block -- weights and running statistics do not change
+    while evaluating, so transformed filters, stacked decoder weights and the BatchNorms' channel coefficients are made
+    once, not per item.  ``graph=True`` [default on a GPU, ``FPSG_EVAL_GRAPH=0`` to switch off]: an item is ~200 launches of a
     few microseconds and the eager loop is ~17 % host / drain-bound, so everything in front of the EMD -- both encoders,
     the query decode, K1, the clouds' diameter -- is captured once per input shape and replayed; the Sinkhorn form's
     annealing schedule depends on that diameter (geomloss' rule), so the loop reads it (its one mid-item host read, as
@@ -236,27 +236,24 @@ class EvalItem:
         self._graphs = {}
         self._eager = {}
         self._block = None
-        self._registered = False        # the filter bank has seen the layers in an EARLIER block
 
     def __enter__(self):
-        self._block = winograd.weights_frozen()
+        # constant: weights and running statistics stay as they are for the block's whole life, so a capture inside may
+        # read what the eager items before it left in the block's cache (transformed filters, stacked decoder weights,
+        # BatchNorm coefficients): none of those launches is in the graph
+        self._block = winograd.weights_frozen(constant=True)
         self._block.__enter__()
         self._no_grad = torch.no_grad()
         self._no_grad.__enter__()
         return self
 
     def __exit__(self, *exc):
+        self._graphs.clear()            # they read tensors of the block's cache, which ends here
+        self._eager.clear()
         self._no_grad.__exit__(*exc)
         self._block.__exit__(*exc)
         self._block = None
         return False
-
-    def _reopen_block(self):
-        """Leaves and re-enters the frozen block: the filters registered in the block that just ended are refreshed into
-        the bank's persistent buffers when the new one opens, which is where a captured graph reads them."""
-        self._block.__exit__(None, None, None)
-        self._block = winograd.weights_frozen()
-        self._block.__enter__()
 
     def _default_metrics(self) -> bool:
         from .metrics import chamfer_distance
@@ -276,7 +273,6 @@ class EvalItem:
             if n < 2:
                 self._eager[key] = n + 1
                 return model._return_reconstruction(sample)
-            self._reopen_block()                                   # bank refreshed: the capture reads its buffers
             static = {k: sample[k].clone() for k in self._KEYS}
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, capture_error_mode="thread_local"):

@@ -224,15 +224,49 @@ def filter_bank_enabled() -> bool:
     return os.environ.get("FPSG_FILTER_BANK", "1") != "0"
 
 
+class _ReadOnlyView:
+    """The block's cache as a capture sees it when the block is ``constant``: entries made before the capture can be
+    read (ordinary persistent tensors that outlive every replay inside the block), nothing is added (a capture's own
+    tensors live in the graph's pool)."""
+
+    def __init__(self, d):
+        self._d = d
+
+    def __contains__(self, k):
+        return k in self._d
+
+    def __getitem__(self, k):
+        return self._d[k]
+
+    def get(self, k, default=None):
+        return self._d.get(k, default)
+
+    def __setitem__(self, k, v):
+        pass
+
+    def __iter__(self):
+        return iter(self._d)
+
+
+_frozen_constant = False     # the active block promised that weights AND running statistics stay constant for its whole life
+
+
 class weights_frozen:
     """Context manager: the convolution weights do not change inside the block (the episodes of
     one optimizer step), so each transformed filter is computed once and reused: the filters registered by earlier
     steps all at once when the block opens (``_FilterBank``), others when first needed.  The step-scoped cache is not
-    used while a hipGraph is being captured (a replay must not reuse that step's tensors); the bank is."""
+    used while a hipGraph is being captured (a replay must not reuse that step's tensors); the bank is.
+    ``constant=True`` (the evaluation loop: nothing changes for the block's whole life, and graphs captured inside are
+    replayed only inside): a capture may READ the entries made before it."""
+
+    def __init__(self, constant: bool = False):
+        self._constant = bool(constant)
 
     def __enter__(self):
-        global _frozen_cache
+        global _frozen_cache, _frozen_constant
         self._outer = _frozen_cache
+        self._outer_constant = _frozen_constant
+        _frozen_constant = self._constant or (_frozen_constant and _frozen_cache is not None)
         _frozen_cache = {} if _frozen_cache is None else _frozen_cache
         # (a graph captured with the bank reads its pinned buffers whatever FPSG_FILTER_BANK says later)
         if self._outer is None and (filter_bank_enabled() or _bank.has_pinned()) and torch.cuda.is_available() \
@@ -241,8 +275,9 @@ class weights_frozen:
         return self
 
     def __exit__(self, *exc):
-        global _frozen_cache
+        global _frozen_cache, _frozen_constant
         _frozen_cache = self._outer
+        _frozen_constant = self._outer_constant
         if self._outer is None:
             _bank.valid = False
         return False
@@ -251,8 +286,10 @@ class weights_frozen:
 def frozen_cache():
     """The step-scoped cache of a ``weights_frozen`` block (None outside one, or while a hipGraph is captured):
     derived forms of the weights -- transformed filters here, the decoder's stacked weights -- keyed by the caller."""
-    if _frozen_cache is None or (torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()):
+    if _frozen_cache is None:
         return None
+    if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+        return _ReadOnlyView(_frozen_cache) if _frozen_constant else None
     return _frozen_cache
 
 
@@ -297,14 +334,14 @@ def _filter(m, w, flip):
         return banked
     cache = _frozen_cache
     if cache is not None and capturing:
-        cache = None
+        cache = _ReadOnlyView(cache) if _frozen_constant else None
     if cache is not None and key in cache:
         return cache[key]
     K, C = w.shape[0], w.shape[1]
     a2 = (m + 2) ** 2
     U = torch.empty((a2, C, K) if flip else (a2, K, C), dtype=torch.float32, device=w.device)
     _call("fpsg_wino_filter_transform", m, _hip.ptr(w), K, C, 1 if flip else 0, _hip.ptr(U), _hip.stream_of(w))
-    if cache is not None:
+    if cache is not None and not capturing:
         cache[key] = U
         if filter_bank_enabled():
             _bank.register(key, w.detach(), U)      # refreshed with the others from the next block on
