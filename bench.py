@@ -496,8 +496,11 @@ def eval_leg(device, probe, items=20, warmup=3):
     torch.cuda.empty_cache()
     return {"items_per_s": items / el, "ms_per_item": el / items * 1e3, "items": items,
             "workload": "evaluation loop, configs[2] episode: 32-shot 5-query PointNet, eval mode, no_grad; per item "
-                        "_return_reconstruction (37 images + 64 clouds encoded, 5 query clouds decoded, Chamfer K1 + "
-                        "Sinkhorn-form EMD K2b on B=5 x 2048 x 2048) + two .item() reads",
+                        "_return_reconstruction (5 query images + 32 support clouds encoded -- the reference also encodes "
+                        "the 32 ad images and 32 ad clouds and drops their features unused; in eval mode they do not "
+                        "influence the outputs --, 5 query clouds decoded, Chamfer K1 + Sinkhorn-form EMD K2b on "
+                        "B=5 x 2048 x 2048) + two .item() reads; FPSG_EVAL_PRUNE=0: the reference's full forward",
+            "eval_prune": os.environ.get("FPSG_EVAL_PRUNE", "1") != "0",
             "hip_graph": graphed,
             "k1_chamfer_us_per_item": sec.get("chamfer_fwd", 0.0) / items * 1e6,
             "k2b_sinkhorn_us_per_item": sec.get("sinkhorn", 0.0) / items * 1e6,

@@ -116,6 +116,24 @@ class ImgPCProtoNet(nn.Module):
             pc_z = self.pc_encoder(pc_corpus)
         return (*_split_rows(img_z, n_support), *_split_rows(pc_z, n_support))
 
+    def _encode_for_eval(self, img_q, pc_s):
+        """``(img_zq, pc_z_proto)`` for the evaluation outputs.  The reference's ``_return_reconstruction``
+        (``few_shot.py:131-176``) runs the training forward -- it also encodes the S "ad" images and the S "ad" clouds --
+        and then drops ``img_zad`` / ``pc_z_ad`` unused (``:146,161``: only ``img_zq`` and ``pc_z_proto`` reach the
+        decoder).  In evaluation mode (``model.eval()``, ``evaluate_Network.py:99``) BatchNorm normalises with its running
+        statistics, so a sample's features do not depend on what else is in the batch: encoding only the Q query images
+        and the S support clouds gives the same features (to the last bits of a GEMM's summation order: measured
+        <= 1e-7 on ``cd_loss`` / ``emd_loss``) for 5/37 of the image trunk's and half of the point encoder's work.  Only
+        when every module is in evaluation mode; ``FPSG_EVAL_PRUNE=0``: the full forward (A/B, tests)."""
+        n_support, n_query = pc_s.size(1), img_q.size(1)
+        img_zq = self.img_encoder(img_q.reshape(n_query, *img_q.shape[2:]))
+        pc_z_proto = self.pc_encoder(pc_s.reshape(n_support, *pc_s.shape[2:]).transpose(2, 1))
+        return img_zq, pc_z_proto
+
+    def _eval_prune(self) -> bool:
+        return (os.environ.get("FPSG_EVAL_PRUNE", "1") != "0" and not self.training
+                and not any(m.training for m in self.modules()))
+
     def _decode_queries(self, img_zq, pc_z_proto, pack=None):
         """Class prototype = mean of the support features, broadcast to every query
         (reference :104-107)."""
@@ -187,8 +205,10 @@ class ImgPCProtoNet(nn.Module):
         """The part of ``_return_reconstruction`` in front of the EMD: ``(syn_pc, ref_pc_q, cd_loss, diameter)`` with no host
         read in it (``engine.EvalItem`` replays it as a hipGraph).  ``diameter`` (0-dim device tensor) is what the Sinkhorn
         form's annealing schedule starts from -- ``metrics.sinkhorn_divergence`` would compute the same value itself."""
-        img_zad, img_zq, pc_z_proto, _ = self._encode(sample["xs"], sample["xq"], sample["xad"],
-                                                      sample["pcs"], sample["pcad"])
+        if self._eval_prune():
+            img_zq, pc_z_proto = self._encode_for_eval(sample["xq"], sample["pcs"])
+        else:
+            _, img_zq, pc_z_proto, _ = self._encode(sample["xs"], sample["xq"], sample["xad"], sample["pcs"], sample["pcad"])
         syn_pc = self._decode_queries(img_zq, pc_z_proto)
         ref_pc_q = sample["pcq"].squeeze(0).contiguous()
         loss_rec_q = self.pc_metric(syn_pc, ref_pc_q).sum()
@@ -197,8 +217,10 @@ class ImgPCProtoNet(nn.Module):
         return syn_pc, ref_pc_q, self.query_factor * loss_rec_q, diameter
 
     def _return_reconstruction(self, sample):
-        img_zad, img_zq, pc_z_proto, _ = self._encode(sample["xs"], sample["xq"], sample["xad"],
-                                                      sample["pcs"], sample["pcad"])
+        if self._eval_prune():
+            img_zq, pc_z_proto = self._encode_for_eval(sample["xq"], sample["pcs"])
+        else:
+            _, img_zq, pc_z_proto, _ = self._encode(sample["xs"], sample["xq"], sample["xad"], sample["pcs"], sample["pcad"])
         syn_pc = self._decode_queries(img_zq, pc_z_proto)
         ref_pc_q = sample["pcq"].squeeze(0).contiguous()
         loss_rec_q = self.pc_metric(syn_pc, ref_pc_q).sum()

@@ -80,7 +80,8 @@ def test_gemm_tuning_records_load_and_keep_results(gpu):
 def test_evaluation_item_replayed_as_a_graph_equals_the_plain_method(gpu, monkeypatch):
     """``engine.EvalItem`` (the body of evaluate_Network's loop: everything in front of the EMD captured once per input
     shape and replayed as a hipGraph, BatchNorm coefficients and transformed filters made once per block) against
-    ``ImgPCProtoNet._return_reconstruction`` on the same items with the decoder's patch grids pinned: ``cd_loss`` and
+    ``ImgPCProtoNet._return_reconstruction`` in the reference's full form (``FPSG_EVAL_PRUNE=0``: the ad images and ad
+    clouds, whose features evaluation drops unused, encoded too) on the same items with the patch grids pinned: ``cd_loss`` and
     ``emd_loss`` within 1e-6, on items the graph was NOT captured on; no coefficient kernel runs
     for a BatchNorm the block has already seen."""
     import torch
@@ -95,9 +96,11 @@ def test_evaluation_item_replayed_as_a_graph_equals_the_plain_method(gpu, monkey
     model.pc_decoder.forward = lambda h, grid=None, generator=None, pack=None: orig(h, grid=grids, pack=pack)
     eps = [synthetic_episode(S, Q, n_pts=2048, img_size=96, seed=40 + i, device=gpu) for i in range(5)]
     monkeypatch.setenv("FPSG_EVAL_CHAN_CACHE", "0")
+    monkeypatch.setenv("FPSG_EVAL_PRUNE", "0")             # the reference's full forward (ad images and ad clouds encoded too)
     with torch.no_grad():
         plain = [model._return_reconstruction(ep) for ep in eps]
     monkeypatch.delenv("FPSG_EVAL_CHAN_CACHE")
+    monkeypatch.delenv("FPSG_EVAL_PRUNE")
     with EvalItem(model) as item:
         got = [item(ep) for ep in eps]                     # two eager items, then the capture and replays
         assert item._graphs, "the third item of a shape must have been captured"
