@@ -532,6 +532,48 @@ def _are_rows_of_one_block(tensors) -> bool:
     return hit
 
 
+class _BmmSplit(torch.autograd.Function):
+    """``torch.bmm(w, h)`` for the patch MLPs' wide layers (``w [G, out, in]``, ``h [G, in, B*P]``: 1539 -> 769 and
+    769 -> 384 of ``PrimitiveNode``, reference ``point_cloud_net.py:66-79``) on K10 (``FPSG_GEMM_SPLIT=1``, opt-in): forward
+    ``w . h``, ``dh = w^T . g`` (the transposed weights are made once per optimizer step: ``winograd.weights_frozen``'s
+    cache) and ``dw = g . h^T`` (the reduction over the B*P points split over workgroups)."""
+
+    @staticmethod
+    def forward(ctx, w, h):
+        from .gemm_split import bmm_split
+        w, h = w.contiguous(), h.contiguous()
+        ctx.save_for_backward(w, h)
+        return bmm_split(w, h, False)
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import winograd
+        from .gemm_split import bmm_split
+        w, h = ctx.saved_tensors
+        g = g.contiguous()
+        gw = gh = None
+        if ctx.needs_input_grad[1]:
+            cache = winograd.frozen_cache()
+            key = ("bmm_wT", w.data_ptr(), tuple(w.shape))
+            wT = cache.get(key) if cache is not None else None
+            if wT is None:
+                wT = w.transpose(1, 2).contiguous()
+                if cache is not None:
+                    cache[key] = wT
+            gh = bmm_split(wT, g, False)
+        if ctx.needs_input_grad[0]:
+            gw = bmm_split(g, h, True)
+        return gw, gh
+
+
+def _bmm_wide(w, h):
+    """``torch.bmm(w, h)``; layers of at least 128 inputs and outputs through K10 when ``FPSG_GEMM_SPLIT=1``."""
+    from . import gemm_split
+    if gemm_split.enabled() and w.is_cuda and min(w.shape[1], w.shape[2]) >= 128:
+        return _BmmSplit.apply(w, h)
+    return torch.bmm(w, h)
+
+
 def _stack(key, tensors):
     tensors = list(tensors)
     if tensors[0].is_cuda and _are_rows_of_one_block(tensors):
@@ -733,9 +775,9 @@ class PCDecoder(nn.Module):
         with torch.no_grad():
             _update_running_calls(bn1s, 1, stats)
         w, b = pack["n2"]
-        h = _group_batch_norm_rows(torch.bmm(w, h), [n.bn2 for n in nodes], 1, act, pack["nbn2"], b.reshape(-1), seg_lens)
+        h = _group_batch_norm_rows(_bmm_wide(w, h), [n.bn2 for n in nodes], 1, act, pack["nbn2"], b.reshape(-1), seg_lens)
         w, b = pack["n3"]
-        h = _group_batch_norm_rows(torch.bmm(w, h), [n.bn3 for n in nodes], 1, act, pack["nbn3"], b.reshape(-1), seg_lens)
+        h = _group_batch_norm_rows(_bmm_wide(w, h), [n.bn3 for n in nodes], 1, act, pack["nbn3"], b.reshape(-1), seg_lens)
         w, b = pack["n4"]
         out = torch.tanh(torch.baddbmm(b, w, h))                                        # [G,3,B*P]
         return out.view(G, 3, B, P).permute(2, 0, 3, 1).reshape(B, G * P, 3).contiguous()
@@ -833,9 +875,9 @@ class PCDecoder(nn.Module):
             h = torch.bmm(w_pts, pts).view(G, D, B, P) + h_lat.unsqueeze(-1)
             h = _group_batch_norm(h.view(G, D, B * P), bn1s, 1, act, pack["nbn1"])
         w, b = pack["n2"]
-        h = _group_batch_norm(torch.bmm(w, h), [n.bn2 for n in nodes], 1, act, pack["nbn2"], b.reshape(-1))
+        h = _group_batch_norm(_bmm_wide(w, h), [n.bn2 for n in nodes], 1, act, pack["nbn2"], b.reshape(-1))
         w, b = pack["n3"]
-        h = _group_batch_norm(torch.bmm(w, h), [n.bn3 for n in nodes], 1, act, pack["nbn3"], b.reshape(-1))
+        h = _group_batch_norm(_bmm_wide(w, h), [n.bn3 for n in nodes], 1, act, pack["nbn3"], b.reshape(-1))
         w, b = pack["n4"]
         out = torch.tanh(torch.baddbmm(b, w, h))                                        # [G,3,B*P]
         return out.view(G, 3, B, P).permute(2, 0, 3, 1).reshape(B, G * P, 3).contiguous()

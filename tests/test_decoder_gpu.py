@@ -41,8 +41,11 @@ def _make(B, seed):
     return dec, hidden, grids
 
 
-@pytest.mark.parametrize("mode,B", [("train", 5), ("train", 32), ("eval", 3)])
-def test_batched_decoder_vs_literal_float64(gpu, mode, B):
+@pytest.mark.parametrize("mode,B", [("train", 5), ("train", 32), ("eval", 3), ("train-split", 5)])
+def test_batched_decoder_vs_literal_float64(gpu, mode, B, monkeypatch):
+    if mode == "train-split":       # FPSG_GEMM_SPLIT=1 (opt-in): the wide layers' three products by K10, same bounds
+        monkeypatch.setenv("FPSG_GEMM_SPLIT", "1")
+        mode = "train"
     dec, hidden, grids = _make(B, 7)
     dec.train(mode == "train")
     ref = copy.deepcopy(dec).double()
