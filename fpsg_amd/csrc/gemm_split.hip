@@ -959,6 +959,8 @@ constexpr Tile kTiles[] = {
     {256, 256, 16, 512, 1},   // 4: tile 0 with the split, LDS stores and loads placed among the MFMAs of one stream
     {128, 128, 16, 256, 3},   // 5: tile 2, the same
     {128, 256, 16, 256, 2},   // 6: tile 3, the same
+    {256, 128, 16, 512, 2},   // 7: 2 x 4 waves of 128 x 32 within 128 registers, two workgroups per CU (half the B
+                              //    conversions of the 128-row tiles when M >= 256)
 };
 constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 
@@ -1190,7 +1192,8 @@ extern "C" int fpsg_gemm_split(const float* A, const float* B, float* C, int bat
     case 3: FPSG_GEMM_LAUNCH(128, 256, 16, 1, 4, 2); break;
     case 4: FPSG_GEMM_LAUNCH_PIPE(256, 256, 16, 2, 4, 2); break;
     case 5: FPSG_GEMM_LAUNCH_PIPE(128, 128, 16, 2, 2, 3); break;
-    default: FPSG_GEMM_LAUNCH_PIPE(128, 256, 16, 1, 4, 2); break;
+    case 6: FPSG_GEMM_LAUNCH_PIPE(128, 256, 16, 1, 4, 2); break;
+    default: FPSG_GEMM_LAUNCH_PIPE(256, 128, 16, 2, 4, 4); break;
   }
 #undef FPSG_GEMM_LAUNCH
 #undef FPSG_GEMM_LAUNCH_PIPE

@@ -27,7 +27,7 @@ def _check(A, B, transB, variant, bound=4e-7):
     return err, lib_err
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, -1])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, -1])
 @pytest.mark.parametrize("b,M,N,K", [(2, 256, 300, 32), (3, 100, 70, 48), (1, 512, 257, 128), (2, 37, 1000, 64)])
 def test_nn_matches_float64(gpu, variant, b, M, N, K):
     g = torch.Generator(device="cpu").manual_seed(b * 1000 + M + N + K)
@@ -36,7 +36,7 @@ def test_nn_matches_float64(gpu, variant, b, M, N, K):
     _check(A, B, False, variant)
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 20, 31, 52, 73, 24, 35, 46, -1])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 20, 31, 52, 73, 24, 35, 46, 27, -1])
 @pytest.mark.parametrize("b,M,N,K", [(2, 256, 256, 1813), (1, 100, 130, 53), (3, 256, 128, 592), (1, 512, 512, 7252)])
 def test_nt_split_reduction_matches_float64(gpu, variant, b, M, N, K):
     g = torch.Generator(device="cpu").manual_seed(b * 1000 + M + N + K)
@@ -51,7 +51,7 @@ def test_exact_on_integers_and_asymmetric_operands(gpu):
     g = torch.Generator(device="cpu").manual_seed(5)
     A = torch.randint(-8, 9, (2, 300, 80), generator=g).float().to(gpu)
     B = torch.randint(-8, 9, (2, 80, 500), generator=g).float().to(gpu)
-    for v in (0, 1, 2, 3, 4, 5, 6):
+    for v in (0, 1, 2, 3, 4, 5, 6, 7):
         C = gemm_split(A, B, False, v)
         assert torch.equal(C, torch.bmm(A.double(), B.double()).float())
     Bt = B.transpose(1, 2).contiguous()

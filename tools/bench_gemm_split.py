@@ -47,6 +47,7 @@ def main():
     ap.add_argument("--quick", action="store_true", help="256 -> 256 @56 only")
     ap.add_argument("--err-batches", type=int, default=3)
     ap.add_argument("--dist", default="randn", choices=["randn", "wino"])
+    ap.add_argument("--decoder", action="store_true", help="the decoder's wide layers instead of the trunk's products")
     ap.add_argument("--no-tuning", action="store_true", help="library GEMMs by the libraries' default heuristic")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -57,15 +58,18 @@ def main():
     base_variants = [int(v) for v in args.variants.split(",")]
     shapes = ((256, 256, 56),) if args.quick else ((128, 128, 112), (128, 256, 56), (256, 256, 56), (256, 512, 28),
                                                    (512, 512, 28), (512, 512, 14))
+    if args.decoder:     # the patch MLPs' wide layers: 16 patches, (in -> out) on 37 x 128 points (H = 0 marks them)
+        shapes = ((1539, 769, 0), (769, 384, 0), (769, 1539, 0))
     for C, K, H in shapes:
-        P = args.n_img * ((H + 3) // 4) ** 2
-        U = torch.randn(36, K, C, device=dev)
-        V = torch.randn(36, C, P, device=dev)
-        gM = torch.randn(36, K, P, device=dev)
+        P = args.n_img * ((H + 3) // 4) ** 2 if H else args.n_img * 128
+        nb_ = 36 if H else 16
+        U = torch.randn(nb_, K, C, device=dev)
+        V = torch.randn(nb_, C, P, device=dev)
+        gM = torch.randn(nb_, K, P, device=dev)
         if args.dist == "wino":       # the spread of magnitudes of transform-domain data: per-xi scales over 3 decades
             s = torch.logspace(-1.5, 1.5, 36, device=dev).view(36, 1, 1)
             U, V, gM = U / s, V * s, gM * s
-        flop = 2.0 * 36 * K * C * P
+        flop = 2.0 * nb_ * K * C * P
         packed = {int(v): pack_a(U, int(v)) for v in args.packed.split(",") if v != ""}
 
         if args.persistent and 0 not in packed:
@@ -90,7 +94,7 @@ def main():
             else:
                 ref = torch.bmm(gM[:nb].double(), V[:nb].double().transpose(1, 2))
             e_lib = _errors(lib_fn()[:nb], ref)
-            row = {"shape": f"{C}->{K} @{H}", "leg": leg, "dims": f"36 x [{K}x{C}].[{C}x{P}]" if leg == "fwd" else f"36 x [{K}x{P}].[{P}x{C}]",
+            row = {"shape": f"{C}->{K} @{H}", "leg": leg, "dims": f"{nb_} x [{K}x{C}].[{C}x{P}]" if leg == "fwd" else f"{nb_} x [{K}x{P}].[{P}x{C}]",
                    "lib_err_max": e_lib[0], "lib_err_med": e_lib[1]}
             outs = {}
             for v in variants:
