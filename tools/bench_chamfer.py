@@ -62,7 +62,9 @@ def main():
             return lambda: getattr(lib, name)(p1.data_ptr(), p2.data_ptr(), i1.data_ptr(), i2.data_ptr(), g1.data_ptr(),
                                               g2.data_ptr(), B, N, M, gx1.data_ptr(), gx2.data_ptr(), s)
 
-        runs = [("fwd two-pass", two_pass(-1), FWD_BYTES), ("fwd tiled", tiled(-1), FWD_BYTES)]
+        runs = [("fwd two-pass", two_pass(-1), FWD_BYTES)]
+        if lib.fpsg_chamfer_workspace_bytes(B, N, M, -1) > 0:       # the one-pass form does not serve fewer than ~7 pairs
+            runs.append(("fwd tiled", tiled(-1), FWD_BYTES))
         if args.sweep:
             runs += [(f"fwd two-pass[cfg{c}]", two_pass(c), FWD_BYTES) for c in range(7)]
             runs += [(f"fwd tiled[{v}]", tiled(v), FWD_BYTES) for v in TILED]
