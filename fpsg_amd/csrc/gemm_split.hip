@@ -935,6 +935,271 @@ __global__ __launch_bounds__(512, 2) void gemm_split_pnn_kernel(const PersistArg
   }
 }
 
+// ---- the persistent forward form with the waves SPECIALISED (round 5, fourth version): waves 0-3 only multiply, waves 4-7
+// only stage.  What the measurements of the earlier forms say (profiles/r05/gemm_split_ablation.txt): the product loop
+// alone is worth 1.5-1.8 PFLOP/s, but (1) a wave that also loads must wait for its own tile stores before it can consume a
+// later load (the vmcnt counter is in order); (2) an LDS-DMA instruction stalls the issuing wave 100-180 cycles; (3) the
+// split's vector instructions and LDS stores sit in the MFMA waves' streams.  With the roles split, a SIMD holds one
+// consumer (fragment reads + 48 MFMAs per step; its stores are never waited for: it issues no load) and one producer.
+// Producers move BOTH operands by LDS-DMA (A: the packed pieces straight into the ring slot two stages ahead; B: the raw
+// fp32 rows into a three-deep raw ring, three stages ahead -- a register-staged B could not be prefetched deeper than one
+// step without hipcc's own vmcnt waits, which do not count DMAs, draining the younger loads: measured 250 us), then split
+// the raw stage that landed a step ago from LDS into the bf16 planes.  Every vmcnt wait is written by hand; one
+// workgroup-wide s_barrier per step hands a ring slot over.  Same ranges / pieces as gemm_split_pnn_kernel; tile 256 x BN.
+// Needs ldb, sB, the range starts (multiples of 32) and B itself aligned to 4 floats (16-byte DMA of B rows).
+// ABL (measurement builds, results meaningless): 1 = producers only meet the barriers, 3 = no B path, 4 = consumers only
+// meet the barriers, 5 = consumers without the tile stores, 6 = 1 + 5
+// Two builds: BM 256 / rings of 3 (one workgroup per CU, 138 KB of LDS), and BM 128 / A ring of 2 (two workgroups per CU,
+// 76 KB each, 128 registers: one workgroup's store burst and barrier waits overlap the other's products).
+template <int BM, int BN, int RA, int RR, int MINW, bool KTAIL, int ABL = 0>
+__global__ __launch_bounds__(512, MINW) void gemm_split_ws_kernel(const PersistArgs g) {
+  constexpr int BK = 16, KG = 2, NC = 4, NP = 4;                           // consumer / producer waves
+  constexpr int TI = BM / NC / 32, TJ = BN / 32;                           // a consumer: BM / 4 rows x BN columns
+  constexpr int PSA = BM * 16 + 64, PSB = BN * 16 + 64;
+  constexpr int A_BYTES = 3 * KG * PSA, B_BYTES = 3 * KG * PSB;
+  constexpr int CHUNKS = 3 * KG * BM / 64, DMA_A = CHUNKS / NP;             // one-KB pieces per packed stage
+  constexpr int RAW = BK * BN * 4, RAW_CHUNKS = RAW / 1024, DMA_B = RAW_CHUNKS / NP;   // raw B stage: [16 k][BN] fp32
+  constexpr int ROWS_PER_DMA = 1024 / (BN * 4), LANES_PER_ROW = BN / 4;    // 16 B per lane
+  constexpr int B_ITEMS = BN * KG, B_PER_THREAD = B_ITEMS / (64 * NP);      // (column, k-group) items per producer thread
+  static_assert(B_ITEMS % (64 * NP) == 0 && CHUNKS % NP == 0 && RAW_CHUNKS % NP == 0, "stage / producer mismatch");
+  static_assert((RA == 2 || RA == 3) && (RR == 2 || RR == 3), "ring depths");
+  // LDS: RA slots of packed A | 2 slots of split B | RR slots of raw B | the piece table
+  __shared__ __attribute__((aligned(16))) unsigned char lds[RA * A_BYTES + 2 * B_BYTES + RR * RAW + kMaxPieces * 16];
+  unsigned char* const ldsB = lds + RA * A_BYTES;
+  unsigned char* const raw_ring = ldsB + 2 * B_BYTES;
+  int* ptab = reinterpret_cast<int*>(raw_ring + RR * RAW);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nsteps = g.stages;
+
+  if (tid == 0) {
+    auto cut = [&](long b) {
+      if (b >= gridDim.x) return g.total;
+      const long raw = g.total / gridDim.x * b + g.total % gridDim.x * b / gridDim.x;
+      const long q = raw / g.N, c = (raw % g.N) & ~31L;
+      return q * g.N + c;
+    };
+    const long nb = gridDim.x, bid = blockIdx.x, q8 = nb / 8, r8 = nb % 8, x8 = bid % 8;
+    const long id = (x8 < r8 ? x8 * (q8 + 1) : r8 * (q8 + 1) + (x8 - r8) * q8) + bid / 8;
+    long pos = cut(id);
+    const long end = cut(id + 1);
+    int np = 0;
+    // g.nt_c bit 1: a first piece of 32 / 64 / 96 / 128 columns by workgroup, so that the CUs do not finish their tiles (and
+    // burst their stores) all at the same moment
+    long first = (g.nt_c & 2) ? 32 * (1 + (id & 3)) : BN;
+    while (pos < end && np < kMaxPieces - 1) {
+      const long q = pos / g.N, c = pos % g.N;
+      long w = g.N - c;
+      if (w > BN) w = BN;
+      if (w > first) w = first;
+      first = BN;
+      if (w > end - pos) w = end - pos;
+      ptab[4 * np] = (int)q; ptab[4 * np + 1] = (int)c; ptab[4 * np + 2] = (int)w;
+      pos += w;
+      ++np;
+    }
+    ptab[4 * (kMaxPieces - 1)] = np;
+  }
+  __syncthreads();
+  const int npieces = __builtin_amdgcn_readfirstlane(ptab[4 * (kMaxPieces - 1)]);
+  if (npieces == 0) return;
+  const int S = npieces * nsteps;
+  auto piece_q = [&](int p) { return __builtin_amdgcn_readfirstlane(ptab[4 * p]); };
+  auto piece_c = [&](int p) { return __builtin_amdgcn_readfirstlane(ptab[4 * p + 1]); };
+  auto piece_w = [&](int p) { return __builtin_amdgcn_readfirstlane(ptab[4 * p + 2]); };
+
+  if (wave >= NC) {
+    // ------------------------------------------------------------------ producers
+    const int pw = wave - NC, pt = tid - 64 * NC;
+    if constexpr (ABL == 1 || ABL == 6) {
+      __builtin_amdgcn_s_barrier();
+      for (int s = 0; s < S; ++s) __builtin_amdgcn_s_barrier();
+      return;
+    }
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<u32x4*>(g.Ap), 0, (int)((long)g.batchq * nsteps * (CHUNKS * 1024)), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(g.B), 0, (int)(((long)(g.batchq / g.tiles_m - 1) * g.sB + (long)(g.K - 1) * g.ldb + g.N) * 4), 0x00020000);
+    const unsigned ld4 = (unsigned)g.ldb * 4u;
+    struct Cursor { int p, kt, q, c0; };
+    auto enter = [&](Cursor& cu, int p) { cu.p = p; cu.kt = 0; cu.q = piece_q(p); cu.c0 = piece_c(p); };
+    auto advance = [&](Cursor& cu) {
+      if (cu.kt + 1 < nsteps) { ++cu.kt; }
+      else if (cu.p + 1 < npieces) enter(cu, cu.p + 1);
+    };
+    auto dma_a = [&](const Cursor& cu, int slot) {
+      const unsigned base = ((unsigned)cu.q * (unsigned)nsteps + (unsigned)cu.kt) * (unsigned)(CHUNKS * 1024);
+      unsigned char* d = lds + slot * A_BYTES;
+#pragma unroll
+      for (int q = 0; q < DMA_A; ++q) {
+        const int c = pw + q * NP;
+        const int plane = c / (BM / 64), r64 = c % (BM / 64);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(d + plane * PSA + r64 * 1024), 16,
+                                                 lane * 16, base + c * 1024, 0, 0);
+      }
+    };
+    // raw B stage [16 k][BN] fp32: one DMA = ROWS_PER_DMA k-rows; columns at or beyond N and k-rows at or beyond K read zeros
+    const int b_lrow = lane / LANES_PER_ROW, b_lcol = (lane % LANES_PER_ROW) * 4;
+    auto dma_b = [&](const Cursor& cu, int rslot) {
+      const int batch = cu.q / g.tiles_m;
+      const unsigned sbase = (unsigned)((long)batch * g.sB * 4) + (unsigned)(cu.kt * BK) * ld4;
+      const int col = cu.c0 + b_lcol;
+      unsigned char* d = raw_ring + rslot * RAW;
+#pragma unroll
+      for (int q = 0; q < DMA_B; ++q) {
+        const int c = pw + q * NP;
+        const int krow = c * ROWS_PER_DMA + b_lrow;
+        const bool ok = col < g.N && (!KTAIL || cu.kt * BK + krow < g.K);
+        const unsigned voff = ok ? (unsigned)col * 4u + (unsigned)krow * ld4 : kOut;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (__attribute__((address_space(3))) void*)(d + c * 1024), 16, voff, sbase, 0, 0);
+      }
+    };
+    auto convert_b = [&](int rslot, int slot) {                             // raw fp32 (LDS) -> three bf16 planes (LDS)
+#pragma unroll
+      for (int n = 0; n < B_PER_THREAD; ++n) {
+        const int it = pt + n * 64 * NP;
+        const int col = it % BN, gq = it / BN;
+        const float* src = reinterpret_cast<const float*>(raw_ring + rslot * RAW) + gq * 8 * BN + col;
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = src[j * BN];
+        u32x4 p1, p2, p3;
+        split8(v, p1, p2, p3);
+        unsigned char* d = ldsB + slot * B_BYTES + gq * PSB + col * 16;
+        *reinterpret_cast<u32x4*>(d) = p1;
+        *reinterpret_cast<u32x4*>(d + KG * PSB) = p2;
+        *reinterpret_cast<u32x4*>(d + 2 * KG * PSB) = p3;
+      }
+    };
+    // stage t: packed A in A slot t % RA (brought in during step t - RA + 1), raw B in raw slot t % RR (during step t - RR),
+    // split B in B slot t % 2 (converted during step t - 1)
+    Cursor ca, cb;
+    enter(ca, 0);
+    enter(cb, 0);
+#pragma unroll
+    for (int t = 0; t < RR; ++t) { dma_b(cb, t); advance(cb); }
+#pragma unroll
+    for (int t = 0; t < RA - 1; ++t) { dma_a(ca, t); advance(ca); }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                    // (P) every producer's DMAs have landed
+    convert_b(0, 0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                    // (0) stage 0 complete
+    int sa = 0, sr = 0, sb = 0;                      // s % RA, s % RR, s % 2
+    for (int s = 0; s < S; ++s) {
+      const int sa_new = sa == 0 ? RA - 1 : sa - 1;  // (s + RA - 1) % RA: the slot stage s - 1 was read from
+      const int sr1 = sr == RR - 1 ? 0 : sr + 1;
+      // raw B(s+1) landed before the previous barrier
+      if constexpr (ABL != 3) convert_b(sr1, sb ^ 1);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      // before stage s+1 is handed over, A(s+1) and raw B(s+2) must have landed: with RA = 3 both were issued a step ago
+      // (only this step's operations may be outstanding); with RA = 2 A(s+1) is issued now, FIRST, and only this step's raw
+      // B(s+RR) may be outstanding
+      if constexpr (RA == 3) {
+        if constexpr (ABL != 3) dma_b(cb, sr);       // raw(s+RR) -> the slot of raw(s), converted in step s-1
+        dma_a(ca, sa_new);
+        if constexpr (ABL != 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_A + DMA_B) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_A) : "memory");
+      } else {
+        dma_a(ca, sa_new);
+        if constexpr (ABL != 3) dma_b(cb, sr);
+        if constexpr (ABL != 3 && RR == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_B) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      advance(ca);
+      advance(cb);
+      sa = sa == RA - 1 ? 0 : sa + 1;
+      sr = sr1;
+      sb ^= 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (DMAs past the end repeat the last stage into free slots)
+    return;
+  }
+
+  // -------------------------------------------------------------------- consumers
+  f32x16 acc[TI][TJ];
+#pragma unroll
+  for (int i = 0; i < TI; ++i)
+#pragma unroll
+    for (int j = 0; j < TJ; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  const int r = lane & 31, h = lane >> 5;
+  const int a_off = h * PSA + (wave * (BM / NC) + r) * 16;                 // + 512 per row block
+  const int b_off = h * PSB + r * 16;                                      // + 512 per column block
+  if constexpr (ABL != 1 && ABL != 6) __builtin_amdgcn_s_barrier();        // (P)
+  __builtin_amdgcn_s_barrier();                                            // (0)
+  if constexpr (ABL == 4) {
+    for (int s = 0; s < S; ++s) __builtin_amdgcn_s_barrier();
+    return;
+  }
+  int kt = 0, piece = 0, sa = 0, sb = 0;
+  int nj = (piece_w(0) + 31) / 32;
+  for (int s = 0; s < S; ++s) {
+    const unsigned char* curA = lds + sa * A_BYTES + a_off;
+    const unsigned char* curB = ldsB + sb * B_BYTES + b_off;
+    frag_t fa[TI][3], fb[2][3];
+    auto read_b = [&](int j, frag_t (&dst)[3]) {
+#pragma unroll
+      for (int t = 0; t < 3; ++t) dst[t] = lds_frag((curB + t * KG * PSB + j * 512));
+    };
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+      for (int t = 0; t < 3; ++t) fa[i][t] = lds_frag((curA + t * KG * PSA + i * 512));
+    read_b(0, fb[0]);
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) {
+      if (j < nj) {                                                         // wave-uniform: a narrower piece costs less
+        if (j + 1 < TJ) read_b(j + 1, fb[(j + 1) & 1]);
+        const frag_t (&b)[3] = fb[j & 1];
+#pragma unroll
+        for (int i = 0; i < TI; ++i) {
+          f32x16 c = acc[i][j];
+          c = mfma_bf16(b[0], fa[i][2], c);
+          c = mfma_bf16(b[1], fa[i][1], c);
+          c = mfma_bf16(b[2], fa[i][0], c);
+          c = mfma_bf16(b[0], fa[i][1], c);
+          c = mfma_bf16(b[1], fa[i][0], c);
+          c = mfma_bf16(b[0], fa[i][0], c);
+          acc[i][j] = c;
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (++kt == nsteps) {                                                  // tile finished: stores nobody waits for
+      const int q = piece_q(piece), c0 = piece_c(piece), w = piece_w(piece);
+      const int batch = q / g.tiles_m, tm = q - batch * g.tiles_m;
+      if ((ABL != 5 && ABL != 6) || g.M < 0)
+        store_tile<TI, TJ>(acc, g.C + batch * g.sC, g.M, g.N, g.ldc, tm * BM + wave * (BM / NC), c0, c0 + w, lane, 0);
+      else {
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+          for (int j = 0; j < TJ; ++j) keep_alive(acc[i][j]);
+      }
+#pragma unroll
+      for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+      kt = 0;
+      ++piece;
+      if (piece < npieces) nj = (piece_w(piece) + 31) / 32;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    sa = sa == RA - 1 ? 0 : sa + 1;
+    sb ^= 1;
+  }
+}
+
 // out[i] = slab 0 + slab 1 + ... (fixed order), n floats per slab
 __global__ __launch_bounds__(256) void gemm_split_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out, long n,
                                                                 long s_split, int splits) {
@@ -1081,26 +1346,52 @@ extern "C" int fpsg_gemm_split_nn_persistent(const void* Ap, const float* B, flo
                                              int ldc, long sB, long sC, int variant, fpsg_stream_t stream) {
   using namespace fpsg;
   FPSG_REQUIRE(batch > 0 && M > 0 && N > 0 && K > 0 && ldb >= N && ldc >= N, FPSG_E_SHAPE, "fpsg_gemm_split_nn_persistent: bad shape");
-  FPSG_REQUIRE(variant >= -1 && variant <= 5, FPSG_E_SHAPE, "fpsg_gemm_split_nn_persistent: unknown variant %d", variant);
+  FPSG_REQUIRE(variant >= -1 && variant <= 14, FPSG_E_SHAPE, "fpsg_gemm_split_nn_persistent: unknown variant %d", variant);
   FPSG_REQUIRE_PTR(Ap);
   FPSG_REQUIRE_PTR(B);
   FPSG_REQUIRE_PTR(C);
-  const int bn = variant == 1 ? 128 : 256;
+  const int bn = (variant == 1 || variant >= 6) ? 128 : 256;
   PersistArgs g;
   g.Ap = static_cast<const u32x4*>(Ap); g.B = B; g.C = C;
   g.M = M; g.N = N; g.K = K; g.ldb = ldb; g.ldc = ldc; g.sB = sB; g.sC = sC;
-  g.tiles_m = (M + 255) / 256; g.stages = (K + 15) / 16; g.batchq = batch * g.tiles_m;
+  const int bm = variant >= 13 ? 128 : 256;
+  g.tiles_m = (M + bm - 1) / bm; g.stages = (K + 15) / 16; g.batchq = batch * g.tiles_m;
   g.total = (long)g.batchq * N;
   g.nt_c = 0;     // (non-temporal stores measured and rejected: see fpsg_gemm_split)
   FPSG_REQUIRE(((long)(batch - 1) * sB + (long)K * ldb) < (1L << 30) && (long)M * ldc < (1L << 29) &&
                    (long)g.batchq * g.stages * 24576 < (1L << 31),
                FPSG_E_LIMIT, "fpsg_gemm_split_nn_persistent: B must stay below 4 GiB, one C matrix and packed A below 2 GiB");
   // one workgroup per CU; more (a multiple of 256) only when a range would hold more tiles than the piece table
-  long grid = 256;
+  long grid = variant >= 13 ? 512 : 256;
   while ((g.total + grid - 1) / grid > (long)(kMaxPieces - 4) * bn) grid += 256;
   if (g.total / 32 < grid) grid = g.total / 32 > 0 ? g.total / 32 : 1;     // tiny problems: at least 32 columns each
   hipStream_t s = static_cast<hipStream_t>(stream);
   const bool ktail = K % 16 != 0;
+  if (variant >= 6) {
+    FPSG_REQUIRE(ldb % 4 == 0 && sB % 4 == 0 && (reinterpret_cast<uintptr_t>(B) & 15) == 0, FPSG_E_SHAPE,
+                 "fpsg_gemm_split_nn_persistent: the specialised-wave form moves B rows by 16-byte DMA (ldb, sB, B aligned to 4 floats)");
+    // 6 / 12: 256 x 128 tiles, one workgroup per CU (12: staggered first pieces); 13 / 14: 128 x 128 tiles, two per CU
+    // (A packed for 128-row tiles: fpsg_gemm_split_pack_a variant 2); 7..11: ablation builds of 6 (ABL 1, 6, 3, 4, 5)
+    const dim3 gr((unsigned)grid), bl(512);
+#define FPSG_WS(BM_, RA_, RR_, MINW_, ABL_)                                                                               \
+  do {                                                                                                                    \
+    if (ktail) hipLaunchKernelGGL((gemm_split_ws_kernel<BM_, 128, RA_, RR_, MINW_, true, ABL_>), gr, bl, 0, s, g);        \
+    else hipLaunchKernelGGL((gemm_split_ws_kernel<BM_, 128, RA_, RR_, MINW_, false, ABL_>), gr, bl, 0, s, g);             \
+  } while (0)
+    switch (variant) {
+      case 12: g.nt_c |= 2; [[fallthrough]];
+      case 6: FPSG_WS(256, 3, 3, 2, 0); break;
+      case 14: g.nt_c |= 2; [[fallthrough]];
+      case 13: FPSG_WS(128, 2, 3, 4, 0); break;
+      case 7: FPSG_WS(256, 3, 3, 2, 1); break;
+      case 8: FPSG_WS(256, 3, 3, 2, 6); break;
+      case 9: FPSG_WS(256, 3, 3, 2, 3); break;
+      case 10: FPSG_WS(256, 3, 3, 2, 4); break;
+      default: FPSG_WS(256, 3, 3, 2, 5); break;
+    }
+#undef FPSG_WS
+    return launch_status("fpsg_gemm_split_nn_persistent (specialised waves)");
+  }
   if (variant >= 2) {       // ablation builds (measurements: tools/bench_gemm_split.py --persistent 2,3,4,5)
     if (variant == 2) hipLaunchKernelGGL((gemm_split_pnn_kernel<256, false, 1>), dim3((unsigned)grid), dim3(512), 0, s, g);
     else if (variant == 3) hipLaunchKernelGGL((gemm_split_pnn_kernel<256, false, 2>), dim3((unsigned)grid), dim3(512), 0, s, g);

@@ -99,17 +99,25 @@ def test_packed_a_exact_on_integers(gpu):
         assert torch.equal(bmm_packed(pack_a(A, v), A.shape, B, v), torch.bmm(A.double(), B.double()).float())
 
 
-@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("variant", [0, 1, 6, 12, 13, 14])
 @pytest.mark.parametrize("b,M,N,K", [(2, 256, 300, 32), (3, 100, 70, 48), (1, 512, 257, 128), (2, 37, 1000, 72),
-                                     (36, 256, 592, 256), (5, 512, 1813, 64), (1, 256, 40000, 16), (7, 300, 33, 16)])
+                                     (36, 256, 592, 256), (5, 512, 1813, 64), (1, 256, 40000, 16), (7, 300, 36, 16),
+                                     (3, 100, 72, 48), (1, 512, 260, 131), (9, 256, 7252, 48)])
 def test_persistent_form_equals_the_tiled_kernels(gpu, variant, b, M, N, K):
     """``fpsg_gemm_split_nn_persistent`` (one launch, a range of the flattened column space per workgroup, pipeline across
-    tile boundaries) against the generic tiled kernel with the same 16-deep k-steps: bit-identical; ranges that start in
-    the middle of a batch entry, span several, hold one ragged tile or dozens."""
+    tile boundaries; variants 6 / 12 / 13 / 14: the forms with consumer and producer waves, 12 and 14 with staggered first pieces) against
+    the generic tiled kernel with the same 16-deep k-steps: bit-identical; ranges that start in the middle of a batch
+    entry, span several, hold one ragged tile or dozens.  The specialised form moves B rows by 16-byte DMA: row lengths
+    that are no multiple of 4 floats are refused loudly."""
+    from fpsg_amd._hip import FpsgHipError
     from fpsg_amd.gemm_split import bmm_persistent, pack_a
     g = torch.Generator(device="cpu").manual_seed(b * 999 + M + N + K)
     A = torch.randn(b, M, K, generator=g).to(gpu)
     B = torch.randn(b, K, N, generator=g).to(gpu)
     C = torch.full((b, M, N), float("nan"), device=gpu)
-    bmm_persistent(pack_a(A, 0), A.shape, B, variant, out=C)
+    if variant >= 6 and N % 4:
+        with pytest.raises(FpsgHipError, match="16-byte DMA"):
+            bmm_persistent(pack_a(A, 0), A.shape, B, variant, out=C)
+        return
+    bmm_persistent(pack_a(A, 2 if variant >= 13 else 0), A.shape, B, variant, out=C)      # 13, 14: 128-row tiles
     assert torch.equal(C, gemm_split(A, B, False, 2))

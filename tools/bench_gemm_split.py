@@ -74,10 +74,12 @@ def main():
 
         if args.persistent and 0 not in packed:
             packed[0] = pack_a(U, 0)
+        if args.persistent and 2 not in packed:      # 128-row tiles (the persistent form's variants 13, 14)
+            packed[2] = pack_a(U, 2)
 
         def fwd_fn(v):      # variant ids 100 ..: the packed-A form's variant v - 100; 200 ..: the persistent form's
-            if 200 <= v < 210:
-                return bmm_persistent(packed[0], U.shape, V, v - 200)
+            if 200 <= v < 220:
+                return bmm_persistent(packed[2 if v - 200 >= 13 else 0], U.shape, V, v - 200)
             return bmm_packed(packed[v - 100], U.shape, V, v - 100) if 100 <= v < 110 else gemm_split(U, V, False, v)
 
         legs = {
