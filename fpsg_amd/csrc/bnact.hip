@@ -23,6 +23,8 @@
 // 64-channel, 37x224x224 tensor still fills the chip (the per-channel workgroup of the library
 // kernel cannot).  Deterministic: fixed partial layout, no atomics.
 #include <algorithm>
+#include <atomic>
+#include <cstdlib>
 
 #include "fpsg_common.h"
 
@@ -68,13 +70,34 @@ __device__ __forceinline__ void block_reduce2(float& a, float& b, float* red /*[
   }
 }
 
+// FOLD (round 5; opt-in by FPSG_BN_FOLD=1): the forward finalize runs in the LAST-ARRIVING workgroup of
+// each channel instead of in a launch of its own.  The partial sums leave the CU as agent-scope (sc1) stores, the wave
+// drains them (vmcnt 0) and takes a ticket from the channel's counter; the workgroup that draws ticket S - 1 reads all S
+// partials back with agent-scope loads (per-XCD L2s are not coherent: plain loads could be stale), sums them in the
+// finalize kernel's own order -- so the result does not depend on which workgroup came last -- and puts the counter
+// back to zero.  Counters live in the library (zero at load, every use leaves them zero), kBnFoldBanks banks handed out
+// round robin so that calls in flight on different streams do not share one.
+constexpr int kBnFoldBanks = 16, kBnFoldChannels = 4096;
+__device__ unsigned g_bn_fold_counters[kBnFoldBanks * kBnFoldChannels];
+struct BnFoldArgs {
+  const float* gamma; const float* beta;
+  double count; float eps, momentum;
+  float* chan; float* batch_mean; float* batch_var_unbiased; float* run_mean; float* run_var;
+  unsigned* counters;
+};
+__device__ __forceinline__ void wave_sum2(double& a, double& b);
+__device__ __forceinline__ void bn_fwd_finalize_channel(double s0, double s1, int c, int C, const float* gamma, const float* beta,
+                                                        double count, float eps, float* chan, float* batch_mean,
+                                                        float* batch_var_unbiased, float* run_mean, float* run_var, float momentum);
+
 // Work items of channel c: (n, seg) pairs, seg over ceil(L / kBnSeg) segments of a row.
 // Block (s, c) takes items s, s + S, ...
 // MODE 0: sums of x and x^2.   MODE 1: sums of dz and dz*xhat (dz = dy * act'(x*scale+shift)).
-template <int MODE, int ACT, bool NT = false>
+template <int MODE, int ACT, bool NT = false, bool FOLD = false>
 __global__ __launch_bounds__(kBnThreads) void bn_reduce_kernel(
     const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ chan /*[4][C]: scale, shift, mean, rstd*/,
-    const float* __restrict__ pb, int N, int C, int L, int S, float slope, float* __restrict__ part /*[C][S][2]*/) {
+    const float* __restrict__ pb, int N, int C, int L, int S, float slope, float* __restrict__ part /*[C][S][2]*/,
+    const BnFoldArgs f = BnFoldArgs{}) {
   __shared__ float red[8];
   const int c = blockIdx.y, s = blockIdx.x;
   const float b = pb ? pb[c] : 0.0f;
@@ -137,6 +160,30 @@ __global__ __launch_bounds__(kBnThreads) void bn_reduce_kernel(
     }
   }
   block_reduce2(a0, a1, red);
+  if constexpr (FOLD) {
+    __shared__ int last;
+    if (threadIdx.x == 0) {
+      __hip_atomic_store(&part[((size_t)c * S + s) * 2 + 0], a0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&part[((size_t)c * S + s) * 2 + 1], a1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const unsigned t = __hip_atomic_fetch_add(&f.counters[c], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      last = t == (unsigned)S - 1u;
+    }
+    __syncthreads();
+    if (!last || threadIdx.x >= 64) return;
+    const int lane = threadIdx.x;
+    double s0 = 0.0, s1 = 0.0;
+    for (int sl = lane; sl < S; sl += 64) {
+      s0 += __hip_atomic_load(&part[((size_t)c * S + sl) * 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s1 += __hip_atomic_load(&part[((size_t)c * S + sl) * 2 + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    wave_sum2(s0, s1);
+    if (lane != 0) return;
+    bn_fwd_finalize_channel(s0, s1, c, C, f.gamma, f.beta, f.count, f.eps, f.chan, f.batch_mean, f.batch_var_unbiased,
+                            f.run_mean, f.run_var, f.momentum);
+    __hip_atomic_store(&f.counters[c], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return;
+  }
   if (threadIdx.x == 0) {
     part[((size_t)c * S + s) * 2 + 0] = a0;
     part[((size_t)c * S + s) * 2 + 1] = a1;
@@ -162,6 +209,12 @@ __global__ __launch_bounds__(64) void bn_fwd_finalize_kernel(const float* __rest
   for (int sl = lane; sl < S; sl += 64) { s0 += part[((size_t)c * S + sl) * 2]; s1 += part[((size_t)c * S + sl) * 2 + 1]; }
   wave_sum2(s0, s1);
   if (lane != 0) return;
+  bn_fwd_finalize_channel(s0, s1, c, C, gamma, beta, count, eps, chan, batch_mean, batch_var_unbiased, run_mean, run_var, momentum);
+}
+
+__device__ __forceinline__ void bn_fwd_finalize_channel(double s0, double s1, int c, int C, const float* gamma, const float* beta,
+                                                        double count, float eps, float* chan, float* batch_mean,
+                                                        float* batch_var_unbiased, float* run_mean, float* run_var, float momentum) {
   const double mean = s0 / count;
   double var = s1 / count - mean * mean;
   var = var > 0.0 ? var : 0.0;
@@ -1091,12 +1144,28 @@ extern "C" int fpsg_bn_act_fwd(const float* x, const float* pre_bias, const floa
   if (training) {
     FPSG_REQUIRE_PTR(ws);
     const int S = slices_for(N, L);
-    launch_reduce<0>(kActNone, x, nullptr, nullptr, pre_bias, N, C, L, S, 0.0f, ws, s);
-    if ((rc = launch_status("fpsg_bn_act_fwd(stats)"))) return rc;
-    hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3(C), dim3(64), 0, s, ws, gamma, beta, C, S,
-                       (double)N * (double)L, eps, chan, batch_mean, batch_var_unbiased, running_mean, running_var,
-                       momentum);
-    if ((rc = launch_status("fpsg_bn_act_fwd(finalize)"))) return rc;
+    const char* fold = getenv("FPSG_BN_FOLD");
+    if (fold && fold[0] == '1' && C <= kBnFoldChannels) {      // opt-in: the finalize in the last-arriving workgroup
+      static std::atomic<unsigned> next_bank{0};
+      unsigned* counters = nullptr;
+      FPSG_REQUIRE(hipGetSymbolAddress(reinterpret_cast<void**>(&counters), HIP_SYMBOL(g_bn_fold_counters)) == hipSuccess &&
+                       counters, FPSG_E_LIMIT, "fpsg_bn_act_fwd: the fold counters are not addressable");
+      BnFoldArgs f{gamma, beta, (double)N * (double)L, eps, momentum, chan, batch_mean, batch_var_unbiased, running_mean,
+                   running_var, counters + (size_t)(next_bank.fetch_add(1) % kBnFoldBanks) * kBnFoldChannels};
+      const dim3 grid(S, C);
+      if (beyond_cache((size_t)N * C * L * sizeof(float)))
+        hipLaunchKernelGGL((bn_reduce_kernel<0, kActNone, true, true>), grid, dim3(kBnThreads), 0, s, x, nullptr, nullptr, pre_bias, N, C, L, S, 0.0f, ws, f);
+      else
+        hipLaunchKernelGGL((bn_reduce_kernel<0, kActNone, false, true>), grid, dim3(kBnThreads), 0, s, x, nullptr, nullptr, pre_bias, N, C, L, S, 0.0f, ws, f);
+      if ((rc = launch_status("fpsg_bn_act_fwd(stats + finalize)"))) return rc;
+    } else {
+      launch_reduce<0>(kActNone, x, nullptr, nullptr, pre_bias, N, C, L, S, 0.0f, ws, s);
+      if ((rc = launch_status("fpsg_bn_act_fwd(stats)"))) return rc;
+      hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3(C), dim3(64), 0, s, ws, gamma, beta, C, S,
+                         (double)N * (double)L, eps, chan, batch_mean, batch_var_unbiased, running_mean, running_var,
+                         momentum);
+      if ((rc = launch_status("fpsg_bn_act_fwd(finalize)"))) return rc;
+    }
   } else if (!chan_given) {
     hipLaunchKernelGGL(bn_eval_chan_kernel, dim3((C + 255) / 256), dim3(256), 0, s, running_mean, running_var,
                        gamma, beta, C, eps, chan);
