@@ -346,6 +346,9 @@ int fpsg_dec1_bwd_ld(const float* dout, int ld_dout, const float* hlat, int ld_h
  * fl(x + pre_bias) formed in registers; bwd additionally returns dpre_bias[c] = sum over (n,l)
  * of dx (optional, NULL = skip) -- the bias gradient autograd would reduce from dx.
  * ws: fpsg_bn_workspace_floats(N,C,L) floats.  x, y, dy, dx 16-byte aligned.  Deterministic.
+ * Environment FPSG_BN_FOLD=1 (measurement switch, default off): fpsg_bn_act_fwd's finalize runs in the last-arriving
+ * workgroup of the statistics kernel instead of in its own launch -- the same bits, measured 10-93 us SLOWER per call
+ * (profiles/r05/bn_finalize_fold_rejected.txt).
  */
 size_t fpsg_bn_workspace_floats(int N, int C, int L);
 int fpsg_bn_act_fwd(const float* x, const float* pre_bias, const float* gamma, const float* beta,
@@ -544,8 +547,13 @@ int fpsg_gemm_split_nn_packed(const void* Ap, const float* B, float* C, int batc
 /* The same product as fpsg_gemm_split_nn_packed (Ap packed with variant 0 or 1: 256-row tiles) as ONE persistent launch:
  * a workgroup per CU walks an equal share of the flattened (batch, row tile, column) space, the load / split / MFMA
  * pipeline runs across tile boundaries (no per-tile launch, prologue or drain; 1044 tiles on 256 CUs cost 4.08 rounds, not
- * 5).  Same values as fpsg_gemm_split_nn_packed bit for bit.  variant: -1 / 0 = 256 columns per tile, 1 = 128.  B below
- * 4 GiB in total, one C matrix and the packed A below 2 GiB. */
+ * 5).  Same values as fpsg_gemm_split_nn_packed bit for bit.  variant: -1 / 0 = 256 columns per tile, 1 = 128;
+ * 6 / 12 = the form with specialised waves (4 waves only multiply, 4 only stage: LDS-DMA of both operands, the split of B
+ * from LDS), 256 x 128 tiles, 12 with staggered first pieces; 13 / 14 = the same with 128 x 128 tiles and two workgroups
+ * per CU (Ap packed with variant 2).  6 and 12-14 move B rows by 16-byte DMA: B, ldb and sB aligned to 4 floats
+ * (FPSG_E_SHAPE otherwise).  2-5 and 7-11 are measurement builds (wrong results by design).  Measured: none of the
+ * persistent forms beats the tiled kernel (profiles/r05/gemm_split_ablation.txt); they are kept as measured evidence and
+ * are not on any product path.  B below 4 GiB in total, one C matrix and the packed A below 2 GiB. */
 int fpsg_gemm_split_nn_persistent(const void* Ap, const float* B, float* C, int batch, int M, int N, int K, int ldb, int ldc,
                                   long sB, long sC, int variant, fpsg_stream_t stream);
 
