@@ -41,7 +41,8 @@ def _make(B, seed):
     return dec, hidden, grids
 
 
-@pytest.mark.parametrize("mode,B", [("train", 5), ("train", 32), ("eval", 3), ("train-split", 5)])
+# (("train", 5) went in round 5 to keep the suite inside its time budget: ("train", 32) and ("train-split", 5) run the same code)
+@pytest.mark.parametrize("mode,B", [("train", 32), ("eval", 3), ("train-split", 5)])
 def test_batched_decoder_vs_literal_float64(gpu, mode, B, monkeypatch):
     if mode == "train-split":       # FPSG_GEMM_SPLIT=1 (opt-in): the wide layers' three products by K10, same bounds
         monkeypatch.setenv("FPSG_GEMM_SPLIT", "1")
