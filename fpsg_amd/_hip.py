@@ -172,6 +172,8 @@ SIGNATURES = {
                                   ctypes.c_long, ctypes.c_long, _c_int, _c_stream],
     "fpsg_gemm_split_nn_persistent": [ctypes.c_void_p, _c_f32p, _c_f32p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
                                       ctypes.c_long, ctypes.c_long, _c_int, _c_stream],
+    "fpsg_gemm_f32_nn": [_c_f32p, _c_f32p, _c_f32p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
+                         ctypes.c_long, ctypes.c_long, ctypes.c_long, _c_int, _c_stream],
     "fpsg_emd_workspace_floats": [_c_int, _c_int, _c_int],
     "fpsg_emd_approx": [_c_f32p, _c_f32p, _c_int, _c_int, _c_int, _c_f32p, _c_f32p, _c_f32p, _c_f32p,
                         _c_stream],

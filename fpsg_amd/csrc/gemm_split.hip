@@ -1200,6 +1200,227 @@ __global__ __launch_bounds__(512, MINW) void gemm_split_ws_kernel(const PersistA
   }
 }
 
+// ---- K11 (round 5): the SAME batched product on the fp32 matrix pipe (v_mfma_f32_32x32x2_f32), hand-written ---------------
+// The headline step keeps fp32 MFMA arithmetic; its library GEMMs run at 0.73-0.90 of the pipe's sustained rate (137 TFLOP/s
+// at the ~2.09 GHz the card holds under fp32 MFMAs).  This is the specialised-wave skeleton of gemm_split_ws_kernel without
+// the split: four producer waves bring fp32 A (k-contiguous rows -> four planes [256 rows][4 k], 16 bytes per lane with a
+// per-lane source address: no packing pass) and fp32 B (rows of BN columns as they lie) into a ring of three LDS stages by
+// LDS-DMA, two stages ahead; four consumer waves (one per SIMD) read their fragments -- A as two ds_read_b128 per 32 rows
+// (8 k values per lane), B as one ds_read_b32 per MFMA and column block -- and issue 64 MFMAs of 64 cycles per k-step of
+// 16: staging, barrier and stores are a small fraction of that.  Persistent ranges / pieces as in the split kernels
+// (1044 tiles on 256 CUs cost 4.08 rounds, not 5).  lane (x, h) of an MFMA holds k = 8 h + jj for the stage's jj-th
+// MFMA (any pairing of the 16 k values is a valid order of the fp32 sum).  Needs lda, ldb, sA, sB multiples of 4 floats,
+// 16-byte aligned bases and K a multiple of 4 (16-byte DMA pieces must not straddle the end of a row).
+struct F32Args {
+  const float* A; const float* B; float* C;
+  int M, N, K;
+  int lda, ldb, ldc;
+  long sA, sB, sC;
+  int tiles_m, stages, batchq;
+  long total;
+  int stagger;
+};
+
+// Two builds: 256 x 128 tiles, consumers 4 x 1, one workgroup per CU; 128 x 128 tiles, consumers 2 x 2, TWO workgroups per
+// CU (128 registers): one workgroup's tile stores and barrier waits overlap the other's MFMAs.
+template <int BM, int BN, int WR, int MINW, bool KTAIL>
+__global__ __launch_bounds__(512, MINW) void gemm_f32_ws_kernel(const F32Args g) {
+  constexpr int BK = 16, NC = 4, NP = 4, WC = NC / WR;
+  constexpr int TI = BM / WR / 32, TJ = BN / WC / 32;
+  constexpr int PLA = BM * 16 + 64;                                        // one k-quad plane of A: [256 rows][4 floats]
+  constexpr int A_BYTES = 4 * PLA, B_BYTES = BK * BN * 4, STAGE = A_BYTES + B_BYTES;
+  constexpr int A_CHUNKS = 4 * (BM / 64), DMA_A = A_CHUNKS / NP;            // one-KB pieces of A per stage
+  constexpr int B_CHUNKS = B_BYTES / 1024, DMA_B = B_CHUNKS / NP;
+  constexpr int ROWS_PER_DMA = 1024 / (BN * 4), LANES_PER_ROW = BN / 4;
+  static_assert(B_CHUNKS % NP == 0 && A_CHUNKS % NP == 0 && WR * WC == NC, "stage / producer mismatch");
+  __shared__ __attribute__((aligned(16))) unsigned char lds[3 * STAGE + kMaxPieces * 16];
+  int* ptab = reinterpret_cast<int*>(lds + 3 * STAGE);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nsteps = g.stages;
+
+  if (tid == 0) {
+    auto cut = [&](long b) {
+      if (b >= gridDim.x) return g.total;
+      const long raw = g.total / gridDim.x * b + g.total % gridDim.x * b / gridDim.x;
+      const long q = raw / g.N, c = (raw % g.N) & ~31L;
+      return q * g.N + c;
+    };
+    const long nb = gridDim.x, bid = blockIdx.x, q8 = nb / 8, r8 = nb % 8, x8 = bid % 8;
+    const long id = (x8 < r8 ? x8 * (q8 + 1) : r8 * (q8 + 1) + (x8 - r8) * q8) + bid / 8;
+    long pos = cut(id);
+    const long end = cut(id + 1);
+    int np = 0;
+    long first = g.stagger ? 32 * (1 + (id & 3)) : BN;
+    while (pos < end && np < kMaxPieces - 1) {
+      const long q = pos / g.N, c = pos % g.N;
+      long w = g.N - c;
+      if (w > BN) w = BN;
+      if (w > first) w = first;
+      first = BN;
+      if (w > end - pos) w = end - pos;
+      ptab[4 * np] = (int)q; ptab[4 * np + 1] = (int)c; ptab[4 * np + 2] = (int)w;
+      pos += w;
+      ++np;
+    }
+    ptab[4 * (kMaxPieces - 1)] = np;
+  }
+  __syncthreads();
+  const int npieces = __builtin_amdgcn_readfirstlane(ptab[4 * (kMaxPieces - 1)]);
+  if (npieces == 0) return;
+  const int S = npieces * nsteps;
+  auto piece_q = [&](int p) { return __builtin_amdgcn_readfirstlane(ptab[4 * p]); };
+  auto piece_c = [&](int p) { return __builtin_amdgcn_readfirstlane(ptab[4 * p + 1]); };
+  auto piece_w = [&](int p) { return __builtin_amdgcn_readfirstlane(ptab[4 * p + 2]); };
+
+  if (wave >= NC) {
+    // ------------------------------------------------------------------ producers
+    const int pw = wave - NC;
+    const int nbatch = g.batchq / g.tiles_m;
+    const __amdgpu_buffer_rsrc_t rsA = make_rsrc(g.A, (long)(nbatch - 1) * g.sA + (long)(g.M - 1) * g.lda + g.K);
+    const __amdgpu_buffer_rsrc_t rsB = make_rsrc(g.B, (long)(nbatch - 1) * g.sB + (long)(g.K - 1) * g.ldb + g.N);
+    const unsigned lda4 = (unsigned)g.lda * 4u, ldb4 = (unsigned)g.ldb * 4u;
+    struct Cursor { int p, kt, q, c0; };
+    auto enter = [&](Cursor& cu, int p) { cu.p = p; cu.kt = 0; cu.q = piece_q(p); cu.c0 = piece_c(p); };
+    auto advance = [&](Cursor& cu) {
+      if (cu.kt + 1 < nsteps) { ++cu.kt; }
+      else if (cu.p + 1 < npieces) enter(cu, cu.p + 1);
+    };
+    const int b_lrow = lane / LANES_PER_ROW, b_lcol = (lane % LANES_PER_ROW) * 4;
+    auto dma = [&](const Cursor& cu, int slot) {
+      const int batch = cu.q / g.tiles_m, tm = cu.q - batch * g.tiles_m;
+      unsigned char* d = lds + slot * STAGE;
+      {   // A: pieces (k-quad plane p, group of 64 rows)
+        const unsigned sbase = (unsigned)((long)batch * g.sA * 4) + (unsigned)(cu.kt * BK) * 4u;
+#pragma unroll
+        for (int q = 0; q < DMA_A; ++q) {
+          const int c = pw + q * NP;
+          const int p = c / (BM / 64), rg = c % (BM / 64);
+          const int row = tm * BM + rg * 64 + lane;
+          const bool ok = row < g.M && (!KTAIL || cu.kt * BK + 4 * p < g.K);
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(d + p * PLA + rg * 1024), 16,
+                                                   ok ? (unsigned)row * lda4 + p * 16u : kOut, sbase, 0, 0);
+        }
+      }
+      {   // B: rows of BN columns
+        const unsigned sbase = (unsigned)((long)batch * g.sB * 4) + (unsigned)(cu.kt * BK) * ldb4;
+        const int col = cu.c0 + b_lcol;
+#pragma unroll
+        for (int q = 0; q < DMA_B; ++q) {
+          const int c = pw + q * NP;
+          const int krow = c * ROWS_PER_DMA + b_lrow;
+          const bool ok = col < g.N && (!KTAIL || cu.kt * BK + krow < g.K);
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (__attribute__((address_space(3))) void*)(d + A_BYTES + c * 1024), 16,
+                                                   ok ? (unsigned)col * 4u + (unsigned)krow * ldb4 : kOut, sbase, 0, 0);
+        }
+      }
+    };
+    Cursor cu;
+    enter(cu, 0);
+    dma(cu, 0); advance(cu);
+    dma(cu, 1); advance(cu);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_A + DMA_B) : "memory");      // stage 0 has landed (stage 1 may be in flight)
+    __builtin_amdgcn_s_barrier();
+    int slot = 0;
+    for (int s = 0; s < S; ++s) {
+      const int slot2 = slot == 0 ? 2 : slot - 1;                            // (s + 2) % 3: the slot stage s - 1 was read from
+      dma(cu, slot2);                                                        // stage s + 2 (beyond the end: a harmless repeat)
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_A + DMA_B) : "memory");    // stage s + 1 has landed
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      advance(cu);
+      slot = slot == 2 ? 0 : slot + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    return;
+  }
+
+  // -------------------------------------------------------------------- consumers
+  f32x16 acc[TI][TJ];
+#pragma unroll
+  for (int i = 0; i < TI; ++i)
+#pragma unroll
+    for (int j = 0; j < TJ; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  const int r = lane & 31, h = lane >> 5;
+  const int wr = wave / WC, wc = wave % WC;                                 // this consumer's (row, column) share of the tile
+  const int a_off = 2 * h * PLA + (wr * (BM / WR) + r) * 16;                // planes 2h, 2h + 1; + 512 per row block
+  const int b_off = A_BYTES + (8 * h * BN + wc * (BN / WC) + r) * 4;        // + jj * BN * 4 per MFMA, + 128 per column block
+  __builtin_amdgcn_s_barrier();
+  int kt = 0, piece = 0, slot = 0;
+  auto blocks_of = [&](int w) {                                             // 32-column blocks of this consumer inside a piece
+    const int mine = w - wc * (BN / WC);
+    return mine <= 0 ? 0 : (mine + 31) / 32;
+  };
+  int nj = blocks_of(piece_w(0));
+  // The step's barrier sits in front of its LAST column block's MFMAs: by then every fragment of the stage is in registers,
+  // so the slot can be handed back, and the next stage's first fragments are requested right behind the barrier -- their
+  // LDS latency and the barrier's skew hide under that block's 8 TI MFMAs instead of opening every step.
+  float fa[TI][8], fb[2][8];
+  auto read_a = [&](const unsigned char* cur, float (&dst)[TI][8]) {
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const u32x4 v = *reinterpret_cast<const u32x4*>(cur + a_off + q * PLA + i * 512);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) dst[i][4 * q + t] = __uint_as_float(v[t]);
+      }
+  };
+  auto read_b = [&](const unsigned char* cur, int j, float (&dst)[8]) {
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj) dst[jj] = *reinterpret_cast<const float*>(cur + b_off + jj * BN * 4 + j * 128);
+  };
+  read_a(lds, fa);
+  read_b(lds, 0, fb[0]);
+  for (int s = 0; s < S; ++s) {
+    const unsigned char* cur = lds + slot * STAGE;
+    const int slot1 = slot == 2 ? 0 : slot + 1;
+    float fa_next[TI][8];
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) {
+      if (j + 1 < TJ) {
+        read_b(cur, j + 1, fb[(j + 1) & 1]);
+      } else {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        read_a(lds + slot1 * STAGE, fa_next);                               // (past the last stage: a stale slot, unused)
+        read_b(lds + slot1 * STAGE, 0, fb[TJ & 1]);
+      }
+      if (j < nj) {
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj)
+#pragma unroll
+          for (int i = 0; i < TI; ++i)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[j & 1][jj], fa[i][jj], acc[i][j], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (++kt == nsteps) {
+      const int q = piece_q(piece), c0 = piece_c(piece), w = piece_w(piece);
+      const int batch = q / g.tiles_m, tm = q - batch * g.tiles_m;
+      store_tile<TI, TJ>(acc, g.C + batch * g.sC, g.M, g.N, g.ldc, tm * BM + wr * (BM / WR), c0 + wc * (BN / WC), c0 + w, lane, 0);
+#pragma unroll
+      for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+      kt = 0;
+      ++piece;
+      if (piece < npieces) nj = blocks_of(piece_w(piece));
+    }
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+      for (int t = 0; t < 8; ++t) fa[i][t] = fa_next[i][t];
+    slot = slot1;
+  }
+}
+
 // out[i] = slab 0 + slab 1 + ... (fixed order), n floats per slab
 __global__ __launch_bounds__(256) void gemm_split_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out, long n,
                                                                 long s_split, int splits) {
@@ -1495,4 +1716,42 @@ extern "C" int fpsg_gemm_split(const float* A, const float* B, float* C, int bat
   const int rblocks = (int)std::min<long>((n + 255) / 256, 2048);
   hipLaunchKernelGGL(gemm_split_reduce_kernel, dim3(rblocks), dim3(256), 0, s, ws, C, n, g.s_split, p.splits);
   return launch_status("fpsg_gemm_split (reduce)");
+}
+
+extern "C" int fpsg_gemm_f32_nn(const float* A, const float* B, float* C, int batch, int M, int N, int K, int lda, int ldb,
+                                int ldc, long sA, long sB, long sC, int variant, fpsg_stream_t stream) {
+  using namespace fpsg;
+  FPSG_REQUIRE(batch > 0 && M > 0 && N > 0 && K > 0 && lda >= K && ldb >= N && ldc >= N, FPSG_E_SHAPE, "fpsg_gemm_f32_nn: bad shape");
+  FPSG_REQUIRE(variant >= -1 && variant <= 3, FPSG_E_SHAPE, "fpsg_gemm_f32_nn: unknown variant %d", variant);
+  FPSG_REQUIRE_PTR(A);
+  FPSG_REQUIRE_PTR(B);
+  FPSG_REQUIRE_PTR(C);
+  FPSG_REQUIRE(K % 4 == 0 && lda % 4 == 0 && ldb % 4 == 0 && sA % 4 == 0 && sB % 4 == 0 &&
+                   ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) & 15) == 0,
+               FPSG_E_ALIGN, "fpsg_gemm_f32_nn: K, lda, ldb, sA, sB must be multiples of 4 floats and A, B 16-byte aligned (16-byte DMA pieces)");
+  F32Args g;
+  g.A = A; g.B = B; g.C = C;
+  g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.sA = sA; g.sB = sB; g.sC = sC;
+  // variants: 0 / 1 = 256 x 128 tiles, one workgroup per CU (1: staggered first pieces); 2 / 3 = 128 x 128, two per CU
+  const bool small = variant < 0 || variant >= 2;
+  const int bm = small ? 128 : 256;
+  g.tiles_m = (M + bm - 1) / bm; g.stages = (K + 15) / 16; g.batchq = batch * g.tiles_m;
+  g.total = (long)g.batchq * N;
+  g.stagger = variant == 1 || variant == 3;
+  FPSG_REQUIRE(((long)(batch - 1) * sA + (long)M * lda) < (1L << 30) && ((long)(batch - 1) * sB + (long)K * ldb) < (1L << 30) &&
+                   (long)M * ldc < (1L << 29),
+               FPSG_E_LIMIT, "fpsg_gemm_f32_nn: A and B must stay below 4 GiB in total, one C matrix below 2 GiB");
+  long grid = small ? 512 : 256;
+  while ((g.total + grid - 1) / grid > (long)(kMaxPieces - 4) * 128) grid += 256;
+  if (g.total / 32 < grid) grid = g.total / 32 > 0 ? g.total / 32 : 1;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const dim3 gr((unsigned)grid), bl(512);
+  if (small) {
+    if (K % 16 != 0) hipLaunchKernelGGL((gemm_f32_ws_kernel<128, 128, 2, 4, true>), gr, bl, 0, s, g);
+    else hipLaunchKernelGGL((gemm_f32_ws_kernel<128, 128, 2, 4, false>), gr, bl, 0, s, g);
+  } else {
+    if (K % 16 != 0) hipLaunchKernelGGL((gemm_f32_ws_kernel<256, 128, 4, 2, true>), gr, bl, 0, s, g);
+    else hipLaunchKernelGGL((gemm_f32_ws_kernel<256, 128, 4, 2, false>), gr, bl, 0, s, g);
+  }
+  return launch_status("fpsg_gemm_f32_nn");
 }

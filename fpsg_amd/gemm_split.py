@@ -87,3 +87,25 @@ def bmm_persistent(Ap: torch.Tensor, shape_a, B: torch.Tensor, variant: int = -1
         _hip.check(lib.fpsg_gemm_split_nn_persistent(_hip.ptr(Ap), _hip.ptr(B), _hip.ptr(C), b, M, N, K, N, N, K * N,
                                                      M * N, variant, _hip.stream_of(B)), "fpsg_gemm_split_nn_persistent")
     return C
+
+
+def bmm_f32(A: torch.Tensor, B: torch.Tensor, variant: int = -1, out: torch.Tensor | None = None):
+    """``torch.bmm(A, B)`` for contiguous fp32 ``A [b, M, K]``, ``B [b, K, N]`` by K11 (``fpsg_gemm_f32_nn``: fp32 MFMA,
+    hand-written persistent kernel).  Raises ``FpsgHipError`` where the entry point's alignment rules do not hold."""
+    lib = _hip.load()
+    _hip.dev_tensor(A, torch.float32, "A")
+    _hip.dev_tensor(B, torch.float32, "B")
+    b, M, K = A.shape
+    if B.shape[0] != b or B.shape[1] != K:
+        raise ValueError(f"bmm_f32: shapes {tuple(A.shape)} x {tuple(B.shape)} do not match")
+    N = B.shape[2]
+    C = out if out is not None else torch.empty((b, M, N), dtype=torch.float32, device=A.device)
+    with torch.cuda.device(A.device):
+        _hip.check(lib.fpsg_gemm_f32_nn(_hip.ptr(A), _hip.ptr(B), _hip.ptr(C), b, M, N, K, K, N, N, M * K, K * N, M * N,
+                                        variant, _hip.stream_of(A)), "fpsg_gemm_f32_nn")
+    return C
+
+
+def f32_eligible(b: int, M: int, N: int, K: int) -> bool:
+    """Shapes ``fpsg_gemm_f32_nn`` serves for contiguous operands (16-byte DMA pieces)."""
+    return K % 4 == 0 and N % 4 == 0 and (M * K) % 4 == 0 and (K * N) % 4 == 0

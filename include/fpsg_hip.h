@@ -557,6 +557,19 @@ int fpsg_gemm_split_nn_packed(const void* Ap, const float* B, float* C, int batc
 int fpsg_gemm_split_nn_persistent(const void* Ap, const float* B, float* C, int batch, int M, int N, int K, int ldb, int ldc,
                                   long sB, long sC, int variant, fpsg_stream_t stream);
 
+/* ---- K11: batched fp32 GEMM on the fp32 matrix pipe, hand-written (round 5) -------------------------------------------
+ * C[b] [M x N] = A[b] [M x K] . B[b] [K x N], row-major, leading dimensions / batch strides in floats: the product
+ * torch.bmm hands to rocBLAS / hipBLASLt for the Winograd-domain GEMMs of torchvision vgg16_bn.features
+ * (src/models/image_net.py:14,21-24) and the decoder's wide layers (src/models/point_cloud_net.py:66-79), with the same
+ * arithmetic class (v_mfma_f32_32x32x2_f32: fp32 products, fp32 accumulation; the order of the sum differs from the
+ * library's, so results agree to fp32 round-off, not bit for bit).  One persistent launch: a workgroup per CU walks an
+ * equal share of the flattened (batch, row tile, column) space; four waves stage both operands by LDS-DMA, four multiply.
+ * K, lda, ldb, sA, sB multiples of 4 floats, A and B 16-byte aligned (FPSG_E_ALIGN otherwise: the caller then takes the
+ * library GEMM); A and B below 4 GiB each in total, one C matrix below 2 GiB.  variant: -1 / 0 default, 1 = staggered
+ * first pieces.  Deterministic. */
+int fpsg_gemm_f32_nn(const float* A, const float* B, float* C, int batch, int M, int N, int K, int lda, int ldb, int ldc,
+                     long sA, long sB, long sC, int variant, fpsg_stream_t stream);
+
 /* K6 in one kernel for 64 input channels (F(4x4,3x3); conv1_2 / conv2_1 of the trunk and their data
  * gradients): y [N,K,H,W] = conv(x [N,64,H,W], w) from U = fpsg_wino_filter_transform(4, w, ...)
  * [36,K,64]; input transform, the 36 MFMA products and the output transform stay on chip -- with 64

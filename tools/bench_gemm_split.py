@@ -16,7 +16,7 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from fpsg_amd.gemm_split import bmm_packed, bmm_persistent, bmm_split as gemm_split, pack_a  # noqa: E402
+from fpsg_amd.gemm_split import bmm_f32, bmm_packed, bmm_persistent, bmm_split as gemm_split, pack_a  # noqa: E402
 
 
 def _time(fn, reps):
@@ -41,6 +41,7 @@ def main():
     ap.add_argument("--variants", default="-1")
     ap.add_argument("--packed", default="", help="variants of the packed-A forward form to time (v100.. columns)")
     ap.add_argument("--persistent", default="", help="variants of the persistent forward form to time (v200.. columns)")
+    ap.add_argument("--f32", default="", help="variants of K11 (fpsg_gemm_f32_nn, fp32 MFMA) to time on the forward leg (v300.. columns)")
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--n-img", type=int, default=37)
@@ -78,6 +79,8 @@ def main():
             packed[2] = pack_a(U, 2)
 
         def fwd_fn(v):      # variant ids 100 ..: the packed-A form's variant v - 100; 200 ..: the persistent form's
+            if 300 <= v < 310:
+                return bmm_f32(U, V, v - 300)
             if 200 <= v < 220:
                 return bmm_persistent(packed[2 if v - 200 >= 13 else 0], U.shape, V, v - 200)
             return bmm_packed(packed[v - 100], U.shape, V, v - 100) if 100 <= v < 110 else gemm_split(U, V, False, v)
@@ -88,7 +91,8 @@ def main():
         }
         for leg, (lib_fn, split_fn) in legs.items():
             variants = base_variants + ([100 + v for v in packed if str(v) in args.packed.split(",")] +
-                                        [200 + int(v) for v in args.persistent.split(",") if v != ""] if leg == "fwd" else [])
+                                        [200 + int(v) for v in args.persistent.split(",") if v != ""] +
+                                        [300 + int(v) for v in args.f32.split(",") if v != ""] if leg == "fwd" else [])
             # errors on the first batches against float64
             nb = args.err_batches
             if leg == "fwd":
