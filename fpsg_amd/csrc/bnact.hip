@@ -70,7 +70,7 @@ __device__ __forceinline__ void block_reduce2(float& a, float& b, float* red /*[
   }
 }
 
-// FOLD (round 5; opt-in by FPSG_BN_FOLD=1): the forward finalize runs in the LAST-ARRIVING workgroup of
+// FOLD (round 5; opt-in by FPSG_BN_FINALIZE_FOLD=1): the forward finalize runs in the LAST-ARRIVING workgroup of
 // each channel instead of in a launch of its own.  The partial sums leave the CU as agent-scope (sc1) stores, the wave
 // drains them (vmcnt 0) and takes a ticket from the channel's counter; the workgroup that draws ticket S - 1 reads all S
 // partials back with agent-scope loads (per-XCD L2s are not coherent: plain loads could be stale), sums them in the
@@ -1144,7 +1144,7 @@ extern "C" int fpsg_bn_act_fwd(const float* x, const float* pre_bias, const floa
   if (training) {
     FPSG_REQUIRE_PTR(ws);
     const int S = slices_for(N, L);
-    const char* fold = getenv("FPSG_BN_FOLD");
+    const char* fold = getenv("FPSG_BN_FINALIZE_FOLD");
     if (fold && fold[0] == '1' && C <= kBnFoldChannels) {      // opt-in: the finalize in the last-arriving workgroup
       static std::atomic<unsigned> next_bank{0};
       unsigned* counters = nullptr;

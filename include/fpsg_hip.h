@@ -346,7 +346,7 @@ int fpsg_dec1_bwd_ld(const float* dout, int ld_dout, const float* hlat, int ld_h
  * fl(x + pre_bias) formed in registers; bwd additionally returns dpre_bias[c] = sum over (n,l)
  * of dx (optional, NULL = skip) -- the bias gradient autograd would reduce from dx.
  * ws: fpsg_bn_workspace_floats(N,C,L) floats.  x, y, dy, dx 16-byte aligned.  Deterministic.
- * Environment FPSG_BN_FOLD=1 (measurement switch, default off): fpsg_bn_act_fwd's finalize runs in the last-arriving
+ * Environment FPSG_BN_FINALIZE_FOLD=1 (measurement switch, default off): fpsg_bn_act_fwd's finalize runs in the last-arriving
  * workgroup of the statistics kernel instead of in its own launch -- the same bits, measured 10-93 us SLOWER per call
  * (profiles/r05/bn_finalize_fold_rejected.txt).
  */

@@ -415,7 +415,7 @@ def test_column_segments_reject_bad_layouts(gpu):
 
 @pytest.mark.parametrize("shape", [(8, 64, 112, 112), (24, 32, 2048), (5, 9, 4096 + 4100), (37, 16, 56, 56), (16, 769, 4736)])
 def test_finalize_in_the_last_arriving_workgroup_equals_the_two_launch_form(gpu, monkeypatch, shape):
-    """``FPSG_BN_FOLD=1`` (opt-in): the forward finalize runs in the last-arriving workgroup of each channel of the
+    """``FPSG_BN_FINALIZE_FOLD=1`` (opt-in): the forward finalize runs in the last-arriving workgroup of each channel of the
     statistics kernel.  It sums the same partials in the finalize kernel's own order, so outputs, saved coefficients and
     running statistics are equal bit for bit, call after call (the counters go back to zero; 40 calls go round the 16
     counter banks more than twice)."""
@@ -430,11 +430,11 @@ def test_finalize_in_the_last_arriving_workgroup_equals_the_two_launch_form(gpu,
     folded = copy.deepcopy(bn)
     xs = [torch.randn(*shape, device=gpu) * (1 + i) + 0.3 * i for i in range(3)]
     outs = []
-    monkeypatch.setenv("FPSG_BN_FOLD", "0")
+    monkeypatch.setenv("FPSG_BN_FINALIZE_FOLD", "0")
     with torch.no_grad():
         for i in range(40):
             outs.append(bn_act(bn, xs[i % 3], "relu").clone() if i % 13 == 0 else bn_act(bn, xs[i % 3], "relu").sum())
-    monkeypatch.setenv("FPSG_BN_FOLD", "1")
+    monkeypatch.setenv("FPSG_BN_FINALIZE_FOLD", "1")
     with torch.no_grad():
         for i in range(40):
             y = bn_act(folded, xs[i % 3], "relu")

@@ -1,5 +1,5 @@
 """A/B of VERDICT r4 item 4: BatchNorm's forward finalize in the last-arriving workgroup of the statistics kernel
-(``FPSG_BN_FOLD=1``) against the two-launch form, through ``fpsg_bn_act_fwd`` at shapes of the c5 step that take the sliced
+(``FPSG_BN_FINALIZE_FOLD=1``) against the two-launch form, through ``fpsg_bn_act_fwd`` at shapes of the c5 step that take the sliced
 path (more than 16,384 values per channel).  Eager calls back to back and the same calls replayed as a hipGraph (how the
 step runs them).
 
@@ -39,7 +39,7 @@ def main():
         x = torch.randn(*shape, device=dev)
         row = {"shape": list(shape)}
         for fold in ("0", "1"):
-            os.environ["FPSG_BN_FOLD"] = fold
+            os.environ["FPSG_BN_FINALIZE_FOLD"] = fold
             with torch.no_grad():
                 eager = sorted(_time(lambda: bn_act(bn, x, "relu"), 50) for _ in range(5))[2]
                 # ten calls in one graph: the gap between the launches of a replayed graph is what the fold removes
