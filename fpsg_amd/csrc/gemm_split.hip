@@ -48,6 +48,8 @@ struct GemmArgs {
   int tiles_m, tiles_n, splits, k_per_split;
   long s_split;              // floats between two splits' slabs
   int nt_c;                  // non-temporal stores of C
+  long packed_floats;        // PACKA builds: A is the packed image (fpsg_gemm_split_pack_a, 128-row tiles), this many floats
+  int stages_a;              //               and ceil(K / 16) stages per row tile
 };
 
 __device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {
@@ -203,6 +205,55 @@ struct ContigStage {
   }
 };
 
+// The A operand already split (fpsg_gemm_split_pack_a: [batch * row tile][stage][piece][k-group][R rows] x 16 B, zero-padded
+// in rows and k): item = (row, k-group) as above, three 16-byte loads (one per piece, 1 KB contiguous per wave instruction)
+// straight into the three LDS stores -- no vector instruction.  Same interface as ContigStage; init takes the stage count
+// and the packed row-tile index where ContigStage takes the leading dimension and the first row.
+template <int R, int BK, int kThreads>
+struct PackedStage {
+  static constexpr int KG = BK / 8;
+  static constexpr int PS = R * 16 + 128 / KG;
+  static constexpr int BYTES = 3 * KG * PS;
+  static constexpr int ITEMS = (R * KG + kThreads - 1) / kThreads;
+  static constexpr bool PARTIAL = R * KG % kThreads != 0;
+  static constexpr int CHUNKS = 3 * KG * (R / 64);       // 1 KB pieces per stage
+  static_assert(!PARTIAL || ITEMS == 1, "tile / thread mismatch");
+  static_assert(BK == 16, "the packed image has 16-deep stages");
+  u32x4 p[ITEMS][3];
+  unsigned off[ITEMS];
+  unsigned qbase;                                        // (row tile index) * stages
+  __device__ __forceinline__ void init(int stages, int q, int /*rows*/, int tid) {
+    qbase = (unsigned)q * (unsigned)stages;
+#pragma unroll
+    for (int n = 0; n < ITEMS; ++n) {
+      const int it = tid + n * kThreads;
+      const int row = it % R, g = it / R;
+      off[n] = it < R * KG ? (unsigned)((g * (R / 64) + row / 64) * 1024 + (row % 64) * 16) : kOut;
+    }
+  }
+  __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t rs, int k0) {
+    const unsigned sbase = (qbase + (unsigned)(k0 / BK)) * (unsigned)(CHUNKS * 1024);
+#pragma unroll
+    for (int n = 0; n < ITEMS; ++n)
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+        p[n][t] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off[n] + t * (KG * (R / 64) * 1024), sbase, 0));
+  }
+  __device__ __forceinline__ void mask_tail(int, int, int) {}
+  __device__ __forceinline__ void split_only() {}
+  __device__ __forceinline__ void store(unsigned char* lds, int tid) const {
+#pragma unroll
+    for (int n = 0; n < ITEMS; ++n) {
+      const int it = tid + n * kThreads;
+      if (PARTIAL && it >= R * KG) break;
+      const int row = it % R, g = it / R;
+      unsigned char* d = lds + g * PS + row * 16;
+#pragma unroll
+      for (int t = 0; t < 3; ++t) *reinterpret_cast<u32x4*>(d + t * KG * PS) = p[n][t];
+    }
+  }
+};
+
 // One operand tile of BK k x R columns, column-contiguous in memory ([K][N]): item = (column, k-group), a lane reads its
 // column of 8 consecutive rows (each wave-instruction is one coalesced 256-byte row segment; the row enters as the
 // scalar offset).  Rows beyond K lie beyond the buffer (zeros); columns beyond N get the out-of-buffer lane offset.
@@ -262,12 +313,12 @@ struct StridedStage {
 
 // WR x WC waves (rows x columns of the tile); MINW: waves per SIMD the register allocation must leave room for
 // ABL (measurements only, results wrong): 1 = no global loads in the loop, 2 = nor LDS stores, 3 = nor the split
-template <int BM, int BN, int BK, int WR, int WC, int MINW, bool TRANSB, bool PRIO, bool PIPE = false, int ABL = 0>
+template <int BM, int BN, int BK, int WR, int WC, int MINW, bool TRANSB, bool PRIO, bool PIPE = false, int ABL = 0, bool PACKA = false>
 __global__ __launch_bounds__(64 * WR * WC, MINW) void gemm_split_kernel(const GemmArgs g) {
   constexpr int kThreads = 64 * WR * WC;
   constexpr int WM = BM / WR, WN = BN / WC, TI = WM / 32, TJ = WN / 32;
   constexpr int KG = BK / 8;
-  using StageA = ContigStage<BM, BK, kThreads>;
+  using StageA = typename std::conditional<PACKA, PackedStage<BM, BK, kThreads>, ContigStage<BM, BK, kThreads>>::type;
   using StageB = typename std::conditional<TRANSB, ContigStage<BN, BK, kThreads>, StridedStage<BN, BK, kThreads>>::type;
   constexpr int PSA = StageA::PS, PSB = StageB::PS;
   constexpr int STAGE = StageA::BYTES + StageB::BYTES;
@@ -293,13 +344,15 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void gemm_split_kernel(const Ge
   const int k_begin = split * g.k_per_split;
   const int k_end = min(g.K, k_begin + g.k_per_split);
   const int nsteps = (k_end - k_begin + BK - 1) / BK;
-  const __amdgpu_buffer_rsrc_t rsA = make_rsrc(g.A + batch * g.sA, (long)(g.M - 1) * g.lda + g.K);
+  const __amdgpu_buffer_rsrc_t rsA =
+      PACKA ? make_rsrc(g.A, g.packed_floats) : make_rsrc(g.A + batch * g.sA, (long)(g.M - 1) * g.lda + g.K);
   const __amdgpu_buffer_rsrc_t rsB =
       make_rsrc(g.B + batch * g.sB, TRANSB ? (long)(g.N - 1) * g.ldb + g.K : (long)(g.K - 1) * g.ldb + g.N);
 
   StageA ra;
   StageB rb;
-  ra.init(g.lda, m0, g.M, tid);
+  if constexpr (PACKA) ra.init(g.stages_a, batch * g.tiles_m + tm, g.M, tid);
+  else ra.init(g.lda, m0, g.M, tid);
   rb.init(g.ldb, n0, g.N, tid);
   auto load = [&](int kt) {                             // stage kt -> registers
     const int k0 = k_begin + kt * BK;
@@ -1499,7 +1552,9 @@ namespace {
 // packed-A tiles: variant 0 = 256 x 128 x 16 (2 x 4 waves of 128 x 32, two workgroups per CU), 1 = 256 x 256 x 16
 // (2 x 4 waves of 128 x 64, one per CU), 2 = 128 x 128 x 16 (2 x 2 waves of 64 x 64, three per CU)
 struct PaTile { int bm, bn, bk, threads; };
-constexpr PaTile kPaTiles[] = {{256, 128, 16, 512}, {256, 256, 16, 512}, {128, 128, 16, 256}};
+// 3 = the generic tiled kernel (128 x 128 x 16, three per CU, the split of B among the MFMAs) with A staged through
+// registers from the image packed for variant 2
+constexpr PaTile kPaTiles[] = {{256, 128, 16, 512}, {256, 256, 16, 512}, {128, 128, 16, 256}, {128, 128, 16, 256}};
 constexpr int kNumPaTiles = sizeof(kPaTiles) / sizeof(kPaTiles[0]);
 inline int pa_tile(int variant) { return variant < 0 ? 0 : variant; }
 }  // namespace
@@ -1546,6 +1601,20 @@ extern "C" int fpsg_gemm_split_nn_packed(const void* Ap, const float* B, float* 
   FPSG_REQUIRE((long)K * ldb < (1L << 29) && (long)M * ldc < (1L << 29), FPSG_E_LIMIT,
                "fpsg_gemm_split_nn_packed: a matrix of one batch entry must stay below 2 GiB (32-bit buffer offsets)");
   const PaTile& p = kPaTiles[t];
+  if (t == 3) {
+    GemmArgs a{};
+    a.A = static_cast<const float*>(Ap); a.B = B; a.C = C;
+    a.M = M; a.N = N; a.K = K; a.lda = K; a.ldb = ldb; a.ldc = ldc; a.sA = 0; a.sB = sB; a.sC = sC;
+    a.tiles_m = (M + 127) / 128; a.tiles_n = (N + 127) / 128; a.splits = 1; a.k_per_split = ((K + 15) / 16) * 16;
+    a.s_split = 0; a.nt_c = 0; a.stages_a = (K + 15) / 16;
+    a.packed_floats = (long)batch * a.tiles_m * a.stages_a * (3 * 2 * 128 * 16) / 4;
+    FPSG_REQUIRE(a.packed_floats < (1L << 30), FPSG_E_LIMIT, "fpsg_gemm_split_nn_packed: the packed A must stay below 4 GiB");
+    const long blocks = (long)batch * a.tiles_m * a.tiles_n;
+    FPSG_REQUIRE(blocks < (1L << 30), FPSG_E_LIMIT, "fpsg_gemm_split_nn_packed: too many tiles");
+    hipLaunchKernelGGL((gemm_split_kernel<128, 128, 16, 2, 2, 3, false, true, true, 0, true>), dim3((unsigned)blocks), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), a);
+    return launch_status("fpsg_gemm_split_nn_packed (register-staged)");
+  }
   PackedArgs g;
   g.Ap = static_cast<const u32x4*>(Ap); g.B = B; g.C = C;
   g.M = M; g.N = N; g.K = K; g.ldb = ldb; g.ldc = ldc; g.sB = sB; g.sC = sC;
@@ -1649,7 +1718,7 @@ extern "C" int fpsg_gemm_split(const float* A, const float* B, float* C, int bat
   FPSG_REQUIRE(plan_for(batch, M, N, K, transB, variant, &p), FPSG_E_SHAPE, "fpsg_gemm_split: unknown variant %d", variant);
   const long blocks = (long)batch * p.tiles_m * p.tiles_n * p.splits;
   FPSG_REQUIRE(blocks < (1L << 30), FPSG_E_LIMIT, "fpsg_gemm_split: too many tiles");
-  GemmArgs g;
+  GemmArgs g{};
   g.A = A; g.B = B;
   g.M = M; g.N = N; g.K = K;
   g.lda = lda; g.ldb = ldb;

@@ -70,12 +70,13 @@ def test_wide_dynamic_range(gpu):
     assert np.isfinite(err)
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3])
 @pytest.mark.parametrize("b,M,N,K", [(2, 256, 300, 32), (3, 100, 70, 48), (1, 512, 257, 128), (2, 37, 1000, 72), (36, 256, 592, 256)])
 def test_packed_a_form_equals_the_generic_kernel(gpu, variant, b, M, N, K):
     """``fpsg_gemm_split_pack_a`` + ``fpsg_gemm_split_nn_packed`` (A split once, brought in by LDS-DMA) against the generic
     kernel that splits both operands on the way into LDS: the same six products per k-step in the same order, so the
-    results are equal bit for bit whenever the k-steps coincide (16 here and in variants 0 / 2 / 3 of the generic
+    results are equal bit for bit whenever the k-steps coincide; variant 3: the generic tiled kernel itself with the packed A
+    staged through registers (no split of A, no DMA) (16 here and in variants 0 / 2 / 3 of the generic
     kernel); and against float64 like the generic kernel.  Ragged rows / columns / K (zero padding in the packed form)."""
     from fpsg_amd.gemm_split import bmm_packed, pack_a
     g = torch.Generator(device="cpu").manual_seed(b * 999 + M + N + K)
@@ -95,7 +96,7 @@ def test_packed_a_exact_on_integers(gpu):
     g = torch.Generator(device="cpu").manual_seed(6)
     A = torch.randint(-8, 9, (2, 300, 80), generator=g).float().to(gpu)
     B = torch.randint(-8, 9, (2, 80, 500), generator=g).float().to(gpu)
-    for v in (0, 1, 2):
+    for v in (0, 1, 2, 3):
         assert torch.equal(bmm_packed(pack_a(A, v), A.shape, B, v), torch.bmm(A.double(), B.double()).float())
 
 
