@@ -125,20 +125,21 @@ SIGNATURES = {
     "fpsg_max_bwd_scatter_workspace_floats": [_c_int, _c_int, _c_int],
     "fpsg_bn_act_max_bwd_coef": [_c_f32p, _c_f32p, _c_f32p, _c_i32p, _c_f32p, _c_int, _c_int, _c_int, _c_int, _c_int,
                                  ctypes.c_float, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_stream],
-    "fpsg_wino_input_transform": [_c_int, _c_f32p, _c_int, _c_int, _c_int, _c_int, _c_f32p, _c_stream],
-    "fpsg_wino_output_transform": [_c_int, _c_f32p, _c_int, _c_int, _c_int, _c_int, _c_f32p, _c_stream],
+    "fpsg_wino_input_transform": [_c_int, _c_f32p, _c_int, _c_int, _c_int, _c_int, _c_f32p, ctypes.c_long, _c_stream],
+    "fpsg_wino_output_transform": [_c_int, _c_f32p, _c_int, _c_int, _c_int, _c_int, _c_f32p, ctypes.c_long, _c_stream],
     "fpsg_wino_stats_parts": [_c_int, _c_int, _c_int, _c_int],
     "fpsg_wino_output_transform_stats": [_c_int, _c_f32p, _c_int, _c_int, _c_int, _c_int, _c_f32p, _c_f32p, _c_f32p,
-                                         _c_stream],
-    "fpsg_wino_grad_output_transform": [_c_int, _c_f32p, _c_int, _c_int, _c_int, _c_int, _c_f32p, _c_stream],
-    "fpsg_wino_grad_transforms": [_c_int, _c_f32p, _c_int, _c_int, _c_int, _c_int, _c_f32p, _c_f32p, _c_stream],
+                                         ctypes.c_long, _c_stream],
+    "fpsg_wino_grad_output_transform": [_c_int, _c_f32p, _c_int, _c_int, _c_int, _c_int, _c_f32p, ctypes.c_long, _c_stream],
+    "fpsg_wino_grad_transforms": [_c_int, _c_f32p, _c_int, _c_int, _c_int, _c_int, _c_f32p, _c_f32p, ctypes.c_long, _c_stream],
     "fpsg_wino_filter_transform": [_c_int, _c_f32p, _c_int, _c_int, _c_int, _c_f32p, _c_stream],
     "fpsg_wino_output_transform_bwd_stats": [_c_int, _c_f32p, _c_int, _c_int, _c_int, _c_int, _c_f32p, _c_f32p, _c_f32p,
-                                             _c_f32p, _c_f32p, _c_stream],
+                                             _c_f32p, _c_f32p, ctypes.c_long, _c_stream],
     "fpsg_wino_filter_transform_batch": [ctypes.c_void_p, _c_int, ctypes.c_long, _c_stream],
     "fpsg_wino_filter_grad_transform": [_c_int, _c_f32p, _c_int, _c_int, _c_f32p, _c_stream],
     "fpsg_wino_conv_fused": [_c_f32p, _c_f32p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_f32p, _c_stream],
-    "fpsg_wino_input_transform_act": [_c_int, _c_f32p, _c_f32p, _c_f32p, _c_int, _c_int, _c_int, _c_int, _c_f32p, _c_stream],
+    "fpsg_wino_input_transform_act": [_c_int, _c_f32p, _c_f32p, _c_f32p, _c_int, _c_int, _c_int, _c_int, _c_f32p, ctypes.c_long,
+                                      _c_stream],
     "fpsg_wino_conv_fused_act": [_c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_f32p,
                                  _c_stream],
     "fpsg_wino_dw_fused_workspace_floats": [_c_int, _c_int, _c_int, _c_int],

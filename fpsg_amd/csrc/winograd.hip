@@ -145,7 +145,7 @@ __device__ __forceinline__ TileIndex tile_of(long p, int Th, int Tw) {
 // arithmetic on the same values: bit-identical to the two separate launches).
 template <int M, bool ACT, bool NT = false, bool RAG = false, bool GO = false>
 __global__ __launch_bounds__(kWinoThreads) void wino_input_kernel(const float* __restrict__ x, int C, int H, int W,
-                                                                   int Th, int Tw, long P, float* __restrict__ V,
+                                                                   int Th, int Tw, long P, long Ps, float* __restrict__ V,
                                                                    const float* __restrict__ chan,
                                                                    const float* __restrict__ pre_bias,
                                                                    float* __restrict__ dM = nullptr) {
@@ -219,9 +219,18 @@ __global__ __launch_bounds__(kWinoThreads) void wino_input_kernel(const float* _
     for (int i = 0; i < A; ++i) col[i] = d[i][j];
     Wino<M>::in(col, t[j]);
   }
-  if (!live) return;
-  const size_t plane = (size_t)C * P;
-  float* vp = V + (size_t)c * P + p;
+  const size_t plane = (size_t)C * Ps;
+  if (!live) {                                   // the pad columns P .. Ps-1 of every row are written as zeros
+    if (p_raw < Ps) {
+#pragma unroll
+      for (int q = 0; q < A * A; ++q) {
+        stream_store<NT>(V + (size_t)c * Ps + p_raw + (size_t)q * plane, 0.0f);
+        if constexpr (GO) stream_store<NT>(dM + (size_t)c * Ps + p_raw + (size_t)q * plane, 0.0f);
+      }
+    }
+    return;
+  }
+  float* vp = V + (size_t)c * Ps + p;
 #pragma unroll
   for (int i = 0; i < A; ++i) {
     float row[A], v[A];
@@ -242,7 +251,7 @@ __global__ __launch_bounds__(kWinoThreads) void wino_input_kernel(const float* _
       for (int i = 0; i < M; ++i) col[i] = mid[1 + i][j];
       Wino<M>::gout(col, r[j]);
     }
-    float* mp = dM + (size_t)c * P + p;
+    float* mp = dM + (size_t)c * Ps + p;
 #pragma unroll
     for (int i = 0; i < A; ++i) {
       float row[M], o[A];
@@ -267,7 +276,7 @@ __global__ __launch_bounds__(kWinoThreads) void wino_input_kernel(const float* _
 // RAG (m = 4 only, see wino_input_kernel): only the pixels inside the image are written (and counted in the sums).
 template <int M, bool STATS, bool BWD = false, bool NT = false, bool RAG = false>
 __global__ __launch_bounds__(kWinoThreads) void wino_output_kernel(const float* __restrict__ Mt, int K, int H, int W,
-                                                                    int Th, int Tw, long P, float* __restrict__ y,
+                                                                    int Th, int Tw, long P, long Ps, float* __restrict__ y,
                                                                     const float* __restrict__ bias,
                                                                     float* __restrict__ parts,
                                                                     const float* __restrict__ xpre = nullptr,
@@ -281,8 +290,8 @@ __global__ __launch_bounds__(kWinoThreads) void wino_output_kernel(const float* 
   const long p = live ? p_raw : P - 1;          // (STATS) dead lanes stay for the reduction and add nothing
   const int k = blockIdx.y;
   const TileIndex ti = tile_of(p, Th, Tw);
-  const size_t plane = (size_t)K * P;
-  const float* mp = Mt + (size_t)k * P + p;
+  const size_t plane = (size_t)K * Ps;
+  const float* mp = Mt + (size_t)k * Ps + p;
   float s[A][M];        // s[j][i]: column j after the transform along rows
 #pragma unroll
   for (int j = 0; j < A; ++j) {
@@ -375,13 +384,19 @@ __global__ __launch_bounds__(kWinoThreads) void wino_output_kernel(const float* 
 // dM = A dY A^T per tile
 template <int M, bool NT = false, bool RAG = false>
 __global__ __launch_bounds__(kWinoThreads) void wino_grad_output_kernel(const float* __restrict__ dy, int K, int H,
-                                                                         int W, int Th, int Tw, long P,
+                                                                         int W, int Th, int Tw, long P, long Ps,
                                                                          float* __restrict__ dM) {
   constexpr int A = Wino<M>::A;
   typedef float vin __attribute__((ext_vector_type(M)));
   const long p = (long)blockIdx.x * kWinoThreads + threadIdx.x;
-  if (p >= P) return;
   const int k = blockIdx.y;
+  if (p >= P) {                                  // the pad columns P .. Ps-1 of every row are written as zeros
+    if (p < Ps) {
+#pragma unroll
+      for (int q = 0; q < A * A; ++q) stream_store<NT>(dM + (size_t)k * Ps + p + (size_t)q * (size_t)K * Ps, 0.0f);
+    }
+    return;
+  }
   const TileIndex ti = tile_of(p, Th, Tw);
   const float* yp = dy + (((size_t)ti.n * K + k) * H + M * ti.th) * W + M * ti.tw;
   float yv[M][M];
@@ -409,8 +424,8 @@ __global__ __launch_bounds__(kWinoThreads) void wino_grad_output_kernel(const fl
     for (int i = 0; i < M; ++i) col[i] = yv[i][j];
     Wino<M>::gout(col, r[j]);
   }
-  const size_t plane = (size_t)K * P;
-  float* mp = dM + (size_t)k * P + p;
+  const size_t plane = (size_t)K * Ps;
+  float* mp = dM + (size_t)k * Ps + p;
 #pragma unroll
   for (int i = 0; i < A; ++i) {
     float row[M], o[A];
@@ -526,24 +541,27 @@ int check_image(const char* fn, int m, int N, int C, int H, int W) {
   if (m == 2) hipLaunchKernelGGL((KERNEL<2>), grid, dim3(kWinoThreads), 0, static_cast<hipStream_t>(stream), __VA_ARGS__); \
   else hipLaunchKernelGGL((KERNEL<4>), grid, dim3(kWinoThreads), 0, static_cast<hipStream_t>(stream), __VA_ARGS__)
 
-extern "C" int fpsg_wino_input_transform(int m, const float* x, int N, int C, int H, int W, float* V,
-                                         fpsg_stream_t stream) {
+extern "C" int fpsg_wino_input_transform(int m, const float* x, int N, int C, int H, int W, float* V, long ldp,
+    fpsg_stream_t stream) {
   using namespace fpsg;
   int rc = check_image("fpsg_wino_input_transform", m, N, C, H, W);
   if (rc) return rc;
   FPSG_REQUIRE_PTR(x); FPSG_REQUIRE_PTR(V);
   FPSG_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0, FPSG_E_ALIGN, "fpsg_wino_input_transform: x must be 16-byte aligned");
   const long P = (long)N * tiles_of(H, m) * tiles_of(W, m);
-  dim3 grid((unsigned)((P + kWinoThreads - 1) / kWinoThreads), C);
-  if (m == 2) hipLaunchKernelGGL((wino_input_kernel<2, false>), grid, dim3(kWinoThreads), 0, static_cast<hipStream_t>(stream), x, C, H, W, tiles_of(H, m), tiles_of(W, m), P, V, nullptr, nullptr);
-  else if (ragged(m, H, W)) hipLaunchKernelGGL((wino_input_kernel<4, false, false, true>), grid, dim3(kWinoThreads), 0, static_cast<hipStream_t>(stream), x, C, H, W, tiles_of(H, m), tiles_of(W, m), P, V, nullptr, nullptr);
-  else if ((size_t)36 * C * P * sizeof(float) > kStreamBytes) hipLaunchKernelGGL((wino_input_kernel<4, false, true>), grid, dim3(kWinoThreads), 0, static_cast<hipStream_t>(stream), x, C, H, W, tiles_of(H, m), tiles_of(W, m), P, V, nullptr, nullptr);
-  else hipLaunchKernelGGL((wino_input_kernel<4, false>), grid, dim3(kWinoThreads), 0, static_cast<hipStream_t>(stream), x, C, H, W, tiles_of(H, m), tiles_of(W, m), P, V, nullptr, nullptr);
+  const long Ps = ldp ? ldp : P;
+  FPSG_REQUIRE(Ps >= P, FPSG_E_SHAPE, "fpsg_wino_input_transform: row stride %ld must be 0 or at least the %ld tiles", ldp, P);
+  dim3 grid((unsigned)((Ps + kWinoThreads - 1) / kWinoThreads), C);
+  if (m == 2) hipLaunchKernelGGL((wino_input_kernel<2, false>), grid, dim3(kWinoThreads), 0, static_cast<hipStream_t>(stream), x, C, H, W, tiles_of(H, m), tiles_of(W, m), P, Ps, V, nullptr, nullptr);
+  else if (ragged(m, H, W)) hipLaunchKernelGGL((wino_input_kernel<4, false, false, true>), grid, dim3(kWinoThreads), 0, static_cast<hipStream_t>(stream), x, C, H, W, tiles_of(H, m), tiles_of(W, m), P, Ps, V, nullptr, nullptr);
+  else if ((size_t)36 * C * Ps * sizeof(float) > kStreamBytes) hipLaunchKernelGGL((wino_input_kernel<4, false, true>), grid, dim3(kWinoThreads), 0, static_cast<hipStream_t>(stream), x, C, H, W, tiles_of(H, m), tiles_of(W, m), P, Ps, V, nullptr, nullptr);
+  else hipLaunchKernelGGL((wino_input_kernel<4, false>), grid, dim3(kWinoThreads), 0, static_cast<hipStream_t>(stream), x, C, H, W, tiles_of(H, m), tiles_of(W, m), P, Ps, V, nullptr, nullptr);
   return launch_status("fpsg_wino_input_transform");
 }
 
 extern "C" int fpsg_wino_input_transform_act(int m, const float* x, const float* chan, const float* pre_bias, int N,
-                                             int C, int H, int W, float* V, fpsg_stream_t stream) {
+                                             int C, int H, int W, float* V, long ldp,
+    fpsg_stream_t stream) {
   using namespace fpsg;
   int rc = check_image("fpsg_wino_input_transform_act", m, N, C, H, W);
   if (rc) return rc;
@@ -551,28 +569,32 @@ extern "C" int fpsg_wino_input_transform_act(int m, const float* x, const float*
   FPSG_REQUIRE(!misaligned4(pre_bias), FPSG_E_ALIGN, "fpsg_wino_input_transform_act: pre_bias not 4-byte aligned");
   FPSG_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0, FPSG_E_ALIGN, "fpsg_wino_input_transform_act: x must be 16-byte aligned");
   const long P = (long)N * tiles_of(H, m) * tiles_of(W, m);
-  dim3 grid((unsigned)((P + kWinoThreads - 1) / kWinoThreads), C);
-  if (m == 2) hipLaunchKernelGGL((wino_input_kernel<2, true>), grid, dim3(kWinoThreads), 0, static_cast<hipStream_t>(stream), x, C, H, W, tiles_of(H, m), tiles_of(W, m), P, V, chan, pre_bias);
-  else if (ragged(m, H, W)) hipLaunchKernelGGL((wino_input_kernel<4, true, false, true>), grid, dim3(kWinoThreads), 0, static_cast<hipStream_t>(stream), x, C, H, W, tiles_of(H, m), tiles_of(W, m), P, V, chan, pre_bias);
-  else if ((size_t)36 * C * P * sizeof(float) > kStreamBytes) hipLaunchKernelGGL((wino_input_kernel<4, true, true>), grid, dim3(kWinoThreads), 0, static_cast<hipStream_t>(stream), x, C, H, W, tiles_of(H, m), tiles_of(W, m), P, V, chan, pre_bias);
-  else hipLaunchKernelGGL((wino_input_kernel<4, true>), grid, dim3(kWinoThreads), 0, static_cast<hipStream_t>(stream), x, C, H, W, tiles_of(H, m), tiles_of(W, m), P, V, chan, pre_bias);
+  const long Ps = ldp ? ldp : P;
+  FPSG_REQUIRE(Ps >= P, FPSG_E_SHAPE, "fpsg_wino_input_transform_act: row stride %ld must be 0 or at least the %ld tiles", ldp, P);
+  dim3 grid((unsigned)((Ps + kWinoThreads - 1) / kWinoThreads), C);
+  if (m == 2) hipLaunchKernelGGL((wino_input_kernel<2, true>), grid, dim3(kWinoThreads), 0, static_cast<hipStream_t>(stream), x, C, H, W, tiles_of(H, m), tiles_of(W, m), P, Ps, V, chan, pre_bias);
+  else if (ragged(m, H, W)) hipLaunchKernelGGL((wino_input_kernel<4, true, false, true>), grid, dim3(kWinoThreads), 0, static_cast<hipStream_t>(stream), x, C, H, W, tiles_of(H, m), tiles_of(W, m), P, Ps, V, chan, pre_bias);
+  else if ((size_t)36 * C * Ps * sizeof(float) > kStreamBytes) hipLaunchKernelGGL((wino_input_kernel<4, true, true>), grid, dim3(kWinoThreads), 0, static_cast<hipStream_t>(stream), x, C, H, W, tiles_of(H, m), tiles_of(W, m), P, Ps, V, chan, pre_bias);
+  else hipLaunchKernelGGL((wino_input_kernel<4, true>), grid, dim3(kWinoThreads), 0, static_cast<hipStream_t>(stream), x, C, H, W, tiles_of(H, m), tiles_of(W, m), P, Ps, V, chan, pre_bias);
   return launch_status("fpsg_wino_input_transform_act");
 }
 
-extern "C" int fpsg_wino_output_transform(int m, const float* M, int N, int K, int H, int W, float* y,
-                                          fpsg_stream_t stream) {
+extern "C" int fpsg_wino_output_transform(int m, const float* M, int N, int K, int H, int W, float* y, long ldp,
+    fpsg_stream_t stream) {
   using namespace fpsg;
   int rc = check_image("fpsg_wino_output_transform", m, N, K, H, W);
   if (rc) return rc;
   FPSG_REQUIRE_PTR(M); FPSG_REQUIRE_PTR(y);
   FPSG_REQUIRE((reinterpret_cast<uintptr_t>(y) & 15) == 0, FPSG_E_ALIGN, "fpsg_wino_output_transform: y must be 16-byte aligned");
   const long P = (long)N * tiles_of(H, m) * tiles_of(W, m);
+  const long Ps = ldp ? ldp : P;
+  FPSG_REQUIRE(Ps >= P, FPSG_E_SHAPE, "fpsg_wino_output_transform: row stride %ld must be 0 or at least the %ld tiles", ldp, P);
   dim3 grid((unsigned)((P + kWinoThreads - 1) / kWinoThreads), K);
   hipStream_t hs = static_cast<hipStream_t>(stream);
-  if (m == 2) hipLaunchKernelGGL((wino_output_kernel<2, false>), grid, dim3(kWinoThreads), 0, hs, M, K, H, W, tiles_of(H, m), tiles_of(W, m), P, y, nullptr, nullptr);
-  else if (ragged(m, H, W)) hipLaunchKernelGGL((wino_output_kernel<4, false, false, false, true>), grid, dim3(kWinoThreads), 0, hs, M, K, H, W, tiles_of(H, m), tiles_of(W, m), P, y, nullptr, nullptr);
-  else if ((size_t)36 * K * P * sizeof(float) > kStreamBytes) hipLaunchKernelGGL((wino_output_kernel<4, false, false, true>), grid, dim3(kWinoThreads), 0, hs, M, K, H, W, tiles_of(H, m), tiles_of(W, m), P, y, nullptr, nullptr);
-  else hipLaunchKernelGGL((wino_output_kernel<4, false>), grid, dim3(kWinoThreads), 0, hs, M, K, H, W, tiles_of(H, m), tiles_of(W, m), P, y, nullptr, nullptr);
+  if (m == 2) hipLaunchKernelGGL((wino_output_kernel<2, false>), grid, dim3(kWinoThreads), 0, hs, M, K, H, W, tiles_of(H, m), tiles_of(W, m), P, Ps, y, nullptr, nullptr);
+  else if (ragged(m, H, W)) hipLaunchKernelGGL((wino_output_kernel<4, false, false, false, true>), grid, dim3(kWinoThreads), 0, hs, M, K, H, W, tiles_of(H, m), tiles_of(W, m), P, Ps, y, nullptr, nullptr);
+  else if ((size_t)36 * K * Ps * sizeof(float) > kStreamBytes) hipLaunchKernelGGL((wino_output_kernel<4, false, false, true>), grid, dim3(kWinoThreads), 0, hs, M, K, H, W, tiles_of(H, m), tiles_of(W, m), P, Ps, y, nullptr, nullptr);
+  else hipLaunchKernelGGL((wino_output_kernel<4, false>), grid, dim3(kWinoThreads), 0, hs, M, K, H, W, tiles_of(H, m), tiles_of(W, m), P, Ps, y, nullptr, nullptr);
   return launch_status("fpsg_wino_output_transform");
 }
 
@@ -583,7 +605,8 @@ extern "C" int fpsg_wino_stats_parts(int m, int N, int H, int W) {
 }
 
 extern "C" int fpsg_wino_output_transform_stats(int m, const float* M, int N, int K, int H, int W, float* y,
-                                                const float* bias, float* parts, fpsg_stream_t stream) {
+                                                const float* bias, float* parts, long ldp,
+    fpsg_stream_t stream) {
   using namespace fpsg;
   int rc = check_image("fpsg_wino_output_transform_stats", m, N, K, H, W);
   if (rc) return rc;
@@ -591,18 +614,21 @@ extern "C" int fpsg_wino_output_transform_stats(int m, const float* M, int N, in
   FPSG_REQUIRE((reinterpret_cast<uintptr_t>(y) & 15) == 0, FPSG_E_ALIGN, "fpsg_wino_output_transform_stats: y must be 16-byte aligned");
   FPSG_REQUIRE(!misaligned4(bias) && !misaligned4(parts), FPSG_E_ALIGN, "fpsg_wino_output_transform_stats: bias / parts not 4-byte aligned");
   const long P = (long)N * tiles_of(H, m) * tiles_of(W, m);
+  const long Ps = ldp ? ldp : P;
+  FPSG_REQUIRE(Ps >= P, FPSG_E_SHAPE, "fpsg_wino_output_transform_stats: row stride %ld must be 0 or at least the %ld tiles", ldp, P);
   dim3 grid((unsigned)((P + kWinoThreads - 1) / kWinoThreads), K);
   hipStream_t hs = static_cast<hipStream_t>(stream);
-  if (m == 2) hipLaunchKernelGGL((wino_output_kernel<2, true>), grid, dim3(kWinoThreads), 0, hs, M, K, H, W, tiles_of(H, m), tiles_of(W, m), P, y, bias, parts);
-  else if (ragged(m, H, W)) hipLaunchKernelGGL((wino_output_kernel<4, true, false, false, true>), grid, dim3(kWinoThreads), 0, hs, M, K, H, W, tiles_of(H, m), tiles_of(W, m), P, y, bias, parts);
-  else if ((size_t)36 * K * P * sizeof(float) > kStreamBytes) hipLaunchKernelGGL((wino_output_kernel<4, true, false, true>), grid, dim3(kWinoThreads), 0, hs, M, K, H, W, tiles_of(H, m), tiles_of(W, m), P, y, bias, parts);
-  else hipLaunchKernelGGL((wino_output_kernel<4, true>), grid, dim3(kWinoThreads), 0, hs, M, K, H, W, tiles_of(H, m), tiles_of(W, m), P, y, bias, parts);
+  if (m == 2) hipLaunchKernelGGL((wino_output_kernel<2, true>), grid, dim3(kWinoThreads), 0, hs, M, K, H, W, tiles_of(H, m), tiles_of(W, m), P, Ps, y, bias, parts);
+  else if (ragged(m, H, W)) hipLaunchKernelGGL((wino_output_kernel<4, true, false, false, true>), grid, dim3(kWinoThreads), 0, hs, M, K, H, W, tiles_of(H, m), tiles_of(W, m), P, Ps, y, bias, parts);
+  else if ((size_t)36 * K * Ps * sizeof(float) > kStreamBytes) hipLaunchKernelGGL((wino_output_kernel<4, true, false, true>), grid, dim3(kWinoThreads), 0, hs, M, K, H, W, tiles_of(H, m), tiles_of(W, m), P, Ps, y, bias, parts);
+  else hipLaunchKernelGGL((wino_output_kernel<4, true>), grid, dim3(kWinoThreads), 0, hs, M, K, H, W, tiles_of(H, m), tiles_of(W, m), P, Ps, y, bias, parts);
   return launch_status("fpsg_wino_output_transform_stats");
 }
 
 extern "C" int fpsg_wino_output_transform_bwd_stats(int m, const float* M, int N, int K, int H, int W, float* y,
                                                     const float* xpre, const float* pre_bias, const float* chan,
-                                                    float* parts, fpsg_stream_t stream) {
+                                                    float* parts, long ldp,
+    fpsg_stream_t stream) {
   using namespace fpsg;
   int rc = check_image("fpsg_wino_output_transform_bwd_stats", m, N, K, H, W);
   if (rc) return rc;
@@ -612,46 +638,52 @@ extern "C" int fpsg_wino_output_transform_bwd_stats(int m, const float* M, int N
   FPSG_REQUIRE(!misaligned4(pre_bias) && !misaligned4(parts) && !misaligned4(chan), FPSG_E_ALIGN,
                "fpsg_wino_output_transform_bwd_stats: pre_bias / chan / parts not 4-byte aligned");
   const long P = (long)N * tiles_of(H, m) * tiles_of(W, m);
+  const long Ps = ldp ? ldp : P;
+  FPSG_REQUIRE(Ps >= P, FPSG_E_SHAPE, "fpsg_wino_output_transform_bwd_stats: row stride %ld must be 0 or at least the %ld tiles", ldp, P);
   dim3 grid((unsigned)((P + kWinoThreads - 1) / kWinoThreads), K);
   hipStream_t hs = static_cast<hipStream_t>(stream);
-  if (m == 2) hipLaunchKernelGGL((wino_output_kernel<2, true, true>), grid, dim3(kWinoThreads), 0, hs, M, K, H, W, tiles_of(H, m), tiles_of(W, m), P, y, pre_bias, parts, xpre, chan);
-  else if (ragged(m, H, W)) hipLaunchKernelGGL((wino_output_kernel<4, true, true, false, true>), grid, dim3(kWinoThreads), 0, hs, M, K, H, W, tiles_of(H, m), tiles_of(W, m), P, y, pre_bias, parts, xpre, chan);
-  else if ((size_t)36 * K * P * sizeof(float) > kStreamBytes) hipLaunchKernelGGL((wino_output_kernel<4, true, true, true>), grid, dim3(kWinoThreads), 0, hs, M, K, H, W, tiles_of(H, m), tiles_of(W, m), P, y, pre_bias, parts, xpre, chan);
-  else hipLaunchKernelGGL((wino_output_kernel<4, true, true>), grid, dim3(kWinoThreads), 0, hs, M, K, H, W, tiles_of(H, m), tiles_of(W, m), P, y, pre_bias, parts, xpre, chan);
+  if (m == 2) hipLaunchKernelGGL((wino_output_kernel<2, true, true>), grid, dim3(kWinoThreads), 0, hs, M, K, H, W, tiles_of(H, m), tiles_of(W, m), P, Ps, y, pre_bias, parts, xpre, chan);
+  else if (ragged(m, H, W)) hipLaunchKernelGGL((wino_output_kernel<4, true, true, false, true>), grid, dim3(kWinoThreads), 0, hs, M, K, H, W, tiles_of(H, m), tiles_of(W, m), P, Ps, y, pre_bias, parts, xpre, chan);
+  else if ((size_t)36 * K * Ps * sizeof(float) > kStreamBytes) hipLaunchKernelGGL((wino_output_kernel<4, true, true, true>), grid, dim3(kWinoThreads), 0, hs, M, K, H, W, tiles_of(H, m), tiles_of(W, m), P, Ps, y, pre_bias, parts, xpre, chan);
+  else hipLaunchKernelGGL((wino_output_kernel<4, true, true>), grid, dim3(kWinoThreads), 0, hs, M, K, H, W, tiles_of(H, m), tiles_of(W, m), P, Ps, y, pre_bias, parts, xpre, chan);
   return launch_status("fpsg_wino_output_transform_bwd_stats");
 }
 
-extern "C" int fpsg_wino_grad_output_transform(int m, const float* dy, int N, int K, int H, int W, float* dM,
-                                               fpsg_stream_t stream) {
+extern "C" int fpsg_wino_grad_output_transform(int m, const float* dy, int N, int K, int H, int W, float* dM, long ldp,
+    fpsg_stream_t stream) {
   using namespace fpsg;
   int rc = check_image("fpsg_wino_grad_output_transform", m, N, K, H, W);
   if (rc) return rc;
   FPSG_REQUIRE_PTR(dy); FPSG_REQUIRE_PTR(dM);
   FPSG_REQUIRE((reinterpret_cast<uintptr_t>(dy) & 15) == 0, FPSG_E_ALIGN, "fpsg_wino_grad_output_transform: dy must be 16-byte aligned");
   const long P = (long)N * tiles_of(H, m) * tiles_of(W, m);
-  dim3 grid((unsigned)((P + kWinoThreads - 1) / kWinoThreads), K);
+  const long Ps = ldp ? ldp : P;
+  FPSG_REQUIRE(Ps >= P, FPSG_E_SHAPE, "fpsg_wino_grad_output_transform: row stride %ld must be 0 or at least the %ld tiles", ldp, P);
+  dim3 grid((unsigned)((Ps + kWinoThreads - 1) / kWinoThreads), K);
   hipStream_t hs = static_cast<hipStream_t>(stream);
-  if (m == 2) hipLaunchKernelGGL((wino_grad_output_kernel<2>), grid, dim3(kWinoThreads), 0, hs, dy, K, H, W, tiles_of(H, m), tiles_of(W, m), P, dM);
-  else if (ragged(m, H, W)) hipLaunchKernelGGL((wino_grad_output_kernel<4, false, true>), grid, dim3(kWinoThreads), 0, hs, dy, K, H, W, tiles_of(H, m), tiles_of(W, m), P, dM);
-  else if ((size_t)36 * K * P * sizeof(float) > kStreamBytes) hipLaunchKernelGGL((wino_grad_output_kernel<4, true>), grid, dim3(kWinoThreads), 0, hs, dy, K, H, W, tiles_of(H, m), tiles_of(W, m), P, dM);
-  else hipLaunchKernelGGL((wino_grad_output_kernel<4>), grid, dim3(kWinoThreads), 0, hs, dy, K, H, W, tiles_of(H, m), tiles_of(W, m), P, dM);
+  if (m == 2) hipLaunchKernelGGL((wino_grad_output_kernel<2>), grid, dim3(kWinoThreads), 0, hs, dy, K, H, W, tiles_of(H, m), tiles_of(W, m), P, Ps, dM);
+  else if (ragged(m, H, W)) hipLaunchKernelGGL((wino_grad_output_kernel<4, false, true>), grid, dim3(kWinoThreads), 0, hs, dy, K, H, W, tiles_of(H, m), tiles_of(W, m), P, Ps, dM);
+  else if ((size_t)36 * K * Ps * sizeof(float) > kStreamBytes) hipLaunchKernelGGL((wino_grad_output_kernel<4, true>), grid, dim3(kWinoThreads), 0, hs, dy, K, H, W, tiles_of(H, m), tiles_of(W, m), P, Ps, dM);
+  else hipLaunchKernelGGL((wino_grad_output_kernel<4>), grid, dim3(kWinoThreads), 0, hs, dy, K, H, W, tiles_of(H, m), tiles_of(W, m), P, Ps, dM);
   return launch_status("fpsg_wino_grad_output_transform");
 }
 
-extern "C" int fpsg_wino_grad_transforms(int m, const float* dy, int N, int K, int H, int W, float* V, float* dM,
-                                         fpsg_stream_t stream) {
+extern "C" int fpsg_wino_grad_transforms(int m, const float* dy, int N, int K, int H, int W, float* V, float* dM, long ldp,
+    fpsg_stream_t stream) {
   using namespace fpsg;
   int rc = check_image("fpsg_wino_grad_transforms", m, N, K, H, W);
   if (rc) return rc;
   FPSG_REQUIRE_PTR(dy); FPSG_REQUIRE_PTR(V); FPSG_REQUIRE_PTR(dM);
   FPSG_REQUIRE((reinterpret_cast<uintptr_t>(dy) & 15) == 0, FPSG_E_ALIGN, "fpsg_wino_grad_transforms: dy must be 16-byte aligned");
   const long P = (long)N * tiles_of(H, m) * tiles_of(W, m);
-  dim3 grid((unsigned)((P + kWinoThreads - 1) / kWinoThreads), K);
+  const long Ps = ldp ? ldp : P;
+  FPSG_REQUIRE(Ps >= P, FPSG_E_SHAPE, "fpsg_wino_grad_transforms: row stride %ld must be 0 or at least the %ld tiles", ldp, P);
+  dim3 grid((unsigned)((Ps + kWinoThreads - 1) / kWinoThreads), K);
   hipStream_t hs = static_cast<hipStream_t>(stream);
-  if (m == 2) hipLaunchKernelGGL((wino_input_kernel<2, false, false, false, true>), grid, dim3(kWinoThreads), 0, hs, dy, K, H, W, tiles_of(H, m), tiles_of(W, m), P, V, nullptr, nullptr, dM);
-  else if (ragged(m, H, W)) hipLaunchKernelGGL((wino_input_kernel<4, false, false, true, true>), grid, dim3(kWinoThreads), 0, hs, dy, K, H, W, tiles_of(H, m), tiles_of(W, m), P, V, nullptr, nullptr, dM);
-  else if ((size_t)36 * K * P * sizeof(float) > kStreamBytes) hipLaunchKernelGGL((wino_input_kernel<4, false, true, false, true>), grid, dim3(kWinoThreads), 0, hs, dy, K, H, W, tiles_of(H, m), tiles_of(W, m), P, V, nullptr, nullptr, dM);
-  else hipLaunchKernelGGL((wino_input_kernel<4, false, false, false, true>), grid, dim3(kWinoThreads), 0, hs, dy, K, H, W, tiles_of(H, m), tiles_of(W, m), P, V, nullptr, nullptr, dM);
+  if (m == 2) hipLaunchKernelGGL((wino_input_kernel<2, false, false, false, true>), grid, dim3(kWinoThreads), 0, hs, dy, K, H, W, tiles_of(H, m), tiles_of(W, m), P, Ps, V, nullptr, nullptr, dM);
+  else if (ragged(m, H, W)) hipLaunchKernelGGL((wino_input_kernel<4, false, false, true, true>), grid, dim3(kWinoThreads), 0, hs, dy, K, H, W, tiles_of(H, m), tiles_of(W, m), P, Ps, V, nullptr, nullptr, dM);
+  else if ((size_t)36 * K * Ps * sizeof(float) > kStreamBytes) hipLaunchKernelGGL((wino_input_kernel<4, false, true, false, true>), grid, dim3(kWinoThreads), 0, hs, dy, K, H, W, tiles_of(H, m), tiles_of(W, m), P, Ps, V, nullptr, nullptr, dM);
+  else hipLaunchKernelGGL((wino_input_kernel<4, false, false, false, true>), grid, dim3(kWinoThreads), 0, hs, dy, K, H, W, tiles_of(H, m), tiles_of(W, m), P, Ps, V, nullptr, nullptr, dM);
   return launch_status("fpsg_wino_grad_transforms");
 }
 

@@ -348,10 +348,32 @@ def _filter(m, w, flip):
     return U
 
 
+def row_stride(P: int) -> int:
+    """The row stride (floats) of the transform-domain tensors ``[A*A, channels, stride]`` for ``P`` tiles: ``P`` rounded
+    up to ``FPSG_WINO_ROW_ALIGN`` floats (default 32 = one 128-byte line; 1 = dense rows as before round 5).  The
+    trunk's P (29008 / 7252 / 1813 / 592) is never a whole number of lines, and the library's batched products run
+    4-13 % faster on line-aligned rows (``profiles/r05/wino_row_stride.txt``).  The pad columns are zeros (written by
+    the transforms), the products simply run over ``stride`` columns, the output transforms read the first ``P``."""
+    a = int(os.environ.get("FPSG_WINO_ROW_ALIGN", "32"))
+    if a < 1 or a > 1024:
+        raise ValueError(f"FPSG_WINO_ROW_ALIGN must be in 1 .. 1024 (got {a})")
+    return (P + a - 1) // a * a
+
+
+def _ldp(T, N, H, W, m):
+    """The row stride of a transform-domain tensor handed to an output transform: its own last dimension (a dense
+    ``[A*A, K, P]`` tensor built by a caller or a padded one from ``_input`` / the products)."""
+    if not T.is_contiguous() or T.shape[2] < N * _tiles(H, W, m):
+        raise ValueError(f"transform-domain tensor {tuple(T.shape)} must be contiguous with at least "
+                         f"{N * _tiles(H, W, m)} columns")
+    return T.shape[2]
+
+
 def _input(m, x):
     N, C, H, W = x.shape
-    V = torch.empty(((m + 2) ** 2, C, N * _tiles(H, W, m)), dtype=torch.float32, device=x.device)
-    _call("fpsg_wino_input_transform", m, _hip.ptr(x), N, C, H, W, _hip.ptr(V), _hip.stream_of(x))
+    Ps = row_stride(N * _tiles(H, W, m))
+    V = torch.empty(((m + 2) ** 2, C, Ps), dtype=torch.float32, device=x.device)
+    _call("fpsg_wino_input_transform", m, _hip.ptr(x), N, C, H, W, _hip.ptr(V), Ps, _hip.stream_of(x))
     return V
 
 
@@ -379,7 +401,8 @@ def _output_bwd_stats(m, M, N, H, W, xpre, pre_bias, chan):
     S = _hip.load().fpsg_wino_stats_parts(m, N, H, W)
     parts = torch.empty((K, S, 2), dtype=torch.float32, device=M.device)
     _call("fpsg_wino_output_transform_bwd_stats", m, _hip.ptr(M), N, K, H, W, _hip.ptr(y), _hip.ptr(xpre),
-          _hip.ptr(pre_bias) if pre_bias is not None else None, _hip.ptr(chan), _hip.ptr(parts), _hip.stream_of(M))
+          _hip.ptr(pre_bias) if pre_bias is not None else None, _hip.ptr(chan), _hip.ptr(parts), _ldp(M, N, H, W, m),
+          _hip.stream_of(M))
     return y, parts
 
 
@@ -388,12 +411,12 @@ def _output(m, M, N, H, W, stats_bias=None, want_parts=False):
     K = M.shape[1]
     y = torch.empty((N, K, H, W), dtype=torch.float32, device=M.device)
     if not want_parts:
-        _call("fpsg_wino_output_transform", m, _hip.ptr(M), N, K, H, W, _hip.ptr(y), _hip.stream_of(M))
+        _call("fpsg_wino_output_transform", m, _hip.ptr(M), N, K, H, W, _hip.ptr(y), _ldp(M, N, H, W, m), _hip.stream_of(M))
         return y
     S = _hip.load().fpsg_wino_stats_parts(m, N, H, W)
     parts = torch.empty((K, S, 2), dtype=torch.float32, device=M.device)
     _call("fpsg_wino_output_transform_stats", m, _hip.ptr(M), N, K, H, W, _hip.ptr(y),
-          _hip.ptr(stats_bias) if stats_bias is not None else None, _hip.ptr(parts), _hip.stream_of(M))
+          _hip.ptr(stats_bias) if stats_bias is not None else None, _hip.ptr(parts), _ldp(M, N, H, W, m), _hip.stream_of(M))
     return y, parts
 
 
@@ -421,8 +444,9 @@ def _fused(x, U):
 
 def _grad_output(m, gy):
     N, K, H, W = gy.shape
-    dM = torch.empty(((m + 2) ** 2, K, N * _tiles(H, W, m)), dtype=torch.float32, device=gy.device)
-    _call("fpsg_wino_grad_output_transform", m, _hip.ptr(gy), N, K, H, W, _hip.ptr(dM), _hip.stream_of(gy))
+    Ps = row_stride(N * _tiles(H, W, m))
+    dM = torch.empty(((m + 2) ** 2, K, Ps), dtype=torch.float32, device=gy.device)
+    _call("fpsg_wino_grad_output_transform", m, _hip.ptr(gy), N, K, H, W, _hip.ptr(dM), Ps, _hip.stream_of(gy))
     return dM
 
 
@@ -435,10 +459,10 @@ def _grad_transforms(m, gy):
     """``(_input(m, gy), _grad_output(m, gy))`` from ONE pass over ``gy`` (``fpsg_wino_grad_transforms``): the weight
     gradient's tile is the interior of the data gradient's patch.  Bit-identical to the two launches."""
     N, K, H, W = gy.shape
-    P = N * _tiles(H, W, m)
-    V = torch.empty(((m + 2) ** 2, K, P), dtype=torch.float32, device=gy.device)
+    Ps = row_stride(N * _tiles(H, W, m))
+    V = torch.empty(((m + 2) ** 2, K, Ps), dtype=torch.float32, device=gy.device)
     dM = torch.empty_like(V)
-    _call("fpsg_wino_grad_transforms", m, _hip.ptr(gy), N, K, H, W, _hip.ptr(V), _hip.ptr(dM), _hip.stream_of(gy))
+    _call("fpsg_wino_grad_transforms", m, _hip.ptr(gy), N, K, H, W, _hip.ptr(V), _hip.ptr(dM), Ps, _hip.stream_of(gy))
     return V, dM
 
 
@@ -516,9 +540,10 @@ class _Conv3x3(torch.autograd.Function):
 
 def _input_act(m, x, chan, pre_bias):
     N, C, H, W = x.shape
-    V = torch.empty(((m + 2) ** 2, C, N * _tiles(H, W, m)), dtype=torch.float32, device=x.device)
+    Ps = row_stride(N * _tiles(H, W, m))
+    V = torch.empty(((m + 2) ** 2, C, Ps), dtype=torch.float32, device=x.device)
     _call("fpsg_wino_input_transform_act", m, _hip.ptr(x), _hip.ptr(chan), _hip.ptr(pre_bias) if pre_bias is not None else None,
-          N, C, H, W, _hip.ptr(V), _hip.stream_of(x))
+          N, C, H, W, _hip.ptr(V), Ps, _hip.stream_of(x))
     return V
 
 

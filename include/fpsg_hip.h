@@ -478,16 +478,25 @@ int fpsg_max_bwd_scatter(float* da, const float* W, const float* k1, const float
  * m = 2: 2.25x fewer multiplications than the direct form, fp32 error a few ulp; m = 4: 4x fewer,
  * error ~1e-5 of the output scale (transform constants up to 8 and 1/24).  All tensors fp32,
  * contiguous, caller-allocated; image tensors 16-byte aligned.  Deterministic.
+ * ldp (round 5): the ROW STRIDE of the transform-domain tensors V / M / dM in floats -- [A*A][channels][ldp], tile p of a
+ * row at offset p -- 0 (= P, dense) or any value >= P.  P is 29008 / 7252 / 1813 / 592 at the trunk's shapes: never a
+ * whole number of 128-byte lines (1813 is odd), so dense rows make every row piece a GEMM tile reads or writes share
+ * its first and last line with the neighbouring tile; with ldp = P rounded up to 32 floats the library's products run
+ * 4-13 % faster (profiles/r05/wino_row_stride.txt).  The transforms that WRITE a transform-domain tensor fill the pad
+ * columns P .. ldp-1 with zeros (the products may then simply run over ldp columns: a zero column adds nothing to the
+ * weight gradient's reduction); the output transforms never read them.
  */
-int fpsg_wino_input_transform(int m, const float* x, int N, int C, int H, int W, float* V, fpsg_stream_t stream);
-int fpsg_wino_output_transform(int m, const float* M, int N, int K, int H, int W, float* y, fpsg_stream_t stream);
+int fpsg_wino_input_transform(int m, const float* x, int N, int C, int H, int W, float* V, long ldp,
+                              fpsg_stream_t stream);
+int fpsg_wino_output_transform(int m, const float* M, int N, int K, int H, int W, float* y, long ldp,
+                               fpsg_stream_t stream);
 /* The same, also accumulating the statistics of the BatchNorm that follows the convolution
  * (nn.Conv2d -> nn.BatchNorm2d of image_net.py:14): parts [K][fpsg_wino_stats_parts(m,N,H,W)][2] =
  * (sum(y + bias[k]), sum((y + bias[k])^2)) per workgroup of 256 tiles (bias optional: the convolution's bias, which K5
  * adds inside the BatchNorm); fpsg_bn_stats / fpsg_bn_act_pool_fwd take them instead of reading y again.  Deterministic. */
 int fpsg_wino_stats_parts(int m, int N, int H, int W);
 int fpsg_wino_output_transform_stats(int m, const float* M, int N, int K, int H, int W, float* y, const float* bias,
-                                     float* parts, fpsg_stream_t stream);
+                                     float* parts, long ldp, fpsg_stream_t stream);
 /* The output transform of a DATA-GRADIENT convolution whose result is the gradient of relu(bn(xpre + pre_bias)):
  * besides y it delivers the two sums BatchNorm's backward starts from -- sum(dz) and sum(dz * (x - mean) * rstd) with
  * dz = y * [fma(x, scale, shift) > 0], x = xpre + pre_bias[k] -- per output channel and workgroup into
@@ -496,14 +505,14 @@ int fpsg_wino_output_transform_stats(int m, const float* M, int N, int K, int H,
  * fpsg_bn_act_bwd_parts then skips its pass over (x, dy). */
 int fpsg_wino_output_transform_bwd_stats(int m, const float* M, int N, int K, int H, int W, float* y,
                                          const float* xpre, const float* pre_bias, const float* chan,
-                                         float* parts, fpsg_stream_t stream);
-int fpsg_wino_grad_output_transform(int m, const float* dy, int N, int K, int H, int W, float* dM,
+                                         float* parts, long ldp, fpsg_stream_t stream);
+int fpsg_wino_grad_output_transform(int m, const float* dy, int N, int K, int H, int W, float* dM, long ldp,
                                     fpsg_stream_t stream);
 /* Both transforms of an output gradient dy [N,K,H,W] in ONE pass (round 4): V = B^T d B of its 6x6 (4x4) patches -- the
  * "input" transform of the data gradient's convolution -- and dM = A dy A^T of its tiles -- the weight gradient's -- the
  * tile being the patch's interior.  V, dM [A*A, K, P]; values bit-identical to fpsg_wino_input_transform(dy) and
  * fpsg_wino_grad_output_transform(dy); one read of dy instead of two. */
-int fpsg_wino_grad_transforms(int m, const float* dy, int N, int K, int H, int W, float* V, float* dM,
+int fpsg_wino_grad_transforms(int m, const float* dy, int N, int K, int H, int W, float* V, float* dM, long ldp,
                               fpsg_stream_t stream);
 int fpsg_wino_filter_transform(int m, const float* w, int K, int C, int flip_transpose, float* U,
                                fpsg_stream_t stream);
@@ -607,7 +616,7 @@ int fpsg_wino_dw_fused(const float* x, const float* chan, const float* pre_bias,
  * stage (conv -> BN -> ReLU -> conv, src/models/image_net.py:14) is folded into the second convolution's
  * load (one read + one write of the activation tensor less per layer).  pre_bias may be NULL. */
 int fpsg_wino_input_transform_act(int m, const float* x, const float* chan, const float* pre_bias, int N, int C,
-                                  int H, int W, float* V, fpsg_stream_t stream);
+                                  int H, int W, float* V, long ldp, fpsg_stream_t stream);
 int fpsg_wino_conv_fused_act(const float* x, const float* chan, const float* pre_bias, const float* U, int N, int C,
                              int K, int H, int W, float* y, fpsg_stream_t stream);
 

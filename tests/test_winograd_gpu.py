@@ -70,13 +70,13 @@ def test_argument_checks(gpu):
     with pytest.raises(ValueError):
         conv3x3(torch.randn(1, 4, 8, 8, device=gpu), torch.randn(4, 5, 3, 3, device=gpu))      # channel mismatch
     lib = _hip.load()
-    assert lib.fpsg_wino_input_transform(2, None, 1, 1, 2, 2, None, None) != 0
+    assert lib.fpsg_wino_input_transform(2, None, 1, 1, 2, 2, None, 0, None) != 0
     assert b"null" in lib.fpsg_last_error()
     x = torch.randn(1, 1, 3, 4, device=gpu)
-    assert lib.fpsg_wino_input_transform(2, _hip.ptr(x), 1, 1, 3, 4, _hip.ptr(x), None) != 0              # odd H
-    assert lib.fpsg_wino_input_transform(4, _hip.ptr(x), 1, 1, 3, 4, _hip.ptr(x), None) != 0              # odd H, m = 4
-    assert lib.fpsg_wino_input_transform(4, _hip.ptr(x), 1, 1, 2, 3, _hip.ptr(x), None) != 0              # odd W
-    assert lib.fpsg_wino_input_transform(3, _hip.ptr(x), 1, 1, 2, 4, _hip.ptr(x), None) != 0              # m
+    assert lib.fpsg_wino_input_transform(2, _hip.ptr(x), 1, 1, 3, 4, _hip.ptr(x), 0, None) != 0           # odd H
+    assert lib.fpsg_wino_input_transform(4, _hip.ptr(x), 1, 1, 3, 4, _hip.ptr(x), 0, None) != 0           # odd H, m = 4
+    assert lib.fpsg_wino_input_transform(4, _hip.ptr(x), 1, 1, 2, 3, _hip.ptr(x), 0, None) != 0           # odd W
+    assert lib.fpsg_wino_input_transform(3, _hip.ptr(x), 1, 1, 2, 4, _hip.ptr(x), 0, None) != 0           # m
     with pytest.raises(ValueError):
         conv3x3(torch.randn(1, 4, 6, 7, device=gpu), torch.randn(4, 4, 3, 3, device=gpu), 4)             # odd W
     # m = 4 on an even side that is not a multiple of 4 is served (half-empty edge tiles), not refused
@@ -755,6 +755,69 @@ def test_both_transforms_of_an_output_gradient_from_one_pass(gpu, m, shape, monk
         wg.conv3x3(xr, wr, m).backward(gy)
         res.append((xr.grad, wr.grad))
     assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+
+
+@pytest.mark.parametrize("m,shape", [(4, (37, 24, 28, 28)), (4, (3, 16, 14, 14)), (2, (3, 16, 14, 14)), (4, (2, 8, 18, 12)),
+                                     (4, (1, 3, 4, 4)), (4, (8, 32, 16, 16))])
+@pytest.mark.parametrize("align", [32, 64, 7])
+def test_padded_rows_of_the_transform_domain_tensors(gpu, m, shape, align, monkeypatch):
+    """Round 5: the transform-domain tensors are [A*A, channels, row stride] with the stride rounded up to whole 128-byte
+    lines (FPSG_WINO_ROW_ALIGN, default 32 floats).  Against the dense form (align 1): the first P columns of every
+    transform are the dense transform's bit for bit, the pad columns are zeros, an output transform reads a padded
+    product as it reads a dense one, and the convolution's value and gradients keep their float64 bounds."""
+    from fpsg_amd import winograd as wg
+    N, C, H, W = shape
+    torch.manual_seed(C + H)
+    x = torch.randn(*shape, device=gpu)
+    chan = torch.stack([torch.rand(C, device=gpu) + 0.5, torch.randn(C, device=gpu), torch.zeros(C, device=gpu),
+                        torch.ones(C, device=gpu)]).contiguous()
+    pb = torch.randn(C, device=gpu)
+    P = N * wg._tiles(H, W, m)
+    out = {}
+    for a in (1, align):
+        monkeypatch.setenv("FPSG_WINO_ROW_ALIGN", str(a))
+        Vg, dMg = wg._grad_transforms(m, x)
+        out[a] = (wg._input(m, x), wg._input_act(m, x, chan, pb), wg._grad_output(m, x), Vg, dMg)
+    Ps = (P + align - 1) // align * align
+    for dense, padded in zip(out[1], out[align]):
+        assert dense.shape[2] == P and padded.shape[2] == Ps
+        assert torch.equal(padded[:, :, :P], dense)
+        assert int(torch.count_nonzero(padded[:, :, P:])) == 0
+    K = 8
+    Md = torch.randn((m + 2) ** 2, K, P, device=gpu)
+    Mp = torch.full(((m + 2) ** 2, K, Ps), float("nan"), device=gpu)        # the pad columns are never read
+    Mp[:, :, :P] = Md
+    y0 = wg._output(m, Md, N, H, W)
+    assert torch.equal(wg._output(m, Mp, N, H, W), y0)
+    bias = torch.randn(K, device=gpu)
+    ys, parts = wg._output(m, Mp, N, H, W, bias, True)
+    yd, parts_d = wg._output(m, Md, N, H, W, bias, True)
+    assert torch.equal(ys, y0) and torch.equal(parts, parts_d)
+    # the convolution through padded rows: value and gradients against float64
+    w = torch.randn(K, C, 3, 3) * (2.0 / (9 * C)) ** 0.5
+    g = torch.randn(N, K, H, W)
+    x64, w64 = x.double().cpu().requires_grad_(), w.double().requires_grad_()
+    y64 = F.conv2d(x64, w64, None, 1, 1)
+    y64.backward(g.double())
+    xg, wgr = x.clone().requires_grad_(), w.to(gpu).requires_grad_()
+    y = wg.conv3x3(xg, wgr, m)
+    y.backward(g.to(gpu))
+    for ours, ref in ((y, y64), (xg.grad, x64.grad), (wgr.grad, w64.grad)):
+        assert _errs(ours.detach(), ref.detach()) <= (1e-5 if m == 2 else 4e-5)
+
+
+def test_row_stride_arguments(gpu, monkeypatch):
+    from fpsg_amd import _hip, winograd as wg
+    lib = _hip.load()
+    x = torch.randn(1, 1, 4, 4, device=gpu)
+    V = torch.empty(36, 1, 8, device=gpu)
+    assert lib.fpsg_wino_input_transform(4, _hip.ptr(x), 1, 1, 4, 4, _hip.ptr(V), -3, None) != 0      # stride below P
+    assert b"row stride" in lib.fpsg_last_error()
+    with pytest.raises(ValueError):
+        wg._output(4, torch.randn(36, 2, 3, device=gpu), 1, 8, 8)                                      # 4 tiles, 3 columns
+    monkeypatch.setenv("FPSG_WINO_ROW_ALIGN", "0")
+    with pytest.raises(ValueError):
+        wg.row_stride(100)
 
 
 SPLIT_SHAPES = [(7, 256, 128, 28, 28, 4), (3, 128, 256, 56, 56, 4), (5, 512, 512, 14, 14, 4), (2, 160, 136, 28, 36, 4),

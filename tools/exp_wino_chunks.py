@@ -28,11 +28,11 @@ def chain(m, x, U, y, Vws, Mws, chunk, transforms=True, products=True):
         V = Vws[: a2 * C * n * tiles].view(a2, C, n * tiles)
         M = Mws[: a2 * K * n * tiles].view(a2, K, n * tiles)
         if transforms:
-            wg._call("fpsg_wino_input_transform", m, x[n0].data_ptr(), n, C, H, W, V.data_ptr(), st)
+            wg._call("fpsg_wino_input_transform", m, x[n0].data_ptr(), n, C, H, W, V.data_ptr(), 0, st)
         if products:
             torch.bmm(U, V, out=M)
         if transforms:
-            wg._call("fpsg_wino_output_transform", m, M.data_ptr(), n, K, H, W, y[n0].data_ptr(), st)
+            wg._call("fpsg_wino_output_transform", m, M.data_ptr(), n, K, H, W, y[n0].data_ptr(), 0, st)
 
 
 def timed(fn, reps=6):
