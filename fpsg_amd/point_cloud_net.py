@@ -22,6 +22,8 @@ caller inject or seed it.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -566,11 +568,53 @@ class _BmmSplit(torch.autograd.Function):
         return gw, gh
 
 
+class _BmmWideT(torch.autograd.Function):
+    """``torch.bmm(w, h)`` for the patch MLPs' wide layers on the library's fp32 GEMMs, with the data gradient
+    ``dh = w^T . g`` taken from a TRANSPOSED COPY of the weights whose rows start on 32-byte boundaries (``[G, in, out]``
+    in a buffer of row stride ``out`` rounded up to 8 floats), made once per optimizer step
+    (``winograd.weights_frozen``'s cache).  Autograd's own backward multiplies by ``w^T`` through its strides -- a
+    transposed-operand kernel reading 1539-float rows (odd: 4-byte aligned) -- 1461 us per episode at 1539 -> 769; the
+    plain product on the aligned copy takes 1317 us (``profiles/r05/decoder_weight_rows.txt``).  Same arithmetic (fp32
+    library GEMM), another kernel's summation order.  ``FPSG_DECODER_WT=0``: autograd's form (A/B)."""
+
+    @staticmethod
+    def forward(ctx, w, h):
+        ctx.save_for_backward(w, h)
+        return torch.bmm(w, h)
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import winograd
+        w, h = ctx.saved_tensors
+        gw = gh = None
+        if ctx.needs_input_grad[1]:
+            cache = winograd.frozen_cache()
+            key = ("bmm_wT_rows", w.data_ptr(), tuple(w.shape), tuple(w.stride()))
+            wT = cache.get(key) if cache is not None else None
+            if wT is None:
+                G, out, cin = w.shape
+                wT = torch.empty((G, cin, (out + 7) // 8 * 8), dtype=w.dtype, device=w.device)[:, :, :out]
+                wT.copy_(w.transpose(1, 2))
+                if cache is not None:
+                    cache[key] = wT
+            gh = torch.bmm(wT, g)
+        if ctx.needs_input_grad[0]:
+            gw = torch.bmm(g, h.transpose(1, 2))
+        return gw, gh
+
+
+_WT_MIN_COLUMNS = 2048      # below 16 clouds x 128 points the copy costs more than the aligned product saves (one-shot episodes)
+
+
 def _bmm_wide(w, h):
-    """``torch.bmm(w, h)``; layers of at least 128 inputs and outputs through K10 when ``FPSG_GEMM_SPLIT=1``."""
+    """``torch.bmm(w, h)``; layers of at least 128 inputs and outputs through K10 when ``FPSG_GEMM_SPLIT=1``, otherwise
+    (training, on the GPU) with the data gradient from an aligned transposed copy of the weights (``_BmmWideT``)."""
     from . import gemm_split
     if gemm_split.enabled() and w.is_cuda and min(w.shape[1], w.shape[2]) >= 128:
         return _BmmSplit.apply(w, h)
+    if (w.is_cuda and torch.is_grad_enabled() and h.requires_grad and min(w.shape[1], w.shape[2]) >= 128
+            and h.shape[2] >= _WT_MIN_COLUMNS and os.environ.get("FPSG_DECODER_WT", "1") != "0"):
+        return _BmmWideT.apply(w, h)
     return torch.bmm(w, h)
 
 

@@ -413,3 +413,43 @@ def test_pair_of_decodes_falls_back_where_the_row_batchnorm_cannot_run(gpu, monk
     dev.load_state_dict(state)
     want = torch.cat([dev.forward(a.detach(), ga), dev.forward(b.detach(), gb)])
     assert torch.allclose(out.detach(), want, rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("shape", [(4, 769, 1539, 2304), (3, 384, 769, 2048), (2, 130, 141, 2050)])
+def test_data_gradient_from_the_aligned_transposed_weights(gpu, shape, monkeypatch):
+    """``_BmmWideT`` (round 5): the wide layers' data gradient ``w^T . g`` from a transposed copy of the weights with
+    32-byte-aligned rows instead of autograd's transposed-operand product: the same fp32 library arithmetic, another
+    kernel -- value and both gradients against float64 at the library's own accuracy, the copy made once per
+    ``weights_frozen`` block, the plain form below the size threshold and under ``FPSG_DECODER_WT=0``."""
+    from fpsg_amd import point_cloud_net as pcn, winograd
+    G, out, cin, cols = shape
+    torch.manual_seed(out)
+    w = (torch.randn(G, out, cin, device=gpu) / cin ** 0.5).requires_grad_()
+    h = torch.randn(G, cin, cols, device=gpu).requires_grad_()
+    g = torch.randn(G, out, cols, device=gpu)
+    ref = torch.bmm(w.detach().double(), h.detach().double())
+    gh64 = torch.bmm(w.detach().double().transpose(1, 2), g.double())
+    gw64 = torch.bmm(g.double(), h.detach().double().transpose(1, 2))
+    err = lambda a, r: float((a.detach().double() - r).abs().max() / r.abs().max())
+    with winograd.weights_frozen():
+        y = pcn._bmm_wide(w, h)
+        assert y.grad_fn is not None and type(y.grad_fn).__name__ == "_BmmWideTBackward"
+        y.backward(g)
+        made = [k for k in winograd.frozen_cache() if k[0] == "bmm_wT_rows"]
+        assert len(made) == 1
+        wT = winograd.frozen_cache()[made[0]]
+        assert wT.stride(1) % 8 == 0 and torch.equal(wT, w.detach().transpose(1, 2))
+        gh1, gw1 = h.grad.clone(), w.grad.clone()
+        h.grad = w.grad = None
+        pcn._bmm_wide(w, h).backward(g)                      # second episode of the step: the cached copy
+        assert winograd.frozen_cache()[made[0]] is wT and torch.equal(h.grad, gh1) and torch.equal(w.grad, gw1)
+    assert err(y, ref) < 1e-5 and err(gh1, gh64) < 1e-5 and err(gw1, gw64) < 1e-5, (err(y, ref), err(gh1, gh64), err(gw1, gw64))
+    monkeypatch.setenv("FPSG_DECODER_WT", "0")
+    h.grad = w.grad = None
+    y0 = pcn._bmm_wide(w, h)
+    assert type(y0.grad_fn).__name__ != "_BmmWideTBackward" and torch.equal(y0, y)
+    y0.backward(g)
+    assert err(w.grad, gw64) < 1e-5 and err(h.grad, gh64) < 1e-5
+    monkeypatch.delenv("FPSG_DECODER_WT")
+    small = torch.randn(G, cin, 256, device=gpu, requires_grad=True)
+    assert type(pcn._bmm_wide(w, small).grad_fn).__name__ != "_BmmWideTBackward"

@@ -32,6 +32,41 @@ def _time(fn, reps):
     return e0.elapsed_time(e1) * 1e3 / reps
 
 
+def decoder(args, dev):
+    """The patch MLPs' wide layers (16 patches, 37 x 128 points): w [16, out, in] . h [16, in, 4736] and the two products
+    of its backward, with the odd feature dimensions 1539 / 769 (a) as they are, (b) only the leading dimension of the
+    weights padded to 8 floats (views of padded buffers), (c) the feature dimensions padded to 8 / 32 with zero rows and
+    columns (what a padded activation layout would give)."""
+    G, BP = 16, 37 * 128
+    for cin, cout in ((1539, 769), (769, 384)):
+        legs = {}
+        for tag, pad in (("exact", 1), ("pad8", 8), ("pad32", 32)):
+            ci, co = (cin + pad - 1) // pad * pad, (cout + pad - 1) // pad * pad
+            w = torch.randn(G, co, ci, device=dev)
+            h = torch.randn(G, ci, BP, device=dev)
+            g = torch.randn(G, co, BP, device=dev)
+            wt = w.transpose(1, 2).contiguous()
+            legs[(tag, "fwd")] = lambda w=w, h=h: torch.bmm(w, h)
+            legs[(tag, "dgrad")] = lambda wt=wt, g=g: torch.bmm(wt, g)
+            legs[(tag, "wgrad")] = lambda g=g, h=h: torch.bmm(g, h.transpose(1, 2))
+        # (b): the true sizes, only the weights' rows 32-byte aligned
+        wp = torch.randn(G, cout, (cin + 7) // 8 * 8, device=dev)[:, :, :cin]
+        wtp = torch.randn(G, cin, (cout + 7) // 8 * 8, device=dev)[:, :, :cout]
+        h = torch.randn(G, cin, BP, device=dev)
+        g = torch.randn(G, cout, BP, device=dev)
+        legs[("ld8", "fwd")] = lambda wp=wp, h=h: torch.bmm(wp, h)
+        legs[("ld8", "dgrad")] = lambda wtp=wtp, g=g: torch.bmm(wtp, g)
+        for fn in legs.values():
+            fn()
+            fn()
+        torch.cuda.synchronize()
+        best = {k: float("inf") for k in legs}
+        for _ in range(args.rounds):
+            for k, fn in legs.items():
+                best[k] = min(best[k], _time(fn, args.reps))
+        print(json.dumps({"layer": f"{cin}->{cout}", **{f"{t}_{n}_us": round(v, 1) for (t, n), v in best.items()}}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--pads", default="1,32,64")
@@ -39,6 +74,7 @@ def main():
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--quick", action="store_true")
     ap.add_argument("--no-split", action="store_true")
+    ap.add_argument("--decoder", action="store_true", help="the decoder's wide layers with padded feature dimensions instead")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
@@ -46,6 +82,10 @@ def main():
     os.close(fd)
     shutil.copyfile(gemm_tuning.DEFAULT_FILE, records)
     print(json.dumps(gemm_tuning.enable(records, tune=True)), file=sys.stderr)
+    if args.decoder:
+        decoder(args, dev)
+        os.remove(records) if os.path.exists(records) else None
+        return
     shapes = ((256, 256, 56), (512, 512, 28)) if args.quick else ((128, 128, 112), (128, 256, 56), (256, 256, 56),
                                                                  (256, 512, 28), (512, 512, 28), (512, 512, 14))
     pads = [int(p) for p in args.pads.split(",")]
