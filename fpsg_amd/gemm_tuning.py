@@ -49,8 +49,13 @@ def enable(path: str | None = None, tune: bool | None = None) -> dict:
     tunable.set_filename(records, insert_device_ordinal=False)
     tunable.tuning_enable(bool(tune))
     if tune:
-        tunable.set_max_tuning_duration(30)
-        tunable.set_max_tuning_iterations(10)
+        # FPSG_GEMM_TUNE_MS / _ITERS: time per candidate kernel; FPSG_GEMM_TUNE_ROTATE_MB: size of the operand copies the
+        # timing loop rotates through (TunableOp's default only defeats the L2; the 256 MB Infinity Cache keeps the
+        # operands of most of this path's products warm, which the step's products do not find)
+        tunable.set_max_tuning_duration(int(os.environ.get("FPSG_GEMM_TUNE_MS", "30")))
+        tunable.set_max_tuning_iterations(int(os.environ.get("FPSG_GEMM_TUNE_ITERS", "10")))
+        if os.environ.get("FPSG_GEMM_TUNE_ROTATE_MB"):
+            tunable.set_rotating_buffer_size(int(os.environ["FPSG_GEMM_TUNE_ROTATE_MB"]))
     loaded = bool(os.path.exists(records) and tunable.read_file(records))
     return {"gemm_tuning": "tune" if tune else "file", "gemm_records": os.path.basename(path),
             "gemm_records_loaded": loaded}
