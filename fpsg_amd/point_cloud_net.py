@@ -834,6 +834,25 @@ class PCDecoder(nn.Module):
         second, accumulating gradient for each of the 264 per-patch parameters."""
         if not self.batched:
             return None
+        # Without autograd (the evaluation loop) inside a ``winograd.weights_frozen`` block the parameters do not change:
+        # the pack is made by the block's first item and reused (35 stacking launches per evaluated item otherwise; a
+        # hipGraph captured inside a ``constant`` block reads the entry and holds none of them).
+        cache = key = None
+        if not torch.is_grad_enabled() and os.environ.get("FPSG_EVAL_PACK_CACHE", "1") != "0":
+            from . import winograd
+            cache = winograd.frozen_cache()
+            first = next(self.parameters())
+            key = ("decoder_pack", id(self), first.data_ptr(), first.device)
+            if cache is not None and key in cache:
+                return cache[key]
+        pack = self._build_pack()
+        if cache is not None and not (first.is_cuda and torch.cuda.is_current_stream_capturing()):
+            if callable(pack.get("n1_split")):
+                pack["n1_split"]()        # no lazily made tensor may first appear inside a later capture
+            cache[key] = pack
+        return pack
+
+    def _build_pack(self):
         clusters = list(self.cluster_pool)
         R = self.num_nodes
         defs = [c.deformer for c in clusters]

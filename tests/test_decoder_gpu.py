@@ -453,3 +453,31 @@ def test_data_gradient_from_the_aligned_transposed_weights(gpu, shape, monkeypat
     monkeypatch.delenv("FPSG_DECODER_WT")
     small = torch.randn(G, cin, 256, device=gpu, requires_grad=True)
     assert type(pcn._bmm_wide(w, small).grad_fn).__name__ != "_BmmWideTBackward"
+
+
+def test_evaluation_reuses_the_stacked_parameters_inside_a_frozen_block(gpu, monkeypatch):
+    """Without autograd inside ``winograd.weights_frozen`` the decoder's stacked parameters are made once per block
+    (``PCDecoder.pack_parameters``; the evaluation loop spent 35 stacking launches per item on them): the same pack
+    object, the same clouds as with a fresh pack, a new pack in the next block, and none cached with autograd on."""
+    from fpsg_amd import winograd
+    dec, hidden, grids = _make(3, 21)
+    dec = dec.to(gpu).eval()
+    hidden = hidden.to(gpu)
+    grids = [[g.to(gpu) for g in per_cluster] for per_cluster in grids]
+    with torch.no_grad():
+        ref = dec(hidden, grid=grids)
+        with winograd.weights_frozen(constant=True):
+            p1 = dec.pack_parameters()
+            out1 = dec(hidden, grid=grids)
+            assert dec.pack_parameters() is p1
+            out2 = dec(hidden, grid=grids)
+        with winograd.weights_frozen():
+            p2 = dec.pack_parameters()
+            assert p2 is not p1 and dec.pack_parameters() is p2
+        assert dec.pack_parameters() is not dec.pack_parameters()            # outside a block: nothing is kept
+    assert torch.equal(out1, ref) and torch.equal(out2, ref)
+    with winograd.weights_frozen():
+        assert dec.pack_parameters() is not dec.pack_parameters()            # autograd on: the training path's own caching
+    monkeypatch.setenv("FPSG_EVAL_PACK_CACHE", "0")
+    with torch.no_grad(), winograd.weights_frozen():
+        assert dec.pack_parameters() is not dec.pack_parameters()
