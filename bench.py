@@ -388,14 +388,17 @@ def trunk_kernel_rooflines(device, entry):
     # (torch.bmm = the library's fp32-MFMA batched GEMM): forward U.V and the weight gradient gM.V^T
     for C, K, H in ((128, 128, 112), (256, 256, 56), (512, 512, 28)):
         P = n_img * (H // 4) ** 2
+        Ps = wg.row_stride(P)        # the step's tensors: rows padded to whole 128-byte lines, zero pad columns
         U = torch.randn(36, K, C, device=device)
-        V = torch.randn(36, C, P, device=device)
-        gM = torch.randn(36, K, P, device=device)
-        flop = 2.0 * 36 * K * C * P
+        V = torch.randn(36, C, Ps, device=device)
+        gM = torch.randn(36, K, Ps, device=device)
+        V[:, :, P:] = 0
+        gM[:, :, P:] = 0
+        flop = 2.0 * 36 * K * C * P      # the P real tiles; the products run over the Ps columns
         for leg, fn in (("fwd", lambda: torch.bmm(U, V)), ("dw", lambda: torch.bmm(gM, V.transpose(1, 2)))):
             t = _event_time(fn, 10)
             out[f"K6g_batched_gemm_{C}to{K}_{leg}"] = entry(
-                "mfma", flop / t / 1e12, F32_PEAK / 1e12, "TFLOP/s", t, f"36 x [{K} x {C}].[{C} x {P}]",
+                "mfma", flop / t / 1e12, F32_PEAK / 1e12, "TFLOP/s", t, f"36 x [{K} x {C}].[{C} x {P}] (row stride {Ps})",
                 "library GEMM (hipBLASLt / rocBLAS through torch.bmm, tuning records of fpsg_amd/tuning); "
                 "Winograd-domain flop", hbm_GBps=(U.numel() + V.numel() + gM.numel()) * 4 / t / 1e9)
         del U, V, gM
@@ -441,8 +444,11 @@ def split_gemm_error(device):
     library's (tuned record) on this box."""
     from fpsg_amd.gemm_split import bmm_split
     g = torch.Generator(device="cpu").manual_seed(11)
+    from fpsg_amd.winograd import row_stride
+    P = 37 * 196
     U = torch.randn(36, 256, 256, generator=g).to(device)
-    V = torch.randn(36, 256, 37 * 196, generator=g).to(device)
+    V = torch.zeros(36, 256, row_stride(P), device=device)         # the step's layout: rows padded to whole lines, zero pads
+    V[:, :, :P] = torch.randn(36, 256, P, generator=g).to(device)
     ref = torch.bmm(U[:3].double(), V[:3].double())
     scale = ref.pow(2).mean().sqrt()
 
@@ -453,7 +459,7 @@ def split_gemm_error(device):
     e_lib, e_split = err(torch.bmm(U, V)), err(bmm_split(U, V))
     t_lib = _event_time(lambda: torch.bmm(U, V), 10)
     t_split = _event_time(lambda: bmm_split(U, V), 10)
-    return {"shape": "36 x [256x256].[256x7252]", "library_fp32_max": e_lib[0], "library_fp32_median": e_lib[1],
+    return {"shape": f"36 x [256x256].[256x{P}] (row stride {V.shape[2]})", "library_fp32_max": e_lib[0], "library_fp32_median": e_lib[1],
             "split_max": e_split[0], "split_median": e_split[1], "max_ratio": e_split[0] / e_lib[0],
             "median_ratio": e_split[1] / e_lib[1], "library_us": t_lib * 1e6, "split_us": t_split * 1e6,
             "speedup": t_lib / t_split,
