@@ -50,6 +50,9 @@ struct GemmArgs {
   int nt_c;                  // non-temporal stores of C
   long packed_floats;        // PACKA builds: A is the packed image (fpsg_gemm_split_pack_a, 128-row tiles), this many floats
   int stages_a;              //               and ceil(K / 16) stages per row tile
+  int stagger_mode;          // measurement (variant >= 100000): the first round's workgroups of one CU start stagger_ticks
+  int stagger_per_cu;        //   (10 ns units) apart, so that their tile stores do not coincide; mode 1: co-resident
+  int stagger_ticks;         //   workgroups = blockIdx 256 apart, mode 2: consecutive blockIdx
 };
 
 __device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {
@@ -335,6 +338,13 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void gemm_split_kernel(const Ge
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform for the compiler too (scalar offsets, no waterfall)
+  if (g.stagger_mode && bid < 256 * g.stagger_per_cu) {
+    const int phase = g.stagger_mode == 1 ? (bid / 256) % g.stagger_per_cu : bid % g.stagger_per_cu;
+    if (phase) {
+      const unsigned long long t0 = __builtin_amdgcn_s_memrealtime(), wait = (unsigned long long)phase * g.stagger_ticks;
+      while (__builtin_amdgcn_s_memrealtime() - t0 < wait) __builtin_amdgcn_s_sleep(32);
+    }
+  }
   // Co-resident waves of one SIMD run the same program; under the default (round-robin) arbitration they fall into
   // lock-step -- all in their MFMA block, then all in their conversion block with the matrix pipe idle (measured:
   // SQ_WAIT_INST_ANY = 3x the MFMA busy time, pipe 46 % busy).  Distinct static priorities make the arbitration strict:
@@ -1507,10 +1517,18 @@ struct Plan {
   int tile, bm, bn, bk, tiles_m, tiles_n, splits, k_per_split;
   bool prio;
   int abl;
+  int stagger_mode, stagger_us;
 };
 
 // variant: -1 automatic; else tile + 10 * splits (splits 0 = automatic)
 bool plan_for(int batch, int M, int N, int K, int transB, int variant, Plan* p) {
+  p->stagger_mode = p->stagger_us = 0;
+  if (variant >= 100000) {      // measurement: 100000 * mode + 10 * microseconds + tile (GemmArgs::stagger_*)
+    p->stagger_mode = variant / 100000;
+    p->stagger_us = (variant % 100000) / 10;
+    if (p->stagger_mode > 2) return false;
+    variant %= 10;
+  }
   int tile = variant < 0 ? -1 : variant % 10;
   int splits = variant < 0 ? 0 : (variant / 10) % 100;
   p->prio = variant < 0 || variant < 1000 || variant >= 2000;   // + 1000: without the static wave priorities (A/B)
@@ -1732,6 +1750,7 @@ extern "C" int fpsg_gemm_split(const float* A, const float* B, float* C, int bat
   } else {
     g.C = C; g.ldc = ldc; g.sC = sC; g.s_split = 0;
   }
+  g.stagger_mode = p.stagger_mode; g.stagger_per_cu = kTiles[p.tile].per_cu; g.stagger_ticks = p.stagger_us * 100;
   g.nt_c = 0;     // measured: non-temporal stores of an output beyond the Infinity Cache (128 -> 128 @112: 535 MB) 260 -> 480 us
   FPSG_REQUIRE((long)M * lda < (1L << 29) && (long)(transB ? N : K) * ldb < (1L << 29) && (long)M * ldc < (1L << 29),
                FPSG_E_LIMIT, "fpsg_gemm_split: a matrix of one batch entry must stay below 2 GiB (32-bit buffer offsets)");

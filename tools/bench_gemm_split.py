@@ -16,6 +16,7 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from fpsg_amd.winograd import row_stride  # noqa: E402
 from fpsg_amd.gemm_split import bmm_f32, bmm_packed, bmm_persistent, bmm_split as gemm_split, pack_a  # noqa: E402
 
 
@@ -62,7 +63,7 @@ def main():
     if args.decoder:     # the patch MLPs' wide layers: 16 patches, (in -> out) on 37 x 128 points (H = 0 marks them)
         shapes = ((1539, 769, 0), (769, 384, 0), (769, 1539, 0))
     for C, K, H in shapes:
-        P = args.n_img * ((H + 3) // 4) ** 2 if H else args.n_img * 128
+        P = row_stride(args.n_img * ((H + 3) // 4) ** 2) if H else args.n_img * 128      # the step's padded rows
         nb_ = 36 if H else 16
         U = torch.randn(nb_, K, C, device=dev)
         V = torch.randn(nb_, C, P, device=dev)
