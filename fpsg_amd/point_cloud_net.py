@@ -578,25 +578,32 @@ class _BmmWideT(torch.autograd.Function):
     library GEMM), another kernel's summation order.  ``FPSG_DECODER_WT=0``: autograd's form (A/B)."""
 
     @staticmethod
+    def _aligned(w, transposed):
+        """``w`` (``transposed``: ``w^T``) in a buffer whose rows start on 32-byte boundaries, once per optimizer step."""
+        from . import winograd
+        cache = winograd.frozen_cache()
+        key = ("bmm_wT_rows" if transposed else "bmm_w_rows", w.data_ptr(), tuple(w.shape), tuple(w.stride()))
+        a = cache.get(key) if cache is not None else None
+        if a is None:
+            src = w.transpose(1, 2) if transposed else w
+            G, rows, cols = src.shape
+            a = torch.empty((G, rows, (cols + 7) // 8 * 8), dtype=w.dtype, device=w.device)[:, :, :cols]
+            a.copy_(src)
+            if cache is not None:
+                cache[key] = a
+        return a
+
+    @staticmethod
     def forward(ctx, w, h):
         ctx.save_for_backward(w, h)
-        return torch.bmm(w, h)
+        return torch.bmm(w, h)      # (the forward from an aligned copy too: measured, no difference -- profiles/r05/decoder_weight_rows.txt)
 
     @staticmethod
     def backward(ctx, g):
-        from . import winograd
         w, h = ctx.saved_tensors
         gw = gh = None
         if ctx.needs_input_grad[1]:
-            cache = winograd.frozen_cache()
-            key = ("bmm_wT_rows", w.data_ptr(), tuple(w.shape), tuple(w.stride()))
-            wT = cache.get(key) if cache is not None else None
-            if wT is None:
-                G, out, cin = w.shape
-                wT = torch.empty((G, cin, (out + 7) // 8 * 8), dtype=w.dtype, device=w.device)[:, :, :out]
-                wT.copy_(w.transpose(1, 2))
-                if cache is not None:
-                    cache[key] = wT
+            wT = _BmmWideT._aligned(w, True)
             gh = torch.bmm(wT, g)
         if ctx.needs_input_grad[0]:
             gw = torch.bmm(g, h.transpose(1, 2))
