@@ -34,6 +34,8 @@ from __future__ import annotations
 import argparse
 import json
 import os
+
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")   # before the HIP runtime initialises (fpsg_amd/__init__.py)
 import sys
 import time
 

@@ -14,6 +14,8 @@ reference's commented-out "OPTION 2" (``:111``).
 from __future__ import annotations
 
 import os
+
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")   # before the HIP runtime initialises (fpsg_amd/__init__.py)
 import statistics
 from collections import defaultdict
 

@@ -17,6 +17,8 @@ from __future__ import annotations
 
 import itertools
 import os
+
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")   # before the HIP runtime initialises (fpsg_amd/__init__.py)
 import statistics
 import time
 from collections import defaultdict

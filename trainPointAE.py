@@ -22,6 +22,8 @@ from __future__ import annotations
 
 import argparse
 import os
+
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")   # before the HIP runtime initialises (fpsg_amd/__init__.py)
 import time
 
 import torch
