@@ -37,7 +37,7 @@ def decoder(args, dev):
     of its backward, with the odd feature dimensions 1539 / 769 (a) as they are, (b) only the leading dimension of the
     weights padded to 8 floats (views of padded buffers), (c) the feature dimensions padded to 8 / 32 with zero rows and
     columns (what a padded activation layout would give)."""
-    G, BP = 16, 37 * 128
+    G, BP = 16, args.n_img * 128
     for cin, cout in ((1539, 769), (769, 384)):
         legs = {}
         for tag, pad in (("exact", 1), ("pad8", 8), ("pad32", 32)):
@@ -74,6 +74,7 @@ def main():
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--quick", action="store_true")
     ap.add_argument("--no-split", action="store_true")
+    ap.add_argument("--n-img", type=int, default=37, help="images per product (two episodes batched: 74)")
     ap.add_argument("--decoder", action="store_true", help="the decoder's wide layers with padded feature dimensions instead")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -90,7 +91,7 @@ def main():
                                                                  (256, 512, 28), (512, 512, 28), (512, 512, 14))
     pads = [int(p) for p in args.pads.split(",")]
     for C, K, H in shapes:
-        P = 37 * ((H + 3) // 4) ** 2
+        P = args.n_img * ((H + 3) // 4) ** 2
         legs = {}
         for pad in pads:
             Pp = (P + pad - 1) // pad * pad
